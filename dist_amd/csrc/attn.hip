@@ -1,0 +1,252 @@
+// Attention kernels.
+//
+// (1) dist_op_attention: per-frame multi-head self-attention of the frozen ViT
+//     (nn.MultiheadAttention in ResidualAttentionBlockMid, reference clip.py:155,166-168).
+//     One workgroup per (frame, head); K (row-major) and V (transposed) of the head live in
+//     LDS (L <= 257 keys x 64 dims), each wave walks 16-query tiles with an online softmax
+//     over 32-key slabs.  Both products are issued "swapped":
+//         S^T = K Q^T   -> a lane holds, for ONE query (lane & 15), 4 keys per 16-key tile
+//         O^T = V^T P^T -> the P^T fragment a lane needs is exactly what it already holds,
+//     so the softmax is lane-local plus two cross-group shuffles and P never touches LDS.
+// (2) dist_op_xattn1q(+_bwd): the one-query cross attention of the ada-pooling network
+//     (CrossAttentionBlockGenral, clip.py:139-147; dist.py:144,158): latency-bound, one
+//     wave per (batch element, head).
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int HD = 64;           // head dim
+constexpr int KPAD = 8;
+
+template <typename T>
+__global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int heads, int Lp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int KLD = HD + KPAD, VLD = Lp + KPAD;
+    T* Ks = reinterpret_cast<T*>(smem);          // [Lp][KLD]
+    T* Vt = Ks + Lp * KLD;                       // [HD][VLD]
+
+    const int f = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int d = heads * HD, ld = 3 * d;
+    const T* base = qkv + (long)f * L * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+
+    // K: row-major, 16-B vectors, d fastest
+    for (int v = tid; v < Lp * (HD / 8); v += NT) {
+        const int key = v / (HD / 8), dv = v % (HD / 8);
+        Frag<T> fr;
+        frag_zero(fr);
+        if (key < L) frag_load(fr, base + (long)key * ld + d + h * HD + dv * 8);
+        frag_store(fr, Ks + key * KLD + dv * 8);
+    }
+    // V: transposed, key fastest (conflict-free LDS writes)
+    for (int v = tid; v < Lp * (HD / 8); v += NT) {
+        const int key = v % Lp, dv = v / Lp;
+        Frag<T> fr;
+        frag_zero(fr);
+        if (key < L) frag_load(fr, base + (long)key * ld + 2 * d + h * HD + dv * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Vt[(dv * 8 + e) * VLD + key] = from_f<T>(frag_get(fr, e));
+    }
+    __syncthreads();
+
+    const int nq = (L + 15) / 16, nslab = Lp / 32;
+    for (int qt = wid; qt < nq; qt += 4) {
+        const int q = qt * 16 + li;
+        Frag<T> fq[2];
+        frag_zero(fq[0]); frag_zero(fq[1]);
+        if (q < L) {
+            frag_load(fq[0], base + (long)q * ld + h * HD + lg * 8);
+            frag_load(fq[1], base + (long)q * ld + h * HD + 32 + lg * 8);
+        }
+        f32x4 o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float mrun = -1e30f, lrun = 0.f;
+
+        for (int s = 0; s < nslab; ++s) {
+            f32x4 st[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const T* kp = Ks + (s * 32 + t * 16 + li) * KLD + lg * 8;
+                Frag<T> fk;
+                frag_load(fk, kp);
+                mma16(fk, fq[0], st[t]);
+                frag_load(fk, kp + 32);
+                mma16(fk, fq[1], st[t]);
+            }
+            float mx = -1e30f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = s * 32 + t * 16 + lg * 4 + r;
+                    st[t][r] = key < L ? st[t][r] * 0.125f : -1e30f;
+                    mx = fmaxf(mx, st[t][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(mrun, mx);
+            const float scale = __expf(mrun - mnew);
+            mrun = mnew;
+            Frag<T> fp;
+            float ps = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = s * 32 + t * 16 + lg * 4 + r;
+                    const float pv = key < L ? __expf(st[t][r] - mnew) : 0.f;
+                    ps += pv;
+                    frag_set(fp, t * 4 + r, pv);
+                }
+            lrun = lrun * scale + ps;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[j][r] *= scale;
+                // V^T fragment: row = dcol j*16+li, k-slots = keys (s*32 + 4lg + e | +16)
+                const T* vp = Vt + (j * 16 + li) * VLD + s * 32 + lg * 4;
+                Frag<T> fv;
+                frag_load44(fv, vp, vp + 16);
+                mma16(fv, fp, o[j]);
+            }
+        }
+        lrun += __shfl_xor(lrun, 16, 64);
+        lrun += __shfl_xor(lrun, 32, 64);
+        const float inv = 1.f / lrun;
+        if (q < L) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v4[4] = {o[j][0] * inv, o[j][1] * inv, o[j][2] * inv, o[j][3] * inv};
+                store4(out + ((long)f * L + q) * d + h * HD + j * 16 + lg * 4, v4);
+            }
+        }
+    }
+}
+
+// ---- one-query cross attention ---------------------------------------------------------
+// q [B, C], kv [B*S, 2C] (k = cols [0,C), v = cols [C,2C)), heads = C/64; one wave per (B, head)
+template <typename T>
+__global__ __launch_bounds__(64) void xattn1q_fwd(const T* __restrict__ q, const T* __restrict__ kv, T* __restrict__ o,
+                                                  float* __restrict__ probs, int S, int C) {
+    extern __shared__ float sp[];      // [S]
+    const int H = C / HD;
+    const int bi = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
+    const T* qp = q + (long)bi * C + h * HD;
+    const T* kvb = kv + (long)bi * S * 2 * C;
+    float mx = -1e30f;
+    for (int s = lane; s < S; s += 64) {
+        const T* kp = kvb + (long)s * 2 * C + h * HD;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int e = 0; e < HD; ++e) acc += to_f(qp[e]) * to_f(kp[e]);
+        acc *= 0.125f;
+        sp[s] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    mx = wave_max(mx, 64);
+    float sum = 0.f;
+    for (int s = lane; s < S; s += 64) { const float e = __expf(sp[s] - mx); sp[s] = e; sum += e; }
+    sum = wave_sum(sum, 64);
+    const float inv = 1.f / sum;
+    __syncthreads();
+    float* pr = probs + ((long)bi * H + h) * S;
+    for (int s = lane; s < S; s += 64) { const float pv = sp[s] * inv; sp[s] = pv; pr[s] = pv; }
+    __syncthreads();
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += sp[s] * to_f(kvb[(long)s * 2 * C + C + h * HD + lane]);
+    o[(long)bi * C + h * HD + lane] = from_f<T>(acc);
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void xattn1q_bwd(const T* __restrict__ q, const T* __restrict__ kv, const float* __restrict__ probs,
+                                                  const T* __restrict__ d_o, T* __restrict__ dq, T* __restrict__ dkv, int S, int C) {
+    extern __shared__ float sp[];      // [2][S]: p, ds
+    float* sds = sp + S;
+    const int H = C / HD;
+    const int bi = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
+    const T* kvb = kv + (long)bi * S * 2 * C;
+    T* dkvb = dkv + (long)bi * S * 2 * C;
+    const float* pr = probs + ((long)bi * H + h) * S;
+    const T* dop = d_o + (long)bi * C + h * HD;
+    float dot = 0.f;
+    for (int s = lane; s < S; s += 64) {
+        const T* vp = kvb + (long)s * 2 * C + C + h * HD;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int e = 0; e < HD; ++e) acc += to_f(dop[e]) * to_f(vp[e]);
+        const float pv = pr[s];
+        sp[s] = pv;
+        sds[s] = acc;              // dp
+        dot += pv * acc;
+    }
+    dot = wave_sum(dot, 64);
+    __syncthreads();
+    for (int s = lane; s < S; s += 64) sds[s] = sp[s] * (sds[s] - dot) * 0.125f;   // ds / sqrt(64)
+    __syncthreads();
+    const float qd = to_f(q[(long)bi * C + h * HD + lane]);
+    const float dod = to_f(dop[lane]);
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const long off = (long)s * 2 * C + h * HD + lane;
+        acc += sds[s] * to_f(kvb[off]);
+        dkvb[off] = from_f<T>(sds[s] * qd);
+        dkvb[off + C] = from_f<T>(sp[s] * dod);
+    }
+    dq[(long)bi * C + h * HD + lane] = from_f<T>(acc);
+}
+
+template <typename T>
+int launch_attn(const void* qkv, void* out, int frames, int L, int heads, hipStream_t s) {
+    const int Lp = (L + 31) / 32 * 32;
+    const size_t smem = ((size_t)Lp * (HD + KPAD) + (size_t)HD * (Lp + KPAD)) * sizeof(T);
+    if (smem > 160 * 1024) return DIST_ERR_ARG;
+    static size_t attr_smem = 0;
+    if (smem > attr_smem) {
+        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_smem = smem;
+    }
+    hipLaunchKernelGGL(attn_kernel<T>, dim3(frames * heads), dim3(NT), smem, s, static_cast<const T*>(qkv), static_cast<T*>(out), L, heads, Lp);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+
+}  // namespace
+
+extern "C" int dist_op_attention(const void* qkv, void* out, int frames, int L, int heads, int dtype, void* stream) {
+    if (!qkv || !out || frames <= 0 || L <= 0 || heads <= 0) return DIST_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == DIST_BF16 ? launch_attn<bf16_t>(qkv, out, frames, L, heads, s) : launch_attn<float>(qkv, out, frames, L, heads, s);
+}
+
+extern "C" int dist_op_xattn1q(const void* q, const void* kv, void* o, float* probs, int B, int S, int C, int dtype, void* stream) {
+    if (!q || !kv || !o || !probs || B <= 0 || S <= 0 || C % HD) return DIST_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int H = C / HD;
+    const size_t smem = (size_t)S * sizeof(float);
+    if (dtype == DIST_BF16)
+        hipLaunchKernelGGL(xattn1q_fwd<bf16_t>, dim3(B * H), dim3(64), smem, s, (const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)o, probs, S, C);
+    else
+        hipLaunchKernelGGL(xattn1q_fwd<float>, dim3(B * H), dim3(64), smem, s, (const float*)q, (const float*)kv, (float*)o, probs, S, C);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+
+extern "C" int dist_op_xattn1q_bwd(const void* q, const void* kv, const float* probs, const void* d_o,
+                                   void* dq, void* dkv, int B, int S, int C, int dtype, void* stream) {
+    if (!q || !kv || !probs || !d_o || !dq || !dkv || B <= 0 || S <= 0 || C % HD) return DIST_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int H = C / HD;
+    const size_t smem = (size_t)2 * S * sizeof(float);
+    if (dtype == DIST_BF16)
+        hipLaunchKernelGGL(xattn1q_bwd<bf16_t>, dim3(B * H), dim3(64), smem, s, (const bf16_t*)q, (const bf16_t*)kv, probs, (const bf16_t*)d_o,
+                           (bf16_t*)dq, (bf16_t*)dkv, S, C);
+    else
+        hipLaunchKernelGGL(xattn1q_bwd<float>, dim3(B * H), dim3(64), smem, s, (const float*)q, (const float*)kv, probs, (const float*)d_o,
+                           (float*)dq, (float*)dkv, S, C);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}

@@ -1,0 +1,231 @@
+// C[omap(m)][n] = epi( sum_tap sum_k A[amap(m,tap)][k] * B[n][tap*K + k] )
+//
+// One MFMA GEMM family for every Linear / Conv on the DiST hot path (both operands
+// K-contiguous: torch Linear weights are used as stored).  Convolutions are row-mapped
+// GEMMs: the A loader resolves (row, tap) -> source row (or the zero padding) on the fly,
+// so no im2col buffer ever exists in HBM.
+//
+// Tile: BM x BN x BK, 256 threads = 4 waves (64-wide), each wave owns a (BM/WM) x (BN/WN)
+// sub-tile as 16x16 MFMA fragments.  Global -> registers -> LDS double buffer, one barrier
+// per K tile.  LDS rows are padded by 8 elements (16 B bf16) so the 16 rows a 16-lane
+// ds_read_b128 group touches land on 16 distinct 16-B slots of the 256-B bank row.
+// The MFMA is issued "swapped" (B fragment as the A operand), so each lane ends up with
+// 4 CONSECUTIVE output columns of one output row: bias / residual / activation epilogues
+// and the stores are 4-wide vectors.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int PAD = 8;
+
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool GENERIC>
+__global__ __launch_bounds__(NT) void gemm_nt_kernel(const dist_gemm_args p) {
+    constexpr int LD = BK + PAD;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int FM = WTM / 16, FN = WTN / 16;
+    constexpr int KV = BK / 8;
+    constexpr int A_IT = (BM * KV + NT - 1) / NT, B_IT = (BN * KV + NT - 1) / NT;
+    static_assert(WM * WN == 4, "4 waves");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* As = reinterpret_cast<T*>(smem);                 // [2][BM][LD]
+    T* Bs = As + 2 * BM * LD;                           // [2][BN][LD]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int li = lane & 15, lg = lane >> 4;
+
+    // XCD-aware, bijective block remap: consecutive remapped ids share one XCD's L2, and the
+    // n-tile index runs fastest so the blocks that re-read one A row panel are neighbours.
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (int)((p.M + BM - 1) / BM);
+    const int nblk = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8, x = bid % 8, y = bid / 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int M = (int)p.M, N = p.N, K = p.K, taps = p.taps;
+
+    const T* __restrict__ A = static_cast<const T*>(p.A);
+    const T* __restrict__ B = static_cast<const T*>(p.B);
+
+    const int ktp = (K + BK - 1) / BK;          // K tiles per tap
+    const int total = ktp * taps;
+
+    Frag<T> ra[A_IT], rb[B_IT];
+
+    auto gload = [&](int tt) {
+        const int tap = tt / ktp, k0 = (tt - tap * ktp) * BK;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int v = tid + i * NT;
+            frag_zero(ra[i]);
+            if (v < BM * KV) {
+                const int row = v / KV, kk = k0 + (v % KV) * 8;
+                const int m = m0 + row;
+                if (m < M && kk < K) {
+                    const int src = GENERIC ? rowmap_src(p.amap, m, tap, taps) : m;
+                    if (src >= 0) frag_load(ra[i], A + (long)src * p.lda + kk);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int v = tid + i * NT;
+            frag_zero(rb[i]);
+            if (v < BN * KV) {
+                const int row = v / KV, kk = k0 + (v % KV) * 8;
+                const int n = n0 + row;
+                if (n < N && kk < K) frag_load(rb[i], B + (long)n * p.ldb + (long)tap * K + kk);
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int v = tid + i * NT;
+            if (v < BM * KV) frag_store(ra[i], As + (buf * BM + v / KV) * LD + (v % KV) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int v = tid + i * NT;
+            if (v < BN * KV) frag_store(rb[i], Bs + (buf * BN + v / KV) * LD + (v % KV) * 8);
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int tt = 0; tt < total; ++tt) {
+        if (tt + 1 < total) gload(tt + 1);
+        const T* as = As + (cur * BM + wm * WTM + li) * LD + lg * 8;
+        const T* bs = Bs + (cur * BN + wn * WTN + li) * LD + lg * 8;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            Frag<T> fa[FM], fb[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) frag_load(fa[i], as + i * 16 * LD + kk * 32);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) frag_load(fb[j], bs + j * 16 * LD + kk * 32);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) mma16(fb[j], fa[i], acc[i][j]);   // swapped: D[n][m]
+        }
+        if (tt + 1 < total) sstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: lane holds, per fragment, row m = ..+li and columns n = ..+4*lg+{0..3}
+    T* __restrict__ C = static_cast<T*>(p.C);
+    T* __restrict__ C2 = static_cast<T*>(p.C2);
+    const T* __restrict__ R = static_cast<const T*>(p.res);
+    const T* __restrict__ X = static_cast<const T*>(p.aux);
+    const int flags = p.flags;
+
+    auto emit = [&](long dest, int ncol, int n, const f32x4& a) {
+        float v[4] = {a[0], a[1], a[2], a[3]};
+        if (flags & DIST_EPI_BIAS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += p.bias[n + r];
+        }
+        if (flags & DIST_EPI_MULG) {
+            float x[4];
+            load4(X + dest * p.ldaux + ncol, x);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= qgelu_grad(x[r]);
+        }
+        if (flags & DIST_EPI_RES) {
+            float x[4];
+            load4(R + dest * p.ldres + ncol, x);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += x[r];
+        }
+        if (C) {
+            store4(C + dest * p.ldc + ncol, v);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = to_f(from_f<T>(v[r]));      // activation sees the stored value
+        }
+        if (flags & DIST_EPI_ACT2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = qgelu(v[r]);
+            store4(C2 + dest * p.ldc2 + ncol, v);
+        }
+    };
+
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + li;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * WTN + j * 16 + lg * 4;
+            if (n >= N) continue;
+            if (!GENERIC || p.omap.mode == DIST_OM_PLAIN) {
+                emit(m, n, n, acc[i][j]);
+            } else if (p.omap.mode == DIST_OM_INSERTCLS) {
+                const int bj = m / p.omap.p0, nn = m % p.omap.p0;
+                emit((long)bj * (p.omap.p0 + 1) + 1 + nn, n, n, acc[i][j]);
+            } else if (p.omap.mode == DIST_OM_DUP) {
+                const int bj = m / p.omap.p1, nn = m % p.omap.p1;
+                for (int a = 0; a < p.omap.p0; ++a) emit(((long)bj * p.omap.p0 + a) * p.omap.p1 + nn, n, n, acc[i][j]);
+            } else {   // DIST_OM_SPLITCOLS
+                const int bj = m / p.omap.p1, nn = m % p.omap.p1;
+                const int a = n / p.omap.p2;
+                emit(((long)bj * p.omap.p0 + a) * p.omap.p1 + nn, n - a * p.omap.p2, n, acc[i][j]);
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool GENERIC>
+int launch(const dist_gemm_args& a, hipStream_t s) {
+    constexpr size_t smem = (size_t)2 * (BM + BN) * (BK + PAD) * sizeof(T);
+    static bool attr_done = false;
+    auto kern = gemm_nt_kernel<T, BM, BN, BK, WM, WN, GENERIC>;
+    if (!attr_done) {
+        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_done = true;
+    }
+    const long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NT), smem, s, a);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+
+template <typename T>
+int dispatch(const dist_gemm_args& a, hipStream_t s) {
+    const bool plain = a.amap.mode == DIST_RM_PLAIN && a.omap.mode == DIST_OM_PLAIN && a.taps == 1;
+    const bool n96 = (a.N % 96 == 0) && (a.N % 128 != 0);
+    if (n96) return launch<T, 128, 96, 32, 4, 1, true>(a, s);
+    if (plain && a.K % 64 == 0) return launch<T, 128, 128, 64, 2, 2, false>(a, s);
+    return launch<T, 128, 128, 32, 2, 2, true>(a, s);
+}
+
+}  // namespace
+
+extern "C" int dist_op_gemm_nt(const dist_gemm_args* a, void* stream) {
+    if (!a || !a->A || !a->B || a->M <= 0 || a->N <= 0 || a->K <= 0 || a->taps <= 0) return DIST_ERR_ARG;
+    if (a->K % 8 || a->N % 4 || a->lda % 8 || a->ldb % 8) return DIST_ERR_ARG;
+    if (a->M > (1 << 30)) return DIST_ERR_ARG;
+    if (!a->C && !(a->flags & DIST_EPI_ACT2)) return DIST_ERR_ARG;
+    if ((a->flags & DIST_EPI_ACT2) && !a->C2) return DIST_ERR_ARG;
+    if ((a->flags & DIST_EPI_BIAS) && !a->bias) return DIST_ERR_ARG;
+    if ((a->flags & DIST_EPI_RES) && !a->res) return DIST_ERR_ARG;
+    if ((a->flags & DIST_EPI_MULG) && !a->aux) return DIST_ERR_ARG;
+    if (a->omap.mode == DIST_OM_SPLITCOLS && (a->omap.p2 % 4 || a->N != a->omap.p0 * a->omap.p2)) return DIST_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return a->dtype == DIST_BF16 ? dispatch<bf16_t>(*a, s) : dispatch<float>(*a, s);
+}

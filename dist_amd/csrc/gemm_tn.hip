@@ -1,0 +1,217 @@
+// out[i][tap, c] += sum_m A[amap(m)][i] * B[bmap(m, tap)][c]       (weight gradients)
+//
+// Both operands are reduced over their ROW index, i.e. both MFMA fragments need 8 values
+// that are strided in memory.  Tiles of 32 rows are staged row-major in LDS (coalesced
+// 16-B global loads) and the fragments are gathered with gfx950's LDS transpose read
+// (ds_read_b64_tr_b16: a 16-lane group reads a 4x16 bf16 block and every lane receives one
+// COLUMN of it), two reads per fragment with k-slot (g,e) <-> row 4g+e / 16+4g+(e-4).
+// fp32 (parity mode) gathers with scalar ds_read_b32; `use_tr = 0` keeps a scalar
+// ds_read_u16 gather for bf16 as the cross-check of the transpose-read path.
+//
+// The output is tiny (e.g. 96 x 288) and the reduction long (50k-100k rows), so the row
+// range is split across blocks and partial tiles are combined with fp32 atomics
+// (hardware global_atomic_add_f32, compiled with -munsafe-fp-atomics) straight into the
+// flat gradient buffer, in the reference's parameter layout (so_* strides).
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int PADT = 8;
+constexpr int BR = 32;   // rows (reduction) per step
+
+template <typename T, bool TR>
+DEV void gather_frag(Frag<T>& f, const T* tile, int ld, int col0, int li, int lg);
+
+template <>
+DEV void gather_frag<float, false>(Frag<float>& f, const float* tile, int ld, int col0, int li, int lg) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int r = (e < 4) ? 4 * lg + e : 16 + 4 * lg + (e - 4);
+        f.v[e] = tile[r * ld + col0 + li];
+    }
+}
+template <>
+DEV void gather_frag<float, true>(Frag<float>& f, const float* tile, int ld, int col0, int li, int lg) {
+    gather_frag<float, false>(f, tile, ld, col0, li, lg);
+}
+template <>
+DEV void gather_frag<bf16_t, false>(Frag<bf16_t>& f, const bf16_t* tile, int ld, int col0, int li, int lg) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int r = (e < 4) ? 4 * lg + e : 16 + 4 * lg + (e - 4);
+        f.v[e] = tile[r * ld + col0 + li];
+    }
+}
+template <>
+DEV void gather_frag<bf16_t, true>(Frag<bf16_t>& f, const bf16_t* tile, int ld, int col0, int li, int lg) {
+    // lane li of the 16-lane group supplies the address of 4 contiguous bf16 of block row li>>2;
+    // it receives column li of the 4x16 block (rows 4g..4g+3, then 16+4g..16+4g+3).
+    typedef s16x4 __attribute__((address_space(3))) * lds_v4;
+    const bf16_t* p0 = tile + (4 * lg + (li >> 2)) * ld + col0 + (li & 3) * 4;
+    const bf16_t* p1 = p0 + 16 * ld;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p0));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p1));
+    union { s16x4 s[2]; bf16x8 v; } u;
+    u.s[0] = a; u.s[1] = b;
+    f.v = u.v;
+}
+
+template <typename T, int BI, int BJ, int WI, int WJ, bool TR>
+__global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, int chunk, int tiles_i, int tiles_c) {
+    constexpr int LDI = BI + PADT, LDJ = BJ + PADT;
+    constexpr int WTI = BI / WI, WTJ = BJ / WJ;
+    constexpr int FI = WTI / 16, FJ = WTJ / 16;
+    constexpr int VI = BI / 8, VJ = BJ / 8;
+    constexpr int I_IT = (BR * VI + NT - 1) / NT, J_IT = (BR * VJ + NT - 1) / NT;
+    static_assert(WI * WJ == 4, "4 waves");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Ys = reinterpret_cast<T*>(smem);          // [2][BR][LDI]
+    T* Xs = Ys + 2 * BR * LDI;                   // [2][BR][LDJ]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wi = wid / WJ, wj = wid % WJ;
+    const int li = lane & 15, lg = lane >> 4;
+
+    const int tiles_ij = tiles_i * tiles_c * p.taps;
+    const int ms = blockIdx.x / tiles_ij;
+    int t = blockIdx.x % tiles_ij;
+    const int ti = t % tiles_i; t /= tiles_i;
+    const int tc = t % tiles_c; const int tap = t / tiles_c;
+    const int i0 = ti * BI, c0 = tc * BJ;
+    const int M = (int)p.M;
+    const int mbeg = ms * chunk, mend = min(M, mbeg + chunk);
+    if (mbeg >= mend) return;
+
+    const T* __restrict__ A = static_cast<const T*>(p.A);
+    const T* __restrict__ B = static_cast<const T*>(p.B);
+
+    Frag<T> ra[I_IT], rb[J_IT];
+    auto gload = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < I_IT; ++i) {
+            const int v = tid + i * NT;
+            frag_zero(ra[i]);
+            if (v < BR * VI) {
+                const int m = mb + v / VI, col = i0 + (v % VI) * 8;
+                if (m < mend && col < p.NI) {
+                    const int src = rowmap_src(p.amap, m, 0, 1);
+                    if (src >= 0) frag_load(ra[i], A + (long)src * p.lda + col);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < J_IT; ++i) {
+            const int v = tid + i * NT;
+            frag_zero(rb[i]);
+            if (v < BR * VJ) {
+                const int m = mb + v / VJ, col = c0 + (v % VJ) * 8;
+                if (m < mend && col < p.K) {
+                    const int src = rowmap_src(p.bmap, m, tap, p.taps);
+                    if (src >= 0) frag_load(rb[i], B + (long)src * p.ldb + col);
+                }
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < I_IT; ++i) {
+            const int v = tid + i * NT;
+            if (v < BR * VI) frag_store(ra[i], Ys + (buf * BR + v / VI) * LDI + (v % VI) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < J_IT; ++i) {
+            const int v = tid + i * NT;
+            if (v < BR * VJ) frag_store(rb[i], Xs + (buf * BR + v / VJ) * LDJ + (v % VJ) * 8);
+        }
+    };
+
+    f32x4 acc[FI][FJ];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    gload(mbeg);
+    sstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int mb = mbeg; mb < mend; mb += BR) {
+        if (mb + BR < mend) gload(mb + BR);
+        const T* ys = Ys + cur * BR * LDI;
+        const T* xs = Xs + cur * BR * LDJ;
+        Frag<T> fa[FI], fb[FJ];
+#pragma unroll
+        for (int i = 0; i < FI; ++i) gather_frag<T, TR>(fa[i], ys, LDI, wi * WTI + i * 16, li, lg);
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) gather_frag<T, TR>(fb[j], xs, LDJ, wj * WTJ + j * 16, li, lg);
+#pragma unroll
+        for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) mma16(fa[i], fb[j], acc[i][j]);     // D[i][c]: row = 4*lg + r, col = li
+        if (mb + BR < mend) sstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) {
+        const int c = c0 + wj * WTJ + j * 16 + li;
+        if (c >= p.K) continue;
+        const long jo = (long)tap * p.so_tap + (long)(c / p.inner) * p.so_outer + (c % p.inner);
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ii = i0 + wi * WTI + i * 16 + lg * 4 + r;
+                if (ii < p.NI) atomicAdd(p.out + (long)ii * p.so_i + jo, acc[i][j][r]);
+            }
+        }
+    }
+}
+
+template <typename T, int BI, int BJ, int WI, int WJ, bool TR>
+int launch(const dist_gemm_tn_args& a, hipStream_t s) {
+    constexpr size_t smem = (size_t)2 * BR * (BI + BJ + 2 * PADT) * sizeof(T);
+    static bool attr_done = false;
+    auto kern = gemm_tn_kernel<T, BI, BJ, WI, WJ, TR>;
+    if (!attr_done) {
+        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_done = true;
+    }
+    const int tiles_i = (a.NI + BI - 1) / BI, tiles_c = (a.K + BJ - 1) / BJ;
+    const long tiles = (long)tiles_i * tiles_c * a.taps;
+    // split the reduction so that ~1024 blocks are in flight, at least 256 rows per block
+    long msplit = (1024 + tiles - 1) / tiles;
+    const long max_split = (a.M + 255) / 256;
+    if (msplit > max_split) msplit = max_split;
+    if (msplit < 1) msplit = 1;
+    int chunk = (int)((a.M + msplit - 1) / msplit);
+    chunk = (chunk + BR - 1) / BR * BR;
+    msplit = (a.M + chunk - 1) / chunk;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * msplit)), dim3(NT), smem, s, a, chunk, tiles_i, tiles_c);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+
+template <typename T, bool TR>
+int dispatch(const dist_gemm_tn_args& a, hipStream_t s) {
+    const bool i96 = (a.NI % 96 == 0) && (a.NI % 128 != 0);
+    const bool j96 = (a.K % 96 == 0) && (a.K % 128 != 0);
+    if (i96 && j96) return launch<T, 96, 96, 2, 2, TR>(a, s);
+    if (i96) return launch<T, 96, 128, 2, 2, TR>(a, s);
+    if (j96) return launch<T, 128, 96, 2, 2, TR>(a, s);
+    return launch<T, 128, 128, 2, 2, TR>(a, s);
+}
+
+}  // namespace
+
+extern "C" int dist_op_gemm_tn(const dist_gemm_tn_args* a, void* stream) {
+    if (!a || !a->A || !a->B || !a->out || a->M <= 0 || a->NI <= 0 || a->K <= 0 || a->taps <= 0) return DIST_ERR_ARG;
+    if (a->NI % 8 || a->lda % 8 || a->ldb % 8 || a->inner <= 0 || (a->K + 7) / 8 * 8 > a->ldb) return DIST_ERR_ARG;
+    if (a->M > (1 << 30)) return DIST_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a->dtype == DIST_BF16) return a->use_tr ? dispatch<bf16_t, true>(*a, s) : dispatch<bf16_t, false>(*a, s);
+    return dispatch<float, false>(*a, s);
+}

@@ -1,0 +1,30 @@
+// Engine-internal kernel launchers (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/dist_amd.h"
+
+// weight packing: master fp32 tensors (reference layouts) -> GEMM-ready working copies
+enum { PACK_F = 0, PACK_B = 1, PACK_FT = 2 };
+constexpr int PACK_PER_BLOCK = 8192;
+struct PackDesc {
+    long src_off;        // elements into theta (src_kind 0) or visual (src_kind 1)
+    long dst_off;        // elements into the packed buffer (after its header)
+    int src_kind;
+    int layout;          // PACK_F: [co][tap*kpad + ci] | PACK_B: [ci][tap*co_n + co] | PACK_FT: [tap*kpad + ci][co]
+    int rows, cols;      // destination shape
+    int co, kin, kpad;   // number of outputs, inputs per tap, padded inputs per tap
+    int inner;           // source index = co*s_co + tap*s_tap + (ci/inner)*s_outer + ci%inner
+    long s_co, s_tap, s_outer;
+};
+
+int dist_k_pack(const PackDesc* descs_dev, const int* blk_desc_dev, const int* blk_first_dev, int nblocks,
+                const float* theta, const float* visual, void* dst_base, int dtype, hipStream_t s);
+int dist_k_cls_rows(void* dst, const void* src, const float* table, int nbj, int L, int C, int period, int dtype, hipStream_t s);
+int dist_k_cls_rows_bwd(const void* d, float* dtable, int nbj, int L, int C, int period, int dtype, hipStream_t s);
+int dist_k_add_table(const void* x, const float* table, void* out, long rows, int C, int period, int dtype, hipStream_t s);
+int dist_k_pair_sum(const void* x, void* out, long nbj, int rowlen, int alpha, int dtype, hipStream_t s);
+int dist_k_mean_cls(const void* feat, void* out, int b, int t, int L, int C, int dtype, hipStream_t s);
+int dist_k_bcast_rows(const float* table, void* out, long rows, int C, int dtype, hipStream_t s);
+int dist_k_logits_loss(const void* v, const float* text, const float* logit_scale, const float* soft_target,
+                       float* logits, float* vid_norm, float* loss, void* dv, float* dlogit_scale,
+                       const float* dlogits_in, float* dlogits_out, int b, int E, int K, int dtype, void* stream);

@@ -1,0 +1,438 @@
+// Small HBM-/latency-bound kernels of the DiST hot path: patch gather, elementwise ops,
+// column sums (bias gradients), token-row helpers, cosine-logits + soft-target CE
+// (forward and backward), fused multi-tensor AdamW, weight packing.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+inline int grid1d(long n, int per_block, int cap = 4096) {
+    long g = (n + per_block - 1) / per_block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---- patchify: [b,3,T,H,W] fp32 -> rows (b,k,n) x cols (c,py,px), zero padded to Kp ----
+template <typename T>
+__global__ __launch_bounds__(NT) void patchify_kernel(const float* __restrict__ video, T* __restrict__ out,
+                                                      int b, int Tn, int H, int W, int P, int Kp) {
+    const int G = W / P, Gy = H / P, N = G * Gy, PP = P * P;
+    const long total = (long)b * Tn * N * Kp;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int col = (int)(i % Kp);
+        const long row = i / Kp;
+        float v = 0.f;
+        if (col < 3 * PP) {
+            const int c = col / PP, py = (col % PP) / P, px = col % P;
+            const int n = (int)(row % N);
+            const long bk = row / N;
+            const int k = (int)(bk % Tn), bi = (int)(bk / Tn);
+            const int y = (n / G) * P + py, x = (n % G) * P + px;
+            v = video[(((long)bi * 3 + c) * Tn + k) * H * W + (long)y * W + x];
+        }
+        out[i] = from_f<T>(v);
+    }
+}
+
+// ---- elementwise --------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NT) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long nvec) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < nvec; i += (long)gridDim.x * NT) {
+        Frag<T> x, y;
+        frag_load(x, a + i * 8); frag_load(y, b + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) frag_set(x, e, frag_get(x, e) + frag_get(y, e));
+        frag_store(x, o + i * 8);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ pre, T* __restrict__ dx, long nvec) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < nvec; i += (long)gridDim.x * NT) {
+        Frag<T> x, y;
+        frag_load(x, dy + i * 8); frag_load(y, pre + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) frag_set(x, e, frag_get(x, e) * qgelu_grad(frag_get(y, e)));
+        frag_store(x, dx + i * 8);
+    }
+}
+
+// ---- column sums (bias gradients): out[c] += sum_rows x[map(row)][c] ------------------------
+template <typename T>
+__global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long rows, int C, int ld,
+                                                    dist_rowmap map, int rows_per_block) {
+    __shared__ float red[1024];
+    const int tid = threadIdx.x;
+    const int cg = C / 4;                         // column groups of 4
+    const int nslot = NT / cg > 0 ? NT / cg : 1;
+    for (int i = tid; i < C; i += NT) red[i] = 0.f;
+    __syncthreads();
+    const int slot = tid / cg, c4 = (tid % cg) * 4;
+    if (slot < nslot) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const long r0 = (long)blockIdx.x * rows_per_block;
+        const long r1 = min(rows, r0 + rows_per_block);
+        for (long r = r0 + slot; r < r1; r += nslot) {
+            const int src = rowmap_src(map, (int)r, 0, 1);
+            float v[4];
+            load4(x + (long)src * ld + c4, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(&red[c4 + e], acc[e]);
+    }
+    __syncthreads();
+    for (int i = tid; i < C; i += NT) atomicAdd(out + i, red[i]);
+}
+
+// ---- token-row helpers -----------------------------------------------------------------------
+// dst[(bj)*L + 0][:] = (src ? src[(bj)*L][:] : 0) + table[(bj % period)][:]     (fp32 table)
+template <typename T>
+__global__ __launch_bounds__(NT) void cls_rows_kernel(T* __restrict__ dst, const T* __restrict__ src, const float* __restrict__ table,
+                                                      int nbj, int L, int C, int period) {
+    const long total = (long)nbj * C;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        const long bj = i / C;
+        const float s = src ? to_f(src[bj * L * C + c]) : 0.f;
+        dst[bj * L * C + c] = from_f<T>(s + table[(bj % period) * C + c]);
+    }
+}
+// dtable[(bj % period)][c] += sum over bj of d[(bj)*L][c]
+template <typename T>
+__global__ __launch_bounds__(NT) void cls_rows_bwd_kernel(const T* __restrict__ d, float* __restrict__ dtable, int nbj, int L, int C, int period) {
+    const long total = (long)period * C;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        const int j = (int)(i / C);
+        float acc = 0.f;
+        for (long bj = j; bj < nbj; bj += period) acc += to_f(d[bj * L * C + c]);
+        atomicAdd(dtable + i, acc);
+    }
+}
+// out[(b, j)][c] = x[(b,j)][c] + table[j][c]
+template <typename T>
+__global__ __launch_bounds__(NT) void add_table_kernel(const T* __restrict__ x, const float* __restrict__ table, T* __restrict__ out,
+                                                       long rows, int C, int period) {
+    const long total = rows * C;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        const long r = i / C;
+        out[i] = from_f<T>(to_f(x[i]) + table[(r % period) * C + c]);
+    }
+}
+// out[(bj, n)][c] = sum_a x[((bj*alpha + a), n)][c]          (backward of nearest upsample x alpha in T)
+template <typename T>
+__global__ __launch_bounds__(NT) void pair_sum_kernel(const T* __restrict__ x, T* __restrict__ out, long nbj, int rowlen, int alpha) {
+    const long total = nbj * rowlen / 8;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long bj = (i * 8) / rowlen, off = (i * 8) % rowlen;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int a = 0; a < alpha; ++a) {
+            Frag<T> f;
+            frag_load(f, x + (bj * alpha + a) * rowlen + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += frag_get(f, e);
+        }
+        Frag<T> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) frag_set(o, e, acc[e]);
+        frag_store(o, out + bj * rowlen + off);
+    }
+}
+// out[b][c] = mean_j feat[(b*t + j)*L + 0][c]
+template <typename T>
+__global__ __launch_bounds__(NT) void mean_cls_kernel(const T* __restrict__ feat, T* __restrict__ out, int b, int t, int L, int C) {
+    const long total = (long)b * C;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        const long bi = i / C;
+        float acc = 0.f;
+        for (int j = 0; j < t; ++j) acc += to_f(feat[((bi * t + j) * (long)L) * C + c]);
+        out[i] = from_f<T>(acc / (float)t);
+    }
+}
+// broadcast rows: out[r][c] = table[c]  (fp32 param -> T rows)
+template <typename T>
+__global__ __launch_bounds__(NT) void bcast_rows_kernel(const float* __restrict__ table, T* __restrict__ out, long rows, int C) {
+    const long total = rows * C;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) out[i] = from_f<T>(table[i % C]);
+}
+// dtable[c] += sum_rows d[r][c]  -> use colsum
+
+// ---- cosine logits + soft-target CE, forward and backward -------------------------------------
+// one block per clip.  v [E] -> vn = v/|v|; logits[k] = exp(ls) * vn . (text_k/|text_k|)
+// loss += -sum_k y_k log_softmax(logits)_k / b ; dlogits = (softmax * sum(y) - y)/b (or given)
+// dv = (dvn - vn (vn.dvn)) / |v| with dvn = exp(ls) * sum_k dlogits_k tn_k ; dls += sum_k dlogits_k logits_k
+template <typename T>
+__global__ __launch_bounds__(NT) void logits_loss_kernel(const T* __restrict__ v, const float* __restrict__ text, const float* __restrict__ logit_scale,
+                                                         const float* __restrict__ soft_target, float* __restrict__ logits, float* __restrict__ vid_norm,
+                                                         float* __restrict__ loss, T* __restrict__ dv, float* __restrict__ dlogit_scale,
+                                                         const float* __restrict__ dlogits_in, float* __restrict__ dlogits_out,
+                                                         int b, int E, int K) {
+    extern __shared__ float sm[];     // vn[E], lg[K], dl[K], red[NT]
+    float* vn = sm; float* lg = vn + E; float* dl = lg + K; float* red = dl + K;
+    const int bi = blockIdx.x, tid = threadIdx.x;
+    auto block_sum = [&](float x) {
+        red[tid] = x; __syncthreads();
+        for (int o = NT / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+        const float r = red[0]; __syncthreads();
+        return r;
+    };
+    auto block_max = [&](float x) {
+        red[tid] = x; __syncthreads();
+        for (int o = NT / 2; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+        const float r = red[0]; __syncthreads();
+        return r;
+    };
+    float ss = 0.f;
+    for (int e = tid; e < E; e += NT) { const float x = to_f(v[(long)bi * E + e]); vn[e] = x; ss += x * x; }
+    const float nrm = sqrtf(block_sum(ss));
+    const float inv = 1.f / nrm;
+    for (int e = tid; e < E; e += NT) { vn[e] *= inv; if (vid_norm) vid_norm[(long)bi * E + e] = vn[e]; }
+    __syncthreads();
+    const float sc = __expf(logit_scale[0]);
+    for (int k = tid; k < K; k += NT) {
+        const float* tk = text + (long)k * E;
+        float dot = 0.f, tt = 0.f;
+        for (int e = 0; e < E; ++e) { dot += vn[e] * tk[e]; tt += tk[e] * tk[e]; }
+        const float l = sc * dot * rsqrtf(tt);
+        lg[k] = l;
+        if (logits) logits[(long)bi * K + k] = l;
+    }
+    __syncthreads();
+    if (!dv && !soft_target) return;
+    if (dlogits_in) {
+        for (int k = tid; k < K; k += NT) dl[k] = dlogits_in[(long)bi * K + k];
+    } else {
+        float mx = -1e30f;
+        for (int k = tid; k < K; k += NT) mx = fmaxf(mx, lg[k]);
+        mx = block_max(mx);
+        float se = 0.f, sy = 0.f, syl = 0.f;
+        for (int k = tid; k < K; k += NT) {
+            const float y = soft_target[(long)bi * K + k];
+            se += __expf(lg[k] - mx); sy += y; syl += y * lg[k];
+        }
+        se = block_sum(se); sy = block_sum(sy); syl = block_sum(syl);
+        const float lse = mx + logf(se);
+        if (tid == 0 && loss) atomicAdd(loss, (sy * lse - syl) / (float)b);
+        for (int k = tid; k < K; k += NT) {
+            const float y = soft_target[(long)bi * K + k];
+            dl[k] = (__expf(lg[k] - lse) * sy - y) / (float)b;
+            if (dlogits_out) dlogits_out[(long)bi * K + k] = dl[k];
+        }
+    }
+    if (!dv) return;
+    __syncthreads();
+    float dls = 0.f;
+    for (int k = tid; k < K; k += NT) dls += dl[k] * lg[k];
+    dls = block_sum(dls);
+    if (tid == 0 && dlogit_scale) atomicAdd(dlogit_scale, dls);
+    // dvn[e] = sc * sum_k dl[k] * tn[k][e]; needs |text_k| again: fold 1/|t_k| into dl
+    for (int k = tid; k < K; k += NT) {
+        const float* tk = text + (long)k * E;
+        float tt = 0.f;
+        for (int e = 0; e < E; ++e) tt += tk[e] * tk[e];
+        dl[k] *= sc * rsqrtf(tt);
+    }
+    __syncthreads();
+    float proj = 0.f;
+    float dvn_loc[4];            // E <= 4*NT
+    int cnt = 0;
+    for (int e = tid; e < E; e += NT, ++cnt) {
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc += dl[k] * text[(long)k * E + e];
+        dvn_loc[cnt] = acc;
+        proj += acc * vn[e];
+    }
+    proj = block_sum(proj);
+    cnt = 0;
+    for (int e = tid; e < E; e += NT, ++cnt) dv[(long)bi * E + e] = from_f<T>((dvn_loc[cnt] - vn[e] * proj) * inv);
+}
+
+// ---- fused multi-tensor AdamW (torch.optim.AdamW single-tensor math) ---------------------------
+__global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   const dist_adamw_seg* __restrict__ segs, int nseg, long n,
+                                                   float b1, float b2, float eps, float bc1, float bc2s, float gscale) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        int lo = 0, hi = nseg - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (segs[mid].end <= i) lo = mid + 1; else hi = mid; }
+        const dist_adamw_seg sg = segs[lo];
+        if (i < sg.begin || i >= sg.end) continue;
+        const float gr = g[i] * gscale;
+        float pp = p[i] * (1.f - sg.lr * sg.weight_decay);
+        const float mm = b1 * m[i] + (1.f - b1) * gr;
+        const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
+        const float denom = sqrtf(vv) / bc2s + eps;
+        pp -= (sg.lr / bc1) * mm / denom;
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+// ---- weight packing -------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NT) void pack_kernel(const PackDesc* __restrict__ descs, const int* __restrict__ blk_desc, const int* __restrict__ blk_first,
+                                                  const float* __restrict__ src0, const float* __restrict__ src1, T* __restrict__ dst_base) {
+    const int di = blk_desc[blockIdx.x];
+    const PackDesc d = descs[di];
+    const float* src = (d.src_kind ? src1 : src0) + d.src_off;
+    T* dst = dst_base + d.dst_off;
+    const long total = (long)d.rows * d.cols;
+    const long beg = (long)(blockIdx.x - blk_first[di]) * PACK_PER_BLOCK;
+    const long end = min(total, beg + PACK_PER_BLOCK);
+    for (long i = beg + threadIdx.x; i < end; i += NT) {
+        const int r = (int)(i / d.cols), c = (int)(i % d.cols);
+        int co, tap, ci;
+        if (d.layout == PACK_F) { co = r; tap = c / d.kpad; ci = c % d.kpad; }
+        else if (d.layout == PACK_B) { ci = r; tap = c / d.co; co = c % d.co; }
+        else { tap = r / d.kpad; ci = r % d.kpad; co = c; }      // PACK_FT
+        float v = 0.f;
+        if (ci < d.kin) v = src[(long)co * d.s_co + (long)tap * d.s_tap + (long)(ci / d.inner) * d.s_outer + (ci % d.inner)];
+        dst[i] = from_f<T>(v);
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" int dist_op_patchify(const float* video, void* patches, int b, int T, int H, int W, int P, int dtype, void* stream) {
+    if (!video || !patches || b <= 0 || T <= 0 || H % P || W % P) return DIST_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Kp = (3 * P * P + 7) / 8 * 8;
+    const long total = (long)b * T * (H / P) * (W / P) * Kp;
+    if (dtype == DIST_BF16) hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid1d(total, NT * 8)), dim3(NT), 0, s, video, (bf16_t*)patches, b, T, H, W, P, Kp);
+    else hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid1d(total, NT * 8)), dim3(NT), 0, s, video, (float*)patches, b, T, H, W, P, Kp);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+
+extern "C" int dist_op_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream) {
+    if (!a || !b || !out || n <= 0 || n % 8) return DIST_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == DIST_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(grid1d(n / 8, NT)), dim3(NT), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, (long)(n / 8));
+    else hipLaunchKernelGGL(add_kernel<float>, dim3(grid1d(n / 8, NT)), dim3(NT), 0, s, (const float*)a, (const float*)b, (float*)out, (long)(n / 8));
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+
+extern "C" int dist_op_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int dtype, void* stream) {
+    if (!dy || !pre || !dx || n <= 0 || n % 8) return DIST_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == DIST_BF16) hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, dim3(grid1d(n / 8, NT)), dim3(NT), 0, s, (const bf16_t*)dy, (const bf16_t*)pre, (bf16_t*)dx, (long)(n / 8));
+    else hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(grid1d(n / 8, NT)), dim3(NT), 0, s, (const float*)dy, (const float*)pre, (float*)dx, (long)(n / 8));
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+
+extern "C" int dist_op_colsum(const void* x, float* out, int64_t rows, int C, int ld, dist_rowmap map, int dtype, void* stream) {
+    if (!x || !out || rows <= 0 || C % 4 || C > 1024 || ld % 4) return DIST_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rpb = 512;
+    long grid = (rows + rpb - 1) / rpb;
+    if (grid > 1024) { rpb = (int)((rows + 1023) / 1024); grid = (rows + rpb - 1) / rpb; }
+    if (dtype == DIST_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((unsigned)grid), dim3(NT), 0, s, (const bf16_t*)x, out, (long)rows, C, ld, map, rpb);
+    else hipLaunchKernelGGL(colsum_kernel<float>, dim3((unsigned)grid), dim3(NT), 0, s, (const float*)x, out, (long)rows, C, ld, map, rpb);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+
+extern "C" int dist_op_logits_loss(const void* v, const float* text, const float* logit_scale, const float* soft_target,
+                                   float* logits, float* vid_norm, float* loss, void* dv, float* dlogit_scale,
+                                   const float* dlogits_in, int b, int E, int K, int dtype, void* stream) {
+    return dist_k_logits_loss(v, text, logit_scale, soft_target, logits, vid_norm, loss, dv, dlogit_scale, dlogits_in, nullptr, b, E, K, dtype, stream);
+}
+
+int dist_k_logits_loss(const void* v, const float* text, const float* logit_scale, const float* soft_target,
+                       float* logits, float* vid_norm, float* loss, void* dv, float* dlogit_scale,
+                       const float* dlogits_in, float* dlogits_out, int b, int E, int K, int dtype, void* stream) {
+    if (!v || !text || !logit_scale || b <= 0 || E <= 0 || K <= 0 || E > 4 * NT) return DIST_ERR_ARG;
+    if (dv && !dlogits_in && !soft_target) return DIST_ERR_ARG;
+    if (dlogits_in && soft_target) return DIST_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t smem = (size_t)(E + 2 * K + NT) * sizeof(float);
+    if (dtype == DIST_BF16)
+        hipLaunchKernelGGL(logits_loss_kernel<bf16_t>, dim3(b), dim3(NT), smem, s, (const bf16_t*)v, text, logit_scale, soft_target, logits, vid_norm,
+                           loss, (bf16_t*)dv, dlogit_scale, dlogits_in, dlogits_out, b, E, K);
+    else
+        hipLaunchKernelGGL(logits_loss_kernel<float>, dim3(b), dim3(NT), smem, s, (const float*)v, text, logit_scale, soft_target, logits, vid_norm,
+                           loss, (float*)dv, dlogit_scale, dlogits_in, dlogits_out, b, E, K);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+
+extern "C" int dist_op_adamw(float* param, const float* grad, float* m, float* v, const dist_adamw_seg* segs_dev, int nseg,
+                             int64_t n, float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
+    if (!param || !grad || !m || !v || !segs_dev || nseg <= 0 || n <= 0 || step <= 0) return DIST_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid1d(n, NT * 4)), dim3(NT), 0, s, param, grad, m, v, segs_dev, nseg, (long)n, beta1, beta2, eps, bc1, bc2s, grad_scale);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+
+// ---- engine-internal launchers (kernels.h) ------------------------------------------------------------
+namespace {
+template <typename F> int with_type(int dtype, F&& f) { return dtype == DIST_BF16 ? f(bf16_t{}) : f(float{}); }
+}
+
+int dist_k_pack(const PackDesc* descs_dev, const int* blk_desc_dev, const int* blk_first_dev, int nblocks,
+                const float* theta, const float* visual, void* dst_base, int dtype, hipStream_t s) {
+    return with_type(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        hipLaunchKernelGGL(pack_kernel<T>, dim3(nblocks), dim3(NT), 0, s, descs_dev, blk_desc_dev, blk_first_dev, theta, visual, (T*)dst_base);
+        HIP_CHECK_RET(hipGetLastError());
+        return (int)DIST_OK;
+    });
+}
+int dist_k_cls_rows(void* dst, const void* src, const float* table, int nbj, int L, int C, int period, int dtype, hipStream_t s) {
+    return with_type(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        hipLaunchKernelGGL(cls_rows_kernel<T>, dim3(grid1d((long)nbj * C, NT)), dim3(NT), 0, s, (T*)dst, (const T*)src, table, nbj, L, C, period);
+        HIP_CHECK_RET(hipGetLastError());
+        return (int)DIST_OK;
+    });
+}
+int dist_k_cls_rows_bwd(const void* d, float* dtable, int nbj, int L, int C, int period, int dtype, hipStream_t s) {
+    return with_type(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        hipLaunchKernelGGL(cls_rows_bwd_kernel<T>, dim3(grid1d((long)period * C, NT)), dim3(NT), 0, s, (const T*)d, dtable, nbj, L, C, period);
+        HIP_CHECK_RET(hipGetLastError());
+        return (int)DIST_OK;
+    });
+}
+int dist_k_add_table(const void* x, const float* table, void* out, long rows, int C, int period, int dtype, hipStream_t s) {
+    return with_type(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        hipLaunchKernelGGL(add_table_kernel<T>, dim3(grid1d(rows * C, NT)), dim3(NT), 0, s, (const T*)x, table, (T*)out, rows, C, period);
+        HIP_CHECK_RET(hipGetLastError());
+        return (int)DIST_OK;
+    });
+}
+int dist_k_pair_sum(const void* x, void* out, long nbj, int rowlen, int alpha, int dtype, hipStream_t s) {
+    return with_type(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        hipLaunchKernelGGL(pair_sum_kernel<T>, dim3(grid1d(nbj * rowlen / 8, NT)), dim3(NT), 0, s, (const T*)x, (T*)out, nbj, rowlen, alpha);
+        HIP_CHECK_RET(hipGetLastError());
+        return (int)DIST_OK;
+    });
+}
+int dist_k_mean_cls(const void* feat, void* out, int b, int t, int L, int C, int dtype, hipStream_t s) {
+    return with_type(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        hipLaunchKernelGGL(mean_cls_kernel<T>, dim3(grid1d((long)b * C, NT)), dim3(NT), 0, s, (const T*)feat, (T*)out, b, t, L, C);
+        HIP_CHECK_RET(hipGetLastError());
+        return (int)DIST_OK;
+    });
+}
+int dist_k_bcast_rows(const float* table, void* out, long rows, int C, int dtype, hipStream_t s) {
+    return with_type(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        hipLaunchKernelGGL(bcast_rows_kernel<T>, dim3(grid1d(rows * C, NT)), dim3(NT), 0, s, table, (T*)out, rows, C);
+        HIP_CHECK_RET(hipGetLastError());
+        return (int)DIST_OK;
+    });
+}

@@ -1,0 +1,155 @@
+"""ctypes binding of libdist_amd.so (include/dist_amd.h).  No CPU fallback: every
+compute entry point raises if the HIP library is missing or a call fails."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdist_amd.so")
+
+F32, BF16 = 0, 1
+RM_PLAIN, RM_SHIFT, RM_SPATIAL, RM_STRIDED, RM_SKIPCLS = range(5)
+OM_PLAIN, OM_DUP, OM_INSERTCLS, OM_SPLITCOLS = range(4)
+EPI_BIAS, EPI_MULG, EPI_RES, EPI_ACT2 = 1, 2, 4, 8
+
+
+class RowMap(C.Structure):
+    _fields_ = [("mode", C.c_int), ("p0", C.c_int), ("p1", C.c_int), ("sign", C.c_int)]
+
+
+class OutMap(C.Structure):
+    _fields_ = [("mode", C.c_int), ("p0", C.c_int), ("p1", C.c_int), ("p2", C.c_int)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("C2", C.c_void_p),
+                ("bias", C.c_void_p), ("res", C.c_void_p), ("aux", C.c_void_p),
+                ("M", C.c_int64), ("N", C.c_int), ("K", C.c_int), ("taps", C.c_int),
+                ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int), ("ldc2", C.c_int), ("ldres", C.c_int), ("ldaux", C.c_int),
+                ("amap", RowMap), ("omap", OutMap), ("flags", C.c_int), ("dtype", C.c_int)]
+
+
+class GemmTnArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("out", C.c_void_p),
+                ("M", C.c_int64), ("NI", C.c_int), ("K", C.c_int), ("taps", C.c_int),
+                ("lda", C.c_int), ("ldb", C.c_int), ("amap", RowMap), ("bmap", RowMap),
+                ("so_i", C.c_int64), ("so_tap", C.c_int64), ("so_outer", C.c_int64), ("inner", C.c_int),
+                ("dtype", C.c_int), ("use_tr", C.c_int)]
+
+
+class LnArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("y2", C.c_void_p),
+                ("w", C.c_void_p), ("b", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("addend", C.c_void_p), ("addend_period", C.c_int),
+                ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("rows", C.c_int64), ("C", C.c_int), ("dtype", C.c_int), ("eps", C.c_float)]
+
+
+class LnBwdArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("dy", C.c_void_p), ("w", C.c_void_p), ("dy2", C.c_void_p), ("w2", C.c_void_p),
+                ("dx", C.c_void_p), ("accumulate_dx", C.c_int),
+                ("dw", C.c_void_p), ("db", C.c_void_p), ("dw2", C.c_void_p), ("db2", C.c_void_p),
+                ("rows", C.c_int64), ("C", C.c_int), ("dtype", C.c_int)]
+
+
+class AdamwSeg(C.Structure):
+    _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("lr", C.c_float), ("weight_decay", C.c_float)]
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "dtype", "batch", "frames", "alpha", "resolution", "patch", "width", "layers",
+        "integration_dim", "temporal_dim", "temporal_kernel", "temporal_patch", "int_temporal_div",
+        "ada_layers", "num_classes", "embed_dim", "use_tr")]
+
+
+class DistError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def _sig(lib, name, argtypes=None, restype=None):
+    try:
+        fn = getattr(lib, name)
+    except AttributeError:
+        raise DistError(f"libdist_amd.so does not export {name} (stale build? re-run build())")
+    if argtypes is not None:
+        fn.argtypes = argtypes
+    if restype is not None or name.endswith("destroy"):
+        fn.restype = restype
+
+
+def load():
+    """Load the HIP library or fail loudly (there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DistError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950).  dist_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    _sig(lib, "dist_strerror", restype=C.c_char_p)
+    _sig(lib, "dist_strerror", argtypes=[C.c_int])
+    _sig(lib, "dist_last_error", restype=C.c_char_p)
+    _sig(lib, "dist_last_error", argtypes=[C.c_void_p])
+    _sig(lib, "dist_param_name", restype=C.c_char_p)
+    _sig(lib, "dist_param_name", argtypes=[C.c_void_p, C.c_int, C.c_int])
+    for fn in ("dist_param_dim", "dist_param_offset", "dist_param_total"):
+        _sig(lib, fn, restype=C.c_int64)
+    _sig(lib, "dist_param_dim", argtypes=[C.c_void_p, C.c_int, C.c_int, C.c_int])
+    _sig(lib, "dist_param_offset", argtypes=[C.c_void_p, C.c_int, C.c_int])
+    _sig(lib, "dist_param_total", argtypes=[C.c_void_p, C.c_int])
+    _sig(lib, "dist_param_count", argtypes=[C.c_void_p, C.c_int])
+    _sig(lib, "dist_param_ndim", argtypes=[C.c_void_p, C.c_int, C.c_int])
+    _sig(lib, "dist_param_group", argtypes=[C.c_void_p, C.c_int])
+    _sig(lib, "dist_workspace_bytes", restype=C.c_size_t)
+    _sig(lib, "dist_workspace_bytes", argtypes=[C.c_void_p])
+    _sig(lib, "dist_packed_bytes", restype=C.c_size_t)
+    _sig(lib, "dist_packed_bytes", argtypes=[C.c_void_p])
+    _sig(lib, "dist_create", argtypes=[C.POINTER(Config), C.POINTER(C.c_void_p)])
+    _sig(lib, "dist_destroy", argtypes=[C.c_void_p])
+    _sig(lib, "dist_destroy", restype=None)
+    _sig(lib, "dist_bind", argtypes=[C.c_void_p] * 8)
+    _sig(lib, "dist_pack_weights", argtypes=[C.c_void_p, C.c_int, C.c_void_p])
+    _sig(lib, "dist_vit_forward", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_void_p])
+    _sig(lib, "dist_branch_forward", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
+    _sig(lib, "dist_branch_backward", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p])
+    _sig(lib, "dist_loss", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
+    _sig(lib, "dist_debug_tensor", argtypes=[C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)])
+    _sig(lib, "dist_op_gemm_nt", argtypes=[C.POINTER(GemmArgs), C.c_void_p])
+    _sig(lib, "dist_op_gemm_tn", argtypes=[C.POINTER(GemmTnArgs), C.c_void_p])
+    _sig(lib, "dist_op_layernorm", argtypes=[C.POINTER(LnArgs), C.c_void_p])
+    _sig(lib, "dist_op_layernorm_bwd", argtypes=[C.POINTER(LnBwdArgs), C.c_void_p])
+    _sig(lib, "dist_op_attention", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p])
+    _sig(lib, "dist_op_xattn1q", argtypes=[C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p])
+    _sig(lib, "dist_op_xattn1q_bwd", argtypes=[C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p])
+    _sig(lib, "dist_op_patchify", argtypes=[C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p])
+    _sig(lib, "dist_op_add", argtypes=[C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p])
+    _sig(lib, "dist_op_gelu_bwd", argtypes=[C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p])
+    _sig(lib, "dist_op_colsum", argtypes=[C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, RowMap, C.c_int, C.c_void_p])
+    _sig(lib, "dist_op_logits_loss", argtypes=[C.c_void_p] * 10 + [C.c_int] * 4 + [C.c_void_p])
+    _sig(lib, "dist_op_adamw", argtypes=[C.c_void_p] * 5 + [C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_void_p])
+    _lib = lib
+    return lib
+
+
+def check(code, handle=None):
+    if code != 0:
+        lib = load()
+        msg = lib.dist_strerror(code).decode()
+        if handle is not None:
+            extra = lib.dist_last_error(handle)
+            if extra:
+                msg += ": " + extra.decode()
+        raise DistError(f"dist_amd error {code}: {msg}")
+
+
+def exported_symbols():
+    """Every `dist_*` function declared in include/dist_amd.h."""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "dist_amd.h")
+    txt = open(hdr).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dist_[a-z0-9_]+)\s*\(", txt)))

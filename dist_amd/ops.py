@@ -1,0 +1,179 @@
+"""Thin torch-tensor wrappers over the operator-level C ABI (include/dist_amd.h).
+
+torch is only the device-memory container here: every function passes raw device
+pointers + sizes to libdist_amd.so on torch's current HIP stream.  No fallback: a
+missing library or a non-zero return code raises DistError.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return L.F32
+    if t.dtype == torch.bfloat16:
+        return L.BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def rowmap(mode=L.RM_PLAIN, p0=0, p1=0, sign=1):
+    return L.RowMap(mode, p0, p1, sign)
+
+
+def outmap(mode=L.OM_PLAIN, p0=0, p1=0, p2=0):
+    return L.OutMap(mode, p0, p1, p2)
+
+
+def gemm_nt(A, B, M, N, K, *, taps=1, bias=None, res=None, aux=None, amap=None, omap=None,
+            C_out=None, C2_out=None, lda=None, ldc=None):
+    """C[omap(m)][n] = epi(sum_tap sum_k A[amap(m,tap)][k] B[n][tap*K+k]); returns None (writes C_out / C2_out)."""
+    lib = L.load()
+    a = L.GemmArgs()
+    a.A, a.B, a.C, a.C2 = _p(A), _p(B), _p(C_out), _p(C2_out)
+    a.bias, a.res, a.aux = _p(bias), _p(res), _p(aux)
+    a.M, a.N, a.K, a.taps = M, N, K, taps
+    a.lda = lda if lda is not None else A.shape[-1]
+    a.ldb = B.shape[-1]
+    ldo = ldc if ldc is not None else (C_out.shape[-1] if C_out is not None else C2_out.shape[-1])
+    a.ldc = ldo
+    a.ldc2 = C2_out.shape[-1] if C2_out is not None else ldo
+    a.ldres = res.shape[-1] if res is not None else ldo
+    a.ldaux = aux.shape[-1] if aux is not None else ldo
+    a.amap = amap or rowmap()
+    a.omap = omap or outmap()
+    a.flags = (L.EPI_BIAS if bias is not None else 0) | (L.EPI_RES if res is not None else 0) | \
+              (L.EPI_MULG if aux is not None else 0) | (L.EPI_ACT2 if C2_out is not None else 0)
+    a.dtype = _dt(A)
+    L.check(lib.dist_op_gemm_nt(C.byref(a), _stream()))
+
+
+def gemm_tn(A, B, out, M, NI, K, *, taps=1, amap=None, bmap=None, so_i=None, so_tap=None, so_outer=1, inner=1, use_tr=1):
+    lib = L.load()
+    a = L.GemmTnArgs()
+    a.A, a.B, a.out = _p(A), _p(B), _p(out)
+    a.M, a.NI, a.K, a.taps = M, NI, K, taps
+    a.lda, a.ldb = A.shape[-1], B.shape[-1]
+    a.amap = amap or rowmap()
+    a.bmap = bmap or rowmap()
+    a.so_i = so_i if so_i is not None else taps * K
+    a.so_tap = so_tap if so_tap is not None else K
+    a.so_outer, a.inner = so_outer, inner
+    a.dtype, a.use_tr = _dt(A), use_tr
+    L.check(lib.dist_op_gemm_tn(C.byref(a), _stream()))
+
+
+def layernorm(x, w, b, *, y=None, y2=None, w2=None, b2=None, addend=None, period=0, mean=None, rstd=None, eps=1e-5):
+    lib = L.load()
+    rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
+    y = torch.empty_like(x) if y is None else y
+    a = L.LnArgs()
+    a.x, a.y, a.y2 = _p(x), _p(y), _p(y2)
+    a.w, a.b, a.w2, a.b2 = _p(w), _p(b), _p(w2), _p(b2)
+    a.addend, a.addend_period = _p(addend), period
+    a.mean, a.rstd = _p(mean), _p(rstd)
+    a.rows, a.C, a.dtype, a.eps = rows, Cc, _dt(x), eps
+    L.check(lib.dist_op_layernorm(C.byref(a), _stream()))
+    return y
+
+
+def layernorm_bwd(x, mean, rstd, dy, w, *, dy2=None, w2=None, dx=None, accumulate=False, dw=None, db=None, dw2=None, db2=None):
+    lib = L.load()
+    rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
+    a = L.LnBwdArgs()
+    a.x, a.mean, a.rstd = _p(x), _p(mean), _p(rstd)
+    a.dy, a.w, a.dy2, a.w2 = _p(dy), _p(w), _p(dy2), _p(w2)
+    a.dx, a.accumulate_dx = _p(dx), int(accumulate)
+    a.dw, a.db, a.dw2, a.db2 = _p(dw), _p(db), _p(dw2), _p(db2)
+    a.rows, a.C, a.dtype = rows, Cc, _dt(x)
+    L.check(lib.dist_op_layernorm_bwd(C.byref(a), _stream()))
+
+
+def attention(qkv, frames, Ltok, heads):
+    lib = L.load()
+    out = torch.empty(qkv.shape[0], qkv.shape[1] // 3, dtype=qkv.dtype, device=qkv.device)
+    L.check(lib.dist_op_attention(_p(qkv), _p(out), frames, Ltok, heads, _dt(qkv), _stream()))
+    return out
+
+
+def xattn1q(q, kv, B, S, Cc):
+    lib = L.load()
+    o = torch.empty(B, Cc, dtype=q.dtype, device=q.device)
+    probs = torch.empty(B, Cc // 64, S, dtype=torch.float32, device=q.device)
+    L.check(lib.dist_op_xattn1q(_p(q), _p(kv), _p(o), _p(probs), B, S, Cc, _dt(q), _stream()))
+    return o, probs
+
+
+def xattn1q_bwd(q, kv, probs, d_o, B, S, Cc):
+    lib = L.load()
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    L.check(lib.dist_op_xattn1q_bwd(_p(q), _p(kv), _p(probs), _p(d_o), _p(dq), _p(dkv), B, S, Cc, _dt(q), _stream()))
+    return dq, dkv
+
+
+def patchify(video, P, dtype):
+    lib = L.load()
+    b, _, T, H, W = video.shape
+    Kp = (3 * P * P + 7) // 8 * 8
+    out = torch.empty(b * T * (H // P) * (W // P), Kp, dtype=dtype, device=video.device)
+    L.check(lib.dist_op_patchify(_p(video), _p(out), b, T, H, W, P, _dt(out), _stream()))
+    return out
+
+
+def add(a, b):
+    lib = L.load()
+    out = torch.empty_like(a)
+    L.check(lib.dist_op_add(_p(a), _p(b), _p(out), a.numel(), _dt(a), _stream()))
+    return out
+
+
+def gelu_bwd(dy, pre):
+    lib = L.load()
+    out = torch.empty_like(dy)
+    L.check(lib.dist_op_gelu_bwd(_p(dy), _p(pre), _p(out), dy.numel(), _dt(dy), _stream()))
+    return out
+
+
+def colsum(x, out, rows, Cc, ld=None, rmap=None):
+    lib = L.load()
+    L.check(lib.dist_op_colsum(_p(x), _p(out), rows, Cc, ld or x.shape[-1], rmap or rowmap(), _dt(x), _stream()))
+
+
+def logits_loss(v, text, logit_scale, soft_target=None, dlogits_in=None, want_grad=True):
+    lib = L.load()
+    b, E = v.shape
+    K = text.shape[0]
+    dev = v.device
+    logits = torch.empty(b, K, dtype=torch.float32, device=dev)
+    vid = torch.empty(b, E, dtype=torch.float32, device=dev)
+    loss = torch.zeros((), dtype=torch.float32, device=dev)
+    dls = torch.zeros((), dtype=torch.float32, device=dev)
+    dv = torch.empty_like(v) if want_grad else None
+    L.check(lib.dist_op_logits_loss(_p(v), _p(text), _p(logit_scale), _p(soft_target), _p(logits), _p(vid), _p(loss), _p(dv), _p(dls),
+                                    _p(dlogits_in), b, E, K, _dt(v), _stream()))
+    return logits, vid, loss, dv, dls
+
+
+def adamw(param, grad, m, v, segs, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    """segs: device uint8 tensor holding an array of dist_adamw_seg."""
+    lib = L.load()
+    nseg = segs.numel() // C.sizeof(L.AdamwSeg)
+    L.check(lib.dist_op_adamw(_p(param), _p(grad), _p(m), _p(v), _p(segs), nseg, param.numel(), beta1, beta2, eps, step, grad_scale, _stream()))
+
+
+def make_segs(entries, device):
+    """entries: list of (begin, end, lr, wd) -> device byte tensor."""
+    arr = (L.AdamwSeg * len(entries))(*[L.AdamwSeg(int(b), int(e), float(lr), float(wd)) for b, e, lr, wd in entries])
+    buf = bytes(arr)
+    return torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(device)

@@ -1,0 +1,208 @@
+/* dist_amd.h — C ABI of the MI355X-native DiST training hot path.
+ *
+ * The reference (alibaba-mmai-research/DiST) is pure Python/PyTorch and has no FFI
+ * (SURVEY.md §8(b)); its operator interface for this path is
+ *   models/base/backbone.py:228-251   ClipVisionTextTransformer.forward
+ *   models/base/clip.py:263-300       VisionTransformer.forward   (frozen ViT)
+ *   models/base/clip.py:482-533       CLIP.forward_with_text      (cosine logits)
+ *   models/module_zoo/branches/dist.py:222-247  DiSTNetwork.forward
+ *   models/utils/losses.py:20-31      SoftTargetCrossEntropy
+ *   models/utils/optimizer.py:67-73,138-186     AdamW over the dist_net groups
+ * Each entry point below names the reference interface it replaces.  INTEGRATION.md
+ * shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions: every function returns 0 on success or a negative error code
+ * (dist_strerror()); no C++ exception crosses the boundary; all device buffers are
+ * caller-allocated and caller-owned (the library never allocates device memory);
+ * every call is asynchronous on the hipStream_t passed as `void* stream`; one
+ * handle per (device, stream), not thread-safe.  Device pointers only, no torch types.
+ */
+#ifndef DIST_AMD_H
+#define DIST_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { DIST_F32 = 0, DIST_BF16 = 1 };
+
+enum {
+    DIST_OK = 0,
+    DIST_ERR_ARG = -1,        /* invalid argument / unsupported shape */
+    DIST_ERR_STATE = -2,      /* call order (e.g. backward before forward) */
+    DIST_ERR_WORKSPACE = -3,  /* workspace too small / not bound */
+    DIST_ERR_UNBOUND = -4     /* a weight or buffer was not bound */
+    /* <= -1000: -(hipError_t) - 1000 */
+};
+
+const char* dist_strerror(int code);
+int dist_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Operator level (also what the unit parity tests drive).
+ * ------------------------------------------------------------------------------------- */
+
+/* logical-row -> source-row maps: conv taps and token re-layouts without im2col */
+enum { DIST_RM_PLAIN = 0, DIST_RM_SHIFT = 1, DIST_RM_SPATIAL = 2, DIST_RM_STRIDED = 3, DIST_RM_SKIPCLS = 4 };
+typedef struct dist_rowmap { int mode, p0, p1, sign; } dist_rowmap;
+enum { DIST_OM_PLAIN = 0, DIST_OM_DUP = 1, DIST_OM_INSERTCLS = 2, DIST_OM_SPLITCOLS = 3 };
+typedef struct dist_outmap { int mode, p0, p1, p2; } dist_outmap;
+
+enum {
+    DIST_EPI_BIAS = 1,   /* v += bias[n] */
+    DIST_EPI_MULG = 2,   /* v *= quickgelu'(aux[dest][n])   (backward through an activation) */
+    DIST_EPI_RES = 4,    /* v += res[dest][n] */
+    DIST_EPI_ACT2 = 8    /* C2[dest][n] = quickgelu(v)  (C, if non-null, keeps the pre-activation) */
+};
+
+/* C[omap(m)][n] = epi( sum_tap sum_k A[amap(m,tap)][k] * B[n][tap*K + k] )
+ * replaces nn.Linear / nn.Conv3d (kernel (kt,1,1), (1,3,3), strided (a,1,1)) / Conv2d patch
+ * embedding call sites: clip.py:116-123,155-161,232; dist.py:23-36,54-60,75,97,178-198. */
+typedef struct dist_gemm_args {
+    const void* A; const void* B; void* C; void* C2;
+    const float* bias; const void* res; const void* aux;
+    int64_t M; int N; int K; int taps;
+    int lda, ldb, ldc, ldc2, ldres, ldaux;
+    dist_rowmap amap; dist_outmap omap;
+    int flags; int dtype;
+} dist_gemm_args;
+int dist_op_gemm_nt(const dist_gemm_args* a, void* stream);
+
+/* out[i*so_i + tap*so_tap + (c/inner)*so_outer + c%inner] += sum_m A[amap(m)][i] * B[bmap(m,tap)][c]
+ * (fp32 atomics; weight gradients of every Linear / Conv3d on the path, autograd in the reference) */
+typedef struct dist_gemm_tn_args {
+    const void* A; const void* B; float* out;
+    int64_t M; int NI; int K; int taps;
+    int lda, ldb;
+    dist_rowmap amap; dist_rowmap bmap;
+    int64_t so_i, so_tap, so_outer; int inner;
+    int dtype; int use_tr;   /* use_tr: bf16 LDS transpose reads (ds_read_b64_tr_b16) */
+} dist_gemm_tn_args;
+int dist_op_gemm_tn(const dist_gemm_tn_args* a, void* stream);
+
+/* LayerNorm over the last axis (clip.py:181-187), optional periodic addend before the
+ * norm (cls/positional embedding, clip.py:274-276) and optional second affine output
+ * that shares the statistics (IntegrationNetwork.ln / ln_temporal, dist.py:35-36,43-45). */
+typedef struct dist_ln_args {
+    const void* x; void* y; void* y2;
+    const float* w; const float* b; const float* w2; const float* b2;
+    const float* addend; int addend_period;        /* x[r] += addend[r % period] (fp32 table) */
+    float* mean; float* rstd;                       /* optional, saved for backward */
+    int64_t rows; int C; int dtype; float eps;
+} dist_ln_args;
+int dist_op_layernorm(const dist_ln_args* a, void* stream);
+
+/* dx (+)= LN'(dy [, dy2]); dw/db (+= atomics), all optional except x/mean/rstd */
+typedef struct dist_ln_bwd_args {
+    const void* x; const float* mean; const float* rstd;
+    const void* dy; const float* w; const void* dy2; const float* w2;
+    void* dx; int accumulate_dx;
+    float* dw; float* db; float* dw2; float* db2;
+    int64_t rows; int C; int dtype;
+} dist_ln_bwd_args;
+int dist_op_layernorm_bwd(const dist_ln_bwd_args* a, void* stream);
+
+/* per-frame multi-head self-attention on packed qkv [frames*L, 3*d] -> [frames*L, d]
+ * (nn.MultiheadAttention inside ResidualAttentionBlockMid, clip.py:155,166-168) */
+int dist_op_attention(const void* qkv, void* out, int frames, int L, int heads, int dtype, void* stream);
+
+/* one-query cross attention (CrossAttentionBlockGenral, clip.py:139-147; dist.py:144,158):
+ * q [B, C], kv [B*S, 2C] -> o [B, C], probs [B, H, S] (fp32, saved for backward) */
+int dist_op_xattn1q(const void* q, const void* kv, void* o, float* probs, int B, int S, int C, int dtype, void* stream);
+int dist_op_xattn1q_bwd(const void* q, const void* kv, const float* probs, const void* d_o,
+                        void* dq, void* dkv, int B, int S, int C, int dtype, void* stream);
+
+/* [b,3,T,H,W] fp32 frames -> patch rows [b*T*N, 3*P*P] (c,py,px order) in `dtype` */
+int dist_op_patchify(const float* video, void* patches, int b, int T, int H, int W, int P, int dtype, void* stream);
+
+/* misc elementwise (dtype-generic) */
+int dist_op_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+int dist_op_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int dtype, void* stream);
+int dist_op_colsum(const void* x, float* out, int64_t rows, int C, int ld, dist_rowmap map, int dtype, void* stream);
+
+/* cosine logits + SoftTargetCrossEntropy forward and backward in one pass
+ * (clip.py:509-518, base_blocks.py:579-585, losses.py:29-31).
+ * v [b,E] (dtype), text [K,E] fp32 unit or not; outputs fp32. */
+int dist_op_logits_loss(const void* v, const float* text, const float* logit_scale, const float* soft_target,
+                        float* logits, float* vid_norm, float* loss, void* dv, float* dlogit_scale,
+                        const float* dlogits_in, int b, int E, int K, int dtype, void* stream);
+
+/* fused multi-tensor AdamW over a flat fp32 buffer split into segments
+ * (torch.optim.AdamW as constructed in models/utils/optimizer.py:67-73) */
+typedef struct dist_adamw_seg { int64_t begin, end; float lr, weight_decay; } dist_adamw_seg;
+int dist_op_adamw(float* param, const float* grad, float* m, float* v, const dist_adamw_seg* segs_dev, int nseg,
+                  int64_t n, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Engine level: the whole hot path behind one handle.
+ * ------------------------------------------------------------------------------------- */
+typedef struct dist_config {
+    int dtype;            /* DIST_F32 | DIST_BF16: activation / working-weight storage */
+    int batch;            /* clips per call (max) */
+    int frames;           /* DATA.NUM_INPUT_FRAMES (T) */
+    int alpha;            /* DATA.SPARSE_SAMPLE_ALPHA */
+    int resolution;       /* frame H = W */
+    int patch;            /* ViT patch = DIST.S_PATCH_SIZE */
+    int width;            /* ViT width d */
+    int layers;           /* ViT layers = len(DIST.SELECTED_LAYERS) */
+    int integration_dim;  /* DIST.INTEGRATION_DIM */
+    int temporal_dim;     /* DIST.TEMPORAL_DIM */
+    int temporal_kernel;  /* DIST.TEMPORAL_KERNEL_SIZE */
+    int temporal_patch;   /* DIST.T_PATCH_SIZE */
+    int int_temporal_div; /* 1 / DIST.INTEGRATION_TEMPORAL_MLP_RATIO (4) */
+    int ada_layers;       /* DIST.ADA_POOLING_LAYERS */
+    int num_classes;      /* VIDEO.HEAD.NUM_CLASSES */
+    int embed_dim;        /* CLIP embed dim E */
+    int use_tr;           /* bf16 dW GEMMs use LDS transpose reads */
+} dist_config;
+
+typedef struct dist_handle dist_handle;
+
+int dist_create(const dist_config* cfg, dist_handle** out);
+void dist_destroy(dist_handle* h);
+const char* dist_last_error(const dist_handle* h);
+
+/* parameter tables (reference state-dict names and shapes).
+ * kind 0: dist_net.* trainable tensors, laid out back to back in ONE flat fp32 buffer
+ *         (offsets in elements); kind 1: frozen visual.* tensors, flat fp32 as well. */
+int dist_param_count(const dist_handle* h, int kind);
+const char* dist_param_name(const dist_handle* h, int kind, int i);
+int dist_param_ndim(const dist_handle* h, int kind, int i);
+int64_t dist_param_dim(const dist_handle* h, int kind, int i, int d);
+int64_t dist_param_offset(const dist_handle* h, int kind, int i);
+int64_t dist_param_total(const dist_handle* h, int kind);
+int dist_param_group(const dist_handle* h, int i);   /* DiST optimizer group 0..4 (optimizer.py:138-186 as intended) */
+
+/* bytes the caller must provide */
+size_t dist_workspace_bytes(const dist_handle* h);   /* activations saved for backward + scratch */
+size_t dist_packed_bytes(const dist_handle* h);      /* working copies of all weights in cfg.dtype */
+
+/* borrowed device pointers; the caller keeps them alive while the handle uses them */
+int dist_bind(dist_handle* h, float* theta /*dist_net flat fp32*/, float* grads /*same size*/,
+              const float* visual /*flat fp32*/, float* logit_scale, float* dlogit_scale,
+              void* packed, void* workspace);
+
+/* refresh the cfg.dtype working copies (GEMM layouts, transposes) from theta / visual.
+ * what: 1 = visual, 2 = dist_net, 3 = both.  Call after load_state_dict / optimizer.step. */
+int dist_pack_weights(dist_handle* h, int what, void* stream);
+
+/* VisionTransformer.forward under eval()+no_grad (clip.py:263-300,454-458): video [b,3,T,H,W] fp32
+ * -> mid_feat kept inside the workspace ([layers][b,t,L,d]); optional copy-out pointer per layer. */
+int dist_vit_forward(dist_handle* h, const float* video, int b, void* stream);
+/* DiSTNetwork.forward + cosine logits (dist.py:222-247, clip.py:509-518): -> logits [b,K] fp32,
+ * vid_logits [b,E] fp32 (L2-normalised video embedding) */
+int dist_branch_forward(dist_handle* h, const float* text_features, int b, float* logits, float* vid_logits, void* stream);
+/* backward of the branch given dlogits [b,K] fp32 (autograd in the reference, runs/train.py:110);
+ * accumulates into the bound flat grads buffer (zeroed first when zero_grads != 0). */
+int dist_branch_backward(dist_handle* h, const float* dlogits, int b, int zero_grads, void* stream);
+/* SoftTargetCrossEntropy value and dlogits for the logits of the last branch_forward */
+int dist_loss(dist_handle* h, const float* soft_target, int b, float* loss, float* dlogits, void* stream);
+/* read back an intermediate for tests: name in {"feat.<i>","stem","tn_out.<i>","int_out.<i>","x_temporal.<i>","mid.<i>"} */
+int dist_debug_tensor(dist_handle* h, const char* name, const void** ptr, int64_t* rows, int* cols);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,337 @@
+"""Per-kernel parity tests (GPU): every HIP operator behind the C ABI vs a plain
+PyTorch fp32/fp64 statement of the same op on the same seeded inputs.
+
+fp32 mode (exact-f32 MFMA) is held to tight tolerances; bf16 mode is held to one
+bf16 rounding of the output (inputs are identical bf16 values, accumulation is fp32).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype, scale=1.0):
+    return dict(rtol=2e-5, atol=2e-5 * scale) if dtype == torch.float32 else dict(rtol=1.2e-2, atol=1.2e-2 * scale)
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device="cuda") * scale).to(dtype)
+
+
+def qgelu(x):
+    return x * torch.sigmoid(1.702 * x)
+
+
+def qgelu_grad(x):
+    s = torch.sigmoid(1.702 * x)
+    return s * (1 + 1.702 * x * (1 - s))
+
+
+# ---- python statement of the row maps (include/dist_amd.h) ------------------------------
+def src_rows(mode, M, tap, taps, p0=0, p1=0, sign=1):
+    m = torch.arange(M, device="cuda")
+    if mode == "plain":
+        return m, torch.ones_like(m, dtype=torch.bool)
+    if mode == "shift":
+        off = sign * (tap - taps // 2) * p1
+        r = m % p0 + off
+        return m + off, (r >= 0) & (r < p0)
+    if mode == "spatial":
+        g = p0
+        dy, dx = (tap // 3 - 1) * sign, (tap % 3 - 1) * sign
+        n = m % (g * g)
+        y, x = n // g + dy, n % g + dx
+        return m + dy * g + dx, (y >= 0) & (y < g) & (x >= 0) & (x < g)
+    if mode == "strided":
+        bj, n = m // p1, m % p1
+        return (bj * p0 + tap) * p1 + n, torch.ones_like(m, dtype=torch.bool)
+    if mode == "skipcls":
+        bj, n = m // p0, m % p0
+        return bj * (p0 + 1) + 1 + n, torch.ones_like(m, dtype=torch.bool)
+    raise KeyError(mode)
+
+
+MODES = {"plain": 0, "shift": 1, "spatial": 2, "strided": 3, "skipcls": 4}
+
+
+def gather(A, mode, M, tap, taps, **kw):
+    src, ok = src_rows(mode, M, tap, taps, **kw)
+    out = A.double()[src.clamp(0, A.shape[0] - 1)]
+    return out * ok[:, None]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(3152, 768, 768), (591, 2304, 768), (1000, 96, 96), (777, 384, 3072), (130, 1152, 384), (64, 512, 384), (257, 192, 96)])
+def test_gemm_nt_plain(gpu_lib, dtype, M, N, K):
+    from dist_amd import ops
+    A, B = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
+    bias = rnd((N,), torch.float32, 3)
+    res = rnd((M, N), dtype, 4)
+    C, C2 = torch.empty(M, N, dtype=dtype, device="cuda"), torch.empty(M, N, dtype=dtype, device="cuda")
+    ops.gemm_nt(A, B, M, N, K, bias=bias, res=res, C_out=C, C2_out=C2)
+    ref = A.double() @ B.double().t() + bias.double() + res.double()
+    torch.testing.assert_close(C.double(), ref, **tol(dtype))
+    torch.testing.assert_close(C2.double(), qgelu(C.double()), **tol(dtype))
+    # activation-only output (no pre-activation kept) and MULG epilogue
+    C3 = torch.empty(M, N, dtype=dtype, device="cuda")
+    ops.gemm_nt(A, B, M, N, K, bias=bias, C2_out=C3)
+    torch.testing.assert_close(C3.double(), qgelu(A.double() @ B.double().t() + bias.double()), **tol(dtype))
+    aux = rnd((M, N), dtype, 5)
+    C4 = torch.empty(M, N, dtype=dtype, device="cuda")
+    ops.gemm_nt(A, B, M, N, K, aux=aux, C_out=C4)
+    torch.testing.assert_close(C4.double(), (A.double() @ B.double().t()) * qgelu_grad(aux.double()), **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("mode,kw,taps,N", [
+    ("shift", dict(p0=8 * 9, p1=9), 3, 96), ("shift", dict(p0=8 * 9, p1=9, sign=-1), 3, 128), ("shift", dict(p0=6 * 16, p1=16), 5, 32),
+    ("spatial", dict(p0=4), 9, 96), ("spatial", dict(p0=3, sign=-1), 9, 32), ("spatial", dict(p0=14), 9, 96),
+    ("strided", dict(p0=2, p1=9), 2, 384), ("skipcls", dict(p0=9), 1, 96)])
+def test_gemm_nt_rowmaps(gpu_lib, dtype, mode, kw, taps, N):
+    from dist_amd import ops, lib as L
+    K = 96
+    if mode == "shift":
+        M = kw["p0"] * 5
+    elif mode == "spatial":
+        M = kw["p0"] ** 2 * 7
+    else:
+        M = 9 * 11
+    rowsA = {"strided": M * 2, "skipcls": (M // 9) * 10}.get(mode, M)
+    A = rnd((rowsA, K), dtype, 1)
+    B = rnd((N, taps * K), dtype, 2, (taps * K) ** -0.5)
+    bias = rnd((N,), torch.float32, 3)
+    C = torch.empty(M, N, dtype=dtype, device="cuda")
+    ops.gemm_nt(A, B, M, N, K, taps=taps, bias=bias, C_out=C,
+                amap=ops.rowmap(MODES[mode], kw.get("p0", 0), kw.get("p1", 0), kw.get("sign", 1)))
+    ref = bias.double().expand(M, N).clone()
+    for tap in range(taps):
+        ref += gather(A, mode, M, tap, taps, **kw) @ B.double()[:, tap * K:(tap + 1) * K].t()
+    torch.testing.assert_close(C.double(), ref, **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_nt_outmaps(gpu_lib, dtype):
+    from dist_amd import ops, lib as L
+    Nn, alpha, nbj, K = 9, 2, 11, 128
+    M = nbj * Nn
+    A = rnd((M, K), dtype, 1)
+    # DUP: (bj, n) -> rows (bj*alpha + a, n), residual read at the destination
+    B = rnd((96, K), dtype, 2, K ** -0.5)
+    res = rnd((M * alpha, 96), dtype, 3)
+    C = torch.zeros(M * alpha, 96, dtype=dtype, device="cuda")
+    ops.gemm_nt(A, B, M, 96, K, res=res, C_out=C, omap=ops.outmap(L.OM_DUP, alpha, Nn))
+    Y = (A.double() @ B.double().t()).reshape(nbj, 1, Nn, 96).expand(nbj, alpha, Nn, 96).reshape(M * alpha, 96)
+    torch.testing.assert_close(C.double(), Y + res.double(), **tol(dtype))
+    # INSERTCLS: (bj, n) -> row bj*(N+1) + 1 + n; cls rows untouched
+    res2 = rnd((nbj * (Nn + 1), 96), dtype, 4)
+    C = torch.full((nbj * (Nn + 1), 96), 7.0, dtype=dtype, device="cuda")
+    ops.gemm_nt(A, B, M, 96, K, res=res2, C_out=C, omap=ops.outmap(L.OM_INSERTCLS, Nn))
+    Cr = C.double().reshape(nbj, Nn + 1, 96)
+    torch.testing.assert_close(Cr[:, 1:], (A.double() @ B.double().t()).reshape(nbj, Nn, 96) + res2.double().reshape(nbj, Nn + 1, 96)[:, 1:], **tol(dtype))
+    assert (Cr[:, 0] == 7.0).all()
+    # SPLITCOLS: column block a of (bj, n) -> row (bj*alpha + a, n)
+    B2 = rnd((alpha * 32, K), dtype, 5, K ** -0.5)
+    res3 = rnd((M * alpha, 32), dtype, 6)
+    C = torch.zeros(M * alpha, 32, dtype=dtype, device="cuda")
+    ops.gemm_nt(A, B2, M, alpha * 32, K, res=res3, C_out=C, omap=ops.outmap(L.OM_SPLITCOLS, alpha, Nn, 32), ldc=32)
+    Y = (A.double() @ B2.double().t()).reshape(nbj, Nn, alpha, 32).permute(0, 2, 1, 3).reshape(M * alpha, 32)
+    torch.testing.assert_close(C.double(), Y + res3.double(), **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype,use_tr", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, 1)])
+@pytest.mark.parametrize("M,NI,K", [(3152, 384, 768), (1000, 96, 96), (5000, 96, 288), (333, 128, 64), (2048, 768, 384)])
+def test_gemm_tn_plain(gpu_lib, dtype, use_tr, M, NI, K):
+    from dist_amd import ops
+    A, B = rnd((M, NI), dtype, 1), rnd((M, K), dtype, 2)
+    out = torch.zeros(NI, K, dtype=torch.float32, device="cuda")
+    ops.gemm_tn(A, B, out, M, NI, K, use_tr=use_tr)
+    ref = A.double().t() @ B.double()
+    torch.testing.assert_close(out.double(), ref, rtol=1e-4, atol=1e-4 * M ** 0.5)
+
+
+@pytest.mark.parametrize("dtype,use_tr", [(torch.float32, 0), (torch.bfloat16, 1)])
+@pytest.mark.parametrize("mode,kw,taps", [("shift", dict(p0=8 * 9, p1=9), 3), ("spatial", dict(p0=4), 9), ("strided", dict(p0=2, p1=9), 2)])
+def test_gemm_tn_taps_conv_layout(gpu_lib, dtype, use_tr, mode, kw, taps):
+    """dW of a conv in the reference's [Co][Ci][taps] parameter layout."""
+    from dist_amd import ops
+    NI, K = 96, 32
+    M = {"shift": 72 * 5, "spatial": 16 * 7, "strided": 9 * 11}[mode]
+    rowsB = M * 2 if mode == "strided" else M
+    A, B = rnd((M, NI), dtype, 1), rnd((rowsB, K), dtype, 2)
+    out = torch.zeros(NI, K, taps, dtype=torch.float32, device="cuda")
+    ops.gemm_tn(A, B, out, M, NI, K, taps=taps, bmap=ops.rowmap(MODES[mode], kw.get("p0", 0), kw.get("p1", 0), 1),
+                so_i=K * taps, so_tap=1, so_outer=taps, inner=1, use_tr=use_tr)
+    for tap in range(taps):
+        ref = A.double().t() @ gather(B, mode, M, tap, taps, **kw)
+        torch.testing.assert_close(out[:, :, tap].double(), ref, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_tn_skipcls_a(gpu_lib, dtype):
+    from dist_amd import ops, lib as L
+    Nn, nbj, NI, K = 9, 13, 128, 96
+    M = nbj * Nn
+    A, B = rnd((nbj * (Nn + 1), NI), dtype, 1), rnd((M, K), dtype, 2)
+    out = torch.zeros(NI, K, dtype=torch.float32, device="cuda")
+    ops.gemm_tn(A, B, out, M, NI, K, amap=ops.rowmap(L.RM_SKIPCLS, Nn))
+    ref = A.double().reshape(nbj, Nn + 1, NI)[:, 1:].reshape(M, NI).t() @ B.double()
+    torch.testing.assert_close(out.double(), ref, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,C", [(3152, 768), (1000, 96), (777, 384), (100, 1024), (50, 32), (64, 128)])
+def test_layernorm_fwd_bwd(gpu_lib, dtype, rows, C):
+    from dist_amd import ops
+    x = rnd((rows, C), dtype, 1, 2.0)
+    w, b = 1 + 0.1 * rnd((C,), torch.float32, 2), 0.1 * rnd((C,), torch.float32, 3)
+    w2, b2 = 1 + 0.1 * rnd((C,), torch.float32, 4), 0.1 * rnd((C,), torch.float32, 5)
+    mean = torch.empty(rows, device="cuda"); rstd = torch.empty(rows, device="cuda")
+    y2 = torch.empty_like(x)
+    y = ops.layernorm(x, w, b, y2=y2, w2=w2, b2=b2, mean=mean, rstd=rstd)
+    xd = x.double().requires_grad_(True)
+    wd, bd, w2d, b2d = [t.double().requires_grad_(True) for t in (w, b, w2, b2)]
+    ry = torch.nn.functional.layer_norm(xd, (C,), wd, bd, 1e-5)
+    ry2 = torch.nn.functional.layer_norm(xd, (C,), w2d, b2d, 1e-5)
+    torch.testing.assert_close(y.double(), ry, **tol(dtype))
+    torch.testing.assert_close(y2.double(), ry2, **tol(dtype))
+    dy, dy2 = rnd((rows, C), dtype, 6), rnd((rows, C), dtype, 7)
+    (ry * dy.double() + ry2 * dy2.double()).sum().backward()
+    dx0 = rnd((rows, C), dtype, 8)
+    dx = dx0.clone()
+    dw, db, dw2, db2 = [torch.zeros(C, device="cuda") for _ in range(4)]
+    ops.layernorm_bwd(x, mean, rstd, dy, w, dy2=dy2, w2=w2, dx=dx, accumulate=True, dw=dw, db=db, dw2=dw2, db2=db2)
+    torch.testing.assert_close(dx.double(), xd.grad + dx0.double(), **tol(dtype, 4.0))
+    for got, ref in ((dw, wd.grad), (db, bd.grad), (dw2, w2d.grad), (db2, b2d.grad)):
+        torch.testing.assert_close(got.double(), ref, rtol=1e-3, atol=2e-3 * rows ** 0.5)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_layernorm_addend(gpu_lib, dtype):
+    from dist_amd import ops
+    L_, C, frames = 10, 128, 6
+    x = rnd((frames * L_, C), dtype, 1)
+    pos = rnd((L_, C), torch.float32, 2)
+    w, b = 1 + 0.1 * rnd((C,), torch.float32, 3), 0.1 * rnd((C,), torch.float32, 4)
+    y = ops.layernorm(x, w, b, addend=pos, period=L_)
+    ref = torch.nn.functional.layer_norm(x.double().reshape(frames, L_, C) + pos.double(), (C,), w.double(), b.double(), 1e-5)
+    torch.testing.assert_close(y.double().reshape(frames, L_, C), ref, **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("frames,L_,heads", [(6, 197, 12), (3, 257, 16), (5, 17, 2), (4, 10, 2), (2, 32, 1)])
+def test_vit_attention(gpu_lib, dtype, frames, L_, heads):
+    from dist_amd import ops
+    d = heads * 64
+    qkv = rnd((frames * L_, 3 * d), dtype, 1)
+    out = ops.attention(qkv, frames, L_, heads)
+    q, k, v = qkv.double().reshape(frames, L_, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    att = torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1)
+    ref = (att @ v).permute(0, 2, 1, 3).reshape(frames * L_, d)
+    torch.testing.assert_close(out.double(), ref, **(dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,S,C", [(16, 197, 384), (4, 8, 384), (6, 10, 128)])
+def test_xattn1q(gpu_lib, dtype, B, S, C):
+    from dist_amd import ops
+    H = C // 64
+    q, kv = rnd((B, C), dtype, 1), rnd((B * S, 2 * C), dtype, 2)
+    o, probs = ops.xattn1q(q, kv, B, S, C)
+    qd = q.double().requires_grad_(True)
+    kvd = kv.double().requires_grad_(True)
+    qh = qd.reshape(B, H, 1, 64)
+    kh = kvd.reshape(B, S, 2, H, 64)[:, :, 0].permute(0, 2, 1, 3)
+    vh = kvd.reshape(B, S, 2, H, 64)[:, :, 1].permute(0, 2, 1, 3)
+    att = torch.softmax(qh @ kh.transpose(-1, -2) / 8.0, dim=-1)
+    ref = (att @ vh).reshape(B, C)
+    torch.testing.assert_close(o.double(), ref, **tol(dtype))
+    torch.testing.assert_close(probs.double(), att.reshape(B, H, S), rtol=1e-4, atol=1e-5)
+    do = rnd((B, C), dtype, 3)
+    (ref * do.double()).sum().backward()
+    dq, dkv = ops.xattn1q_bwd(q, kv, probs, do, B, S, C)
+    torch.testing.assert_close(dq.double(), qd.grad, **tol(dtype))
+    torch.testing.assert_close(dkv.double(), kvd.grad, **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("P,res", [(16, 64), (14, 56)])
+def test_patchify(gpu_lib, dtype, P, res):
+    from dist_amd import ops
+    b, T = 2, 4
+    video = rnd((b, 3, T, res, res), torch.float32, 1)
+    out = ops.patchify(video, P, dtype)
+    G = res // P
+    ref = video.permute(0, 2, 1, 3, 4).reshape(b, T, 3, G, P, G, P).permute(0, 1, 3, 5, 2, 4, 6).reshape(b * T * G * G, 3 * P * P)
+    assert out.shape[1] == (3 * P * P + 7) // 8 * 8
+    torch.testing.assert_close(out[:, :3 * P * P].float(), ref.to(dtype).float(), rtol=0, atol=0)
+    assert (out[:, 3 * P * P:] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_elementwise_colsum(gpu_lib, dtype):
+    from dist_amd import ops, lib as L
+    a, b = rnd((1000, 96), dtype, 1), rnd((1000, 96), dtype, 2)
+    torch.testing.assert_close(ops.add(a, b).double(), (a.double() + b.double()), **tol(dtype))
+    torch.testing.assert_close(ops.gelu_bwd(a, b).double(), a.double() * qgelu_grad(b.double()), **tol(dtype))
+    for rows, C in ((5000, 96), (3000, 384), (100, 768), (77, 32)):
+        x = rnd((rows, C), dtype, 3)
+        out = torch.zeros(C, device="cuda")
+        ops.colsum(x, out, rows, C)
+        torch.testing.assert_close(out.double(), x.double().sum(0), rtol=1e-4, atol=1e-3)
+    Nn, nbj, C = 9, 7, 128
+    x = rnd((nbj * (Nn + 1), C), dtype, 4)
+    out = torch.zeros(C, device="cuda")
+    ops.colsum(x, out, nbj * Nn, C, rmap=ops.rowmap(L.RM_SKIPCLS, Nn))
+    torch.testing.assert_close(out.double(), x.double().reshape(nbj, Nn + 1, C)[:, 1:].sum((0, 1)), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("b,E,K", [(4, 512, 174), (3, 64, 10), (2, 768, 400)])
+def test_logits_loss(gpu_lib, dtype, b, E, K):
+    from dist_amd import ops
+    v = rnd((b, E), dtype, 1)
+    text = rnd((K, E), torch.float32, 2)
+    ls = torch.tensor(2.659, device="cuda")
+    y = torch.softmax(rnd((b, K), torch.float32, 3), -1)
+    logits, vid, loss, dv, dls = ops.logits_loss(v, text, ls, soft_target=y)
+    vd = v.double().requires_grad_(True)
+    lsd = ls.double().requires_grad_(True)
+    vn = vd / vd.norm(dim=1, keepdim=True)
+    tn = text.double() / text.double().norm(dim=1, keepdim=True)
+    rl = lsd.exp() * vn @ tn.t()
+    rloss = torch.sum(-y.double() * torch.log_softmax(rl, -1), -1).mean()
+    rloss.backward()
+    torch.testing.assert_close(logits.double(), rl, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(vid.double(), vn, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(loss.double(), rloss, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dv.double(), vd.grad, **tol(dtype, 0.05))
+    torch.testing.assert_close(dls.double(), lsd.grad, rtol=1e-3, atol=1e-4)
+    # externally supplied dlogits (the drop-in autograd path)
+    dl = rnd((b, K), torch.float32, 4, 0.01)
+    _, _, _, dv2, dls2 = ops.logits_loss(v, text, ls, dlogits_in=dl)
+    vd.grad = None; lsd.grad = None
+    vn = vd / vd.norm(dim=1, keepdim=True)
+    ((lsd.exp() * vn @ tn.t()) * dl.double()).sum().backward()
+    torch.testing.assert_close(dv2.double(), vd.grad, **tol(dtype, 0.05))
+    torch.testing.assert_close(dls2.double(), lsd.grad, rtol=1e-3, atol=1e-4)
+
+
+def test_adamw(gpu_lib):
+    from dist_amd import ops
+    n = 10000
+    p0 = rnd((n,), torch.float32, 1)
+    segs_spec = [(0, 3000, 3.2e-4, 1e-4), (3000, 3004, 1e-3, 0.0), (3004, n, 3.2e-4, 0.0)]
+    ps = [torch.nn.Parameter(p0[b:e].clone()) for b, e, _, _ in segs_spec]
+    opt = torch.optim.AdamW([{"params": [q], "lr": lr, "weight_decay": wd} for q, (_, _, lr, wd) in zip(ps, segs_spec)], betas=(0.9, 0.999))
+    p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    segs = ops.make_segs(segs_spec, "cuda")
+    for step in range(1, 4):
+        g = rnd((n,), torch.float32, 10 + step)
+        for q, (b, e, _, _) in zip(ps, segs_spec):
+            q.grad = g[b:e].clone()
+        opt.step()
+        ops.adamw(p, g, m, v, segs, step)
+        torch.testing.assert_close(p, torch.cat([q.data for q in ps]), rtol=1e-5, atol=1e-6)
