@@ -1,5 +1,433 @@
+// Engine: the whole DiST hot path behind one handle (include/dist_amd.h, "Engine level").
+//
+//   dist_vit_forward     frozen CLIP ViT (reference clip.py:263-300, eval + no_grad)
+//   dist_branch_forward  DiSTNetwork.forward + cosine logits (dist.py:222-247, clip.py:509-518)
+//   dist_loss            SoftTargetCrossEntropy (losses.py:29-31)
+//   dist_branch_backward hand-derived backward of the branch (autograd in the reference)
+//
+// Token layouts: integration / ViT tokens S[b, j, l, c] as rows
+// (b*t + j)*L + l, temporal map X[b, k, n, c] as rows (b*T + k)*N + n.  Every Linear and
+// Conv3d is one launch of the row-mapped MFMA GEMM (gemm_nt.hip) with fused epilogues; no
+// im2col, permute or upsample tensor is ever materialised.  The host side only sequences
+// launches on the caller's stream; it never allocates device memory and never syncs.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
 #include "common.h"
 #include "kernels.h"
+
+namespace {
+
+struct Param {
+    std::string name;
+    int ndim = 0;
+    int64_t dim[5] = {0, 0, 0, 0, 0};
+    int64_t offset = 0;
+    int64_t numel = 0;
+    int group = -1;
+};
+
+struct PW { long f = -1, b = -1; };          // packed working copies (element offsets): forward / data-gradient layout
+
+struct Lin {                                 // y = x W^T + bias, W [N][K] (optionally conv taps)
+    long w = -1, bias = -1;                  // offsets into theta / visual (fp32 master)
+    PW pk;
+    int N = 0, K = 0, taps = 1;
+};
+struct LNp { long w = -1, b = -1; int C = 0; };
+
+struct VitLayer { LNp ln1, ln2; Lin qkv, out, fc, proj; };
+struct DistLayer {
+    LNp tn_ln; Lin tn_fc1, tn_fc2;           // TemporalNet
+    Lin in_lin, i2t, t2i; long cls_token = -1;
+    LNp in_ln, in_ln_t; Lin ffn_fc, ffn_proj, tf_fc1, tf_fc2, tf_proj;   // IntegrationNetwork
+};
+struct XAttn { LNp ln1; Lin q, kv, out; };   // CrossAttentionBlockGenral (in_proj split into q / kv rows)
+struct AdaLayer { long pos = -1; XAttn sp, tm; LNp ln_sp, ln_tm; Lin sp_fc, sp_proj, tm_fc, tm_proj; };
+
+template <typename T> struct Buf { T* p = nullptr; };
+
+struct Arena {
+    char* base = nullptr;
+    size_t off = 0;
+    void* take(size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+struct DistLayerWs {
+    void *X, *U, *z, *V, *p, *Xp, *M, *Mp, *Na, *Nb, *zf, *hf, *h1, *h2, *g2, *R;
+    float *tn_mean, *tn_rstd, *in_mean, *in_rstd;
+};
+struct AdaWs {
+    void *kn, *kv, *qn, *q, *o, *s1, *sn, *zs, *hs, *c, *kn2, *kv2, *qn2, *q2, *o2, *u1, *un, *zu, *hu;
+    float *kn_mean, *kn_rstd, *qn_mean, *qn_rstd, *s1_mean, *s1_rstd, *kn2_mean, *kn2_rstd, *qn2_mean, *qn2_rstd, *u1_mean, *u1_rstd;
+    float *probs, *probs2;
+};
+
+}  // namespace
+
+struct dist_handle {
+    dist_config cfg;
+    int es = 2;                                  // element size of cfg.dtype
+    // derived geometry
+    int G = 0, N = 0, L = 0, t = 0, heads = 0, C4 = 0, Kp = 0, PP3 = 0, iheads = 0;
+    std::vector<Param> params[2];
+    std::unordered_map<std::string, int> index[2];
+    int64_t total[2] = {0, 0};
+    // model tables
+    Lin conv1; long class_emb = -1, pos_emb = -1; LNp ln_pre;
+    std::vector<VitLayer> vit;
+    Lin stem; std::vector<DistLayer> dl; std::vector<AdaLayer> ada;
+    Lin cls_proj; LNp ln_post; Lin proj; long agg_cls = -1, agg_sp_cls = -1;
+    // packing
+    std::vector<PackDesc> descs; std::vector<int> blk_desc, blk_first;
+    int nblk_visual = 0;                         // blocks [0, nblk_visual) pack visual.*, the rest dist_net.*
+    size_t packed_hdr = 0, packed_total = 0; long packed_elems = 0;
+    // bound buffers
+    float *theta = nullptr, *grads = nullptr, *logit_scale = nullptr, *dlogit_scale = nullptr;
+    const float* visual = nullptr;
+    char *packed = nullptr, *ws = nullptr;
+    size_t ws_bytes = 0;
+    // workspace
+    void *patches, *x0, *xa, *hbuf, *qkv, *att, *mlp;
+    std::vector<void*> feat;
+    std::vector<DistLayerWs> lw; std::vector<AdaWs> aw;
+    void* Xlast;
+    std::vector<void*> sbuf, ubuf;
+    void *Fz, *mean_cls, *ysum, *zpost, *v;
+    float *y_mean, *y_rstd, *logits, *dlogits, *loss;
+    // backward scratch
+    void *dR, *dMp, *dXn, *dXp, *dp, *dz, *dU, *dY, *dh2, *dh1, *dzf, *dNa, *dNb, *dkv, *dkn;
+    void *dv, *dzp, *dy, *du, *ds, *dc, *dzu, *dun, *do2, *dq2, *dkv2, *dqn2, *dkn2, *dzs, *dsn, *do_, *dq, *dqn;
+    int fwd_b = 0, branch_b = 0;
+    const float* text = nullptr;               // borrowed: text features of the last branch_forward
+    char err[512] = {0};
+};
+
+namespace {
+
+int fail(dist_handle* h, int rc, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(h->err, sizeof(h->err), fmt, ap);
+    va_end(ap);
+    return rc;
+}
+#define RUN(call)                                                        \
+    do {                                                                 \
+        int rc_ = (call);                                                \
+        if (rc_ != DIST_OK) return fail(h, rc_, "%s failed (%d) at %s:%d", #call, rc_, __FILE__, __LINE__); \
+    } while (0)
+
+std::string fmt(const char* f, ...) {
+    char buf[256];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof(buf), f, ap);
+    va_end(ap);
+    return buf;
+}
+
+long add_param(dist_handle* h, int kind, const std::string& name, std::initializer_list<int64_t> dims) {
+    Param p;
+    p.name = name;
+    p.ndim = (int)dims.size();
+    p.numel = 1;
+    int i = 0;
+    for (int64_t d : dims) { p.dim[i++] = d; p.numel *= d; }
+    p.offset = h->total[kind];
+    h->total[kind] += p.numel;
+    if (kind == 0) {
+        // DiST optimizer groups as intended by models/utils/optimizer.py:138-186
+        const bool one_d = name.find("bias") != std::string::npos || p.ndim == 1;
+        auto ends_with = [&](const char* s) { const size_t n = strlen(s); return name.size() >= n && name.compare(name.size() - n, n, s) == 0; };
+        if (ends_with("cls_token") || ends_with("positional_embedding")) p.group = 0;
+        else if (name.find("adapooling_nets") != std::string::npos) p.group = one_d ? 2 : 1;
+        else p.group = one_d ? 4 : 3;
+    }
+    h->index[kind][name] = (int)h->params[kind].size();
+    h->params[kind].push_back(p);
+    return p.offset;
+}
+
+long pk_alloc(dist_handle* h, long elems) {
+    h->packed_elems = (h->packed_elems + 127) & ~127L;
+    const long o = h->packed_elems;
+    h->packed_elems += elems;
+    return o;
+}
+
+// registers the pack descriptors of one GEMM weight.  `style`: 0 linear [N][K]; 1 conv [Co][Ci][taps] with
+// shift/spatial taps (data-gradient = per-tap transposes); 2 strided conv (data-gradient = plain transpose);
+// 3 patch conv [Co][3][tp][P][P] (forward only, K padded to Kp); 4 [K][N] projection matrix used as x @ W.
+void add_pack(dist_handle* h, Lin& l, int kind, int style, bool need_bwd) {
+    PackDesc d;
+    memset(&d, 0, sizeof(d));
+    d.src_off = l.w; d.src_kind = kind; d.co = l.N; d.kin = l.K; d.kpad = l.K; d.inner = 1;
+    if (style == 0) { d.s_co = l.K; d.s_tap = 0; d.s_outer = 1; }
+    else if (style == 1 || style == 2) { d.s_co = (long)l.K * l.taps; d.s_tap = 1; d.s_outer = l.taps; }
+    else if (style == 3) { d.kin = h->PP3; d.kpad = h->Kp; d.inner = h->PP3 / 3; d.s_co = (long)h->PP3 * l.taps; d.s_tap = h->PP3 / 3; d.s_outer = (long)(h->PP3 / 3) * l.taps; }
+    else { d.s_co = 1; d.s_tap = 0; d.s_outer = l.N; }
+    // forward layout [N][taps*kpad]
+    d.layout = PACK_F; d.rows = l.N; d.cols = l.taps * d.kpad;
+    l.pk.f = d.dst_off = pk_alloc(h, (long)d.rows * d.cols);
+    h->descs.push_back(d);
+    if (!need_bwd) return;
+    if (style == 1) { d.layout = PACK_B; d.rows = l.K; d.cols = l.taps * l.N; }
+    else { d.layout = PACK_FT; d.rows = l.taps * d.kpad; d.cols = l.N; }
+    l.pk.b = d.dst_off = pk_alloc(h, (long)d.rows * d.cols);
+    h->descs.push_back(d);
+}
+
+Lin make_lin(dist_handle* h, int kind, const std::string& prefix, int N, int K, int taps, int style, bool need_bwd,
+             std::initializer_list<int64_t> wdims, bool has_bias = true, const char* wname = "weight") {
+    Lin l;
+    l.N = N; l.K = K; l.taps = taps;
+    l.w = add_param(h, kind, prefix + wname, wdims);
+    if (has_bias) l.bias = add_param(h, kind, prefix + "bias", {N});
+    add_pack(h, l, kind, style, need_bwd);
+    return l;
+}
+LNp make_ln(dist_handle* h, int kind, const std::string& prefix, int C) {
+    LNp l;
+    l.C = C;
+    l.w = add_param(h, kind, prefix + "weight", {C});
+    l.b = add_param(h, kind, prefix + "bias", {C});
+    return l;
+}
+
+// nn.MultiheadAttention parameters: in_proj_weight [3C, C] split into the q rows and the k,v rows
+XAttn make_xattn(dist_handle* h, const std::string& prefix, int C) {
+    XAttn x;
+    const long w = add_param(h, 0, prefix + "attn.in_proj_weight", {3 * C, C});
+    const long b = add_param(h, 0, prefix + "attn.in_proj_bias", {3 * C});
+    x.q.N = C; x.q.K = C; x.q.w = w; x.q.bias = b;
+    x.kv.N = 2 * C; x.kv.K = C; x.kv.w = w + (long)C * C; x.kv.bias = b + C;
+    add_pack(h, x.q, 0, 0, true);
+    add_pack(h, x.kv, 0, 0, true);
+    x.out = make_lin(h, 0, prefix + "attn.out_proj.", C, C, 1, 0, true, {C, C});
+    x.ln1 = make_ln(h, 0, prefix + "ln_1.", C);
+    return x;
+}
+
+void build_tables(dist_handle* h) {
+    const dist_config& c = h->cfg;
+    const int d = c.width, Ci = c.integration_dim, Ct = c.temporal_dim, P = c.patch, C4 = h->C4, t = h->t;
+    // ---- frozen visual.* (kind 1), OpenAI-CLIP names (reference clip.py:218-247) ----
+    h->conv1.N = d; h->conv1.K = h->Kp; h->conv1.taps = 1;
+    h->conv1.w = add_param(h, 1, "visual.conv1.weight", {d, 3, P, P});
+    add_pack(h, h->conv1, 1, 3, false);
+    h->class_emb = add_param(h, 1, "visual.class_embedding", {d});
+    h->pos_emb = add_param(h, 1, "visual.positional_embedding", {h->L, d});
+    h->ln_pre = make_ln(h, 1, "visual.ln_pre.", d);
+    h->vit.resize(c.layers);
+    for (int i = 0; i < c.layers; ++i) {
+        VitLayer& v = h->vit[i];
+        const std::string p = fmt("visual.transformer.resblocks.%d.", i);
+        v.qkv = make_lin(h, 1, p + "attn.in_proj_", 3 * d, d, 1, 0, false, {3 * d, d});
+        v.out = make_lin(h, 1, p + "attn.out_proj.", d, d, 1, 0, false, {d, d});
+        v.ln1 = make_ln(h, 1, p + "ln_1.", d);
+        v.ln2 = make_ln(h, 1, p + "ln_2.", d);
+        v.fc = make_lin(h, 1, p + "mlp.c_fc.", 4 * d, d, 1, 0, false, {4 * d, d});
+        v.proj = make_lin(h, 1, p + "mlp.c_proj.", d, 4 * d, 1, 0, false, {d, 4 * d});
+    }
+    add_param(h, 1, "visual.ln_post.weight", {d});
+    add_param(h, 1, "visual.ln_post.bias", {d});
+    add_param(h, 1, "visual.proj", {d, c.embed_dim});
+    const int ndesc_visual = (int)h->descs.size();
+
+    // ---- trainable dist_net.* (kind 0) (reference dist.py:165-202) ----
+    h->stem.N = Ct; h->stem.K = h->Kp; h->stem.taps = c.temporal_patch;
+    h->stem.w = add_param(h, 0, "dist_net.temporal_stem.weight", {Ct, 3, c.temporal_patch, P, P});
+    h->stem.bias = add_param(h, 0, "dist_net.temporal_stem.bias", {Ct});
+    add_pack(h, h->stem, 0, 3, false);
+    h->dl.resize(c.layers);
+    for (int i = 0; i < c.layers; ++i) {
+        DistLayer& l = h->dl[i];
+        l.in_lin = make_lin(h, 0, fmt("dist_net.input_linears.%d.", i), Ci, d, 1, 0, false, {Ci, d});
+        l.i2t = make_lin(h, 0, fmt("dist_net.integration2temporal_nets.%d.linear_fuse.", i), Ct, Ci, 1, 0, true, {Ct, Ci});
+        l.cls_token = add_param(h, 0, fmt("dist_net.temporal2integration_nets.%d.cls_token", i), {1, 1, t, Ci});
+        l.t2i = make_lin(h, 0, fmt("dist_net.temporal2integration_nets.%d.linear_fuse.", i), Ci, Ct, c.alpha, 2, true, {Ci, Ct, c.alpha, 1, 1});
+        std::string p = fmt("dist_net.temporal_nets.%d.", i);
+        l.tn_fc1 = make_lin(h, 0, p + "temporal_net.c_fc1.", Ct, Ct, c.temporal_kernel, 1, true, {Ct, Ct, c.temporal_kernel, 1, 1});
+        l.tn_fc2 = make_lin(h, 0, p + "temporal_net.c_fc2.", Ct, Ct, 9, 1, true, {Ct, Ct, 1, 3, 3});
+        l.tn_ln = make_ln(h, 0, p + "ln.", Ct);
+        p = fmt("dist_net.integration_nets.%d.", i);
+        l.ffn_fc = make_lin(h, 0, p + "ffn.c_fc.", Ci, Ci, 1, 0, true, {Ci, Ci});
+        l.ffn_proj = make_lin(h, 0, p + "ffn.c_proj.", Ci, Ci, 1, 0, true, {Ci, Ci});
+        l.tf_fc1 = make_lin(h, 0, p + "temporal_ffn.c_fc1.", C4, Ci, 1, 0, true, {C4, Ci, 1, 1, 1});
+        l.tf_fc2 = make_lin(h, 0, p + "temporal_ffn.c_fc2.", C4, C4, c.temporal_kernel, 1, true, {C4, C4, c.temporal_kernel, 1, 1});
+        l.tf_proj = make_lin(h, 0, p + "temporal_ffn.c_proj.", Ci, C4, 1, 0, true, {Ci, C4, 1, 1, 1});
+        l.in_ln = make_ln(h, 0, p + "ln.", Ci);
+        l.in_ln_t = make_ln(h, 0, p + "ln_temporal.", Ci);
+    }
+    h->ada.resize(c.ada_layers);
+    for (int a = 0; a < c.ada_layers; ++a) {
+        AdaLayer& A = h->ada[a];
+        const std::string p = fmt("dist_net.adapooling_nets.%d.", a);
+        A.pos = add_param(h, 0, p + "positional_embedding", {1, t, Ci});
+        A.tm = make_xattn(h, p + "temporal_transformer.", Ci);
+        A.sp = make_xattn(h, p + "spatial_transformer.", Ci);
+        A.tm_fc = make_lin(h, 0, p + "output_map_cls_token.c_fc.", 4 * Ci, Ci, 1, 0, true, {4 * Ci, Ci});
+        A.tm_proj = make_lin(h, 0, p + "output_map_cls_token.c_proj.", Ci, 4 * Ci, 1, 0, true, {Ci, 4 * Ci});
+        A.sp_fc = make_lin(h, 0, p + "output_map_spatial_cls_token.c_fc.", 4 * Ci, Ci, 1, 0, true, {4 * Ci, Ci});
+        A.sp_proj = make_lin(h, 0, p + "output_map_spatial_cls_token.c_proj.", Ci, 4 * Ci, 1, 0, true, {Ci, 4 * Ci});
+        A.ln_tm = make_ln(h, 0, p + "ln_out_temp_cls_token.", Ci);
+        A.ln_sp = make_ln(h, 0, p + "ln_out_spat_cls_token.", Ci);
+    }
+    h->cls_proj = make_lin(h, 0, "dist_net.proj_spatial_cls_token.", Ci, d, 1, 0, false, {Ci, d});
+    h->ln_post = make_ln(h, 0, "dist_net.ln_post.", Ci);
+    h->proj.N = c.embed_dim; h->proj.K = Ci;
+    h->proj.w = add_param(h, 0, "dist_net.proj", {Ci, c.embed_dim});
+    add_pack(h, h->proj, 0, 4, true);
+    h->agg_cls = add_param(h, 0, "dist_net.aggregated_cls_token", {1, 1, Ci});
+    h->agg_sp_cls = add_param(h, 0, "dist_net.aggregated_spatial_cls_token", {1, 1, Ci});
+
+    // ---- pack launch table: one block per PACK_PER_BLOCK destination elements ----
+    for (size_t di = 0; di < h->descs.size(); ++di) {
+        if ((int)di == ndesc_visual) h->nblk_visual = (int)h->blk_desc.size();
+        const long total = (long)h->descs[di].rows * h->descs[di].cols;
+        const int nb = (int)((total + PACK_PER_BLOCK - 1) / PACK_PER_BLOCK);
+        h->blk_first.push_back((int)h->blk_desc.size());
+        for (int b = 0; b < nb; ++b) h->blk_desc.push_back((int)di);
+    }
+    size_t hdr = h->descs.size() * sizeof(PackDesc);
+    hdr = (hdr + 255) & ~(size_t)255;
+    hdr += h->blk_desc.size() * sizeof(int);
+    hdr = (hdr + 255) & ~(size_t)255;
+    hdr += h->blk_first.size() * sizeof(int);
+    hdr = (hdr + 255) & ~(size_t)255;
+    h->packed_hdr = hdr;
+    h->packed_total = hdr + (size_t)(h->packed_elems + 128) * h->es;
+}
+
+// workspace carve-up; run with base == nullptr to size it
+size_t layout_ws(dist_handle* h, char* base) {
+    const dist_config& c = h->cfg;
+    Arena a;
+    a.base = base;
+    const size_t es = h->es;
+    const long b = c.batch;
+    const long rowsX = b * c.frames * h->N, rowsS = b * h->t * h->L, rowsQ = b * h->t * h->N, bt = b * h->t;
+    const int d = c.width, Ci = c.integration_dim, Ct = c.temporal_dim, C4 = h->C4, H = h->iheads;
+    auto T_ = [&](long rows, long cols) { return a.take((size_t)rows * cols * es); };
+    auto F_ = [&](long n) { return static_cast<float*>(a.take((size_t)n * sizeof(float))); };
+    h->patches = T_(rowsX, h->Kp);
+    h->x0 = T_(rowsS, d); h->xa = T_(rowsS, d); h->hbuf = T_(rowsS, d);
+    h->qkv = T_(rowsS, 3 * d); h->att = T_(rowsS, d); h->mlp = T_(rowsS, 4 * d);
+    h->feat.resize(c.layers);
+    for (int i = 0; i < c.layers; ++i) h->feat[i] = T_(rowsS, d);
+    h->lw.resize(c.layers);
+    for (int i = 0; i < c.layers; ++i) {
+        DistLayerWs& w = h->lw[i];
+        w.X = T_(rowsX, Ct); w.U = T_(rowsX, Ct); w.z = T_(rowsX, Ct); w.V = T_(rowsX, Ct); w.p = T_(rowsX, Ct); w.Xp = T_(rowsX, Ct);
+        w.M = T_(rowsS, Ci); w.Mp = T_(rowsS, Ci); w.Na = T_(rowsS, Ci); w.Nb = T_(rowsS, Ci); w.zf = T_(rowsS, Ci); w.hf = T_(rowsS, Ci);
+        w.h1 = T_(rowsS, C4); w.h2 = T_(rowsS, C4); w.g2 = T_(rowsS, C4); w.R = T_(rowsS, Ci);
+        w.tn_mean = F_(rowsX); w.tn_rstd = F_(rowsX); w.in_mean = F_(rowsS); w.in_rstd = F_(rowsS);
+    }
+    h->Xlast = T_(rowsX, Ct);
+    h->aw.resize(c.ada_layers);
+    h->sbuf.resize(c.ada_layers + 1); h->ubuf.resize(c.ada_layers + 1);
+    for (int k = 0; k <= c.ada_layers; ++k) { h->sbuf[k] = T_(bt, Ci); h->ubuf[k] = T_(b, Ci); }
+    for (int k = 0; k < c.ada_layers; ++k) {
+        AdaWs& w = h->aw[k];
+        w.kn = T_(rowsS, Ci); w.kv = T_(rowsS, 2 * Ci); w.qn = T_(bt, Ci); w.q = T_(bt, Ci); w.o = T_(bt, Ci); w.s1 = T_(bt, Ci);
+        w.sn = T_(bt, Ci); w.zs = T_(bt, 4 * Ci); w.hs = T_(bt, 4 * Ci); w.c = T_(bt, Ci); w.kn2 = T_(bt, Ci); w.kv2 = T_(bt, 2 * Ci);
+        w.qn2 = T_(b, Ci); w.q2 = T_(b, Ci); w.o2 = T_(b, Ci); w.u1 = T_(b, Ci); w.un = T_(b, Ci); w.zu = T_(b, 4 * Ci); w.hu = T_(b, 4 * Ci);
+        w.kn_mean = F_(rowsS); w.kn_rstd = F_(rowsS); w.qn_mean = F_(bt); w.qn_rstd = F_(bt); w.s1_mean = F_(bt); w.s1_rstd = F_(bt);
+        w.kn2_mean = F_(bt); w.kn2_rstd = F_(bt); w.qn2_mean = F_(b); w.qn2_rstd = F_(b); w.u1_mean = F_(b); w.u1_rstd = F_(b);
+        w.probs = F_(bt * H * h->L); w.probs2 = F_(b * H * h->t);
+    }
+    h->Fz = T_(rowsS, Ci); h->mean_cls = T_(b, d); h->ysum = T_(b, Ci); h->zpost = T_(b, Ci); h->v = T_(b, c.embed_dim);
+    h->y_mean = F_(b); h->y_rstd = F_(b); h->logits = F_(b * c.num_classes); h->dlogits = F_(b * c.num_classes); h->loss = F_(4);
+    // backward scratch
+    h->dR = T_(rowsS, Ci); h->dMp = T_(rowsS, Ci); h->dXn = T_(rowsX, Ct); h->dXp = T_(rowsX, Ct); h->dp = T_(rowsX, Ct);
+    h->dz = T_(rowsX, Ct); h->dU = T_(rowsX, Ct); h->dY = T_(rowsQ, Ct); h->dh2 = T_(rowsS, C4); h->dh1 = T_(rowsS, C4);
+    h->dzf = T_(rowsS, Ci); h->dNa = T_(rowsS, Ci); h->dNb = T_(rowsS, Ci); h->dkv = T_(rowsS, 2 * Ci); h->dkn = T_(rowsS, Ci);
+    h->dv = T_(b, c.embed_dim); h->dzp = T_(b, Ci); h->dy = T_(b, Ci); h->du = T_(b, Ci); h->ds = T_(bt, Ci); h->dc = T_(bt, Ci);
+    h->dzu = T_(bt, 4 * Ci); h->dun = T_(bt, Ci); h->do2 = T_(b, Ci); h->dq2 = T_(b, Ci); h->dkv2 = T_(bt, 2 * Ci); h->dqn2 = T_(b, Ci);
+    h->dkn2 = T_(bt, Ci); h->dzs = T_(bt, 4 * Ci); h->dsn = T_(bt, Ci); h->do_ = T_(bt, Ci); h->dq = T_(bt, Ci); h->dqn = T_(bt, Ci);
+    return a.off + 256;
+}
+
+// ---- launch helpers ---------------------------------------------------------------------------------------
+struct Ctx {
+    dist_handle* h;
+    hipStream_t s;
+    int dtype;
+    const char* pk(long off) const { return h->packed + h->packed_hdr + (size_t)off * h->es; }
+    const float* th(long off) const { return h->theta + off; }
+    const float* vs(long off) const { return h->visual + off; }
+    float* gr(long off) const { return h->grads + off; }
+};
+
+dist_rowmap RM(int mode = DIST_RM_PLAIN, int p0 = 0, int p1 = 0, int sign = 1) { return dist_rowmap{mode, p0, p1, sign}; }
+dist_outmap OM(int mode = DIST_OM_PLAIN, int p0 = 0, int p1 = 0, int p2 = 0) { return dist_outmap{mode, p0, p1, p2}; }
+
+// C (and/or C2) = epi(A[amap] . W^T): thin positional wrapper over dist_op_gemm_nt
+int gemm(const Ctx& c, const void* A, int lda, const void* W, long M, int N, int K, int taps, void* C, int ldc,
+         const float* bias, const void* res, const void* aux, void* C2, dist_rowmap am = RM(), dist_outmap om = OM()) {
+    dist_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.B = W; g.C = C; g.C2 = C2; g.bias = bias; g.res = res; g.aux = aux;
+    g.M = M; g.N = N; g.K = K; g.taps = taps;
+    g.lda = lda; g.ldb = taps * K; g.ldc = ldc; g.ldc2 = ldc; g.ldres = ldc; g.ldaux = ldc;
+    g.amap = am; g.omap = om;
+    g.flags = (bias ? DIST_EPI_BIAS : 0) | (res ? DIST_EPI_RES : 0) | (aux ? DIST_EPI_MULG : 0) | (C2 ? DIST_EPI_ACT2 : 0);
+    g.dtype = c.dtype;
+    return dist_op_gemm_nt(&g, c.s);
+}
+
+// weight gradient of a Lin into the flat grads buffer, in the reference parameter layout
+int wgrad(const Ctx& c, const Lin& l, const void* dY, int ld_dy, const void* X, int ldx, long M,
+          dist_rowmap am = RM(), dist_rowmap bm = RM(), int style = 0) {
+    dist_gemm_tn_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = dY; g.B = X; g.out = c.gr(l.w);
+    g.M = M; g.NI = l.N; g.K = l.K; g.taps = l.taps; g.lda = ld_dy; g.ldb = ldx; g.amap = am; g.bmap = bm;
+    if (style == 0) { g.so_i = l.K; g.so_tap = 0; g.so_outer = 1; g.inner = 1; }
+    else if (style == 1 || style == 2) { g.so_i = (long)l.K * l.taps; g.so_tap = 1; g.so_outer = l.taps; g.inner = 1; }
+    else if (style == 4) { g.NI = l.K; g.K = l.N; g.so_i = l.N; g.so_tap = 0; g.so_outer = 1; g.inner = 1; }   // [K][N] matrix used as x @ W
+    else { const int PP3 = c.h->PP3, PP = PP3 / 3; g.K = PP3; g.so_i = (long)PP3 * l.taps; g.so_tap = PP; g.so_outer = (long)PP * l.taps; g.inner = PP; }
+    g.dtype = c.dtype; g.use_tr = c.h->cfg.use_tr;
+    return dist_op_gemm_tn(&g, c.s);
+}
+int bgrad(const Ctx& c, long bias_off, const void* dY, long rows, int C, dist_rowmap m = RM()) {
+    return dist_op_colsum(dY, c.gr(bias_off), rows, C, C, m, c.dtype, c.s);
+}
+int ln_fwd(const Ctx& c, const float* wbase, const LNp& l, const void* x, void* y, long rows, float* mean, float* rstd,
+           const LNp* l2 = nullptr, void* y2 = nullptr, const float* addend = nullptr, int period = 0) {
+    dist_ln_args a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.y = y; a.y2 = y2; a.w = wbase + l.w; a.b = wbase + l.b;
+    if (l2) { a.w2 = wbase + l2->w; a.b2 = wbase + l2->b; }
+    a.addend = addend; a.addend_period = period; a.mean = mean; a.rstd = rstd;
+    a.rows = rows; a.C = l.C; a.dtype = c.dtype; a.eps = 1e-5f;
+    return dist_op_layernorm(&a, c.s);
+}
+int ln_bwd(const Ctx& c, const LNp& l, const void* x, const float* mean, const float* rstd, const void* dy, void* dx, bool accumulate,
+           long rows, const LNp* l2 = nullptr, const void* dy2 = nullptr) {
+    dist_ln_bwd_args a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.mean = mean; a.rstd = rstd; a.dy = dy; a.w = c.th(l.w); a.dx = dx; a.accumulate_dx = accumulate ? 1 : 0;
+    a.dw = c.gr(l.w); a.db = c.gr(l.b);
+    if (l2) { a.dy2 = dy2; a.w2 = c.th(l2->w); a.dw2 = c.gr(l2->w); a.db2 = c.gr(l2->b); }
+    a.rows = rows; a.C = l.C; a.dtype = c.dtype;
+    return dist_op_layernorm_bwd(&a, c.s);
+}
+
+}  // namespace
+
+// =============================================================================================================
 extern "C" const char* dist_strerror(int code) {
     switch (code) {
         case DIST_OK: return "ok";
@@ -11,26 +439,391 @@ extern "C" const char* dist_strerror(int code) {
     }
 }
 extern "C" int dist_abi_version(void) { return 1; }
-// ---- temporary stubs (replaced by the real engine) ----
-struct dist_handle { int x; };
-extern "C" {
-int dist_create(const dist_config*, dist_handle**) { return DIST_ERR_STATE; }
-void dist_destroy(dist_handle*) {}
-const char* dist_last_error(const dist_handle*) { return ""; }
-int dist_param_count(const dist_handle*, int) { return 0; }
-const char* dist_param_name(const dist_handle*, int, int) { return ""; }
-int dist_param_ndim(const dist_handle*, int, int) { return 0; }
-int64_t dist_param_dim(const dist_handle*, int, int, int) { return 0; }
-int64_t dist_param_offset(const dist_handle*, int, int) { return 0; }
-int64_t dist_param_total(const dist_handle*, int) { return 0; }
-int dist_param_group(const dist_handle*, int) { return 0; }
-size_t dist_workspace_bytes(const dist_handle*) { return 0; }
-size_t dist_packed_bytes(const dist_handle*) { return 0; }
-int dist_bind(dist_handle*, float*, float*, const float*, float*, float*, void*, void*) { return DIST_ERR_STATE; }
-int dist_pack_weights(dist_handle*, int, void*) { return DIST_ERR_STATE; }
-int dist_vit_forward(dist_handle*, const float*, int, void*) { return DIST_ERR_STATE; }
-int dist_branch_forward(dist_handle*, const float*, int, float*, float*, void*) { return DIST_ERR_STATE; }
-int dist_branch_backward(dist_handle*, const float*, int, int, void*) { return DIST_ERR_STATE; }
-int dist_loss(dist_handle*, const float*, int, float*, float*, void*) { return DIST_ERR_STATE; }
-int dist_debug_tensor(dist_handle*, const char*, const void**, int64_t*, int*) { return DIST_ERR_STATE; }
+
+extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
+    if (!cfg || !out) return DIST_ERR_ARG;
+    const dist_config& c = *cfg;
+    if (c.dtype != DIST_F32 && c.dtype != DIST_BF16) return DIST_ERR_ARG;
+    if (c.batch <= 0 || c.frames <= 0 || c.alpha <= 0 || c.frames % c.alpha || c.patch <= 0 || c.resolution % c.patch) return DIST_ERR_ARG;
+    if (c.width % 64 || c.integration_dim % 64 || c.temporal_dim % 8 || c.layers <= 0 || c.ada_layers < 0) return DIST_ERR_ARG;
+    if (c.int_temporal_div <= 0 || c.integration_dim % c.int_temporal_div || (c.integration_dim / c.int_temporal_div) % 8) return DIST_ERR_ARG;
+    if (c.temporal_kernel % 2 == 0 || c.temporal_patch % 2 == 0 || c.num_classes <= 0 || c.embed_dim % 8 || c.embed_dim > 1024) return DIST_ERR_ARG;
+    if (c.width > 1024 || c.integration_dim > 1024) return DIST_ERR_ARG;
+    dist_handle* h = new (std::nothrow) dist_handle();
+    if (!h) return DIST_ERR_ARG;
+    h->cfg = c;
+    h->es = c.dtype == DIST_BF16 ? 2 : 4;
+    h->G = c.resolution / c.patch; h->N = h->G * h->G; h->L = h->N + 1; h->t = c.frames / c.alpha;
+    h->heads = c.width / 64; h->iheads = c.integration_dim / 64; h->C4 = c.integration_dim / c.int_temporal_div;
+    h->PP3 = 3 * c.patch * c.patch; h->Kp = (h->PP3 + 7) / 8 * 8;
+    build_tables(h);
+    h->ws_bytes = layout_ws(h, nullptr);
+    *out = h;
+    return DIST_OK;
+}
+extern "C" void dist_destroy(dist_handle* h) { delete h; }
+extern "C" const char* dist_last_error(const dist_handle* h) { return h ? h->err : ""; }
+
+extern "C" int dist_param_count(const dist_handle* h, int kind) { return (h && (kind == 0 || kind == 1)) ? (int)h->params[kind].size() : 0; }
+static const Param* get_param(const dist_handle* h, int kind, int i) {
+    if (!h || (kind != 0 && kind != 1) || i < 0 || i >= (int)h->params[kind].size()) return nullptr;
+    return &h->params[kind][i];
+}
+extern "C" const char* dist_param_name(const dist_handle* h, int kind, int i) { const Param* p = get_param(h, kind, i); return p ? p->name.c_str() : ""; }
+extern "C" int dist_param_ndim(const dist_handle* h, int kind, int i) { const Param* p = get_param(h, kind, i); return p ? p->ndim : 0; }
+extern "C" int64_t dist_param_dim(const dist_handle* h, int kind, int i, int d) { const Param* p = get_param(h, kind, i); return (p && d >= 0 && d < p->ndim) ? p->dim[d] : 0; }
+extern "C" int64_t dist_param_offset(const dist_handle* h, int kind, int i) { const Param* p = get_param(h, kind, i); return p ? p->offset : -1; }
+extern "C" int64_t dist_param_total(const dist_handle* h, int kind) { return (h && (kind == 0 || kind == 1)) ? h->total[kind] : 0; }
+extern "C" int dist_param_group(const dist_handle* h, int i) { const Param* p = get_param(h, 0, i); return p ? p->group : -1; }
+extern "C" size_t dist_workspace_bytes(const dist_handle* h) { return h ? h->ws_bytes : 0; }
+extern "C" size_t dist_packed_bytes(const dist_handle* h) { return h ? h->packed_total : 0; }
+
+extern "C" int dist_bind(dist_handle* h, float* theta, float* grads, const float* visual, float* logit_scale, float* dlogit_scale,
+                         void* packed, void* workspace) {
+    if (!h) return DIST_ERR_ARG;
+    if (!theta || !visual || !logit_scale || !packed || !workspace) return fail(h, DIST_ERR_UNBOUND, "dist_bind: null buffer");
+    h->theta = theta; h->grads = grads; h->visual = visual; h->logit_scale = logit_scale; h->dlogit_scale = dlogit_scale;
+    h->packed = static_cast<char*>(packed); h->ws = static_cast<char*>(workspace);
+    layout_ws(h, h->ws);
+    // pack tables -> header of the packed buffer (pageable host memory: the copies complete before returning)
+    char* p = h->packed;
+    HIP_CHECK_RET(hipMemcpy(p, h->descs.data(), h->descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
+    size_t off = (h->descs.size() * sizeof(PackDesc) + 255) & ~(size_t)255;
+    HIP_CHECK_RET(hipMemcpy(p + off, h->blk_desc.data(), h->blk_desc.size() * sizeof(int), hipMemcpyHostToDevice));
+    off = (off + h->blk_desc.size() * sizeof(int) + 255) & ~(size_t)255;
+    HIP_CHECK_RET(hipMemcpy(p + off, h->blk_first.data(), h->blk_first.size() * sizeof(int), hipMemcpyHostToDevice));
+    h->fwd_b = h->branch_b = 0;
+    return DIST_OK;
+}
+
+extern "C" int dist_pack_weights(dist_handle* h, int what, void* stream) {
+    if (!h) return DIST_ERR_ARG;
+    if (!h->packed) return fail(h, DIST_ERR_UNBOUND, "dist_pack_weights before dist_bind");
+    const PackDesc* descs = reinterpret_cast<const PackDesc*>(h->packed);
+    size_t off = (h->descs.size() * sizeof(PackDesc) + 255) & ~(size_t)255;
+    const int* blk_desc = reinterpret_cast<const int*>(h->packed + off);
+    off = (off + h->blk_desc.size() * sizeof(int) + 255) & ~(size_t)255;
+    const int* blk_first = reinterpret_cast<const int*>(h->packed + off);
+    const int nblk = (int)h->blk_desc.size();
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    void* dst = h->packed + h->packed_hdr;
+    int first = 0, count = nblk;
+    if (what == 1) count = h->nblk_visual;
+    else if (what == 2) { first = h->nblk_visual; count = nblk - h->nblk_visual; }
+    else if (what != 3) return fail(h, DIST_ERR_ARG, "dist_pack_weights: what must be 1, 2 or 3");
+    RUN(dist_k_pack(descs, blk_desc, blk_first, first, count, h->theta, h->visual, dst, h->cfg.dtype, s));
+    return DIST_OK;
+}
+
+// -------------------------------------------------------------------------------------------------------------
+extern "C" int dist_vit_forward(dist_handle* h, const float* video, int b, void* stream) {
+    if (!h || !video) return DIST_ERR_ARG;
+    if (!h->ws) return fail(h, DIST_ERR_UNBOUND, "dist_vit_forward before dist_bind");
+    if (b <= 0 || b > h->cfg.batch) return fail(h, DIST_ERR_ARG, "batch %d outside (0, %d]", b, h->cfg.batch);
+    const dist_config& c = h->cfg;
+    Ctx x{h, static_cast<hipStream_t>(stream), c.dtype};
+    const int d = c.width, N = h->N, L = h->L;
+    const long rowsS = (long)b * h->t * L, rowsQ = (long)b * h->t * N;
+
+    RUN(dist_op_patchify(video, h->patches, b, c.frames, c.resolution, c.resolution, c.patch, c.dtype, stream));
+    // patch embedding of the frames k = alpha*j only (the reference embeds all T frames and drops the
+    // others at clip.py:284); rows land behind their frame's cls row
+    RUN(gemm(x, h->patches, h->Kp, x.pk(h->conv1.pk.f), rowsQ, d, h->Kp, 1, h->xa, d, nullptr, nullptr, nullptr, nullptr,
+             RM(DIST_RM_STRIDED, c.alpha, N), OM(DIST_OM_INSERTCLS, N)));
+    RUN(dist_k_cls_rows(h->xa, nullptr, x.vs(h->class_emb), b * h->t, L, d, 1, c.dtype, x.s));
+    RUN(ln_fwd(x, h->visual, h->ln_pre, h->xa, h->x0, rowsS, nullptr, nullptr, nullptr, nullptr, x.vs(h->pos_emb), L));
+    const void* xin = h->x0;
+    for (int i = 0; i < c.layers; ++i) {
+        const VitLayer& v = h->vit[i];
+        RUN(ln_fwd(x, h->visual, v.ln1, xin, h->hbuf, rowsS, nullptr, nullptr));
+        RUN(gemm(x, h->hbuf, d, x.pk(v.qkv.pk.f), rowsS, 3 * d, d, 1, h->qkv, 3 * d, x.vs(v.qkv.bias), nullptr, nullptr, nullptr));
+        RUN(dist_op_attention(h->qkv, h->att, b * h->t, L, h->heads, c.dtype, stream));
+        RUN(gemm(x, h->att, d, x.pk(v.out.pk.f), rowsS, d, d, 1, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr));
+        RUN(ln_fwd(x, h->visual, v.ln2, h->xa, h->hbuf, rowsS, nullptr, nullptr));
+        RUN(gemm(x, h->hbuf, d, x.pk(v.fc.pk.f), rowsS, 4 * d, d, 1, nullptr, 4 * d, x.vs(v.fc.bias), nullptr, nullptr, h->mlp));
+        RUN(gemm(x, h->mlp, 4 * d, x.pk(v.proj.pk.f), rowsS, d, 4 * d, 1, h->feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr));
+        xin = h->feat[i];
+    }
+    h->fwd_b = b;
+    h->branch_b = 0;
+    return DIST_OK;
+}
+
+// one-query cross attention block: s_out = s_in + out_proj(attn(q = W_q LN(s_in), kv = W_kv LN(keys)))
+static int xattn_fwd(dist_handle* h, const Ctx& x, const XAttn& A, const void* s_in, long nq, const void* keys, long nkeys_total, int S,
+                     void* kn, float* kn_mean, float* kn_rstd, void* kv, void* qn, float* qn_mean, float* qn_rstd, void* q, void* o,
+                     float* probs, void* s_out) {
+    const int Ci = h->cfg.integration_dim;
+    RUN(ln_fwd(x, h->theta, A.ln1, keys, kn, nkeys_total, kn_mean, kn_rstd));
+    RUN(gemm(x, kn, Ci, x.pk(A.kv.pk.f), nkeys_total, 2 * Ci, Ci, 1, kv, 2 * Ci, x.th(A.kv.bias), nullptr, nullptr, nullptr));
+    RUN(ln_fwd(x, h->theta, A.ln1, s_in, qn, nq, qn_mean, qn_rstd));
+    RUN(gemm(x, qn, Ci, x.pk(A.q.pk.f), nq, Ci, Ci, 1, q, Ci, x.th(A.q.bias), nullptr, nullptr, nullptr));
+    RUN(dist_op_xattn1q(q, kv, o, probs, (int)nq, S, Ci, x.dtype, x.s));
+    RUN(gemm(x, o, Ci, x.pk(A.out.pk.f), nq, Ci, Ci, 1, s_out, Ci, x.th(A.out.bias), s_in, nullptr, nullptr));
+    return DIST_OK;
+}
+
+extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, int b, float* logits, float* vid_logits, void* stream) {
+    if (!h || !text_features) return DIST_ERR_ARG;
+    if (!h->ws) return fail(h, DIST_ERR_UNBOUND, "dist_branch_forward before dist_bind");
+    if (h->fwd_b != b) return fail(h, DIST_ERR_STATE, "dist_branch_forward(b=%d) needs dist_vit_forward with the same batch first (have %d)", b, h->fwd_b);
+    const dist_config& c = h->cfg;
+    Ctx x{h, static_cast<hipStream_t>(stream), c.dtype};
+    const int d = c.width, Ci = c.integration_dim, Ct = c.temporal_dim, C4 = h->C4, N = h->N, L = h->L, T = c.frames, t = h->t, al = c.alpha;
+    const long rowsX = (long)b * T * N, rowsS = (long)b * t * L, rowsQ = (long)b * t * N, bt = (long)b * t;
+    const int nl = c.layers;
+
+    // temporal stem: Conv3d k=(tp,P,P) as a 5-tap row-shifted GEMM over the shared patch rows (dist.py:178-181,225)
+    RUN(gemm(x, h->patches, h->Kp, x.pk(h->stem.pk.f), rowsX, Ct, h->Kp, h->stem.taps, h->lw[0].X, Ct, x.th(h->stem.bias), nullptr, nullptr, nullptr,
+             RM(DIST_RM_SHIFT, T * N, N, 1)));
+    for (int i = 0; i < nl; ++i) {
+        const DistLayer& l = h->dl[i];
+        DistLayerWs& w = h->lw[i];
+        void* Xnext = (i + 1 < nl) ? h->lw[i + 1].X : h->Xlast;
+        // TemporalNet (dist.py:48-65)
+        RUN(ln_fwd(x, h->theta, l.tn_ln, w.X, w.U, rowsX, w.tn_mean, w.tn_rstd));
+        RUN(gemm(x, w.U, Ct, x.pk(l.tn_fc1.pk.f), rowsX, Ct, Ct, l.tn_fc1.taps, w.z, Ct, x.th(l.tn_fc1.bias), nullptr, nullptr, w.V,
+                 RM(DIST_RM_SHIFT, T * N, N, 1)));
+        RUN(gemm(x, w.V, Ct, x.pk(l.tn_fc2.pk.f), rowsX, Ct, Ct, 9, w.p, Ct, x.th(l.tn_fc2.bias), w.X, nullptr, w.Xp, RM(DIST_RM_SPATIAL, h->G, 0, 1)));
+        // mid_feat = input_linear(F_i) + res_feat (dist.py:229)
+        RUN(gemm(x, h->feat[i], d, x.pk(l.in_lin.pk.f), rowsS, Ci, d, 1, w.M, Ci, x.th(l.in_lin.bias), i ? h->lw[i - 1].R : nullptr, nullptr, nullptr));
+        // I2T (dist.py:90-105,231): Linear on the non-cls rows, nearest-upsampled x alpha in T, + x_temporal.
+        // (the last layer's result is discarded by the reference, dist.py:235 -> skipped)
+        if (i + 1 < nl)
+            RUN(gemm(x, w.M, Ci, x.pk(l.i2t.pk.f), rowsQ, Ct, Ci, 1, Xnext, Ct, x.th(l.i2t.bias), w.Xp, nullptr, nullptr,
+                     RM(DIST_RM_SKIPCLS, N), OM(DIST_OM_DUP, al, N)));
+        // T2I (dist.py:68-86,232): strided temporal conv into the patch rows of M', learnable cls row
+        RUN(gemm(x, w.Xp, Ct, x.pk(l.t2i.pk.f), rowsQ, Ci, Ct, al, w.Mp, Ci, x.th(l.t2i.bias), w.M, nullptr, nullptr,
+                 RM(DIST_RM_STRIDED, al, N), OM(DIST_OM_INSERTCLS, N)));
+        RUN(dist_k_cls_rows(w.Mp, w.M, x.th(l.cls_token), (int)bt, L, Ci, t, c.dtype, x.s));
+        // IntegrationNetwork (dist.py:16-45)
+        RUN(ln_fwd(x, h->theta, l.in_ln, w.Mp, w.Na, rowsS, w.in_mean, w.in_rstd, &l.in_ln_t, w.Nb));
+        RUN(gemm(x, w.Na, Ci, x.pk(l.ffn_fc.pk.f), rowsS, Ci, Ci, 1, w.zf, Ci, x.th(l.ffn_fc.bias), nullptr, nullptr, w.hf));
+        RUN(gemm(x, w.Nb, Ci, x.pk(l.tf_fc1.pk.f), rowsS, C4, Ci, 1, w.h1, C4, x.th(l.tf_fc1.bias), nullptr, nullptr, nullptr));
+        RUN(gemm(x, w.h1, C4, x.pk(l.tf_fc2.pk.f), rowsS, C4, C4, l.tf_fc2.taps, w.h2, C4, x.th(l.tf_fc2.bias), nullptr, nullptr, w.g2,
+                 RM(DIST_RM_SHIFT, t * L, L, 1)));
+        RUN(gemm(x, w.hf, Ci, x.pk(l.ffn_proj.pk.f), rowsS, Ci, Ci, 1, w.R, Ci, x.th(l.ffn_proj.bias), nullptr, nullptr, nullptr));
+        RUN(gemm(x, w.g2, C4, x.pk(l.tf_proj.pk.f), rowsS, Ci, C4, 1, w.R, Ci, x.th(l.tf_proj.bias), w.R, nullptr, nullptr));
+    }
+    // current_layer_feat = res_feat + updated_mid_feat (dist.py:239)
+    RUN(dist_op_add(h->lw[nl - 1].R, h->lw[nl - 1].Mp, h->Fz, rowsS * Ci, c.dtype, stream));
+    RUN(dist_k_bcast_rows(x.th(h->agg_sp_cls), h->sbuf[0], bt, Ci, c.dtype, x.s));
+    RUN(dist_k_bcast_rows(x.th(h->agg_cls), h->ubuf[0], b, Ci, c.dtype, x.s));
+    for (int a = 0; a < c.ada_layers; ++a) {
+        const AdaLayer& A = h->ada[a];
+        AdaWs& w = h->aw[a];
+        // spatial: per-frame cls query over the L tokens of its frame (dist.py:144-146)
+        RUN(xattn_fwd(h, x, A.sp, h->sbuf[a], bt, h->Fz, rowsS, L, w.kn, w.kn_mean, w.kn_rstd, w.kv, w.qn, w.qn_mean, w.qn_rstd, w.q, w.o, w.probs, w.s1));
+        RUN(ln_fwd(x, h->theta, A.ln_sp, w.s1, w.sn, bt, w.s1_mean, w.s1_rstd));
+        RUN(gemm(x, w.sn, Ci, x.pk(A.sp_fc.pk.f), bt, 4 * Ci, Ci, 1, w.zs, 4 * Ci, x.th(A.sp_fc.bias), nullptr, nullptr, w.hs));
+        RUN(gemm(x, w.hs, 4 * Ci, x.pk(A.sp_proj.pk.f), bt, Ci, 4 * Ci, 1, h->sbuf[a + 1], Ci, x.th(A.sp_proj.bias), w.s1, nullptr, nullptr));
+        // temporal: per-clip cls query over its t frame tokens (+ positional embedding) (dist.py:153-160)
+        RUN(dist_k_add_table(h->sbuf[a + 1], x.th(A.pos), w.c, bt, Ci, t, c.dtype, x.s));
+        RUN(xattn_fwd(h, x, A.tm, h->ubuf[a], b, w.c, bt, t, w.kn2, w.kn2_mean, w.kn2_rstd, w.kv2, w.qn2, w.qn2_mean, w.qn2_rstd, w.q2, w.o2, w.probs2, w.u1));
+        RUN(ln_fwd(x, h->theta, A.ln_tm, w.u1, w.un, b, w.u1_mean, w.u1_rstd));
+        RUN(gemm(x, w.un, Ci, x.pk(A.tm_fc.pk.f), b, 4 * Ci, Ci, 1, w.zu, 4 * Ci, x.th(A.tm_fc.bias), nullptr, nullptr, w.hu));
+        RUN(gemm(x, w.hu, 4 * Ci, x.pk(A.tm_proj.pk.f), b, Ci, 4 * Ci, 1, h->ubuf[a + 1], Ci, x.th(A.tm_proj.bias), w.u1, nullptr, nullptr));
+    }
+    // x_logits = ln_post(top_cls + proj_spatial_cls_token(mean_t vit_cls)); cls_x = x_logits @ proj (dist.py:242-246)
+    RUN(dist_k_mean_cls(h->feat[nl - 1], h->mean_cls, b, t, L, d, c.dtype, x.s));
+    RUN(gemm(x, h->mean_cls, d, x.pk(h->cls_proj.pk.f), b, Ci, d, 1, h->ysum, Ci, x.th(h->cls_proj.bias), h->ubuf[c.ada_layers], nullptr, nullptr));
+    RUN(ln_fwd(x, h->theta, h->ln_post, h->ysum, h->zpost, b, h->y_mean, h->y_rstd));
+    RUN(gemm(x, h->zpost, Ci, x.pk(h->proj.pk.f), b, c.embed_dim, Ci, 1, h->v, c.embed_dim, nullptr, nullptr, nullptr, nullptr));
+    // cosine logits (clip.py:509-518)
+    RUN(dist_k_logits_loss(h->v, text_features, h->logit_scale, nullptr, h->logits, vid_logits, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           b, c.embed_dim, c.num_classes, c.dtype, stream));
+    if (logits) HIP_CHECK_RET(hipMemcpyAsync(logits, h->logits, (size_t)b * c.num_classes * sizeof(float), hipMemcpyDeviceToDevice, x.s));
+    h->branch_b = b;
+    h->text = text_features;
+    return DIST_OK;
+}
+
+extern "C" int dist_loss(dist_handle* h, const float* soft_target, int b, float* loss, float* dlogits, void* stream) {
+    if (!h || !soft_target) return DIST_ERR_ARG;
+    if (h->branch_b != b || !h->text) return fail(h, DIST_ERR_STATE, "dist_loss(b=%d) needs dist_branch_forward with the same batch first", b);
+    const dist_config& c = h->cfg;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_CHECK_RET(hipMemsetAsync(h->loss, 0, sizeof(float), s));
+    RUN(dist_k_logits_loss(h->v, h->text, h->logit_scale, soft_target, nullptr, nullptr, h->loss, nullptr, nullptr, nullptr, h->dlogits,
+                           b, c.embed_dim, c.num_classes, c.dtype, stream));
+    if (loss) HIP_CHECK_RET(hipMemcpyAsync(loss, h->loss, sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (dlogits) HIP_CHECK_RET(hipMemcpyAsync(dlogits, h->dlogits, (size_t)b * c.num_classes * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return DIST_OK;
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// backward helpers: y = act?(x W^T + b) given dY (already multiplied by act' where needed)
+namespace {
+
+// bias + weight gradients of a plain Linear: db += colsum(dY), dW += dY^T X
+int lin_wb(dist_handle* h, const Ctx& x, const Lin& l, const void* dY, const void* X, long rows) {
+    if (l.bias >= 0) RUN(bgrad(x, l.bias, dY, rows, l.N));
+    RUN(wgrad(x, l, dY, l.N, X, l.K, rows));
+    return DIST_OK;
+}
+// dX = dY W (optionally * gelu'(aux), optionally accumulated through `res`)
+int lin_dx(dist_handle* h, const Ctx& x, const Lin& l, const void* dY, long rows, void* dX, const void* aux = nullptr, const void* res = nullptr) {
+    RUN(gemm(x, dY, l.N, x.pk(l.pk.b), rows, l.K, l.N, 1, dX, l.K, nullptr, res, aux, nullptr));
+    return DIST_OK;
+}
+
+// backward of s_out = s_in + MLP(LN(s_in)) with MLP = c_proj(gelu(c_fc(.))); d (rows x Ci) holds dL/ds_out on entry
+// and dL/ds_in on exit
+int mlp_block_bwd(dist_handle* h, const Ctx& x, const Lin& fc, const Lin& proj, const LNp& ln, const void* s_in, const float* mean, const float* rstd,
+                  const void* sn, const void* zs, const void* hs, void* d, long rows, void* dzs, void* dsn) {
+    RUN(lin_wb(h, x, proj, d, hs, rows));
+    RUN(lin_dx(h, x, proj, d, rows, dzs, zs));
+    RUN(lin_wb(h, x, fc, dzs, sn, rows));
+    RUN(lin_dx(h, x, fc, dzs, rows, dsn));
+    RUN(ln_bwd(x, ln, s_in, mean, rstd, dsn, d, true, rows));
+    return DIST_OK;
+}
+
+// backward of s_out = s_in + out_proj(attn1q(W_q LN(s_in), W_kv LN(keys))); d holds dL/ds_out -> dL/ds_in;
+// dkeys receives (or accumulates) the gradient w.r.t. the key/value source rows.
+int xattn_bwd(dist_handle* h, const Ctx& x, const XAttn& A, const void* s_in, long nq, const void* keys, long nkeys_total, int S,
+              const void* kn, const float* kn_mean, const float* kn_rstd, const void* kv, const void* qn, const float* qn_mean, const float* qn_rstd,
+              const void* q, const void* o, const float* probs, void* d, void* dkeys, bool acc_keys,
+              void* d_o, void* dq, void* dkv, void* dqn, void* dkn) {
+    const int Ci = h->cfg.integration_dim;
+    RUN(lin_wb(h, x, A.out, d, o, nq));
+    RUN(lin_dx(h, x, A.out, d, nq, d_o));
+    RUN(dist_op_xattn1q_bwd(q, kv, probs, d_o, dq, dkv, (int)nq, S, Ci, x.dtype, x.s));
+    RUN(lin_wb(h, x, A.q, dq, qn, nq));
+    RUN(lin_wb(h, x, A.kv, dkv, kn, nkeys_total));
+    RUN(lin_dx(h, x, A.q, dq, nq, dqn));
+    RUN(lin_dx(h, x, A.kv, dkv, nkeys_total, dkn));
+    RUN(ln_bwd(x, A.ln1, s_in, qn_mean, qn_rstd, dqn, d, true, nq));
+    RUN(ln_bwd(x, A.ln1, keys, kn_mean, kn_rstd, dkn, dkeys, acc_keys, nkeys_total));
+    return DIST_OK;
+}
+
+}  // namespace
+
+extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b, int zero_grads, void* stream) {
+    if (!h || !dlogits) return DIST_ERR_ARG;
+    if (!h->grads || !h->dlogit_scale) return fail(h, DIST_ERR_UNBOUND, "dist_branch_backward needs grads and dlogit_scale bound");
+    if (h->branch_b != b || !h->text) return fail(h, DIST_ERR_STATE, "dist_branch_backward(b=%d) needs dist_branch_forward with the same batch first", b);
+    const dist_config& c = h->cfg;
+    Ctx x{h, static_cast<hipStream_t>(stream), c.dtype};
+    const int d = c.width, Ci = c.integration_dim, Ct = c.temporal_dim, C4 = h->C4, N = h->N, L = h->L, T = c.frames, t = h->t, al = c.alpha;
+    const long rowsX = (long)b * T * N, rowsS = (long)b * t * L, rowsQ = (long)b * t * N, bt = (long)b * t;
+    const int nl = c.layers, na = c.ada_layers;
+    const size_t es = h->es;
+
+    if (zero_grads) {
+        HIP_CHECK_RET(hipMemsetAsync(h->grads, 0, (size_t)h->total[0] * sizeof(float), x.s));
+        HIP_CHECK_RET(hipMemsetAsync(h->dlogit_scale, 0, sizeof(float), x.s));
+    }
+    // logits -> v (cosine normalisation backward, clip.py:511-517); logit_scale gets its (never applied) gradient
+    RUN(dist_k_logits_loss(h->v, h->text, h->logit_scale, nullptr, nullptr, nullptr, nullptr, h->dv, h->dlogit_scale, dlogits, nullptr,
+                           b, c.embed_dim, c.num_classes, c.dtype, stream));
+    // cls_x = z @ proj ; z = ln_post(u + cls_proj(mean_cls))
+    RUN(wgrad(x, h->proj, h->zpost, Ci, h->dv, c.embed_dim, b, RM(), RM(), 4));          // dProj[ci][e] = sum_b z[b][ci] dv[b][e]
+    RUN(gemm(x, h->dv, c.embed_dim, x.pk(h->proj.pk.b), b, Ci, c.embed_dim, 1, h->dzp, Ci, nullptr, nullptr, nullptr, nullptr));
+    RUN(ln_bwd(x, h->ln_post, h->ysum, h->y_mean, h->y_rstd, h->dzp, h->du, false, b));
+    RUN(lin_wb(h, x, h->cls_proj, h->du, h->mean_cls, b));
+    // ada-pooling layers in reverse (dist.py:139-162)
+    for (int a = na - 1; a >= 0; --a) {
+        const AdaLayer& A = h->ada[a];
+        AdaWs& w = h->aw[a];
+        const bool first = (a == na - 1);
+        // temporal MLP + temporal cross attention (du: dL/du_{a+1} -> dL/du_a)
+        RUN(mlp_block_bwd(h, x, A.tm_fc, A.tm_proj, A.ln_tm, w.u1, w.u1_mean, w.u1_rstd, w.un, w.zu, w.hu, h->du, b, h->dzu, h->dun));
+        RUN(xattn_bwd(h, x, A.tm, h->ubuf[a], b, w.c, bt, t, w.kn2, w.kn2_mean, w.kn2_rstd, w.kv2, w.qn2, w.qn2_mean, w.qn2_rstd, w.q2, w.o2, w.probs2,
+                      h->du, h->dc, false, h->do2, h->dq2, h->dkv2, h->dqn2, h->dkn2));
+        // c = s_{a+1} + pos: dpos[j] = sum_b dc[b,j]; ds_{a+1} (+)= dc
+        RUN(dist_k_cls_rows_bwd(h->dc, x.gr(A.pos), (int)bt, 1, Ci, t, c.dtype, x.s));
+        if (first) HIP_CHECK_RET(hipMemcpyAsync(h->ds, h->dc, (size_t)bt * Ci * es, hipMemcpyDeviceToDevice, x.s));
+        else RUN(dist_op_add(h->ds, h->dc, h->ds, bt * Ci, c.dtype, stream));
+        // spatial MLP + spatial cross attention (ds: dL/ds_{a+1} -> dL/ds_a; dFz accumulates)
+        RUN(mlp_block_bwd(h, x, A.sp_fc, A.sp_proj, A.ln_sp, w.s1, w.s1_mean, w.s1_rstd, w.sn, w.zs, w.hs, h->ds, bt, h->dzs, h->dsn));
+        RUN(xattn_bwd(h, x, A.sp, h->sbuf[a], bt, h->Fz, rowsS, L, w.kn, w.kn_mean, w.kn_rstd, w.kv, w.qn, w.qn_mean, w.qn_rstd, w.q, w.o, w.probs,
+                      h->ds, h->dR, !first, h->do_, h->dq, h->dkv, h->dqn, h->dkn));
+    }
+    if (na > 0) {
+        RUN(bgrad(x, h->agg_cls, h->du, b, Ci));
+        RUN(bgrad(x, h->agg_sp_cls, h->ds, bt, Ci));
+    } else {
+        HIP_CHECK_RET(hipMemsetAsync(h->dR, 0, (size_t)rowsS * Ci * es, x.s));
+        RUN(bgrad(x, h->agg_cls, h->du, b, Ci));
+    }
+    // Fz = R_last + M'_last: both receive dFz
+    HIP_CHECK_RET(hipMemcpyAsync(h->dMp, h->dR, (size_t)rowsS * Ci * es, hipMemcpyDeviceToDevice, x.s));
+
+    void *dR = h->dR, *dMp = h->dMp, *dXn = h->dXn, *dp = h->dp;
+    for (int i = nl - 1; i >= 0; --i) {
+        const DistLayer& l = h->dl[i];
+        DistLayerWs& w = h->lw[i];
+        const bool last = (i == nl - 1);
+        // ---- IntegrationNetwork backward (dist.py:40-45) ----
+        RUN(bgrad(x, l.ffn_proj.bias, dR, rowsS, Ci));
+        RUN(bgrad(x, l.tf_proj.bias, dR, rowsS, Ci));
+        RUN(wgrad(x, l.ffn_proj, dR, Ci, w.hf, Ci, rowsS));
+        RUN(wgrad(x, l.tf_proj, dR, Ci, w.g2, C4, rowsS));
+        RUN(lin_dx(h, x, l.ffn_proj, dR, rowsS, h->dzf, w.zf));                          // dzf = (dR Wp) * g'(zf)
+        RUN(lin_dx(h, x, l.tf_proj, dR, rowsS, h->dh2, w.h2));                           // dh2 = (dR W3) * g'(h2)
+        RUN(lin_wb(h, x, l.ffn_fc, h->dzf, w.Na, rowsS));
+        RUN(bgrad(x, l.tf_fc2.bias, h->dh2, rowsS, C4));
+        RUN(wgrad(x, l.tf_fc2, h->dh2, C4, w.h1, C4, rowsS, RM(), RM(DIST_RM_SHIFT, t * L, L, 1), 1));
+        RUN(gemm(x, h->dh2, C4, x.pk(l.tf_fc2.pk.b), rowsS, C4, C4, l.tf_fc2.taps, h->dh1, C4, nullptr, nullptr, nullptr, nullptr,
+                 RM(DIST_RM_SHIFT, t * L, L, -1)));
+        RUN(lin_wb(h, x, l.tf_fc1, h->dh1, w.Nb, rowsS));
+        RUN(lin_dx(h, x, l.ffn_fc, h->dzf, rowsS, h->dNa));
+        RUN(lin_dx(h, x, l.tf_fc1, h->dh1, rowsS, h->dNb));
+        RUN(ln_bwd(x, l.in_ln, w.Mp, w.in_mean, w.in_rstd, h->dNa, dMp, last, rowsS, &l.in_ln_t, h->dNb));   // dMp: dL/dM'
+        // ---- T2I backward (dist.py:81-86): M' = M + [cls_token ; conv_strided(X')] ----
+        RUN(dist_k_cls_rows_bwd(dMp, x.gr(l.cls_token), (int)bt, L, Ci, t, c.dtype, x.s));
+        RUN(bgrad(x, l.t2i.bias, dMp, rowsQ, Ci, RM(DIST_RM_SKIPCLS, N)));
+        RUN(wgrad(x, l.t2i, dMp, Ci, w.Xp, Ct, rowsQ, RM(DIST_RM_SKIPCLS, N), RM(DIST_RM_STRIDED, al, N), 2));
+        // dX' = dX_next (identity, absent for the last layer) + conv^T(dQ): column block a of row (bj,n) -> frame bj*alpha+a
+        RUN(gemm(x, dMp, Ci, x.pk(l.t2i.pk.b), rowsQ, al * Ct, Ci, 1, h->dXp, Ct, nullptr, last ? nullptr : dXn, nullptr, nullptr,
+                 RM(DIST_RM_SKIPCLS, N), OM(DIST_OM_SPLITCOLS, al, N, Ct)));
+        // ---- I2T backward (dist.py:100-105): X_next = X' + upsample(Linear(M[1:])) ----
+        if (!last) {
+            RUN(dist_k_pair_sum(dXn, h->dY, bt, N * Ct, al, c.dtype, x.s));
+            RUN(bgrad(x, l.i2t.bias, h->dY, rowsQ, Ct));
+            RUN(wgrad(x, l.i2t, h->dY, Ct, w.M, Ci, rowsQ, RM(), RM(DIST_RM_SKIPCLS, N)));
+            RUN(gemm(x, h->dY, Ct, x.pk(l.i2t.pk.b), rowsQ, Ci, Ct, 1, dMp, Ci, nullptr, dMp, nullptr, nullptr, RM(), OM(DIST_OM_INSERTCLS, N)));
+        }
+        // ---- mid_feat = input_linear(F_i) + R_{i-1}: dMp is now dL/dM; no dF_i (frozen) ----
+        RUN(lin_wb(h, x, l.in_lin, dMp, h->feat[i], rowsS));
+        { void* tmp = dR; dR = dMp; dMp = tmp; }                                         // dR_{i-1} = dM
+        // ---- TemporalNet backward (dist.py:63-65): X' = g(p), p = X + conv3x3(V) + b, V = g(z), z = conv_t(U), U = LN(X) ----
+        RUN(dist_op_gelu_bwd(h->dXp, w.p, dp, rowsX * Ct, c.dtype, stream));
+        RUN(bgrad(x, l.tn_fc2.bias, dp, rowsX, Ct));
+        RUN(wgrad(x, l.tn_fc2, dp, Ct, w.V, Ct, rowsX, RM(), RM(DIST_RM_SPATIAL, h->G, 0, 1), 1));
+        RUN(gemm(x, dp, Ct, x.pk(l.tn_fc2.pk.b), rowsX, Ct, Ct, 9, h->dz, Ct, nullptr, nullptr, w.z, nullptr, RM(DIST_RM_SPATIAL, h->G, 0, -1)));
+        RUN(bgrad(x, l.tn_fc1.bias, h->dz, rowsX, Ct));
+        RUN(wgrad(x, l.tn_fc1, h->dz, Ct, w.U, Ct, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 1));
+        RUN(gemm(x, h->dz, Ct, x.pk(l.tn_fc1.pk.b), rowsX, Ct, Ct, l.tn_fc1.taps, h->dU, Ct, nullptr, nullptr, nullptr, nullptr,
+                 RM(DIST_RM_SHIFT, T * N, N, -1)));
+        RUN(ln_bwd(x, l.tn_ln, w.X, w.tn_mean, w.tn_rstd, h->dU, dp, true, rowsX));      // dp <- dp + LN'(dU) = dL/dX_i
+        { void* tmp = dXn; dXn = dp; dp = tmp; }
+    }
+    // temporal stem (dist.py:178-181): no input gradient
+    RUN(bgrad(x, h->stem.bias, dXn, rowsX, Ct));
+    RUN(wgrad(x, h->stem, dXn, Ct, h->patches, h->Kp, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 3));
+    return DIST_OK;
+}
+
+extern "C" int dist_debug_tensor(dist_handle* h, const char* name, const void** ptr, int64_t* rows, int* cols) {
+    if (!h || !name || !ptr || !rows || !cols) return DIST_ERR_ARG;
+    if (!h->ws) return fail(h, DIST_ERR_UNBOUND, "dist_debug_tensor before dist_bind");
+    const dist_config& c = h->cfg;
+    const long b = h->fwd_b;
+    const long rowsX = b * c.frames * h->N, rowsS = b * h->t * h->L;
+    int i = -1;
+    const char* dot = strchr(name, '.');
+    if (dot) i = atoi(dot + 1);
+    const std::string key(name, dot ? (size_t)(dot - name) : strlen(name));
+    auto layer_ok = [&]() { return i >= 0 && i < c.layers; };
+    if (key == "feat" && layer_ok()) { *ptr = h->feat[i]; *rows = rowsS; *cols = c.width; return DIST_OK; }
+    if (key == "stem") { *ptr = h->lw[0].X; *rows = rowsX; *cols = c.temporal_dim; return DIST_OK; }
+    if (key == "tn_out" && layer_ok()) { *ptr = h->lw[i].Xp; *rows = rowsX; *cols = c.temporal_dim; return DIST_OK; }
+    if (key == "int_out" && layer_ok()) { *ptr = h->lw[i].R; *rows = rowsS; *cols = c.integration_dim; return DIST_OK; }
+    if (key == "x_temporal" && layer_ok()) { *ptr = (i + 1 < c.layers) ? h->lw[i + 1].X : h->Xlast; *rows = rowsX; *cols = c.temporal_dim; return DIST_OK; }
+    if (key == "mid" && layer_ok()) { *ptr = h->lw[i].Mp; *rows = rowsS; *cols = c.integration_dim; return DIST_OK; }
+    if (key == "patches") { *ptr = h->patches; *rows = rowsX; *cols = h->Kp; return DIST_OK; }
+    return fail(h, DIST_ERR_ARG, "unknown debug tensor %s", name);
 }

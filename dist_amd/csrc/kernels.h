@@ -17,7 +17,7 @@ struct PackDesc {
     long s_co, s_tap, s_outer;
 };
 
-int dist_k_pack(const PackDesc* descs_dev, const int* blk_desc_dev, const int* blk_first_dev, int nblocks,
+int dist_k_pack(const PackDesc* descs_dev, const int* blk_desc_dev, const int* blk_first_dev, int first_block, int nblocks,
                 const float* theta, const float* visual, void* dst_base, int dtype, hipStream_t s);
 int dist_k_cls_rows(void* dst, const void* src, const float* table, int nbj, int L, int C, int period, int dtype, hipStream_t s);
 int dist_k_cls_rows_bwd(const void* d, float* dtable, int nbj, int L, int C, int period, int dtype, hipStream_t s);

@@ -61,12 +61,14 @@ __global__ __launch_bounds__(NT) void gelu_bwd_kernel(const T* __restrict__ dy, 
 
 // ---- column sums (bias gradients): out[c] += sum_rows x[map(row)][c] ------------------------
 template <typename T>
-__global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long rows, int C, int ld,
+__global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long rows, int Ctot, int ld,
                                                     dist_rowmap map, int rows_per_block) {
     __shared__ float red[1024];
     const int tid = threadIdx.x;
-    const int cg = C / 4;                         // column groups of 4
-    const int nslot = NT / cg > 0 ? NT / cg : 1;
+    const int cbase = blockIdx.y * 1024;                  // column chunk of <= 1024
+    const int C = min(1024, Ctot - cbase);
+    const int cg = C / 4;                                 // column groups of 4 (<= 256)
+    const int nslot = NT / cg;
     for (int i = tid; i < C; i += NT) red[i] = 0.f;
     __syncthreads();
     const int slot = tid / cg, c4 = (tid % cg) * 4;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, flo
         for (long r = r0 + slot; r < r1; r += nslot) {
             const int src = rowmap_src(map, (int)r, 0, 1);
             float v[4];
-            load4(x + (long)src * ld + c4, v);
+            load4(x + (long)src * ld + cbase + c4, v);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] += v[e];
         }
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, flo
         for (int e = 0; e < 4; ++e) atomicAdd(&red[c4 + e], acc[e]);
     }
     __syncthreads();
-    for (int i = tid; i < C; i += NT) atomicAdd(out + i, red[i]);
+    for (int i = tid; i < C; i += NT) atomicAdd(out + cbase + i, red[i]);
 }
 
 // ---- token-row helpers -----------------------------------------------------------------------
@@ -275,13 +277,14 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const 
 // ---- weight packing -------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(NT) void pack_kernel(const PackDesc* __restrict__ descs, const int* __restrict__ blk_desc, const int* __restrict__ blk_first,
-                                                  const float* __restrict__ src0, const float* __restrict__ src1, T* __restrict__ dst_base) {
-    const int di = blk_desc[blockIdx.x];
+                                                  int first_block, const float* __restrict__ src0, const float* __restrict__ src1, T* __restrict__ dst_base) {
+    const int blk = blockIdx.x + first_block;
+    const int di = blk_desc[blk];
     const PackDesc d = descs[di];
     const float* src = (d.src_kind ? src1 : src0) + d.src_off;
     T* dst = dst_base + d.dst_off;
     const long total = (long)d.rows * d.cols;
-    const long beg = (long)(blockIdx.x - blk_first[di]) * PACK_PER_BLOCK;
+    const long beg = (long)(blk - blk_first[di]) * PACK_PER_BLOCK;
     const long end = min(total, beg + PACK_PER_BLOCK);
     for (long i = beg + threadIdx.x; i < end; i += NT) {
         const int r = (int)(i / d.cols), c = (int)(i % d.cols);
@@ -328,13 +331,13 @@ extern "C" int dist_op_gelu_bwd(const void* dy, const void* pre, void* dx, int64
 }
 
 extern "C" int dist_op_colsum(const void* x, float* out, int64_t rows, int C, int ld, dist_rowmap map, int dtype, void* stream) {
-    if (!x || !out || rows <= 0 || C % 4 || C > 1024 || ld % 4) return DIST_ERR_ARG;
+    if (!x || !out || rows <= 0 || C % 4 || ld % 4) return DIST_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rpb = 512;
     long grid = (rows + rpb - 1) / rpb;
     if (grid > 1024) { rpb = (int)((rows + 1023) / 1024); grid = (rows + rpb - 1) / rpb; }
-    if (dtype == DIST_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((unsigned)grid), dim3(NT), 0, s, (const bf16_t*)x, out, (long)rows, C, ld, map, rpb);
-    else hipLaunchKernelGGL(colsum_kernel<float>, dim3((unsigned)grid), dim3(NT), 0, s, (const float*)x, out, (long)rows, C, ld, map, rpb);
+    if (dtype == DIST_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((unsigned)grid, (C + 1023) / 1024), dim3(NT), 0, s, (const bf16_t*)x, out, (long)rows, C, ld, map, rpb);
+    else hipLaunchKernelGGL(colsum_kernel<float>, dim3((unsigned)grid, (C + 1023) / 1024), dim3(NT), 0, s, (const float*)x, out, (long)rows, C, ld, map, rpb);
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
 }
@@ -379,11 +382,11 @@ namespace {
 template <typename F> int with_type(int dtype, F&& f) { return dtype == DIST_BF16 ? f(bf16_t{}) : f(float{}); }
 }
 
-int dist_k_pack(const PackDesc* descs_dev, const int* blk_desc_dev, const int* blk_first_dev, int nblocks,
+int dist_k_pack(const PackDesc* descs_dev, const int* blk_desc_dev, const int* blk_first_dev, int first_block, int nblocks,
                 const float* theta, const float* visual, void* dst_base, int dtype, hipStream_t s) {
     return with_type(dtype, [&](auto tag) {
         using T = decltype(tag);
-        hipLaunchKernelGGL(pack_kernel<T>, dim3(nblocks), dim3(NT), 0, s, descs_dev, blk_desc_dev, blk_first_dev, theta, visual, (T*)dst_base);
+        hipLaunchKernelGGL(pack_kernel<T>, dim3(nblocks), dim3(NT), 0, s, descs_dev, blk_desc_dev, blk_first_dev, first_block, theta, visual, (T*)dst_base);
         HIP_CHECK_RET(hipGetLastError());
         return (int)DIST_OK;
     });

@@ -1,0 +1,191 @@
+"""Python owner of one `dist_handle` (include/dist_amd.h, engine level).
+
+torch is the allocator / stream provider only: this class allocates the flat fp32
+parameter, gradient and AdamW moment buffers, the packed working-weight buffer and the
+activation workspace as torch tensors, binds their raw pointers into the C engine and
+then drives `dist_vit_forward / dist_branch_forward / dist_loss / dist_branch_backward /
+dist_op_adamw` on torch's current HIP stream.  There is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import ops
+
+
+def config_from_geometry(g, batch, dtype, use_tr=True):
+    """g: dist_amd.synth.Geometry (or any object with the same attributes)."""
+    c = L.Config()
+    c.dtype = L.BF16 if dtype == torch.bfloat16 else L.F32
+    c.batch, c.frames, c.alpha = batch, g.T, g.alpha
+    c.resolution, c.patch, c.width, c.layers = g.res, g.patch, g.d, g.layers
+    c.integration_dim, c.temporal_dim = g.Ci, g.Ct
+    c.temporal_kernel, c.temporal_patch = g.tk, g.tpatch
+    c.int_temporal_div = int(round(1.0 / g.int_t_ratio))
+    c.ada_layers, c.num_classes, c.embed_dim = g.ada, g.K, g.E
+    c.use_tr = int(use_tr)
+    return c
+
+
+class Engine:
+    def __init__(self, cfg, device="cuda"):
+        if not torch.cuda.is_available():
+            raise L.DistError("dist_amd.Engine needs a GPU: the HIP library is the only implementation")
+        self.lib = L.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.dtype = torch.bfloat16 if cfg.dtype == L.BF16 else torch.float32
+        h = C.c_void_p()
+        L.check(self.lib.dist_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.tables = [self._table(0), self._table(1)]
+        n0 = self.lib.dist_param_total(h, 0)
+        n1 = self.lib.dist_param_total(h, 1)
+        dev = self.device
+        self.theta = torch.zeros(n0, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(n0, dtype=torch.float32, device=dev)
+        self.visual = torch.zeros(n1, dtype=torch.float32, device=dev)
+        self.logit_scale = torch.full((1,), float(np.log(1 / 0.07)), dtype=torch.float32, device=dev)
+        self.dlogit_scale = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.packed = torch.empty(self.lib.dist_packed_bytes(h), dtype=torch.uint8, device=dev)
+        self.workspace = torch.empty(self.lib.dist_workspace_bytes(h), dtype=torch.uint8, device=dev)
+        L.check(self.lib.dist_bind(h, self.theta.data_ptr(), self.grads.data_ptr(), self.visual.data_ptr(),
+                                   self.logit_scale.data_ptr(), self.dlogit_scale.data_ptr(),
+                                   self.packed.data_ptr(), self.workspace.data_ptr()), h)
+        self.exp_avg = None
+        self.exp_avg_sq = None
+        self.step_count = 0
+        self._segs = None
+        self._segs_key = None
+        self._text = None
+        self.b = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.dist_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- parameter tables -------------------------------------------------------------------
+    def _table(self, kind):
+        lib, h = self.lib, self.h
+        out = {}
+        for i in range(lib.dist_param_count(h, kind)):
+            name = lib.dist_param_name(h, kind, i).decode()
+            shape = tuple(lib.dist_param_dim(h, kind, i, d) for d in range(lib.dist_param_ndim(h, kind, i)))
+            out[name] = (lib.dist_param_offset(h, kind, i), shape, lib.dist_param_group(h, i) if kind == 0 else -1)
+        return out
+
+    def _flat(self, kind):
+        return self.theta if kind == 0 else self.visual
+
+    def view(self, name, grad=False):
+        for kind in (0, 1):
+            if name in self.tables[kind]:
+                off, shape, _ = self.tables[kind][name]
+                n = int(np.prod(shape)) if shape else 1
+                base = (self.grads if grad else self.theta) if kind == 0 else self.visual
+                return base[off:off + n].view(shape)
+        if name == "logit_scale":
+            return (self.dlogit_scale if grad else self.logit_scale).view(())
+        raise KeyError(name)
+
+    def load_state_dict(self, sd, strict=True):
+        """sd: reference state-dict names -> tensor / ndarray (visual.*, dist_net.*, logit_scale).
+        Text-tower keys are ignored (the text features are an input)."""
+        missing = []
+        for kind in (0, 1):
+            for name, (off, shape, _) in self.tables[kind].items():
+                if name not in sd:
+                    missing.append(name)
+                    continue
+                t = torch.as_tensor(sd[name]).to(torch.float32).reshape(-1)
+                n = int(np.prod(shape)) if shape else 1
+                if t.numel() != n:
+                    raise L.DistError(f"{name}: expected {shape}, got {tuple(torch.as_tensor(sd[name]).shape)}")
+                self._flat(kind)[off:off + n].copy_(t)
+        if "logit_scale" in sd:
+            self.logit_scale.fill_(float(torch.as_tensor(sd["logit_scale"])))
+        if strict and missing:
+            raise L.DistError(f"missing keys: {missing[:8]}{'...' if len(missing) > 8 else ''}")
+        self.pack(3)
+        return missing
+
+    def state_dict(self):
+        sd = {name: self.view(name).detach().clone() for kind in (0, 1) for name in self.tables[kind]}
+        sd["logit_scale"] = self.logit_scale.view(()).clone()
+        return sd
+
+    def pack(self, what=3):
+        L.check(self.lib.dist_pack_weights(self.h, what, ops._stream()), self.h)
+
+    # ---- the hot path ----------------------------------------------------------------------
+    def vit_forward(self, video):
+        assert video.dtype == torch.float32 and video.is_contiguous() and video.is_cuda
+        self.b = video.shape[0]
+        L.check(self.lib.dist_vit_forward(self.h, video.data_ptr(), self.b, ops._stream()), self.h)
+
+    def branch_forward(self, text_features):
+        assert text_features.dtype == torch.float32 and text_features.is_contiguous()
+        self._text = text_features            # keep alive: the engine borrows the pointer until backward
+        logits = torch.empty(self.b, self.cfg.num_classes, dtype=torch.float32, device=self.device)
+        vid = torch.empty(self.b, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
+        L.check(self.lib.dist_branch_forward(self.h, text_features.data_ptr(), self.b, logits.data_ptr(), vid.data_ptr(), ops._stream()), self.h)
+        return logits, vid
+
+    def loss(self, soft_target):
+        assert soft_target.dtype == torch.float32 and soft_target.is_contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=self.device)
+        dlogits = torch.empty(self.b, self.cfg.num_classes, dtype=torch.float32, device=self.device)
+        L.check(self.lib.dist_loss(self.h, soft_target.data_ptr(), self.b, loss.data_ptr(), dlogits.data_ptr(), ops._stream()), self.h)
+        return loss, dlogits
+
+    def backward(self, dlogits, zero_grads=True):
+        assert dlogits.dtype == torch.float32 and dlogits.is_contiguous()
+        L.check(self.lib.dist_branch_backward(self.h, dlogits.data_ptr(), self.b, int(zero_grads), ops._stream()), self.h)
+
+    def forward_backward(self, video, text_features, soft_target):
+        """One reference train step up to the gradients (runs/train.py:101-110)."""
+        self.vit_forward(video)
+        logits, _ = self.branch_forward(text_features)
+        loss, dlogits = self.loss(soft_target)
+        self.backward(dlogits)
+        return loss, logits
+
+    # ---- optimizer (models/utils/optimizer.py:67-73,138-186 as intended) ----------------------
+    def adamw_step(self, lr, weight_decay, lr_mult=1.0, grad_scale=1.0):
+        """lr: base lr of this iteration; groups 1 and 3 get `weight_decay`, groups 0, 2, 4 none;
+        every DiST group uses lr * lr_mult (NEW_NET_LRMULT)."""
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.theta)
+            self.exp_avg_sq = torch.zeros_like(self.theta)
+        key = (float(lr), float(weight_decay), float(lr_mult))
+        if self._segs_key != key:
+            ent = []
+            for name, (off, shape, grp) in self.tables[0].items():
+                n = int(np.prod(shape)) if shape else 1
+                ent.append((off, off + n, lr * lr_mult, weight_decay if grp in (1, 3) else 0.0))
+            ent.sort()
+            merged = []
+            for e in ent:
+                if merged and merged[-1][1] == e[0] and merged[-1][2:] == e[2:]:
+                    merged[-1] = (merged[-1][0], e[1]) + e[2:]
+                else:
+                    merged.append(e)
+            self._segs = ops.make_segs(merged, self.device)
+            self._segs_key = key
+        self.step_count += 1
+        ops.adamw(self.theta, self.grads, self.exp_avg, self.exp_avg_sq, self._segs, self.step_count, grad_scale=grad_scale)
+        self.pack(2)
+
+    def debug(self, name):
+        ptr, rows, cols = C.c_void_p(), C.c_int64(), C.c_int()
+        L.check(self.lib.dist_debug_tensor(self.h, name.encode(), C.byref(ptr), C.byref(rows), C.byref(cols)), self.h)
+        n = rows.value * cols.value
+        es = 2 if self.dtype == torch.bfloat16 else 4
+        off = ptr.value - self.workspace.data_ptr()
+        return self.workspace[off:off + n * es].view(self.dtype).view(rows.value, cols.value)

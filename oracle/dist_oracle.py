@@ -77,8 +77,8 @@ class Oracle:
         b = patches.shape[0]
         with torch.no_grad():
             Wc = self.w("visual.conv1.weight").reshape(g.d, -1)
-            pe = patches[:, ::g.alpha] @ Wc.t()                      # only frames k = alpha*j continue (clip.py:284)
-            cls = p["visual.class_embedding"].expand(b, g.t, 1, g.d)
+            pe = self.rnd(patches[:, ::g.alpha] @ Wc.t())            # only frames k = alpha*j continue (clip.py:284)
+            cls = self.rnd(p["visual.class_embedding"]).expand(b, g.t, 1, g.d)
             x = torch.cat([cls, pe], dim=2) + p["visual.positional_embedding"]
             x = self.rnd(layer_norm(x, p["visual.ln_pre.weight"], p["visual.ln_pre.bias"]))
             feats = []
@@ -181,12 +181,12 @@ class Oracle:
         vh = v.reshape(B, S, H, 64).permute(0, 2, 1, 3)
         att = torch.softmax((qh @ kh.transpose(-1, -2)) / 8.0, dim=-1)
         o = self.rnd((att @ vh).reshape(B, C))
-        return self.rnd(o @ self.w(pre + "attn.out_proj.weight").t() + p[pre + "attn.out_proj.bias"])
+        return o @ self.w(pre + "attn.out_proj.weight").t() + p[pre + "attn.out_proj.bias"]
 
     def mlp(self, pre, x):
         p = self.p
         h = self.rnd(qgelu(self.rnd(x @ self.w(pre + "c_fc.weight").t() + p[pre + "c_fc.bias"])))
-        return self.rnd(h @ self.w(pre + "c_proj.weight").t() + p[pre + "c_proj.bias"])
+        return h @ self.w(pre + "c_proj.weight").t() + p[pre + "c_proj.bias"]
 
     def branch(self, patches, feats, text_features):
         g, p = self.g, self.p
@@ -219,8 +219,8 @@ class Oracle:
             keep[f"x_temporal.{idx}"] = X
             keep[f"mid.{idx}"] = Mp
         Fz = self.rnd(R + Mp)                                                              # dist.py:239
-        u = p["dist_net.aggregated_cls_token"].reshape(1, g.Ci).expand(b, g.Ci)            # dist.py:237
-        s = p["dist_net.aggregated_spatial_cls_token"].reshape(1, g.Ci).expand(b * g.t, g.Ci)
+        u = self.rnd(p["dist_net.aggregated_cls_token"].reshape(1, g.Ci)).expand(b, g.Ci)  # dist.py:237
+        s = self.rnd(p["dist_net.aggregated_spatial_cls_token"].reshape(1, g.Ci)).expand(b * g.t, g.Ci)
         Fzf = Fz.reshape(b * g.t, g.L, g.Ci)
         for a in range(g.ada):                                                             # dist.py:139-162
             pre = f"dist_net.adapooling_nets.{a}."
@@ -235,7 +235,7 @@ class Oracle:
         mean_cls = self.rnd(feats[self.selected[-1]][:, :, 0].mean(dim=1))                 # dist.py:243
         zc = mean_cls @ self.w("dist_net.proj_spatial_cls_token.weight").t() + p["dist_net.proj_spatial_cls_token.bias"]
         z = self.rnd(layer_norm(self.rnd(u + zc), p["dist_net.ln_post.weight"], p["dist_net.ln_post.bias"]))
-        v = z @ self.w("dist_net.proj")                                                    # dist.py:246
+        v = self.rnd(z @ self.w("dist_net.proj"))                                          # dist.py:246
         # cosine logits (clip.py:509-518)
         vn = v / v.norm(dim=1, keepdim=True)
         tn = text_features / text_features.norm(dim=1, keepdim=True)
