@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py — DiST train step throughput on MI355X (contract in the task prompt).
+
+Metric (BASELINE.json): video clips/sec/node, train forward+backward, ViT-B/16 8+16f,
+b=32 clips per GPU, bf16, synthetic frames, procedural random-init weights.
+A "step" = one pass of the hot path over one resident batch:
+    frozen ViT forward -> DiST branch forward -> soft-target CE -> branch backward
+    -> (N>1: RCCL all-reduce of the dist_net gradients only) -> fused AdamW + weight re-pack.
+Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per clip, SURVEY.md §8(d) / BASELINE.md §2 (2*MAC, analytic)
+GF_PER_CLIP = {"b16_8+16f": dict(fwd=325.73, fwd_bwd=398.0)}
+PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(gname, seconds_budget=25.0):
+    """The oracle (CPU restatement of the reference, kind 'port') timed on this host's cores:
+    BASELINE config 1 shape (b=2) forward+backward.  Bounded: threads = the cores this process may
+    use (capped at 32: more threads only add contention for a b=2 problem), and the timed
+    iterations stop once the budget is spent (the first iteration doubles as warm-up when slow)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from dist_amd import synth
+    from dist_oracle import Oracle
+    g = synth.geometry(gname)
+    b = 2
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    threads = max(1, min(32, cores))
+    torch.set_num_threads(threads)
+    o = Oracle(g, synth.state_dict(g), dtype=torch.float32)
+    video, text, tgt = synth.video(g, b), synth.text_features(g), synth.soft_target(g, b)[0]
+    times = []
+    t_all = time.time()
+    for it in range(4):
+        t0 = time.time()
+        o.forward_backward(video, text, tgt)
+        times.append(time.time() - t0)
+        if time.time() - t_all > seconds_budget:
+            break
+    timed = times[1:] if len(times) > 1 else times          # drop the warm-up when there is more than one
+    dt = sorted(timed)[len(timed) // 2]
+    return {"value": round(b / dt, 4), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"{gname} b={b} fp32 fwd+bwd, torch-CPU oracle, median of {len(timed)} iterations ({dt:.2f} s each), host has {cores} usable cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--config", default="b16_8+16f")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP library is the only implementation of the path)")
+    torch.cuda.set_device(local_rank)
+
+    from dist_amd import synth
+    from dist_amd import distributed as du
+    from dist_amd.engine import Engine, config_from_geometry
+
+    if world > 1:
+        du.init_process_group(rank, world, local_rank)
+
+    g = synth.geometry(args.config)
+    b = args.batch
+    eng = Engine(config_from_geometry(g, b, torch.bfloat16))
+    eng.load_state_dict(synth.state_dict(g))
+    # clips are sharded per rank (independent units); every rank gets its own synthetic shard
+    video = torch.from_numpy(synth.video(g, b, seed=1 + rank)).cuda()
+    text = torch.from_numpy(synth.text_features(g)).cuda()
+    tgt = torch.from_numpy(synth.soft_target(g, b, seed=3 + rank)[0]).cuda()
+    lr, wd, mult = 3.2e-5, 1e-4, 10.0      # configs/projects/dist/ssv2/vit-b16-8+16f.yaml:52-58
+    reducer = du.GradReducer(eng, world) if world > 1 else None
+
+    def step():
+        eng.vit_forward(video)
+        eng.branch_forward(text)
+        _, dlogits = eng.loss(tgt)
+        if reducer is not None:
+            reducer.backward_and_reduce(dlogits)
+        else:
+            eng.backward(dlogits)
+        eng.adamw_step(lr, wd, lr_mult=mult, grad_scale=1.0 / world)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        du.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        du.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        du.all_reduce_max(tt)
+        dt = float(tt.item())
+
+    # dominant kernel (plain 128x128x64 MFMA GEMM of the frozen ViT), HIP events on its own stream
+    roof = None
+    if not args.no_roofline:
+        eng.profile_begin()
+        nprof = min(3, args.steps)
+        for _ in range(nprof):
+            step()
+        ms, flops, launches = eng.profile_end()
+        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "kernel": "gemm_nt_kernel<bf16,128,128,64> (ViT QKV/out/MLP)", "launches_per_step": launches // max(nprof, 1),
+                "avg_launch_us": round(ms * 1e3 / max(launches, 1), 1)}
+
+    if rank == 0:
+        clips = world * b * args.steps
+        value = clips / dt
+        gf = GF_PER_CLIP.get(args.config, {}).get("fwd_bwd")
+        out = {
+            "metric": "video clips/sec/node (train fwd+bwd), ViT-B/16 8+16f B=32/GPU",
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"ViT-{args.config} bf16, synthetic 224^2 frames, batch={b}/GPU, fwd+bwd+AdamW, DP{world}",
+                       "global_batch": b * world, "frames": f"{g.t}+{g.T}", "parallelism": f"dp{world}"},
+        }
+        if gf:
+            out["path_tflops_per_gpu"] = round(value / world * gf / 1e3, 1)
+            out["path_mfma_frac"] = round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4)
+        if roof:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.config)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        du.destroy()
+
+
+if __name__ == "__main__":
+    main()

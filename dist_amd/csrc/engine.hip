@@ -110,6 +110,11 @@ struct dist_handle {
     void *dv, *dzp, *dy, *du, *ds, *dc, *dzu, *dun, *do2, *dq2, *dkv2, *dqn2, *dkn2, *dzs, *dsn, *do_, *dq, *dqn;
     int fwd_b = 0, branch_b = 0;
     const float* text = nullptr;               // borrowed: text features of the last branch_forward
+    // measurement hook (dist_profile_begin/end)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;           // pairs (start, stop)
+    int prof_n = 0;
+    double prof_flops = 0.0;
     char err[512] = {0};
 };
 
@@ -384,12 +389,24 @@ int gemm(const Ctx& c, const void* A, int lda, const void* W, long M, int N, int
     g.amap = am; g.omap = om;
     g.flags = (bias ? DIST_EPI_BIAS : 0) | (res ? DIST_EPI_RES : 0) | (aux ? DIST_EPI_MULG : 0) | (C2 ? DIST_EPI_ACT2 : 0);
     g.dtype = c.dtype;
-    return dist_op_gemm_nt(&g, c.s);
+    dist_handle* h = c.h;
+    const bool dominant = h->prof_on && taps == 1 && am.mode == DIST_RM_PLAIN && om.mode == DIST_OM_PLAIN && K % 64 == 0 &&
+                          !(N % 96 == 0 && N % 128 != 0) && M >= 4096;
+    if (!dominant) return dist_op_gemm_nt(&g, c.s);
+    if (h->prof_n + 2 > (int)h->prof_ev.size()) {
+        for (int i = 0; i < 256; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return DIST_ERR_STATE; h->prof_ev.push_back(e); }
+    }
+    hipEventRecord(h->prof_ev[h->prof_n], c.s);
+    const int rc = dist_op_gemm_nt(&g, c.s);
+    hipEventRecord(h->prof_ev[h->prof_n + 1], c.s);
+    h->prof_n += 2;
+    h->prof_flops += 2.0 * (double)M * N * K;
+    return rc;
 }
 
 // weight gradient of a Lin into the flat grads buffer, in the reference parameter layout
 int wgrad(const Ctx& c, const Lin& l, const void* dY, int ld_dy, const void* X, int ldx, long M,
-          dist_rowmap am = RM(), dist_rowmap bm = RM(), int style = 0) {
+          dist_rowmap am = RM(), dist_rowmap bm = RM(), int style = 0, bool with_bias = false) {
     dist_gemm_tn_args g;
     memset(&g, 0, sizeof(g));
     g.A = dY; g.B = X; g.out = c.gr(l.w);
@@ -399,6 +416,7 @@ int wgrad(const Ctx& c, const Lin& l, const void* dY, int ld_dy, const void* X, 
     else if (style == 4) { g.NI = l.K; g.K = l.N; g.so_i = l.N; g.so_tap = 0; g.so_outer = 1; g.inner = 1; }   // [K][N] matrix used as x @ W
     else { const int PP3 = c.h->PP3, PP = PP3 / 3; g.K = PP3; g.so_i = (long)PP3 * l.taps; g.so_tap = PP; g.so_outer = (long)PP * l.taps; g.inner = PP; }
     g.dtype = c.dtype; g.use_tr = c.h->cfg.use_tr;
+    g.colsum = (with_bias && l.bias >= 0) ? c.gr(l.bias) : nullptr;       // db fused into the same pass over dY
     return dist_op_gemm_tn(&g, c.s);
 }
 int bgrad(const Ctx& c, long bias_off, const void* dY, long rows, int C, dist_rowmap m = RM()) {
@@ -461,7 +479,11 @@ extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
     *out = h;
     return DIST_OK;
 }
-extern "C" void dist_destroy(dist_handle* h) { delete h; }
+extern "C" void dist_destroy(dist_handle* h) {
+    if (!h) return;
+    for (hipEvent_t e : h->prof_ev) hipEventDestroy(e);
+    delete h;
+}
 extern "C" const char* dist_last_error(const dist_handle* h) { return h ? h->err : ""; }
 
 extern "C" int dist_param_count(const dist_handle* h, int kind) { return (h && (kind == 0 || kind == 1)) ? (int)h->params[kind].size() : 0; }
@@ -657,8 +679,7 @@ namespace {
 
 // bias + weight gradients of a plain Linear: db += colsum(dY), dW += dY^T X
 int lin_wb(dist_handle* h, const Ctx& x, const Lin& l, const void* dY, const void* X, long rows) {
-    if (l.bias >= 0) RUN(bgrad(x, l.bias, dY, rows, l.N));
-    RUN(wgrad(x, l, dY, l.N, X, l.K, rows));
+    RUN(wgrad(x, l, dY, l.N, X, l.K, rows, RM(), RM(), 0, true));
     return DIST_OK;
 }
 // dX = dY W (optionally * gelu'(aux), optionally accumulated through `res`)
@@ -757,15 +778,12 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         DistLayerWs& w = h->lw[i];
         const bool last = (i == nl - 1);
         // ---- IntegrationNetwork backward (dist.py:40-45) ----
-        RUN(bgrad(x, l.ffn_proj.bias, dR, rowsS, Ci));
-        RUN(bgrad(x, l.tf_proj.bias, dR, rowsS, Ci));
-        RUN(wgrad(x, l.ffn_proj, dR, Ci, w.hf, Ci, rowsS));
-        RUN(wgrad(x, l.tf_proj, dR, Ci, w.g2, C4, rowsS));
+        RUN(wgrad(x, l.ffn_proj, dR, Ci, w.hf, Ci, rowsS, RM(), RM(), 0, true));
+        RUN(wgrad(x, l.tf_proj, dR, Ci, w.g2, C4, rowsS, RM(), RM(), 0, true));
         RUN(lin_dx(h, x, l.ffn_proj, dR, rowsS, h->dzf, w.zf));                          // dzf = (dR Wp) * g'(zf)
         RUN(lin_dx(h, x, l.tf_proj, dR, rowsS, h->dh2, w.h2));                           // dh2 = (dR W3) * g'(h2)
         RUN(lin_wb(h, x, l.ffn_fc, h->dzf, w.Na, rowsS));
-        RUN(bgrad(x, l.tf_fc2.bias, h->dh2, rowsS, C4));
-        RUN(wgrad(x, l.tf_fc2, h->dh2, C4, w.h1, C4, rowsS, RM(), RM(DIST_RM_SHIFT, t * L, L, 1), 1));
+        RUN(wgrad(x, l.tf_fc2, h->dh2, C4, w.h1, C4, rowsS, RM(), RM(DIST_RM_SHIFT, t * L, L, 1), 1, true));
         RUN(gemm(x, h->dh2, C4, x.pk(l.tf_fc2.pk.b), rowsS, C4, C4, l.tf_fc2.taps, h->dh1, C4, nullptr, nullptr, nullptr, nullptr,
                  RM(DIST_RM_SHIFT, t * L, L, -1)));
         RUN(lin_wb(h, x, l.tf_fc1, h->dh1, w.Nb, rowsS));
@@ -774,16 +792,14 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         RUN(ln_bwd(x, l.in_ln, w.Mp, w.in_mean, w.in_rstd, h->dNa, dMp, last, rowsS, &l.in_ln_t, h->dNb));   // dMp: dL/dM'
         // ---- T2I backward (dist.py:81-86): M' = M + [cls_token ; conv_strided(X')] ----
         RUN(dist_k_cls_rows_bwd(dMp, x.gr(l.cls_token), (int)bt, L, Ci, t, c.dtype, x.s));
-        RUN(bgrad(x, l.t2i.bias, dMp, rowsQ, Ci, RM(DIST_RM_SKIPCLS, N)));
-        RUN(wgrad(x, l.t2i, dMp, Ci, w.Xp, Ct, rowsQ, RM(DIST_RM_SKIPCLS, N), RM(DIST_RM_STRIDED, al, N), 2));
+        RUN(wgrad(x, l.t2i, dMp, Ci, w.Xp, Ct, rowsQ, RM(DIST_RM_SKIPCLS, N), RM(DIST_RM_STRIDED, al, N), 2, true));
         // dX' = dX_next (identity, absent for the last layer) + conv^T(dQ): column block a of row (bj,n) -> frame bj*alpha+a
         RUN(gemm(x, dMp, Ci, x.pk(l.t2i.pk.b), rowsQ, al * Ct, Ci, 1, h->dXp, Ct, nullptr, last ? nullptr : dXn, nullptr, nullptr,
                  RM(DIST_RM_SKIPCLS, N), OM(DIST_OM_SPLITCOLS, al, N, Ct)));
         // ---- I2T backward (dist.py:100-105): X_next = X' + upsample(Linear(M[1:])) ----
         if (!last) {
             RUN(dist_k_pair_sum(dXn, h->dY, bt, N * Ct, al, c.dtype, x.s));
-            RUN(bgrad(x, l.i2t.bias, h->dY, rowsQ, Ct));
-            RUN(wgrad(x, l.i2t, h->dY, Ct, w.M, Ci, rowsQ, RM(), RM(DIST_RM_SKIPCLS, N)));
+            RUN(wgrad(x, l.i2t, h->dY, Ct, w.M, Ci, rowsQ, RM(), RM(DIST_RM_SKIPCLS, N), 0, true));
             RUN(gemm(x, h->dY, Ct, x.pk(l.i2t.pk.b), rowsQ, Ci, Ct, 1, dMp, Ci, nullptr, dMp, nullptr, nullptr, RM(), OM(DIST_OM_INSERTCLS, N)));
         }
         // ---- mid_feat = input_linear(F_i) + R_{i-1}: dMp is now dL/dM; no dF_i (frozen) ----
@@ -791,19 +807,35 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         { void* tmp = dR; dR = dMp; dMp = tmp; }                                         // dR_{i-1} = dM
         // ---- TemporalNet backward (dist.py:63-65): X' = g(p), p = X + conv3x3(V) + b, V = g(z), z = conv_t(U), U = LN(X) ----
         RUN(dist_op_gelu_bwd(h->dXp, w.p, dp, rowsX * Ct, c.dtype, stream));
-        RUN(bgrad(x, l.tn_fc2.bias, dp, rowsX, Ct));
-        RUN(wgrad(x, l.tn_fc2, dp, Ct, w.V, Ct, rowsX, RM(), RM(DIST_RM_SPATIAL, h->G, 0, 1), 1));
+        RUN(wgrad(x, l.tn_fc2, dp, Ct, w.V, Ct, rowsX, RM(), RM(DIST_RM_SPATIAL, h->G, 0, 1), 1, true));
         RUN(gemm(x, dp, Ct, x.pk(l.tn_fc2.pk.b), rowsX, Ct, Ct, 9, h->dz, Ct, nullptr, nullptr, w.z, nullptr, RM(DIST_RM_SPATIAL, h->G, 0, -1)));
-        RUN(bgrad(x, l.tn_fc1.bias, h->dz, rowsX, Ct));
-        RUN(wgrad(x, l.tn_fc1, h->dz, Ct, w.U, Ct, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 1));
+        RUN(wgrad(x, l.tn_fc1, h->dz, Ct, w.U, Ct, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 1, true));
         RUN(gemm(x, h->dz, Ct, x.pk(l.tn_fc1.pk.b), rowsX, Ct, Ct, l.tn_fc1.taps, h->dU, Ct, nullptr, nullptr, nullptr, nullptr,
                  RM(DIST_RM_SHIFT, T * N, N, -1)));
         RUN(ln_bwd(x, l.tn_ln, w.X, w.tn_mean, w.tn_rstd, h->dU, dp, true, rowsX));      // dp <- dp + LN'(dU) = dL/dX_i
         { void* tmp = dXn; dXn = dp; dp = tmp; }
     }
     // temporal stem (dist.py:178-181): no input gradient
-    RUN(bgrad(x, h->stem.bias, dXn, rowsX, Ct));
-    RUN(wgrad(x, h->stem, dXn, Ct, h->patches, h->Kp, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 3));
+    RUN(wgrad(x, h->stem, dXn, Ct, h->patches, h->Kp, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 3, true));
+    return DIST_OK;
+}
+
+extern "C" int dist_profile_begin(dist_handle* h) {
+    if (!h) return DIST_ERR_ARG;
+    h->prof_on = true; h->prof_n = 0; h->prof_flops = 0.0;
+    return DIST_OK;
+}
+extern "C" int dist_profile_end(dist_handle* h, double* ms_total, double* flops_total, int* launches) {
+    if (!h || !ms_total || !flops_total || !launches) return DIST_ERR_ARG;
+    h->prof_on = false;
+    double ms = 0.0;
+    for (int i = 0; i + 1 < h->prof_n; i += 2) {
+        HIP_CHECK_RET(hipEventSynchronize(h->prof_ev[i + 1]));
+        float t = 0.f;
+        HIP_CHECK_RET(hipEventElapsedTime(&t, h->prof_ev[i], h->prof_ev[i + 1]));
+        ms += t;
+    }
+    *ms_total = ms; *flops_total = h->prof_flops; *launches = h->prof_n / 2;
     return DIST_OK;
 }
 

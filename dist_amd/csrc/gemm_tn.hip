@@ -87,6 +87,14 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
     const T* __restrict__ A = static_cast<const T*>(p.A);
     const T* __restrict__ B = static_cast<const T*>(p.B);
 
+    // fused bias gradient: the blocks of the first column tile also sum the columns of their A rows
+    const bool do_colsum = p.colsum != nullptr && tc == 0 && tap == 0;
+    float csum[I_IT][8];
+#pragma unroll
+    for (int i = 0; i < I_IT; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[i][e] = 0.f;
+
     Frag<T> ra[I_IT], rb[J_IT];
     auto gload = [&](int mb) {
 #pragma unroll
@@ -99,6 +107,10 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
                     const int src = rowmap_src(p.amap, m, 0, 1);
                     if (src >= 0) frag_load(ra[i], A + (long)src * p.lda + col);
                 }
+            }
+            if (do_colsum) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) csum[i][e] += frag_get(ra[i], e);
             }
         }
 #pragma unroll
@@ -153,6 +165,24 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
         if (mb + BR < mend) sstore(cur ^ 1);
         __syncthreads();
         cur ^= 1;
+    }
+
+    if (do_colsum) {
+        // (tid, i) always maps to the same column vector: v % VI with v = tid + i*NT
+        float* red = reinterpret_cast<float*>(smem);          // the tiles are dead after the last barrier
+        for (int i = tid; i < BI; i += NT) red[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < I_IT; ++i) {
+            const int v = tid + i * NT;
+            if (v < BR * VI) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) atomicAdd(&red[(v % VI) * 8 + e], csum[i][e]);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < BI; i += NT)
+            if (i0 + i < p.NI) atomicAdd(p.colsum + i0 + i, red[i]);
     }
 
 #pragma unroll

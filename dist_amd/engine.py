@@ -182,6 +182,14 @@ class Engine:
         ops.adamw(self.theta, self.grads, self.exp_avg, self.exp_avg_sq, self._segs, self.step_count, grad_scale=grad_scale)
         self.pack(2)
 
+    def profile_begin(self):
+        L.check(self.lib.dist_profile_begin(self.h), self.h)
+
+    def profile_end(self):
+        ms, fl, n = C.c_double(), C.c_double(), C.c_int()
+        L.check(self.lib.dist_profile_end(self.h, C.byref(ms), C.byref(fl), C.byref(n)), self.h)
+        return ms.value, fl.value, n.value
+
     def debug(self, name):
         ptr, rows, cols = C.c_void_p(), C.c_int64(), C.c_int()
         L.check(self.lib.dist_debug_tensor(self.h, name.encode(), C.byref(ptr), C.byref(rows), C.byref(cols)), self.h)

@@ -33,7 +33,7 @@ class GemmTnArgs(C.Structure):
                 ("M", C.c_int64), ("NI", C.c_int), ("K", C.c_int), ("taps", C.c_int),
                 ("lda", C.c_int), ("ldb", C.c_int), ("amap", RowMap), ("bmap", RowMap),
                 ("so_i", C.c_int64), ("so_tap", C.c_int64), ("so_outer", C.c_int64), ("inner", C.c_int),
-                ("dtype", C.c_int), ("use_tr", C.c_int)]
+                ("dtype", C.c_int), ("use_tr", C.c_int), ("colsum", C.c_void_p)]
 
 
 class LnArgs(C.Structure):
@@ -89,6 +89,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise DistError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950).  dist_amd has no CPU fallback.")
+    # torch must be imported first: its bundled libamdhip64 has to be the HIP runtime of the process
+    # (device pointers come from torch's allocator); loading ours first binds a second runtime copy.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     _sig(lib, "dist_strerror", restype=C.c_char_p)
     _sig(lib, "dist_strerror", argtypes=[C.c_int])
@@ -117,6 +120,8 @@ def load():
     _sig(lib, "dist_branch_forward", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_branch_backward", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p])
     _sig(lib, "dist_loss", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
+    _sig(lib, "dist_profile_begin", argtypes=[C.c_void_p])
+    _sig(lib, "dist_profile_end", argtypes=[C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)])
     _sig(lib, "dist_debug_tensor", argtypes=[C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)])
     _sig(lib, "dist_op_gemm_nt", argtypes=[C.POINTER(GemmArgs), C.c_void_p])
     _sig(lib, "dist_op_gemm_tn", argtypes=[C.POINTER(GemmTnArgs), C.c_void_p])

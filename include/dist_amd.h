@@ -79,6 +79,7 @@ typedef struct dist_gemm_tn_args {
     dist_rowmap amap; dist_rowmap bmap;
     int64_t so_i, so_tap, so_outer; int inner;
     int dtype; int use_tr;   /* use_tr: bf16 LDS transpose reads (ds_read_b64_tr_b16) */
+    float* colsum;           /* optional: colsum[i] += sum_m A[amap(m)][i] (the bias gradient), fused into the same pass */
 } dist_gemm_tn_args;
 int dist_op_gemm_tn(const dist_gemm_tn_args* a, void* stream);
 
@@ -199,6 +200,11 @@ int dist_branch_forward(dist_handle* h, const float* text_features, int b, float
 int dist_branch_backward(dist_handle* h, const float* dlogits, int b, int zero_grads, void* stream);
 /* SoftTargetCrossEntropy value and dlogits for the logits of the last branch_forward */
 int dist_loss(dist_handle* h, const float* soft_target, int b, float* loss, float* dlogits, void* stream);
+/* measurement hook for bench.py: between begin and end every launch of the dominant kernel (the plain
+ * 128x128x64 MFMA GEMM of the frozen ViT) is bracketed by HIP events on its own stream; end() synchronises
+ * those events and returns the summed duration, the summed algorithmic FLOPs (2*M*N*K) and the launch count. */
+int dist_profile_begin(dist_handle* h);
+int dist_profile_end(dist_handle* h, double* ms_total, double* flops_total, int* launches);
 /* read back an intermediate for tests: name in {"feat.<i>","stem","tn_out.<i>","int_out.<i>","x_temporal.<i>","mid.<i>"} */
 int dist_debug_tensor(dist_handle* h, const char* name, const void** ptr, int64_t* rows, int* cols);
 

@@ -156,8 +156,8 @@ def test_adamw_steps_vs_reference_golden(gpu_lib):
                     got, ref = eng.view(n).cpu(), torch.from_numpy(gold[k])
                     diff = (got - ref).abs()
                     # Adam's update is ~lr*sign(g): an element whose gradient is ~eps may flip, so a
-                    # handful of elements may be off by up to `step` learning rates; all others are tight.
-                    assert float(diff.max()) <= step * 3.2e-4 * 1.05 + 1e-6, (n, float(diff.max()))
+                    # handful of elements may be off by up to 2*step learning rates; all others are tight.
+                    assert float(diff.max()) <= 2 * step * 3.2e-4 * 1.05 + 1e-6, (n, float(diff.max()))
                     frac = float((diff > 2e-6 + 1e-4 * ref.abs()).float().mean())
                     assert frac < 2e-4, (n, frac)
 

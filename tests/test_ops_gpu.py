@@ -147,9 +147,11 @@ def test_gemm_tn_plain(gpu_lib, dtype, use_tr, M, NI, K):
     from dist_amd import ops
     A, B = rnd((M, NI), dtype, 1), rnd((M, K), dtype, 2)
     out = torch.zeros(NI, K, dtype=torch.float32, device="cuda")
-    ops.gemm_tn(A, B, out, M, NI, K, use_tr=use_tr)
+    cs = torch.zeros(NI, dtype=torch.float32, device="cuda")
+    ops.gemm_tn(A, B, out, M, NI, K, use_tr=use_tr, colsum=cs)
     ref = A.double().t() @ B.double()
     torch.testing.assert_close(out.double(), ref, rtol=1e-4, atol=1e-4 * M ** 0.5)
+    torch.testing.assert_close(cs.double(), A.double().sum(0), rtol=1e-4, atol=1e-4 * M ** 0.5)   # fused bias gradient
 
 
 @pytest.mark.parametrize("dtype,use_tr", [(torch.float32, 0), (torch.bfloat16, 1)])
