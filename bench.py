@@ -126,7 +126,7 @@ def main():
         du.all_reduce_max(tt)
         dt = float(tt.item())
 
-    # dominant kernel (plain 128x128x64 MFMA GEMM of the frozen ViT), HIP events on its own stream
+    # dominant kernel (256x256x32 LDS-DMA MFMA GEMM of the frozen ViT), HIP events on its own stream
     roof = None
     if not args.no_roofline:
         eng.profile_begin()
@@ -137,7 +137,7 @@ def main():
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                "kernel": "gemm_nt_kernel<bf16,128,128,64> (ViT QKV/out/MLP)", "launches_per_step": launches // max(nprof, 1),
+                "kernel": "gemm_fast_kernel 256x256x32 LDS-DMA (ViT QKV/out/MLP + large DiST Linears)", "launches_per_step": launches // max(nprof, 1),
                 "avg_launch_us": round(ms * 1e3 / max(launches, 1), 1)}
 
     if rank == 0:

@@ -390,8 +390,7 @@ int gemm(const Ctx& c, const void* A, int lda, const void* W, long M, int N, int
     g.flags = (bias ? DIST_EPI_BIAS : 0) | (res ? DIST_EPI_RES : 0) | (aux ? DIST_EPI_MULG : 0) | (C2 ? DIST_EPI_ACT2 : 0);
     g.dtype = c.dtype;
     dist_handle* h = c.h;
-    const bool dominant = h->prof_on && taps == 1 && am.mode == DIST_RM_PLAIN && om.mode == DIST_OM_PLAIN && K % 64 == 0 &&
-                          !(N % 96 == 0 && N % 128 != 0) && M >= 4096;
+    const bool dominant = h->prof_on && dist_k_gemm_fast_eligible(&g);
     if (!dominant) return dist_op_gemm_nt(&g, c.s);
     if (h->prof_n + 2 > (int)h->prof_ev.size()) {
         for (int i = 0; i < 256; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return DIST_ERR_STATE; h->prof_ev.push_back(e); }

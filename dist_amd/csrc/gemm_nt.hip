@@ -13,6 +13,7 @@
 // 4 CONSECUTIVE output columns of one output row: bias / residual / activation epilogues
 // and the stores are 4-wide vectors.
 #include "common.h"
+#include "kernels.h"
 
 namespace {
 
@@ -227,5 +228,7 @@ extern "C" int dist_op_gemm_nt(const dist_gemm_args* a, void* stream) {
     if ((a->flags & DIST_EPI_MULG) && !a->aux) return DIST_ERR_ARG;
     if (a->omap.mode == DIST_OM_SPLITCOLS && (a->omap.p2 % 4 || a->N != a->omap.p0 * a->omap.p2)) return DIST_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const int fast = dist_k_gemm_fast(a, s);              // large plain bf16 GEMMs (frozen ViT): LDS-DMA 256x256 kernel
+    if (fast != 0) return fast < 0 ? fast : DIST_OK;
     return a->dtype == DIST_BF16 ? dispatch<bf16_t>(*a, s) : dispatch<float>(*a, s);
 }

@@ -13,6 +13,7 @@
 // (hardware global_atomic_add_f32, compiled with -munsafe-fp-atomics) straight into the
 // flat gradient buffer, in the reference's parameter layout (so_* strides).
 #include "common.h"
+#include "kernels.h"
 
 namespace {
 

@@ -28,3 +28,8 @@ int dist_k_bcast_rows(const float* table, void* out, long rows, int C, int dtype
 int dist_k_logits_loss(const void* v, const float* text, const float* logit_scale, const float* soft_target,
                        float* logits, float* vid_norm, float* loss, void* dv, float* dlogit_scale,
                        const float* dlogits_in, float* dlogits_out, int b, int E, int K, int dtype, void* stream);
+
+// 256x256x32 LDS-DMA GEMM (gemm_fast.hip): 1 = launched, 0 = shape not eligible, <0 = error
+bool dist_k_gemm_fast_eligible(const dist_gemm_args* a);
+int dist_k_gemm_fast(const dist_gemm_args* a, hipStream_t s);
+

@@ -140,6 +140,26 @@ def test_b16_logits_vs_reference_golden_fp32(gpu_lib):
     assert not bad, bad[:10]
 
 
+def test_b16_bf16_vs_reference_golden(gpu_lib):
+    """Same config in bf16 (the LDS-DMA kernels run at these sizes) against the fp32 reference: the
+    honest bf16-vs-fp32 gap, bounded (logits are in +-6; gradient norms within 6 %)."""
+    g, eng, sd, video, text, tgt = build("b16_8+16f", 2, torch.bfloat16)
+    loss, logits = eng.forward_backward(video, text, tgt)
+    gold = np.load(os.path.join(GOLD, "b16_b2.npz"))
+    gap = float((logits.cpu().double() - torch.from_numpy(gold["logits"]).double()).abs().max())
+    print(f"B/16 bf16 vs fp32 reference logits max-abs gap: {gap:.4f}")
+    assert gap < 0.25 and abs(float(loss) - float(gold["loss"])) < 0.05
+    assert (logits.cpu().argmax(1) == torch.from_numpy(gold["logits"]).argmax(1)).all()
+    bad = []
+    for k in gold.files:
+        if k.startswith("gnorm."):
+            n = k[6:]
+            got, ref = float(eng.view(n, grad=True).double().norm()), float(gold[k])
+            if abs(got - ref) > 0.06 * ref + 1e-6:
+                bad.append((n, got, ref))
+    assert len(bad) <= 3, bad[:10]
+
+
 def test_adamw_steps_vs_reference_golden(gpu_lib):
     """3 train steps (fwd+bwd+AdamW with the intended DiST groups) vs torch.optim.AdamW on the reference."""
     g, eng, sd, video, text, tgt = build("tiny", 2, torch.float32)

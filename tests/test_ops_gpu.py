@@ -64,7 +64,8 @@ def gather(A, mode, M, tap, taps, **kw):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("M,N,K", [(3152, 768, 768), (591, 2304, 768), (1000, 96, 96), (777, 384, 3072), (130, 1152, 384), (64, 512, 384), (257, 192, 96)])
+@pytest.mark.parametrize("M,N,K", [(1100, 768, 768), (2048, 256, 64), (1024, 512, 3072), (1500, 448, 160), (1280, 256, 128), (4096, 2304, 768),
+                                   (3152, 768, 768), (591, 2304, 768), (1000, 96, 96), (777, 384, 3072), (130, 1152, 384), (64, 512, 384), (257, 192, 96)])
 def test_gemm_nt_plain(gpu_lib, dtype, M, N, K):
     from dist_amd import ops
     A, B = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
@@ -89,7 +90,10 @@ def test_gemm_nt_plain(gpu_lib, dtype, M, N, K):
 @pytest.mark.parametrize("mode,kw,taps,N", [
     ("shift", dict(p0=8 * 9, p1=9), 3, 96), ("shift", dict(p0=8 * 9, p1=9, sign=-1), 3, 128), ("shift", dict(p0=6 * 16, p1=16), 5, 32),
     ("spatial", dict(p0=4), 9, 96), ("spatial", dict(p0=3, sign=-1), 9, 32), ("spatial", dict(p0=14), 9, 96),
-    ("strided", dict(p0=2, p1=9), 2, 384), ("skipcls", dict(p0=9), 1, 96)])
+    ("strided", dict(p0=2, p1=9), 2, 384), ("skipcls", dict(p0=9), 1, 96),
+    # large enough for the LDS-DMA kernels (gemm_nt2.hip)
+    ("shift", dict(p0=16 * 49, p1=49), 3, 96), ("shift", dict(p0=8 * 197, p1=197, sign=-1), 3, 128), ("shift", dict(p0=16 * 49, p1=49), 5, 96),
+    ("spatial", dict(p0=14, sign=-1), 9, 96), ("strided", dict(p0=2, p1=196), 2, 384), ("skipcls", dict(p0=196), 1, 96)])
 def test_gemm_nt_rowmaps(gpu_lib, dtype, mode, kw, taps, N):
     from dist_amd import ops, lib as L
     K = 96
@@ -98,8 +102,9 @@ def test_gemm_nt_rowmaps(gpu_lib, dtype, mode, kw, taps, N):
     elif mode == "spatial":
         M = kw["p0"] ** 2 * 7
     else:
-        M = 9 * 11
-    rowsA = {"strided": M * 2, "skipcls": (M // 9) * 10}.get(mode, M)
+        M = kw.get("p1", kw["p0"]) * 11 if mode == "strided" else kw["p0"] * 11
+    nn = kw.get("p1", 0) if mode == "strided" else kw["p0"]
+    rowsA = {"strided": M * 2, "skipcls": (M // nn) * (nn + 1) if mode == "skipcls" else M}.get(mode, M)
     A = rnd((rowsA, K), dtype, 1)
     B = rnd((N, taps * K), dtype, 2, (taps * K) ** -0.5)
     bias = rnd((N,), torch.float32, 3)
@@ -113,9 +118,10 @@ def test_gemm_nt_rowmaps(gpu_lib, dtype, mode, kw, taps, N):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_gemm_nt_outmaps(gpu_lib, dtype):
+@pytest.mark.parametrize("Nn,nbj", [(9, 11), (196, 8)])
+def test_gemm_nt_outmaps(gpu_lib, dtype, Nn, nbj):
     from dist_amd import ops, lib as L
-    Nn, alpha, nbj, K = 9, 2, 11, 128
+    alpha, K = 2, 128
     M = nbj * Nn
     A = rnd((M, K), dtype, 1)
     # DUP: (bj, n) -> rows (bj*alpha + a, n), residual read at the destination
@@ -142,7 +148,7 @@ def test_gemm_nt_outmaps(gpu_lib, dtype):
 
 
 @pytest.mark.parametrize("dtype,use_tr", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, 1)])
-@pytest.mark.parametrize("M,NI,K", [(3152, 384, 768), (1000, 96, 96), (5000, 96, 288), (333, 128, 64), (2048, 768, 384)])
+@pytest.mark.parametrize("M,NI,K", [(3152, 384, 768), (1000, 96, 96), (5000, 96, 288), (333, 128, 64), (2048, 768, 384), (6272, 96, 96), (4000, 384, 96), (2500, 96, 384)])
 def test_gemm_tn_plain(gpu_lib, dtype, use_tr, M, NI, K):
     from dist_amd import ops
     A, B = rnd((M, NI), dtype, 1), rnd((M, K), dtype, 2)
@@ -155,12 +161,13 @@ def test_gemm_tn_plain(gpu_lib, dtype, use_tr, M, NI, K):
 
 
 @pytest.mark.parametrize("dtype,use_tr", [(torch.float32, 0), (torch.bfloat16, 1)])
-@pytest.mark.parametrize("mode,kw,taps", [("shift", dict(p0=8 * 9, p1=9), 3), ("spatial", dict(p0=4), 9), ("strided", dict(p0=2, p1=9), 2)])
+@pytest.mark.parametrize("mode,kw,taps", [("shift", dict(p0=8 * 9, p1=9), 3), ("spatial", dict(p0=4), 9), ("strided", dict(p0=2, p1=9), 2),
+                                          ("shift", dict(p0=16 * 49, p1=49), 3), ("spatial", dict(p0=14), 9), ("strided", dict(p0=2, p1=196), 2)])
 def test_gemm_tn_taps_conv_layout(gpu_lib, dtype, use_tr, mode, kw, taps):
     """dW of a conv in the reference's [Co][Ci][taps] parameter layout."""
     from dist_amd import ops
     NI, K = 96, 32
-    M = {"shift": 72 * 5, "spatial": 16 * 7, "strided": 9 * 11}[mode]
+    M = {"shift": kw["p0"] * 5, "spatial": kw["p0"] ** 2 * 12, "strided": kw.get("p1", 1) * 12}[mode]
     rowsB = M * 2 if mode == "strided" else M
     A, B = rnd((M, NI), dtype, 1), rnd((rowsB, K), dtype, 2)
     out = torch.zeros(NI, K, taps, dtype=torch.float32, device="cuda")
@@ -172,9 +179,10 @@ def test_gemm_tn_taps_conv_layout(gpu_lib, dtype, use_tr, mode, kw, taps):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_gemm_tn_skipcls_a(gpu_lib, dtype):
+@pytest.mark.parametrize("Nn", [9, 196])
+def test_gemm_tn_skipcls_a(gpu_lib, dtype, Nn):
     from dist_amd import ops, lib as L
-    Nn, nbj, NI, K = 9, 13, 128, 96
+    nbj, NI, K = 13, 128, 96
     M = nbj * Nn
     A, B = rnd((nbj * (Nn + 1), NI), dtype, 1), rnd((M, K), dtype, 2)
     out = torch.zeros(NI, K, dtype=torch.float32, device="cuda")
