@@ -1,4 +1,4 @@
-// Fast path of dist_op_gemm_nt for the frozen-ViT shapes (bf16, plain row maps):
+// Fast path of dist_op_gemm_nt for the frozen-ViT shapes (bf16; single-tap row maps, plain / insert-cls outputs):
 //   C[m][n] = epi( sum_k A[m][k] * B[n][k] ),  256 x 256 x 32 tiles, 8 waves (2 x 4).
 //
 // CDNA4 structure (cdna_hip_programming.md §5):
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const dist_gemm_args p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int r = (wid * 2 + j) * 16 + lrow;
-        ga[j] = A + (long)min(m0 + r, M - 1) * p.lda + lchunk * 8;
+        ga[j] = A + (long)rowmap_src(p.amap, min(m0 + r, M - 1), 0, 1) * p.lda + lchunk * 8;   // plain / strided / skip-cls rows
         gb[j] = B + (long)min(n0 + r, N - 1) * p.ldb + lchunk * 8;
     }
     // piece q of tile kt: q = 0,1 -> A rows of this wave's two 16-row groups, q = 2,3 -> B
@@ -163,6 +163,8 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const dist_gemm_args p) {
     const int flags = p.flags;
     const int mw = m0 + wm * 128, nw = n0 + wn * 64;
     const int crow = lane >> 3, cchunk = lane & 7;        // coalesced pass: 8 lanes cover one 128-B row
+    const int icls = p.omap.mode == DIST_OM_INSERTCLS ? p.omap.p0 : 0;
+    auto dest_row = [&](int m) -> long { return icls ? (long)(m / icls) * (icls + 1) + 1 + m % icls : (long)m; };
 
     if (flags & DIST_EPI_RES) {
         // all 16 row-pieces of the residual tile are requested back to back (the operand fragment registers are
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const dist_gemm_args p) {
             const int r = it * 8 + crow;
             const int m = mw + r, n = nw + cchunk * 8;
             rv[it] = make_uint4(0, 0, 0, 0);
-            if (m < M && n < N) rv[it] = *reinterpret_cast<const uint4*>(R + (long)m * p.ldres + n);
+            if (m < M && n < N) rv[it] = *reinterpret_cast<const uint4*>(R + dest_row(m) * p.ldres + n);
         }
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const dist_gemm_args p) {
             const int r = it * 8 + crow;
             const int m = mw + r, n = nw + cchunk * 8;
             const uint4 v = *reinterpret_cast<const uint4*>(ew + r * 128 + ((cchunk ^ (r & 7)) << 4));
-            if (m < M && n < N) *reinterpret_cast<uint4*>(dst + (long)m * ld + n) = v;
+            if (m < M && n < N) *reinterpret_cast<uint4*>(dst + dest_row(m) * ld + n) = v;
         }
     };
     if (act_only) {
@@ -245,7 +247,9 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const dist_gemm_args p) {
 }  // namespace
 
 bool dist_k_gemm_fast_eligible(const dist_gemm_args* a) {
-    if (a->dtype != DIST_BF16 || a->taps != 1 || a->amap.mode != DIST_RM_PLAIN || a->omap.mode != DIST_OM_PLAIN) return false;
+    if (a->dtype != DIST_BF16 || a->taps != 1) return false;
+    if (a->amap.mode != DIST_RM_PLAIN && a->amap.mode != DIST_RM_STRIDED && a->amap.mode != DIST_RM_SKIPCLS) return false;
+    if (a->omap.mode != DIST_OM_PLAIN && a->omap.mode != DIST_OM_INSERTCLS) return false;
     if (a->flags & DIST_EPI_MULG) return false;
     if (a->K % BK || a->K < 4 * BK || a->N % 64 || a->N < 256 || a->M < 1024) return false;
     if (a->N % BN > 0 && a->N % BN < 192) return false;   // a mostly empty last column tile: leave it to the 128-wide kernel

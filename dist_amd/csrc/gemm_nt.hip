@@ -129,63 +129,116 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const dist_gemm_args p) {
         cur ^= 1;
     }
 
-    // ---- epilogue: lane holds, per fragment, row m = ..+li and columns n = ..+4*lg+{0..3}
+    // ---- epilogue through LDS.  A lane holds, per fragment, row ..+li and 4 columns ..+4*lg+{0..3}; writing
+    // those 8-byte pieces straight to HBM at a row stride (and fetching the residual the same way) ran at a
+    // fraction of the write bandwidth.  Each wave stages its WTM x WTN sub-tile in LDS instead, so the residual /
+    // activation-derivative tiles are fetched and the result tiles are stored as full 16-byte-per-lane rows.
+    __syncthreads();                                        // operand tiles are dead
+    constexpr int ES = (int)sizeof(T);
+    constexpr int ROWB = WTN * ES + 16;                     // padded staging row (bank spread)
+    constexpr int VPR = WTN * ES / 16, EPV = 16 / ES;       // 16-byte vectors per row, elements per vector
+    static_assert(4 * WTM * ROWB <= 2 * (BM + BN) * LD * ES, "epilogue staging fits in the operand buffers");
+    char* ew = smem + wid * (WTM * ROWB);
     T* __restrict__ C = static_cast<T*>(p.C);
     T* __restrict__ C2 = static_cast<T*>(p.C2);
     const T* __restrict__ R = static_cast<const T*>(p.res);
     const T* __restrict__ X = static_cast<const T*>(p.aux);
     const int flags = p.flags;
+    const int om = GENERIC ? p.omap.mode : (int)DIST_OM_PLAIN;
+    const int op0 = p.omap.p0, op1 = p.omap.p1, op2 = p.omap.p2;
+    const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
+    const int reps = om == DIST_OM_DUP ? op0 : 1;
 
-    auto emit = [&](long dest, int ncol, int n, const f32x4& a) {
-        float v[4] = {a[0], a[1], a[2], a[3]};
-        if (flags & DIST_EPI_BIAS) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += p.bias[n + r];
-        }
-        if (flags & DIST_EPI_MULG) {
-            float x[4];
-            load4(X + dest * p.ldaux + ncol, x);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= qgelu_grad(x[r]);
-        }
-        if (flags & DIST_EPI_RES) {
-            float x[4];
-            load4(R + dest * p.ldres + ncol, x);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += x[r];
-        }
-        if (C) {
-            store4(C + dest * p.ldc + ncol, v);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = to_f(from_f<T>(v[r]));      // activation sees the stored value
-        }
-        if (flags & DIST_EPI_ACT2) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = qgelu(v[r]);
-            store4(C2 + dest * p.ldc2 + ncol, v);
+    // destination (row, column) of logical element (m, n) for repetition `a`
+    auto dest_of = [&](int m, int n, int a, int& ncol) -> long {
+        ncol = n;
+        if (om == DIST_OM_PLAIN) return m;
+        if (om == DIST_OM_INSERTCLS) return (long)(m / op0) * (op0 + 1) + 1 + m % op0;
+        const int bj = m / op1, nn = m % op1;
+        if (om == DIST_OM_SPLITCOLS) { a = n / op2; ncol = n - a * op2; }
+        return ((long)bj * op0 + a) * op1 + nn;
+    };
+    auto stage_in = [&](const T* __restrict__ src, int ld, int a) {
+        for (int v = lane; v < WTM * VPR; v += 64) {
+            const int row = v / VPR, vec = v - row * VPR;
+            const int m = mw + row, n = nw + vec * EPV;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (m < M && n < N) { int nc; const long d = dest_of(m, n, a, nc); val = *reinterpret_cast<const uint4*>(src + d * ld + nc); }
+            *reinterpret_cast<uint4*>(ew + row * ROWB + vec * 16) = val;
         }
     };
+    auto flush = [&](T* __restrict__ dst, int ld, int a) {
+        for (int v = lane; v < WTM * VPR; v += 64) {
+            const int row = v / VPR, vec = v - row * VPR;
+            const int m = mw + row, n = nw + vec * EPV;
+            if (m < M && n < N) {
+                int nc; const long d = dest_of(m, n, a, nc);
+                *reinterpret_cast<uint4*>(dst + d * ld + nc) = *reinterpret_cast<const uint4*>(ew + row * ROWB + vec * 16);
+            }
+        }
+    };
+    auto slot = [&](int i, int j) -> T* { return reinterpret_cast<T*>(ew + (i * 16 + li) * ROWB + (j * 16 + lg * 4) * ES); };
 
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wm * WTM + i * 16 + li;
-        if (m >= M) continue;
+    if (flags & DIST_EPI_BIAS) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn * WTN + j * 16 + lg * 4;
-            if (n >= N) continue;
-            if (!GENERIC || p.omap.mode == DIST_OM_PLAIN) {
-                emit(m, n, n, acc[i][j]);
-            } else if (p.omap.mode == DIST_OM_INSERTCLS) {
-                const int bj = m / p.omap.p0, nn = m % p.omap.p0;
-                emit((long)bj * (p.omap.p0 + 1) + 1 + nn, n, n, acc[i][j]);
-            } else if (p.omap.mode == DIST_OM_DUP) {
-                const int bj = m / p.omap.p1, nn = m % p.omap.p1;
-                for (int a = 0; a < p.omap.p0; ++a) emit(((long)bj * p.omap.p0 + a) * p.omap.p1 + nn, n, n, acc[i][j]);
-            } else {   // DIST_OM_SPLITCOLS
-                const int bj = m / p.omap.p1, nn = m % p.omap.p1;
-                const int a = n / p.omap.p2;
-                emit(((long)bj * p.omap.p0 + a) * p.omap.p1 + nn, n - a * p.omap.p2, n, acc[i][j]);
+            const int n = nw + j * 16 + lg * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float bv = (n + r < N) ? p.bias[n + r] : 0.f;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) acc[i][j][r] += bv;
+            }
+        }
+    }
+    if (flags & DIST_EPI_MULG) {                            // v *= quickgelu'(aux[dest])   (never combined with DUP)
+        stage_in(X, p.ldaux, 0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                float x[4];
+                load4(slot(i, j), x);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] *= qgelu_grad(x[r]);
+            }
+    }
+    const bool act_only = (flags & DIST_EPI_ACT2) && !C;
+    for (int a = 0; a < reps; ++a) {
+        if (flags & DIST_EPI_RES) stage_in(R, p.ldres, a);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (flags & DIST_EPI_RES) {
+                    float x[4];
+                    load4(slot(i, j), x);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += x[r];
+                }
+                if (act_only) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = qgelu(v[r]);
+                }
+                store4(slot(i, j), v);
+            }
+        if (act_only) {
+            flush(C2, p.ldc2, a);
+        } else {
+            flush(C, p.ldc, a);
+            if (flags & DIST_EPI_ACT2) {                    // second output = quickgelu(stored value)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        float x[4];
+                        load4(slot(i, j), x);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) x[r] = qgelu(x[r]);
+                        store4(slot(i, j), x);
+                    }
+                flush(C2, p.ldc2, a);
             }
         }
     }
@@ -219,7 +272,15 @@ int dispatch(const dist_gemm_args& a, hipStream_t s) {
 
 extern "C" int dist_op_gemm_nt(const dist_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->B || a->M <= 0 || a->N <= 0 || a->K <= 0 || a->taps <= 0) return DIST_ERR_ARG;
-    if (a->K % 8 || a->N % 4 || a->lda % 8 || a->ldb % 8) return DIST_ERR_ARG;
+    if (a->K % 8 || a->lda % 8 || a->ldb % 8) return DIST_ERR_ARG;
+    {   // the epilogue moves 16-byte vectors: rows of every output / residual operand must keep that alignment
+        const int epv = a->dtype == DIST_BF16 ? 8 : 4;
+        if (a->N % epv) return DIST_ERR_ARG;
+        if ((a->C && a->ldc % epv) || ((a->flags & DIST_EPI_ACT2) && a->ldc2 % epv) || ((a->flags & DIST_EPI_RES) && a->ldres % epv) ||
+            ((a->flags & DIST_EPI_MULG) && a->ldaux % epv)) return DIST_ERR_ARG;
+        if (a->omap.mode == DIST_OM_SPLITCOLS && a->omap.p2 % epv) return DIST_ERR_ARG;
+        if (a->omap.mode == DIST_OM_DUP && (a->flags & DIST_EPI_MULG)) return DIST_ERR_ARG;
+    }
     if (a->M > (1 << 30)) return DIST_ERR_ARG;
     if (!a->C && !(a->flags & DIST_EPI_ACT2)) return DIST_ERR_ARG;
     if ((a->flags & DIST_EPI_ACT2) && !a->C2) return DIST_ERR_ARG;

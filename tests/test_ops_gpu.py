@@ -117,6 +117,25 @@ def test_gemm_nt_rowmaps(gpu_lib, dtype, mode, kw, taps, N):
     torch.testing.assert_close(C.double(), ref, **tol(dtype))
 
 
+def test_gemm_fast_patch_embed_maps(gpu_lib):
+    """the ViT patch embedding as the 256x256 LDS-DMA kernel sees it: strided source rows (every alpha-th
+    frame), rows inserted behind each frame's cls row, residual read at the destination."""
+    from dist_amd import ops, lib as L
+    dtype = torch.bfloat16
+    Nn, alpha, nbj, K, N = 196, 2, 7, 768, 768
+    M = nbj * Nn
+    A = rnd((M * alpha, K), dtype, 1)
+    B = rnd((N, K), dtype, 2, K ** -0.5)
+    res = rnd((nbj * (Nn + 1), N), dtype, 3)
+    C = torch.full((nbj * (Nn + 1), N), 7.0, dtype=dtype, device="cuda")
+    ops.gemm_nt(A, B, M, N, K, res=res, C_out=C, amap=ops.rowmap(L.RM_STRIDED, alpha, Nn), omap=ops.outmap(L.OM_INSERTCLS, Nn))
+    src = A.double().reshape(nbj, alpha, Nn, K)[:, 0].reshape(M, K)
+    ref = (src @ B.double().t()).reshape(nbj, Nn, N) + res.double().reshape(nbj, Nn + 1, N)[:, 1:]
+    Cr = C.double().reshape(nbj, Nn + 1, N)
+    torch.testing.assert_close(Cr[:, 1:], ref, **tol(dtype))
+    assert (Cr[:, 0] == 7.0).all()
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("Nn,nbj", [(9, 11), (196, 8)])
 def test_gemm_nt_outmaps(gpu_lib, dtype, Nn, nbj):
