@@ -122,6 +122,16 @@ class Engine:
 
     def pack(self, what=3):
         L.check(self.lib.dist_pack_weights(self.h, what, ops._stream()), self.h)
+        self._packed_version = (self.theta._version, self.visual._version)
+
+    def sync_packed(self, param_version=0):
+        """Re-pack the working weight copies if the master weights were written since the last pack
+        (`param_version`: any monotone stamp of the nn.Parameter views, e.g. the sum of their `_version`)."""
+        ver = (self.theta._version, self.visual._version, param_version)
+        last = getattr(self, "_sync_version", None)
+        if last is None or last != ver:
+            self.pack(3)
+            self._sync_version = (self.theta._version, self.visual._version, param_version)
 
     # ---- the hot path ----------------------------------------------------------------------
     def vit_forward(self, video):

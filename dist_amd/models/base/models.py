@@ -1,0 +1,19 @@
+"""`BaseVideoModel` = backbone + head (reference models/base/models.py:12-67)."""
+import torch.nn as nn
+
+from ...utils.registry import Registry
+from .backbone import BACKBONE_REGISTRY
+from .base_blocks import HEAD_REGISTRY
+
+MODEL_REGISTRY = Registry("Model")
+
+
+class BaseVideoModel(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.backbone = BACKBONE_REGISTRY.get(cfg.VIDEO.BACKBONE.META_ARCH)(cfg=cfg)
+        self.head = HEAD_REGISTRY.get(cfg.VIDEO.HEAD.NAME)(cfg=cfg)
+
+    def forward(self, x):
+        return self.head(self.backbone(x))

@@ -1,0 +1,74 @@
+"""DiST branch behind the reference's `DiSTNetwork` surface (reference models/module_zoo/branches/dist.py:165-247).
+
+The module owns the trainable `dist_net.*` parameters (views into the engine's flat fp32 buffer, reference
+names and shapes) and maps the config keys the reference reads (dist.py:19-38,51-61,71-76,170-190) onto
+`dist_config`.  TemporalNet / IntegrationNetwork / Temporal2Integration / Integration2Temporal /
+SpatialTemporalAdaPooling are not separate Python modules here: they are the kernel sequence of
+dist_branch_forward / dist_branch_backward (dist_amd/csrc/engine.hip).
+"""
+import torch
+
+from .... import lib as L
+from ...base.clip import DiSTParams
+
+
+def engine_config(cfg, width, layers, patch, resolution, embed_dim, batch, dtype):
+    d = cfg.VIDEO.BACKBONE.DIST
+    sel = list(d.SELECTED_LAYERS)
+    if sel != list(range(layers)):
+        raise L.DistError(f"SELECTED_LAYERS must be 0..{layers - 1} (every DiST yaml selects all layers), got {sel}")
+    if int(d.S_PATCH_SIZE) != int(patch):
+        raise L.DistError(f"DIST.S_PATCH_SIZE {d.S_PATCH_SIZE} must equal the ViT patch {patch} "
+                          "(the L/14 yamls of the reference carry 16, which fails there as well: SURVEY.md §0)")
+    if float(d.TEMPORAL_CONV_MLP_RATIO) != 1 or float(d.INTEGRATION_MLP_RATIO) != 1:
+        raise L.DistError("TEMPORAL_CONV_MLP_RATIO and INTEGRATION_MLP_RATIO must be 1 (all DiST yamls)")
+    c = L.Config()
+    c.dtype = L.BF16 if dtype == torch.bfloat16 else L.F32
+    c.batch, c.frames, c.alpha = batch, int(cfg.DATA.NUM_INPUT_FRAMES), int(cfg.DATA.SPARSE_SAMPLE_ALPHA)
+    c.resolution, c.patch, c.width, c.layers = resolution, patch, width, layers
+    c.integration_dim, c.temporal_dim = int(d.INTEGRATION_DIM), int(d.TEMPORAL_DIM)
+    c.temporal_kernel, c.temporal_patch = int(d.TEMPORAL_KERNEL_SIZE), int(d.T_PATCH_SIZE)
+    c.int_temporal_div = int(round(1.0 / float(d.INTEGRATION_TEMPORAL_MLP_RATIO)))
+    c.ada_layers, c.num_classes, c.embed_dim = int(d.ADA_POOLING_LAYERS), int(cfg.VIDEO.HEAD.NUM_CLASSES), embed_dim
+    c.use_tr = 1
+    return c
+
+
+class DiSTNetwork(DiSTParams):
+    def __init__(self, cfg, d_model, width, output_dim, engine=None):
+        super().__init__()
+        if engine is None:
+            raise L.DistError("DiSTNetwork is constructed by CLIP with its engine (the HIP library is the only implementation)")
+        self.cfg = cfg
+        self.selected_layers = cfg.VIDEO.BACKBONE.DIST.SELECTED_LAYERS
+        self.alpha = int(cfg.DATA.SPARSE_SAMPLE_ALPHA)
+        self.num_frames = cfg.DATA.NUM_INPUT_FRAMES
+        self._engine = [engine]          # not a submodule / buffer
+        self._adopt(engine, "dist_net.", 0, requires_grad=True)
+        self._init_like_reference()
+
+    def _init_like_reference(self):
+        """trunc_normal(0.02) weights, zero biases, unit LayerNorms (reference dist.py:204-220, 76-78, 120-122, 193-201)."""
+        eng = self._engine[0]
+        with torch.no_grad():
+            for name, (off, shape, grp) in eng.tables[0].items():
+                v = eng.view(name)
+                if name.endswith(("ln.weight", "ln_1.weight", "ln_post.weight", "ln_temporal.weight",
+                                  "ln_out_temp_cls_token.weight", "ln_out_spat_cls_token.weight")):
+                    v.fill_(1.0)
+                elif len(shape) == 1:
+                    v.zero_()
+                elif name == "dist_net.proj":
+                    v.normal_(std=shape[0] ** -0.5)
+                else:
+                    torch.nn.init.trunc_normal_(v, std=0.02)
+        eng.pack(2)
+
+    def forward(self, input):
+        """reference signature `forward(input: dict) -> (cls_x [b,E], input)`; needs the frozen ViT features of the
+        same batch in the engine (CLIP.forward runs dist_vit_forward first)."""
+        eng = self._engine[0]
+        tf = input["text_features"].float().contiguous()
+        logits, vid = eng.branch_forward(tf)
+        input["logits_per_image"] = logits
+        return vid, input

@@ -1,0 +1,79 @@
+"""Checkpoints (reference utils/checkpoint.py:102-143,277-347,452-576; process_dist_cpkt.py:10-30).
+
+Loads the reference's published layout ({"model_state": {"backbone.base_encoder.<clip keys>": ...}},
+`ladder_net.*` -> `dist_net.*` rename included) and OpenAI CLIP state-dicts; saves ONLY dist_net (+ the
+optimizer moments) instead of the whole 168 M-parameter model the reference writes every time."""
+import os
+
+import torch
+
+PREFIX = "backbone.base_encoder."
+
+
+def get_checkpoint_dir(path_to_job):
+    return os.path.join(path_to_job, "checkpoints")
+
+
+def make_checkpoint_dir(path_to_job):
+    d = get_checkpoint_dir(path_to_job)
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def get_path_to_checkpoint(path_to_job, epoch):
+    return os.path.join(get_checkpoint_dir(path_to_job), "checkpoint_epoch_{:05d}.pyth".format(epoch))
+
+
+def get_last_checkpoint(path_to_job):
+    d = get_checkpoint_dir(path_to_job)
+    names = sorted(f for f in os.listdir(d) if "checkpoint" in f) if os.path.isdir(d) else []
+    assert names, f"No checkpoints found in '{d}'."
+    return os.path.join(d, names[-1])
+
+
+def normalize_state_dict(sd):
+    """reference key spellings -> CLIP keys (visual.*, dist_net.*, logit_scale, text tower)."""
+    if "model_state" in sd:
+        sd = sd["model_state"]
+    out = {}
+    for k, v in sd.items():
+        if k.startswith("module."):
+            k = k[7:]
+        if k.startswith(PREFIX):
+            k = k[len(PREFIX):]
+        if k.startswith("ladder_net."):
+            k = "dist_net." + k[len("ladder_net."):]
+        out[k] = v
+    return out
+
+
+def save_checkpoint(path_to_job, model, optimizer, epoch, cfg, full=False):
+    eng = model.backbone.base_encoder.engine
+    names = list(eng.tables[0]) + (list(eng.tables[1]) if full else [])
+    state = {PREFIX + n: eng.view(n).detach().cpu().clone() for n in names}
+    state[PREFIX + "logit_scale"] = eng.logit_scale.view(()).cpu().clone()
+    ck = {"epoch": epoch, "model_state": state, "cfg": cfg.to_dict() if hasattr(cfg, "to_dict") else None,
+          "optimizer_state": {"step": eng.step_count,
+                              "exp_avg": None if eng.exp_avg is None else eng.exp_avg.cpu(),
+                              "exp_avg_sq": None if eng.exp_avg_sq is None else eng.exp_avg_sq.cpu()}}
+    make_checkpoint_dir(path_to_job)
+    path = get_path_to_checkpoint(path_to_job, epoch + 1)
+    torch.save(ck, path)
+    return path
+
+
+def load_checkpoint(path, model, optimizer=None, strict=False):
+    ck = torch.load(path, map_location="cpu")
+    sd = normalize_state_dict(ck)
+    clip = model.backbone.base_encoder
+    missing = clip.load_state_dict(sd, strict=False)
+    if strict and (missing.missing_keys or missing.unexpected_keys):
+        raise KeyError(f"checkpoint mismatch: {missing}")
+    eng = clip.engine
+    if optimizer is not None and isinstance(ck, dict) and ck.get("optimizer_state"):
+        st = ck["optimizer_state"]
+        eng.step_count = int(st.get("step", 0))
+        if st.get("exp_avg") is not None:
+            eng.exp_avg = st["exp_avg"].to(eng.device)
+            eng.exp_avg_sq = st["exp_avg_sq"].to(eng.device)
+    return ck.get("epoch", -1) if isinstance(ck, dict) else -1

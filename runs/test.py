@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Multi-view evaluation (reference runs/test.py:24-178,181-322, utils/meters.py:24-176): forward under
+no_grad (the head applies softmax at eval), all-gather of (preds, labels, video ids), per-video score
+summation over NUM_ENSEMBLE_VIEWS x NUM_SPATIAL_CROPS views, top-1 / top-5."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from dist_amd.dataset.synthetic import build_loader, label_texts
+from dist_amd.models.base.builder import build_model
+from dist_amd.utils import checkpoint as cu
+from dist_amd.utils import distributed as du
+from dist_amd.utils import metrics
+
+
+class TestMeter:
+    def __init__(self, num_videos, num_clips, num_cls):
+        self.num_clips = num_clips
+        self.video_preds = torch.zeros(num_videos, num_cls)
+        self.video_labels = torch.zeros(num_videos, dtype=torch.long)
+        self.clip_count = torch.zeros(num_videos, dtype=torch.long)
+
+    def update_stats(self, preds, labels, clip_ids):
+        for p, l, c in zip(preds, labels, clip_ids):
+            vid = int(c) // self.num_clips
+            if self.clip_count[vid] > 0:
+                assert int(self.video_labels[vid]) == int(l), "label mismatch between views of one video"
+            self.video_labels[vid] = l
+            self.video_preds[vid] += p
+            self.clip_count[vid] += 1
+
+    def finalize_metrics(self, ks=(1, 5)):
+        ok = self.clip_count > 0
+        accs = metrics.topk_accuracies(self.video_preds[ok], self.video_labels[ok], ks)
+        return {f"top{k}_acc": float(a) for k, a in zip(ks, accs)}
+
+
+@torch.no_grad()
+def perform_test(test_loader, model, test_meter, cfg, texts):
+    model.eval()
+    for inputs, labels, video_idx, _ in test_loader:
+        inputs["texts"] = texts
+        preds, _ = model(inputs)
+        preds, lab, idx = du.all_gather([preds, labels["supervised"], video_idx])
+        test_meter.update_stats(preds.cpu(), lab.cpu(), idx.cpu())
+    return test_meter.finalize_metrics()
+
+
+def test(cfg):
+    torch.manual_seed(cfg.RANDOM_SEED)
+    model, _ = build_model(cfg)
+    if getattr(cfg.TEST, "CHECKPOINT_FILE_PATH", ""):
+        cu.load_checkpoint(cfg.TEST.CHECKPOINT_FILE_PATH, model, None)
+    loader = build_loader(cfg, "test")
+    views = cfg.TEST.NUM_ENSEMBLE_VIEWS * cfg.TEST.NUM_SPATIAL_CROPS
+    assert len(loader.dataset) % views == 0
+    meter = TestMeter(len(loader.dataset) // views, views, cfg.VIDEO.HEAD.NUM_CLASSES)
+    texts = label_texts(cfg, vocab=model.backbone.base_encoder.vocab_size)
+    out = perform_test(loader, model, meter, cfg, texts)
+    if du.is_master_proc():
+        print(out)
+    du.synchronize()
+    return out

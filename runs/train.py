@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Train entry point with the reference's step semantics (reference runs/train.py:40-206,331-431):
+mixup -> forward -> soft-target CE -> zero_grad / backward -> (gradient all-reduce of dist_net only)
+-> AdamW with a per-iteration cosine + warm-up learning rate -> one fused metric reduce."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from dist_amd.dataset.synthetic import build_loader, label_texts
+from dist_amd.dataset.utils.mixup import Mixup
+from dist_amd.models.base.builder import build_model
+from dist_amd.models.utils import losses
+from dist_amd.models.utils import optimizer as optim
+from dist_amd.utils import checkpoint as cu
+from dist_amd.utils import distributed as du
+from dist_amd.utils import metrics
+
+
+def train_epoch(train_loader, model, model_ema, optimizer, cur_epoch, mixup_fn, cfg, texts, log=print):
+    model.train()
+    data_size = len(train_loader)
+    t0 = time.time()
+    stats = {}
+    for cur_iter, (inputs, labels, _, meta) in enumerate(train_loader):
+        if mixup_fn is not None:
+            inputs["video"], labels["supervised"] = mixup_fn(inputs["video"], labels["supervised"])
+        inputs["texts"] = texts
+        lr = optim.get_epoch_lr(cur_epoch + cfg.TRAIN.NUM_FOLDS * float(cur_iter) / data_size, cfg)
+        optim.set_lr(optimizer, lr)
+        preds, logits = model(inputs)
+        loss, _, _ = losses.calculate_loss(cfg, preds, logits, labels, cur_epoch + cfg.TRAIN.NUM_FOLDS * float(cur_iter) / data_size)
+        optimizer.zero_grad()
+        loss.backward()
+        model.grad_sync.reduce()
+        optimizer.step()
+        hard = labels["supervised"].argmax(dim=1) if labels["supervised"].dim() == 2 else labels["supervised"]
+        top1, top5 = metrics.topk_errors(preds.detach(), hard, (1, 5))
+        loss_r, top1, top5 = du.all_reduce([loss.detach(), top1, top5])          # one packed collective, one host sync
+        stats = {"epoch": cur_epoch, "iter": cur_iter, "loss": float(loss_r), "top1_err": float(top1), "top5_err": float(top5), "lr": lr}
+        if not torch.isfinite(loss_r):
+            raise RuntimeError("ERROR: Got NaN losses")                             # reference utils/misc.py:25-32
+        if du.is_master_proc() and (cur_iter % max(1, cfg.LOG_PERIOD) == 0):
+            clips = (cur_iter + 1) * inputs["video"].shape[0] * du.get_world_size()
+            log({**stats, "clips_per_s": round(clips / (time.time() - t0), 1)})
+    return stats
+
+
+@torch.no_grad()
+def eval_epoch(val_loader, model, cur_epoch, cfg, texts):
+    model.eval()
+    n, c1, c5 = 0, 0.0, 0.0
+    for inputs, labels, _, _ in val_loader:
+        inputs["texts"] = texts
+        preds, _ = model(inputs)
+        k1, k5 = metrics.topks_correct(preds, labels["supervised"], (1, 5))
+        k1, k5 = du.all_reduce([k1, k5], average=False)
+        c1 += float(k1); c5 += float(k5); n += preds.size(0) * du.get_world_size()
+    return {"epoch": cur_epoch, "top1_acc": 100.0 * c1 / max(n, 1), "top5_acc": 100.0 * c5 / max(n, 1)}
+
+
+def train(cfg):
+    torch.manual_seed(cfg.RANDOM_SEED)
+    model, model_ema = build_model(cfg)
+    optimizer = optim.construct_optimizer(model, cfg)
+    start_epoch = 0
+    if cfg.TRAIN.AUTO_RESUME and os.path.isdir(cu.get_checkpoint_dir(cfg.OUTPUT_DIR)) and os.listdir(cu.get_checkpoint_dir(cfg.OUTPUT_DIR)):
+        start_epoch = cu.load_checkpoint(cu.get_last_checkpoint(cfg.OUTPUT_DIR), model, optimizer) + 1
+    elif getattr(cfg.TRAIN, "CHECKPOINT_FILE_PATH", ""):
+        cu.load_checkpoint(cfg.TRAIN.CHECKPOINT_FILE_PATH, model, None)
+    train_loader = build_loader(cfg, "train")
+    val_loader = build_loader(cfg, "val") if cfg.TRAIN.EVAL_PERIOD > 0 else None
+    texts = label_texts(cfg, vocab=model.backbone.base_encoder.vocab_size)
+    mixup_fn = None
+    if cfg.AUGMENTATION.MIXUP.ENABLE or cfg.AUGMENTATION.CUTMIX.ENABLE:
+        mixup_fn = Mixup(mixup_alpha=cfg.AUGMENTATION.MIXUP.ALPHA if cfg.AUGMENTATION.MIXUP.ENABLE else 0.0,
+                         cutmix_alpha=cfg.AUGMENTATION.CUTMIX.ALPHA if cfg.AUGMENTATION.CUTMIX.ENABLE else 0.0,
+                         prob=cfg.AUGMENTATION.MIXUP.PROB, switch_prob=cfg.AUGMENTATION.MIXUP.SWITCH_PROB,
+                         mode=cfg.AUGMENTATION.MIXUP.MODE, label_smoothing=cfg.AUGMENTATION.LABEL_SMOOTHING,
+                         num_classes=cfg.VIDEO.HEAD.NUM_CLASSES, seed=cfg.RANDOM_SEED + du.get_rank())
+    assert (cfg.OPTIMIZER.MAX_EPOCH - start_epoch) % cfg.TRAIN.NUM_FOLDS == 0, "Total training epochs should be divisible by cfg.TRAIN.NUM_FOLDS."
+    stats = {}
+    for cur_epoch in range(start_epoch, cfg.OPTIMIZER.MAX_EPOCH, cfg.TRAIN.NUM_FOLDS):
+        stats = train_epoch(train_loader, model, model_ema, optimizer, cur_epoch, mixup_fn, cfg, texts)
+        if du.is_master_proc() and cfg.TRAIN.CHECKPOINT_PERIOD > 0 and (cur_epoch + cfg.TRAIN.NUM_FOLDS) % cfg.TRAIN.CHECKPOINT_PERIOD == 0:
+            cu.save_checkpoint(cfg.OUTPUT_DIR, model, optimizer, cur_epoch + cfg.TRAIN.NUM_FOLDS - 1, cfg)
+        if val_loader is not None and (cur_epoch + cfg.TRAIN.NUM_FOLDS) % cfg.TRAIN.EVAL_PERIOD == 0:
+            ev = eval_epoch(val_loader, model, cur_epoch, cfg, texts)
+            if du.is_master_proc():
+                print(ev)
+        if getattr(cfg.TRAIN, "MAX_STEPS_DEBUG", 0):
+            break
+    return stats
