@@ -110,6 +110,9 @@ struct dist_handle {
     void *dv, *dzp, *dy, *du, *ds, *dc, *dzu, *dun, *do2, *dq2, *dkv2, *dqn2, *dkn2, *dzs, *dsn, *do_, *dq, *dqn;
     int fwd_b = 0, branch_b = 0;
     const float* text = nullptr;               // borrowed: text features of the last branch_forward
+    // gradient-ready hook + the slices it reports
+    dist_grad_ready_fn grad_hook = nullptr; void* grad_hook_user = nullptr;
+    std::vector<int64_t> layer_begin, layer_end; int64_t tail_begin = 0;
     // measurement hook (dist_profile_begin/end)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;           // pairs (start, stop)
@@ -256,8 +259,10 @@ void build_tables(dist_handle* h) {
     h->stem.bias = add_param(h, 0, "dist_net.temporal_stem.bias", {Ct});
     add_pack(h, h->stem, 0, 3, false);
     h->dl.resize(c.layers);
+    h->layer_begin.resize(c.layers); h->layer_end.resize(c.layers);
     for (int i = 0; i < c.layers; ++i) {
         DistLayer& l = h->dl[i];
+        h->layer_begin[i] = h->total[0];
         l.in_lin = make_lin(h, 0, fmt("dist_net.input_linears.%d.", i), Ci, d, 1, 0, false, {Ci, d});
         l.i2t = make_lin(h, 0, fmt("dist_net.integration2temporal_nets.%d.linear_fuse.", i), Ct, Ci, 1, 0, true, {Ct, Ci});
         l.cls_token = add_param(h, 0, fmt("dist_net.temporal2integration_nets.%d.cls_token", i), {1, 1, t, Ci});
@@ -274,7 +279,9 @@ void build_tables(dist_handle* h) {
         l.tf_proj = make_lin(h, 0, p + "temporal_ffn.c_proj.", Ci, C4, 1, 0, true, {Ci, C4, 1, 1, 1});
         l.in_ln = make_ln(h, 0, p + "ln.", Ci);
         l.in_ln_t = make_ln(h, 0, p + "ln_temporal.", Ci);
+        h->layer_end[i] = h->total[0];
     }
+    h->tail_begin = h->total[0];
     h->ada.resize(c.ada_layers);
     for (int a = 0; a < c.ada_layers; ++a) {
         AdaLayer& A = h->ada[a];
@@ -768,6 +775,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         HIP_CHECK_RET(hipMemsetAsync(h->dR, 0, (size_t)rowsS * Ci * es, x.s));
         RUN(bgrad(x, h->agg_cls, h->du, b, Ci));
     }
+    if (h->grad_hook) h->grad_hook(h->grad_hook_user, h->tail_begin, h->total[0]);      // ada-pooling + head gradients are final
     // Fz = R_last + M'_last: both receive dFz
     HIP_CHECK_RET(hipMemcpyAsync(h->dMp, h->dR, (size_t)rowsS * Ci * es, hipMemcpyDeviceToDevice, x.s));
 
@@ -813,9 +821,17 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
                  RM(DIST_RM_SHIFT, T * N, N, -1)));
         RUN(ln_bwd(x, l.tn_ln, w.X, w.tn_mean, w.tn_rstd, h->dU, dp, true, rowsX));      // dp <- dp + LN'(dU) = dL/dX_i
         { void* tmp = dXn; dXn = dp; dp = tmp; }
+        if (h->grad_hook) h->grad_hook(h->grad_hook_user, h->layer_begin[i], h->layer_end[i]);
     }
     // temporal stem (dist.py:178-181): no input gradient
     RUN(wgrad(x, h->stem, dXn, Ct, h->patches, h->Kp, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 3, true));
+    if (h->grad_hook) h->grad_hook(h->grad_hook_user, 0, h->layer_begin[0]);
+    return DIST_OK;
+}
+
+extern "C" int dist_set_grad_ready_hook(dist_handle* h, dist_grad_ready_fn fn, void* user) {
+    if (!h) return DIST_ERR_ARG;
+    h->grad_hook = fn; h->grad_hook_user = user;
     return DIST_OK;
 }
 

@@ -192,6 +192,14 @@ class Engine:
         ops.adamw(self.theta, self.grads, self.exp_avg, self.exp_avg_sq, self._segs, self.step_count, grad_scale=grad_scale)
         self.pack(2)
 
+    def set_grad_ready_hook(self, fn):
+        """fn(begin, end) is called while backward is being enqueued, once per finished gradient slice."""
+        if fn is None:
+            self._hook = L.GRAD_HOOK(0)
+        else:
+            self._hook = L.GRAD_HOOK(lambda _user, b, e: fn(int(b), int(e)))
+        L.check(self.lib.dist_set_grad_ready_hook(self.h, self._hook, None), self.h)
+
     def profile_begin(self):
         L.check(self.lib.dist_profile_begin(self.h), self.h)
 

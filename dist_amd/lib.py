@@ -63,6 +63,9 @@ class Config(C.Structure):
         "ada_layers", "num_classes", "embed_dim", "use_tr")]
 
 
+GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
+
+
 class DistError(RuntimeError):
     pass
 
@@ -120,6 +123,7 @@ def load():
     _sig(lib, "dist_branch_forward", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_branch_backward", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p])
     _sig(lib, "dist_loss", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
+    _sig(lib, "dist_set_grad_ready_hook", argtypes=[C.c_void_p, GRAD_HOOK, C.c_void_p])
     _sig(lib, "dist_profile_begin", argtypes=[C.c_void_p])
     _sig(lib, "dist_profile_end", argtypes=[C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)])
     _sig(lib, "dist_debug_tensor", argtypes=[C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)])

@@ -9,21 +9,26 @@ from ...utils import distributed as du
 from .models import MODEL_REGISTRY, BaseVideoModel
 
 
-class DistGradSync:
-    """Call `.reduce()` after backward: one sum all-reduce over the flat dist_net gradients; the
-    1/world average is applied by the fused AdamW (grad_scale)."""
+class DistGradSync(du.GradReducer):
+    """Data-parallel gradient exchange of a built model: the bucketed all-reduces of the flat dist_net gradient
+    buffer are started from the engine's gradient-ready hook DURING `loss.backward()`; `.reduce()` after backward
+    only flushes the last bucket and makes the compute stream wait for the side stream."""
 
     def __init__(self, model):
-        self.engine = model.backbone.base_encoder.engine
-        self.world = du.get_world_size()
-
-    @property
-    def grad_scale(self):
-        return 1.0 / self.world
+        super().__init__(model.backbone.base_encoder.engine, du.get_world_size())
 
     def reduce(self):
-        if self.world > 1:
-            torch.distributed.all_reduce(self.engine.grads)
+        if self.world <= 1:
+            return
+        if not self.overlap:
+            torch.distributed.all_reduce(self.eng.grads)
+            return
+        if self._pending is not None:
+            self._send(*self._pending)
+            self._pending = None
+        done = torch.cuda.Event()
+        done.record(self.comm)
+        torch.cuda.current_stream().wait_event(done)
 
 
 def build_model(cfg, gpu_id=None):

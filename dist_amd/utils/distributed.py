@@ -116,15 +116,58 @@ def all_gather(tensors):
 
 
 class GradReducer:
-    """Sum all-reduce of the flat dist_net gradient buffer (and the 1-element logit_scale grad is
-    left local: it is never optimised).  The 1/world average is folded into AdamW's grad_scale."""
+    """Sum all-reduce of the flat dist_net gradient buffer, overlapped with backward.
 
-    def __init__(self, engine, world):
+    The engine reports each gradient slice as soon as the kernels producing it are enqueued (ada-pooling + head,
+    then layer L-1 ... 0, then the stem); slices are coalesced into buckets of >= `bucket_bytes` and every bucket's
+    all-reduce is issued on a side HIP stream behind an event of the compute stream, so RCCL runs over xGMI while
+    the remaining layers' backward kernels execute.  The 1/world average is folded into AdamW (`grad_scale`);
+    the 1-element logit_scale gradient stays local (it is never optimised)."""
+
+    def __init__(self, engine, world, bucket_bytes=16 << 20, overlap=True):
         self.eng = engine
         self.world = world
         self.grad_scale = 1.0 / world
+        self.bucket_elems = bucket_bytes // 4
+        self.overlap = overlap and world > 1 and torch.cuda.is_available()
+        self.comm = torch.cuda.Stream() if self.overlap else None
+        self._pending = None          # [begin, end) not yet sent (slices arrive in descending order)
+        self.n_collectives = 0
+        if self.overlap:
+            engine.set_grad_ready_hook(self._on_slice)
+
+    def _send(self, begin, end):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.comm.wait_event(ev)
+        with torch.cuda.stream(self.comm):
+            dist.all_reduce(self.eng.grads[begin:end])
+        self.n_collectives += 1
+
+    def _on_slice(self, begin, end):
+        if self._pending is None:
+            self._pending = [begin, end]
+        elif end == self._pending[0]:
+            self._pending[0] = begin
+        else:                          # not adjacent: flush what we have
+            self._send(*self._pending)
+            self._pending = [begin, end]
+        if self._pending[1] - self._pending[0] >= self.bucket_elems:
+            self._send(*self._pending)
+            self._pending = None
 
     def backward_and_reduce(self, dlogits):
+        self.n_collectives = 0
         self.eng.backward(dlogits)
-        if self.world > 1:
-            dist.all_reduce(self.eng.grads)          # RCCL ring/direct over xGMI, enqueued behind backward
+        if self.world <= 1:
+            return
+        if not self.overlap:
+            dist.all_reduce(self.eng.grads)
+            self.n_collectives = 1
+            return
+        if self._pending is not None:
+            self._send(*self._pending)
+            self._pending = None
+        done = torch.cuda.Event()
+        done.record(self.comm)
+        torch.cuda.current_stream().wait_event(done)      # AdamW waits for the last bucket

@@ -198,6 +198,13 @@ int dist_branch_forward(dist_handle* h, const float* text_features, int b, float
 /* backward of the branch given dlogits [b,K] fp32 (autograd in the reference, runs/train.py:110);
  * accumulates into the bound flat grads buffer (zeroed first when zero_grads != 0). */
 int dist_branch_backward(dist_handle* h, const float* dlogits, int b, int zero_grads, void* stream);
+/* Data-parallel overlap hook: during dist_branch_backward, `fn(user, begin, end)` is called on the host right
+ * after the launches that complete the gradient range [begin, end) of the flat dist_net buffer have been
+ * enqueued (ada-pooling + head first, then layer L-1 ... 0, then the stem), so the caller can record an event
+ * on the compute stream and start that slice's all-reduce on a side stream while the rest of backward runs
+ * (replaces DDP's bucket hooks, reference models/base/builder.py:72-74).  fn == NULL removes the hook. */
+typedef void (*dist_grad_ready_fn)(void* user, int64_t begin, int64_t end);
+int dist_set_grad_ready_hook(dist_handle* h, dist_grad_ready_fn fn, void* user);
 /* SoftTargetCrossEntropy value and dlogits for the logits of the last branch_forward */
 int dist_loss(dist_handle* h, const float* soft_target, int b, float* loss, float* dlogits, void* stream);
 /* measurement hook for bench.py: between begin and end every launch of the dominant kernel (the plain

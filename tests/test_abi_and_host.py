@@ -131,3 +131,18 @@ def test_distributed_single_process_defaults():
     assert du.get_world_size() == 1 and du.get_rank() == 0 and du.is_master_proc()
     t = [torch.tensor(2.0)]
     assert du.all_reduce(t)[0] is t[0] and du.all_gather(t)[0] is t[0]
+
+
+def test_grad_reducer_bucketing_logic():
+    """slices arrive in descending order; adjacent ones are coalesced into buckets of >= bucket size."""
+    from dist_amd.utils import distributed as du
+    r = du.GradReducer.__new__(du.GradReducer)
+    r.world, r.bucket_elems, r._pending, r.n_collectives = 2, 300, None, 0
+    sent = []
+    r._send = lambda b, e: sent.append((b, e))
+    for sl in [(800, 1000), (700, 800), (600, 700), (500, 600), (400, 500), (100, 400), (0, 100)]:
+        r._on_slice(*sl)
+    if r._pending:
+        r._send(*r._pending)
+    assert sent == [(700, 1000), (400, 700), (100, 400), (0, 100)]
+    assert sorted(sent)[0][0] == 0 and sum(e - b for b, e in sent) == 1000

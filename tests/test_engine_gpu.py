@@ -195,3 +195,24 @@ def test_smaller_batch_than_capacity_and_errors(gpu_lib):
     eng.vit_forward(video)
     with pytest.raises(L.DistError):
         eng.backward(torch.zeros(4, g.K, device="cuda"))                            # backward before branch_forward
+
+
+def test_grad_ready_hook_covers_the_flat_buffer_once(gpu_lib):
+    """the DP overlap hook: slices arrive tail (ada + head) first, then layers L-1..0, then the stem, and tile
+    [0, total) exactly; gradients are already final when a slice is reported (checked against a hook-free run)."""
+    g, eng, sd, video, text, tgt = build("tiny", 2, torch.float32)
+    loss, _ = eng.forward_backward(video, text, tgt)
+    ref = eng.grads.clone()
+    slices, snaps = [], []
+
+    def hook(b, e):
+        slices.append((b, e))
+        snaps.append(eng.grads[b:e].clone())          # enqueued behind the kernels that produced the slice
+    eng.set_grad_ready_hook(hook)
+    eng.forward_backward(video, text, tgt)
+    eng.set_grad_ready_hook(None)
+    assert len(slices) == g.layers + 2
+    assert slices[0][1] == eng.theta.numel() and slices[-1][0] == 0
+    assert all(slices[i][0] == slices[i + 1][1] for i in range(len(slices) - 1))
+    for (b, e), snap in zip(slices, snaps):
+        torch.testing.assert_close(snap, ref[b:e], rtol=1e-4, atol=1e-6)
