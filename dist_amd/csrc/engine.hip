@@ -106,7 +106,14 @@ struct dist_handle {
     void *Fz, *mean_cls, *ysum, *zpost, *v;
     float *y_mean, *y_rstd, *logits, *dlogits, *loss;
     // backward scratch
-    void *dR, *dMp, *dXn, *dXp, *dp, *dz, *dU, *dY, *dh2, *dh1, *dzf, *dNa, *dNb, *dkv, *dkn;
+    // layer-loop scratch, double-buffered by layer parity (the weight-gradient stream lags the data-gradient chain)
+    struct BwdSet { void *dMp, *dM, *dXp, *dp, *dXo, *dz, *dU, *dY, *dh2, *dh1, *dzf, *dNa, *dNb; } bs[2];
+    void *dR, *dkv, *dkn;
+    // weight-gradient side stream (created once per handle; host-side objects only)
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev_a;              // chain -> side: "buffer produced"
+    std::vector<hipEvent_t> ev_b_dr, ev_b_done; // side -> chain: per layer "dR consumed", "all weight gradients of the layer issued and done"
+    hipEvent_t ev_join = nullptr;
     void *dv, *dzp, *dy, *du, *ds, *dc, *dzu, *dun, *do2, *dq2, *dkv2, *dqn2, *dkn2, *dzs, *dsn, *do_, *dq, *dqn;
     int fwd_b = 0, branch_b = 0;
     const float* text = nullptr;               // borrowed: text features of the last branch_forward
@@ -362,9 +369,13 @@ size_t layout_ws(dist_handle* h, char* base) {
     h->Fz = T_(rowsS, Ci); h->mean_cls = T_(b, d); h->ysum = T_(b, Ci); h->zpost = T_(b, Ci); h->v = T_(b, c.embed_dim);
     h->y_mean = F_(b); h->y_rstd = F_(b); h->logits = F_(b * c.num_classes); h->dlogits = F_(b * c.num_classes); h->loss = F_(4);
     // backward scratch
-    h->dR = T_(rowsS, Ci); h->dMp = T_(rowsS, Ci); h->dXn = T_(rowsX, Ct); h->dXp = T_(rowsX, Ct); h->dp = T_(rowsX, Ct);
-    h->dz = T_(rowsX, Ct); h->dU = T_(rowsX, Ct); h->dY = T_(rowsQ, Ct); h->dh2 = T_(rowsS, C4); h->dh1 = T_(rowsS, C4);
-    h->dzf = T_(rowsS, Ci); h->dNa = T_(rowsS, Ci); h->dNb = T_(rowsS, Ci); h->dkv = T_(rowsS, 2 * Ci); h->dkn = T_(rowsS, Ci);
+    h->dR = T_(rowsS, Ci); h->dkv = T_(rowsS, 2 * Ci); h->dkn = T_(rowsS, Ci);
+    for (int k = 0; k < 2; ++k) {
+        dist_handle::BwdSet& q = h->bs[k];
+        q.dMp = T_(rowsS, Ci); q.dM = T_(rowsS, Ci); q.dXp = T_(rowsX, Ct); q.dp = T_(rowsX, Ct); q.dXo = T_(rowsX, Ct);
+        q.dz = T_(rowsX, Ct); q.dU = T_(rowsX, Ct); q.dY = T_(rowsQ, Ct); q.dh2 = T_(rowsS, C4); q.dh1 = T_(rowsS, C4);
+        q.dzf = T_(rowsS, Ci); q.dNa = T_(rowsS, Ci); q.dNb = T_(rowsS, Ci);
+    }
     h->dv = T_(b, c.embed_dim); h->dzp = T_(b, Ci); h->dy = T_(b, Ci); h->du = T_(b, Ci); h->ds = T_(bt, Ci); h->dc = T_(bt, Ci);
     h->dzu = T_(bt, 4 * Ci); h->dun = T_(bt, Ci); h->do2 = T_(b, Ci); h->dq2 = T_(b, Ci); h->dkv2 = T_(bt, 2 * Ci); h->dqn2 = T_(b, Ci);
     h->dkn2 = T_(bt, Ci); h->dzs = T_(bt, 4 * Ci); h->dsn = T_(bt, Ci); h->do_ = T_(bt, Ci); h->dq = T_(bt, Ci); h->dqn = T_(bt, Ci);
@@ -439,13 +450,14 @@ int ln_fwd(const Ctx& c, const float* wbase, const LNp& l, const void* x, void* 
     return dist_op_layernorm(&a, c.s);
 }
 int ln_bwd(const Ctx& c, const LNp& l, const void* x, const float* mean, const float* rstd, const void* dy, void* dx, bool accumulate,
-           long rows, const LNp* l2 = nullptr, const void* dy2 = nullptr) {
+           long rows, const LNp* l2 = nullptr, const void* dy2 = nullptr, const void* dx_add = nullptr, void* dx_copy = nullptr) {
     dist_ln_bwd_args a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.mean = mean; a.rstd = rstd; a.dy = dy; a.w = c.th(l.w); a.dx = dx; a.accumulate_dx = accumulate ? 1 : 0;
     a.dw = c.gr(l.w); a.db = c.gr(l.b);
     if (l2) { a.dy2 = dy2; a.w2 = c.th(l2->w); a.dw2 = c.gr(l2->w); a.db2 = c.gr(l2->b); }
     a.rows = rows; a.C = l.C; a.dtype = c.dtype;
+    a.dx_add = dx_add; a.dx_copy = dx_copy;
     return dist_op_layernorm_bwd(&a, c.s);
 }
 
@@ -464,6 +476,7 @@ extern "C" const char* dist_strerror(int code) {
 }
 extern "C" int dist_abi_version(void) { return 1; }
 
+extern "C" void dist_destroy(dist_handle* h);
 extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
     if (!cfg || !out) return DIST_ERR_ARG;
     const dist_config& c = *cfg;
@@ -482,12 +495,26 @@ extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
     h->PP3 = 3 * c.patch * c.patch; h->Kp = (h->PP3 + 7) / 8 * 8;
     build_tables(h);
     h->ws_bytes = layout_ws(h, nullptr);
+    // side stream + events of the two-stream backward (host objects; no device memory)
+    bool ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
+    auto mk = [&](hipEvent_t& e) { ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
+    h->ev_a.resize(10 * c.layers + 4); h->ev_b_dr.resize(c.layers); h->ev_b_done.resize(c.layers);
+    for (auto& e : h->ev_a) mk(e);
+    for (auto& e : h->ev_b_dr) mk(e);
+    for (auto& e : h->ev_b_done) mk(e);
+    mk(h->ev_join);
+    if (!ok) { dist_destroy(h); return DIST_ERR_STATE; }
     *out = h;
     return DIST_OK;
 }
 extern "C" void dist_destroy(dist_handle* h) {
     if (!h) return;
     for (hipEvent_t e : h->prof_ev) hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_a) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_b_dr) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_b_done) if (e) hipEventDestroy(e);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->side) hipStreamDestroy(h->side);
     delete h;
 }
 extern "C" const char* dist_last_error(const dist_handle* h) { return h ? h->err : ""; }
@@ -775,57 +802,99 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         HIP_CHECK_RET(hipMemsetAsync(h->dR, 0, (size_t)rowsS * Ci * es, x.s));
         RUN(bgrad(x, h->agg_cls, h->du, b, Ci));
     }
-    if (h->grad_hook) h->grad_hook(h->grad_hook_user, h->tail_begin, h->total[0]);      // ada-pooling + head gradients are final
-    // Fz = R_last + M'_last: both receive dFz
-    HIP_CHECK_RET(hipMemcpyAsync(h->dMp, h->dR, (size_t)rowsS * Ci * es, hipMemcpyDeviceToDevice, x.s));
+    // ---- layer loop on two streams -------------------------------------------------------------------------
+    // The data-gradient chain (dX GEMMs, LayerNorm / activation backward) is the critical path and stays on the
+    // caller's stream `A`.  Every weight / bias gradient GEMM only CONSUMES chain buffers, so it runs on the handle's
+    // side stream `B` behind an event of its producer, up to ~2 layers behind the chain: two latency-bound kernel
+    // sequences share the CUs instead of one.  Hazards: (1) chain scratch is double-buffered by layer parity and A
+    // waits for B's "layer i+2 done" event before reusing a set; (2) the two in-place updates of the single-stream
+    // version are out-of-place here (dM = copy of dM' from the LayerNorm backward, dX_out = dp + LN'(dU)).
+    hipStream_t A = x.s, B = h->side;
+    Ctx xb{h, B, c.dtype};
+    int evn = 0;
+    auto fork = [&]() -> int {           // B waits for everything enqueued on A so far
+        hipEvent_t e = h->ev_a[evn++];
+        if (hipEventRecord(e, A) != hipSuccess || hipStreamWaitEvent(B, e, 0) != hipSuccess) return DIST_ERR_STATE;
+        return DIST_OK;
+    };
+    // the ada / head part above ran on A and produced dFz in h->dR; B must also see the zeroed gradient buffer
+    RUN(fork());
+    if (h->grad_hook) h->grad_hook(h->grad_hook_user, h->tail_begin, h->total[0]);      // ada-pooling + head gradients are final on A
 
-    void *dR = h->dR, *dMp = h->dMp, *dXn = h->dXn, *dp = h->dp;
+    const void* dR = h->dR;               // dL/dR_i (for the last layer: dFz)
+    const void* dXn = nullptr;            // dL/dX_{i+1} (none for the last layer)
+    int hook_next = nl - 1;               // next layer slice to report through the gradient-ready hook
     for (int i = nl - 1; i >= 0; --i) {
         const DistLayer& l = h->dl[i];
         DistLayerWs& w = h->lw[i];
+        dist_handle::BwdSet& q = h->bs[i & 1];
         const bool last = (i == nl - 1);
+        if (i + 2 < nl) {                 // set (i & 1) was last used by layer i+2: its weight gradients must be done
+            HIP_CHECK_RET(hipStreamWaitEvent(A, h->ev_b_done[i + 2], 0));
+            for (; hook_next >= i + 2; --hook_next)
+                if (h->grad_hook) h->grad_hook(h->grad_hook_user, h->layer_begin[hook_next], h->layer_end[hook_next]);
+        }
+        if (i + 1 < nl) HIP_CHECK_RET(hipStreamWaitEvent(A, h->ev_b_dr[i + 1], 0));    // dR_{i+1} (set (i & 1) of layer i+2 ... see below)
+
         // ---- IntegrationNetwork backward (dist.py:40-45) ----
-        RUN(wgrad(x, l.ffn_proj, dR, Ci, w.hf, Ci, rowsS, RM(), RM(), 0, true));
-        RUN(wgrad(x, l.tf_proj, dR, Ci, w.g2, C4, rowsS, RM(), RM(), 0, true));
-        RUN(lin_dx(h, x, l.ffn_proj, dR, rowsS, h->dzf, w.zf));                          // dzf = (dR Wp) * g'(zf)
-        RUN(lin_dx(h, x, l.tf_proj, dR, rowsS, h->dh2, w.h2));                           // dh2 = (dR W3) * g'(h2)
-        RUN(lin_wb(h, x, l.ffn_fc, h->dzf, w.Na, rowsS));
-        RUN(wgrad(x, l.tf_fc2, h->dh2, C4, w.h1, C4, rowsS, RM(), RM(DIST_RM_SHIFT, t * L, L, 1), 1, true));
-        RUN(gemm(x, h->dh2, C4, x.pk(l.tf_fc2.pk.b), rowsS, C4, C4, l.tf_fc2.taps, h->dh1, C4, nullptr, nullptr, nullptr, nullptr,
+        // B: dW/db of ffn.c_proj and temporal_ffn.c_proj read dR (produced before this layer started)
+        RUN(wgrad(xb, l.ffn_proj, dR, Ci, w.hf, Ci, rowsS, RM(), RM(), 0, true));
+        RUN(wgrad(xb, l.tf_proj, dR, Ci, w.g2, C4, rowsS, RM(), RM(), 0, true));
+        HIP_CHECK_RET(hipEventRecord(h->ev_b_dr[i], B));
+        RUN(lin_dx(h, x, l.ffn_proj, dR, rowsS, q.dzf, w.zf));                            // dzf = (dR Wp) * g'(zf)
+        RUN(lin_dx(h, x, l.tf_proj, dR, rowsS, q.dh2, w.h2));                             // dh2 = (dR W3) * g'(h2)
+        RUN(fork());
+        RUN(wgrad(xb, l.ffn_fc, q.dzf, Ci, w.Na, Ci, rowsS, RM(), RM(), 0, true));
+        RUN(wgrad(xb, l.tf_fc2, q.dh2, C4, w.h1, C4, rowsS, RM(), RM(DIST_RM_SHIFT, t * L, L, 1), 1, true));
+        RUN(gemm(x, q.dh2, C4, x.pk(l.tf_fc2.pk.b), rowsS, C4, C4, l.tf_fc2.taps, q.dh1, C4, nullptr, nullptr, nullptr, nullptr,
                  RM(DIST_RM_SHIFT, t * L, L, -1)));
-        RUN(lin_wb(h, x, l.tf_fc1, h->dh1, w.Nb, rowsS));
-        RUN(lin_dx(h, x, l.ffn_fc, h->dzf, rowsS, h->dNa));
-        RUN(lin_dx(h, x, l.tf_fc1, h->dh1, rowsS, h->dNb));
-        RUN(ln_bwd(x, l.in_ln, w.Mp, w.in_mean, w.in_rstd, h->dNa, dMp, last, rowsS, &l.in_ln_t, h->dNb));   // dMp: dL/dM'
+        RUN(fork());
+        RUN(wgrad(xb, l.tf_fc1, q.dh1, C4, w.Nb, Ci, rowsS, RM(), RM(), 0, true));
+        RUN(lin_dx(h, x, l.ffn_fc, q.dzf, rowsS, q.dNa));
+        RUN(lin_dx(h, x, l.tf_fc1, q.dh1, rowsS, q.dNb));
+        // dM' = LN'(dNa, dNb) (+ dFz for the last layer); a second copy becomes dM (updated in place by the I2T term)
+        RUN(ln_bwd(x, l.in_ln, w.Mp, w.in_mean, w.in_rstd, q.dNa, q.dMp, false, rowsS, &l.in_ln_t, q.dNb, last ? dR : nullptr, last ? nullptr : q.dM));
         // ---- T2I backward (dist.py:81-86): M' = M + [cls_token ; conv_strided(X')] ----
-        RUN(dist_k_cls_rows_bwd(dMp, x.gr(l.cls_token), (int)bt, L, Ci, t, c.dtype, x.s));
-        RUN(wgrad(x, l.t2i, dMp, Ci, w.Xp, Ct, rowsQ, RM(DIST_RM_SKIPCLS, N), RM(DIST_RM_STRIDED, al, N), 2, true));
+        RUN(fork());
+        RUN(dist_k_cls_rows_bwd(q.dMp, x.gr(l.cls_token), (int)bt, L, Ci, t, c.dtype, B));
+        RUN(wgrad(xb, l.t2i, q.dMp, Ci, w.Xp, Ct, rowsQ, RM(DIST_RM_SKIPCLS, N), RM(DIST_RM_STRIDED, al, N), 2, true));
         // dX' = dX_next (identity, absent for the last layer) + conv^T(dQ): column block a of row (bj,n) -> frame bj*alpha+a
-        RUN(gemm(x, dMp, Ci, x.pk(l.t2i.pk.b), rowsQ, al * Ct, Ci, 1, h->dXp, Ct, nullptr, last ? nullptr : dXn, nullptr, nullptr,
+        RUN(gemm(x, q.dMp, Ci, x.pk(l.t2i.pk.b), rowsQ, al * Ct, Ci, 1, q.dXp, Ct, nullptr, last ? nullptr : dXn, nullptr, nullptr,
                  RM(DIST_RM_SKIPCLS, N), OM(DIST_OM_SPLITCOLS, al, N, Ct)));
         // ---- I2T backward (dist.py:100-105): X_next = X' + upsample(Linear(M[1:])) ----
+        const void* dM = q.dMp;            // last layer: no I2T path, dM = dM'
         if (!last) {
-            RUN(dist_k_pair_sum(dXn, h->dY, bt, N * Ct, al, c.dtype, x.s));
-            RUN(wgrad(x, l.i2t, h->dY, Ct, w.M, Ci, rowsQ, RM(), RM(DIST_RM_SKIPCLS, N), 0, true));
-            RUN(gemm(x, h->dY, Ct, x.pk(l.i2t.pk.b), rowsQ, Ci, Ct, 1, dMp, Ci, nullptr, dMp, nullptr, nullptr, RM(), OM(DIST_OM_INSERTCLS, N)));
+            RUN(dist_k_pair_sum(dXn, q.dY, bt, N * Ct, al, c.dtype, A));
+            RUN(gemm(x, q.dY, Ct, x.pk(l.i2t.pk.b), rowsQ, Ci, Ct, 1, q.dM, Ci, nullptr, q.dM, nullptr, nullptr, RM(), OM(DIST_OM_INSERTCLS, N)));
+            dM = q.dM;
         }
-        // ---- mid_feat = input_linear(F_i) + R_{i-1}: dMp is now dL/dM; no dF_i (frozen) ----
-        RUN(lin_wb(h, x, l.in_lin, dMp, h->feat[i], rowsS));
-        { void* tmp = dR; dR = dMp; dMp = tmp; }                                         // dR_{i-1} = dM
+        RUN(fork());
+        if (!last) RUN(wgrad(xb, l.i2t, q.dY, Ct, w.M, Ci, rowsQ, RM(), RM(DIST_RM_SKIPCLS, N), 0, true));
+        // ---- mid_feat = input_linear(F_i) + R_{i-1}: no dF_i (frozen ViT) ----
+        RUN(wgrad(xb, l.in_lin, dM, Ci, h->feat[i], d, rowsS, RM(), RM(), 0, true));
         // ---- TemporalNet backward (dist.py:63-65): X' = g(p), p = X + conv3x3(V) + b, V = g(z), z = conv_t(U), U = LN(X) ----
-        RUN(dist_op_gelu_bwd(h->dXp, w.p, dp, rowsX * Ct, c.dtype, stream));
-        RUN(wgrad(x, l.tn_fc2, dp, Ct, w.V, Ct, rowsX, RM(), RM(DIST_RM_SPATIAL, h->G, 0, 1), 1, true));
-        RUN(gemm(x, dp, Ct, x.pk(l.tn_fc2.pk.b), rowsX, Ct, Ct, 9, h->dz, Ct, nullptr, nullptr, w.z, nullptr, RM(DIST_RM_SPATIAL, h->G, 0, -1)));
-        RUN(wgrad(x, l.tn_fc1, h->dz, Ct, w.U, Ct, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 1, true));
-        RUN(gemm(x, h->dz, Ct, x.pk(l.tn_fc1.pk.b), rowsX, Ct, Ct, l.tn_fc1.taps, h->dU, Ct, nullptr, nullptr, nullptr, nullptr,
+        RUN(dist_op_gelu_bwd(q.dXp, w.p, q.dp, rowsX * Ct, c.dtype, stream));
+        RUN(gemm(x, q.dp, Ct, x.pk(l.tn_fc2.pk.b), rowsX, Ct, Ct, 9, q.dz, Ct, nullptr, nullptr, w.z, nullptr, RM(DIST_RM_SPATIAL, h->G, 0, -1)));
+        RUN(fork());
+        RUN(wgrad(xb, l.tn_fc2, q.dp, Ct, w.V, Ct, rowsX, RM(), RM(DIST_RM_SPATIAL, h->G, 0, 1), 1, true));
+        RUN(wgrad(xb, l.tn_fc1, q.dz, Ct, w.U, Ct, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 1, true));
+        HIP_CHECK_RET(hipEventRecord(h->ev_b_done[i], B));
+        RUN(gemm(x, q.dz, Ct, x.pk(l.tn_fc1.pk.b), rowsX, Ct, Ct, l.tn_fc1.taps, q.dU, Ct, nullptr, nullptr, nullptr, nullptr,
                  RM(DIST_RM_SHIFT, T * N, N, -1)));
-        RUN(ln_bwd(x, l.tn_ln, w.X, w.tn_mean, w.tn_rstd, h->dU, dp, true, rowsX));      // dp <- dp + LN'(dU) = dL/dX_i
-        { void* tmp = dXn; dXn = dp; dp = tmp; }
-        if (h->grad_hook) h->grad_hook(h->grad_hook_user, h->layer_begin[i], h->layer_end[i]);
+        RUN(ln_bwd(x, l.tn_ln, w.X, w.tn_mean, w.tn_rstd, q.dU, q.dXo, false, rowsX, nullptr, nullptr, q.dp));   // dX_i = dp + LN'(dU)
+        dR = dM;                          // dL/dR_{i-1}
+        dXn = q.dXo;
     }
     // temporal stem (dist.py:178-181): no input gradient
-    RUN(wgrad(x, h->stem, dXn, Ct, h->patches, h->Kp, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 3, true));
-    if (h->grad_hook) h->grad_hook(h->grad_hook_user, 0, h->layer_begin[0]);
+    RUN(fork());
+    RUN(wgrad(xb, h->stem, dXn, Ct, h->patches, h->Kp, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 3, true));
+    // join: the caller's stream continues only after every weight gradient is complete
+    HIP_CHECK_RET(hipEventRecord(h->ev_join, B));
+    HIP_CHECK_RET(hipStreamWaitEvent(A, h->ev_join, 0));
+    if (h->grad_hook) {
+        for (; hook_next >= 0; --hook_next) h->grad_hook(h->grad_hook_user, h->layer_begin[hook_next], h->layer_end[hook_next]);
+        h->grad_hook(h->grad_hook_user, 0, h->layer_begin[0]);
+    }
     return DIST_OK;
 }
 

@@ -19,7 +19,7 @@ namespace {
 
 constexpr int NT = 256;
 constexpr int PADT = 8;
-constexpr int BR = 32;   // rows (reduction) per step
+constexpr int BR = 64;   // rows (reduction) per step = two 32-row MFMA k-blocks
 
 template <typename T, bool TR>
 DEV void gather_frag(Frag<T>& f, const T* tile, int ld, int col0, int li, int lg);
@@ -58,7 +58,7 @@ DEV void gather_frag<bf16_t, true>(Frag<bf16_t>& f, const bf16_t* tile, int ld, 
     f.v = u.v;
 }
 
-template <typename T, int BI, int BJ, int WI, int WJ, bool TR>
+template <typename T, int BI, int BJ, int WI, int WJ, bool TR, bool PLAIN>
 __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, int chunk, int tiles_i, int tiles_c) {
     constexpr int LDI = BI + PADT, LDJ = BJ + PADT;
     constexpr int WTI = BI / WI, WTJ = BJ / WJ;
@@ -75,9 +75,17 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
     const int wi = wid / WJ, wj = wid % WJ;
     const int li = lane & 15, lg = lane >> 4;
 
+    // XCD-aware, bijective remap: the output tiles (and taps) of ONE row chunk get consecutive ids on the same XCD,
+    // so the chunk's rows of dY and X are fetched from HBM once and re-read by the other tiles from that XCD's L2
     const int tiles_ij = tiles_i * tiles_c * p.taps;
-    const int ms = blockIdx.x / tiles_ij;
-    int t = blockIdx.x % tiles_ij;
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x;
+        const int q = nblk / 8, r = nblk % 8, x = bid % 8, y = bid / 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int ms = bid / tiles_ij;
+    int t = bid % tiles_ij;
     const int ti = t % tiles_i; t /= tiles_i;
     const int tc = t % tiles_c; const int tap = t / tiles_c;
     const int i0 = ti * BI, c0 = tc * BJ;
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
             if (v < BR * VI) {
                 const int m = mb + v / VI, col = i0 + (v % VI) * 8;
                 if (m < mend && col < p.NI) {
-                    const int src = rowmap_src(p.amap, m, 0, 1);
+                    const int src = PLAIN ? m : rowmap_src(p.amap, m, 0, 1);
                     if (src >= 0) frag_load(ra[i], A + (long)src * p.lda + col);
                 }
             }
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
             if (v < BR * VJ) {
                 const int m = mb + v / VJ, col = c0 + (v % VJ) * 8;
                 if (m < mend && col < p.K) {
-                    const int src = rowmap_src(p.bmap, m, tap, p.taps);
+                    const int src = PLAIN ? m : rowmap_src(p.bmap, m, tap, p.taps);
                     if (src >= 0) frag_load(rb[i], B + (long)src * p.ldb + col);
                 }
             }
@@ -154,15 +162,18 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
         if (mb + BR < mend) gload(mb + BR);
         const T* ys = Ys + cur * BR * LDI;
         const T* xs = Xs + cur * BR * LDJ;
-        Frag<T> fa[FI], fb[FJ];
 #pragma unroll
-        for (int i = 0; i < FI; ++i) gather_frag<T, TR>(fa[i], ys, LDI, wi * WTI + i * 16, li, lg);
+        for (int kb = 0; kb < BR / 32; ++kb) {
+            Frag<T> fa[FI], fb[FJ];
 #pragma unroll
-        for (int j = 0; j < FJ; ++j) gather_frag<T, TR>(fb[j], xs, LDJ, wj * WTJ + j * 16, li, lg);
+            for (int i = 0; i < FI; ++i) gather_frag<T, TR>(fa[i], ys + kb * 32 * LDI, LDI, wi * WTI + i * 16, li, lg);
 #pragma unroll
-        for (int i = 0; i < FI; ++i)
+            for (int j = 0; j < FJ; ++j) gather_frag<T, TR>(fb[j], xs + kb * 32 * LDJ, LDJ, wj * WTJ + j * 16, li, lg);
 #pragma unroll
-            for (int j = 0; j < FJ; ++j) mma16(fa[i], fb[j], acc[i][j]);     // D[i][c]: row = 4*lg + r, col = li
+            for (int i = 0; i < FI; ++i)
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) mma16(fa[i], fb[j], acc[i][j]);     // D[i][c]: row = 4*lg + r, col = li
+        }
         if (mb + BR < mend) sstore(cur ^ 1);
         __syncthreads();
         cur ^= 1;
@@ -202,20 +213,21 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
     }
 }
 
-template <typename T, int BI, int BJ, int WI, int WJ, bool TR>
+template <typename T, int BI, int BJ, int WI, int WJ, bool TR, bool PLAIN>
 int launch(const dist_gemm_tn_args& a, hipStream_t s) {
     constexpr size_t smem = (size_t)2 * BR * (BI + BJ + 2 * PADT) * sizeof(T);
     static bool attr_done = false;
-    auto kern = gemm_tn_kernel<T, BI, BJ, WI, WJ, TR>;
+    auto kern = gemm_tn_kernel<T, BI, BJ, WI, WJ, TR, PLAIN>;
     if (!attr_done) {
         HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_done = true;
     }
     const int tiles_i = (a.NI + BI - 1) / BI, tiles_c = (a.K + BJ - 1) / BJ;
     const long tiles = (long)tiles_i * tiles_c * a.taps;
-    // split the reduction so that ~1024 blocks are in flight, at least 256 rows per block
-    long msplit = (1024 + tiles - 1) / tiles;
-    const long max_split = (a.M + 255) / 256;
+    // split the reduction so that ~640 blocks are in flight, at least 512 rows per block (every block ends with
+    // tile-size fp32 atomics: fewer, longer blocks keep that traffic down)
+    long msplit = (640 + tiles - 1) / tiles;
+    const long max_split = (a.M + 511) / 512;
     if (msplit > max_split) msplit = max_split;
     if (msplit < 1) msplit = 1;
     int chunk = (int)((a.M + msplit - 1) / msplit);
@@ -226,14 +238,20 @@ int launch(const dist_gemm_tn_args& a, hipStream_t s) {
     return DIST_OK;
 }
 
-template <typename T, bool TR>
-int dispatch(const dist_gemm_tn_args& a, hipStream_t s) {
+template <typename T, bool TR, bool PLAIN>
+int dispatch2(const dist_gemm_tn_args& a, hipStream_t s) {
     const bool i96 = (a.NI % 96 == 0) && (a.NI % 128 != 0);
     const bool j96 = (a.K % 96 == 0) && (a.K % 128 != 0);
-    if (i96 && j96) return launch<T, 96, 96, 2, 2, TR>(a, s);
-    if (i96) return launch<T, 96, 128, 2, 2, TR>(a, s);
-    if (j96) return launch<T, 128, 96, 2, 2, TR>(a, s);
-    return launch<T, 128, 128, 2, 2, TR>(a, s);
+    if (i96 && j96) return launch<T, 96, 96, 2, 2, TR, PLAIN>(a, s);
+    if (i96) return launch<T, 96, 128, 2, 2, TR, PLAIN>(a, s);
+    if (j96) return launch<T, 128, 96, 2, 2, TR, PLAIN>(a, s);
+    return launch<T, 128, 128, 2, 2, TR, PLAIN>(a, s);
+}
+template <typename T, bool TR>
+int dispatch(const dist_gemm_tn_args& a, hipStream_t s) {
+    // plain row maps on both operands (every Linear's dW): no per-row index arithmetic in the loader
+    const bool plain = a.amap.mode == DIST_RM_PLAIN && a.bmap.mode == DIST_RM_PLAIN && a.taps == 1;
+    return plain ? dispatch2<T, TR, true>(a, s) : dispatch2<T, TR, false>(a, s);
 }
 
 }  // namespace

@@ -85,6 +85,8 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const dist_ln_bwd_args p) {
     const T* __restrict__ DY = static_cast<const T*>(p.dy);
     const T* __restrict__ DY2 = static_cast<const T*>(p.dy2);
     T* __restrict__ DX = static_cast<T*>(p.dx);
+    const T* __restrict__ DXA = static_cast<const T*>(p.dx_add);
+    T* __restrict__ DXC = static_cast<T*>(p.dx_copy);
     const float invC = 1.f / (float)C;
     const bool want_w = p.dw || p.db || p.dw2 || p.db2;
 
@@ -137,10 +139,13 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const dist_ln_bwd_args p) {
                 const int v = lr + it * LPR;
                 if (v < nvec) {
                     Frag<T> o;
-                    if (p.accumulate_dx) frag_load(o, DX + row * C + v * 8); else frag_zero(o);
+                    if (DXA) frag_load(o, DXA + row * C + v * 8);
+                    else if (p.accumulate_dx) frag_load(o, DX + row * C + v * 8);
+                    else frag_zero(o);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) frag_set(o, e, frag_get(o, e) + rstd * (g[it][e] - c1 - xh[it][e] * c2));
                     frag_store(o, DX + row * C + v * 8);
+                    if (DXC) frag_store(o, DXC + row * C + v * 8);
                 }
             }
         }

@@ -49,7 +49,7 @@ class LnBwdArgs(C.Structure):
                 ("dy", C.c_void_p), ("w", C.c_void_p), ("dy2", C.c_void_p), ("w2", C.c_void_p),
                 ("dx", C.c_void_p), ("accumulate_dx", C.c_int),
                 ("dw", C.c_void_p), ("db", C.c_void_p), ("dw2", C.c_void_p), ("db2", C.c_void_p),
-                ("rows", C.c_int64), ("C", C.c_int), ("dtype", C.c_int)]
+                ("rows", C.c_int64), ("C", C.c_int), ("dtype", C.c_int), ("dx_add", C.c_void_p), ("dx_copy", C.c_void_p)]
 
 
 class AdamwSeg(C.Structure):

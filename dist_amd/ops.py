@@ -88,7 +88,8 @@ def layernorm(x, w, b, *, y=None, y2=None, w2=None, b2=None, addend=None, period
     return y
 
 
-def layernorm_bwd(x, mean, rstd, dy, w, *, dy2=None, w2=None, dx=None, accumulate=False, dw=None, db=None, dw2=None, db2=None):
+def layernorm_bwd(x, mean, rstd, dy, w, *, dy2=None, w2=None, dx=None, accumulate=False, dw=None, db=None, dw2=None, db2=None,
+                  dx_add=None, dx_copy=None):
     lib = L.load()
     rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
     a = L.LnBwdArgs()
@@ -97,6 +98,7 @@ def layernorm_bwd(x, mean, rstd, dy, w, *, dy2=None, w2=None, dx=None, accumulat
     a.dx, a.accumulate_dx = _p(dx), int(accumulate)
     a.dw, a.db, a.dw2, a.db2 = _p(dw), _p(db), _p(dw2), _p(db2)
     a.rows, a.C, a.dtype = rows, Cc, _dt(x)
+    a.dx_add, a.dx_copy = _p(dx_add), _p(dx_copy)
     L.check(lib.dist_op_layernorm_bwd(C.byref(a), _stream()))
 
 

@@ -102,6 +102,8 @@ typedef struct dist_ln_bwd_args {
     void* dx; int accumulate_dx;
     float* dw; float* db; float* dw2; float* db2;
     int64_t rows; int C; int dtype;
+    const void* dx_add;      /* optional: dx = dx_add + LN'(...) (out-of-place accumulate; overrides accumulate_dx) */
+    void* dx_copy;           /* optional: second copy of dx */
 } dist_ln_bwd_args;
 int dist_op_layernorm_bwd(const dist_ln_bwd_args* a, void* stream);
 

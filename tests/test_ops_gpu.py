@@ -235,6 +235,11 @@ def test_layernorm_fwd_bwd(gpu_lib, dtype, rows, C):
     torch.testing.assert_close(dx.double(), xd.grad + dx0.double(), **tol(dtype, 4.0))
     for got, ref in ((dw, wd.grad), (db, bd.grad), (dw2, w2d.grad), (db2, b2d.grad)):
         torch.testing.assert_close(got.double(), ref, rtol=1e-3, atol=2e-3 * rows ** 0.5)
+    # out-of-place accumulate + second copy (used by the two-stream backward)
+    dxo, dxc = torch.empty_like(x), torch.empty_like(x)
+    ops.layernorm_bwd(x, mean, rstd, dy, w, dy2=dy2, w2=w2, dx=dxo, dx_add=dx0, dx_copy=dxc)
+    torch.testing.assert_close(dxo.double(), xd.grad + dx0.double(), **tol(dtype, 4.0))
+    assert torch.equal(dxo, dxc)
 
 
 @pytest.mark.parametrize("dtype", DT)
