@@ -113,7 +113,8 @@ struct dist_handle {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev_a;              // chain -> side: "buffer produced"
     std::vector<hipEvent_t> ev_b_dr, ev_b_done; // side -> chain: per layer "dR consumed", "all weight gradients of the layer issued and done"
-    hipEvent_t ev_join = nullptr;
+    hipEvent_t ev_join = nullptr, ev_pre = nullptr;
+    std::vector<hipEvent_t> ev_feat;           // chain -> side: ViT layer i output (mid_feat[i]) is complete
     void *dv, *dzp, *dy, *du, *ds, *dc, *dzu, *dun, *do2, *dq2, *dkv2, *dqn2, *dkn2, *dzs, *dsn, *do_, *dq, *dqn;
     int fwd_b = 0, branch_b = 0;
     const float* text = nullptr;               // borrowed: text features of the last branch_forward
@@ -502,7 +503,9 @@ extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
     for (auto& e : h->ev_a) mk(e);
     for (auto& e : h->ev_b_dr) mk(e);
     for (auto& e : h->ev_b_done) mk(e);
-    mk(h->ev_join);
+    h->ev_feat.resize(c.layers + 1);
+    for (auto& e : h->ev_feat) mk(e);
+    mk(h->ev_join); mk(h->ev_pre);
     if (!ok) { dist_destroy(h); return DIST_ERR_STATE; }
     *out = h;
     return DIST_OK;
@@ -513,7 +516,9 @@ extern "C" void dist_destroy(dist_handle* h) {
     for (hipEvent_t e : h->ev_a) if (e) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_b_dr) if (e) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_b_done) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_feat) if (e) hipEventDestroy(e);
     if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->ev_pre) hipEventDestroy(h->ev_pre);
     if (h->side) hipStreamDestroy(h->side);
     delete h;
 }
@@ -580,7 +585,9 @@ extern "C" int dist_vit_forward(dist_handle* h, const float* video, int b, void*
     const int d = c.width, N = h->N, L = h->L;
     const long rowsS = (long)b * h->t * L, rowsQ = (long)b * h->t * N;
 
+    HIP_CHECK_RET(hipEventRecord(h->ev_pre, x.s));                      // everything queued before this step (re-pack, previous step)
     RUN(dist_op_patchify(video, h->patches, b, c.frames, c.resolution, c.resolution, c.patch, c.dtype, stream));
+    HIP_CHECK_RET(hipEventRecord(h->ev_feat[c.layers], x.s));          // patch rows ready (temporal stem input)
     // patch embedding of the frames k = alpha*j only (the reference embeds all T frames and drops the
     // others at clip.py:284); rows land behind their frame's cls row
     RUN(gemm(x, h->patches, h->Kp, x.pk(h->conv1.pk.f), rowsQ, d, h->Kp, 1, h->xa, d, nullptr, nullptr, nullptr, nullptr,
@@ -597,6 +604,7 @@ extern "C" int dist_vit_forward(dist_handle* h, const float* video, int b, void*
         RUN(ln_fwd(x, h->visual, v.ln2, h->xa, h->hbuf, rowsS, nullptr, nullptr));
         RUN(gemm(x, h->hbuf, d, x.pk(v.fc.pk.f), rowsS, 4 * d, d, 1, nullptr, 4 * d, x.vs(v.fc.bias), nullptr, nullptr, h->mlp));
         RUN(gemm(x, h->mlp, 4 * d, x.pk(v.proj.pk.f), rowsS, d, 4 * d, 1, h->feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr));
+        HIP_CHECK_RET(hipEventRecord(h->ev_feat[i], x.s));              // mid_feat[i] complete: the branch may consume it
         xin = h->feat[i];
     }
     h->fwd_b = b;
@@ -623,10 +631,17 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
     if (!h->ws) return fail(h, DIST_ERR_UNBOUND, "dist_branch_forward before dist_bind");
     if (h->fwd_b != b) return fail(h, DIST_ERR_STATE, "dist_branch_forward(b=%d) needs dist_vit_forward with the same batch first (have %d)", b, h->fwd_b);
     const dist_config& c = h->cfg;
-    Ctx x{h, static_cast<hipStream_t>(stream), c.dtype};
+    // The branch runs on the handle's side stream: layer i only needs mid_feat[i], so it executes underneath the
+    // remaining frozen-ViT layers still queued on the caller's stream (their LayerNorm / attention phases and the
+    // tails of the GEMM rounds leave CUs idle); the caller's stream joins at the end.
+    hipStream_t A = static_cast<hipStream_t>(stream);
+    Ctx x{h, h->side, c.dtype};
     const int d = c.width, Ci = c.integration_dim, Ct = c.temporal_dim, C4 = h->C4, N = h->N, L = h->L, T = c.frames, t = h->t, al = c.alpha;
     const long rowsX = (long)b * T * N, rowsS = (long)b * t * L, rowsQ = (long)b * t * N, bt = (long)b * t;
     const int nl = c.layers;
+    stream = h->side;
+    HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_pre, 0));               // what preceded dist_vit_forward on the caller's stream
+    HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_feat[nl], 0));          // patch rows
 
     // temporal stem: Conv3d k=(tp,P,P) as a 5-tap row-shifted GEMM over the shared patch rows (dist.py:178-181,225)
     RUN(gemm(x, h->patches, h->Kp, x.pk(h->stem.pk.f), rowsX, Ct, h->Kp, h->stem.taps, h->lw[0].X, Ct, x.th(h->stem.bias), nullptr, nullptr, nullptr,
@@ -641,6 +656,7 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
                  RM(DIST_RM_SHIFT, T * N, N, 1)));
         RUN(gemm(x, w.V, Ct, x.pk(l.tn_fc2.pk.f), rowsX, Ct, Ct, 9, w.p, Ct, x.th(l.tn_fc2.bias), w.X, nullptr, w.Xp, RM(DIST_RM_SPATIAL, h->G, 0, 1)));
         // mid_feat = input_linear(F_i) + res_feat (dist.py:229)
+        HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_feat[i], 0));
         RUN(gemm(x, h->feat[i], d, x.pk(l.in_lin.pk.f), rowsS, Ci, d, 1, w.M, Ci, x.th(l.in_lin.bias), i ? h->lw[i - 1].R : nullptr, nullptr, nullptr));
         // I2T (dist.py:90-105,231): Linear on the non-cls rows, nearest-upsampled x alpha in T, + x_temporal.
         // (the last layer's result is discarded by the reference, dist.py:235 -> skipped)
@@ -684,10 +700,13 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
     RUN(gemm(x, h->mean_cls, d, x.pk(h->cls_proj.pk.f), b, Ci, d, 1, h->ysum, Ci, x.th(h->cls_proj.bias), h->ubuf[c.ada_layers], nullptr, nullptr));
     RUN(ln_fwd(x, h->theta, h->ln_post, h->ysum, h->zpost, b, h->y_mean, h->y_rstd));
     RUN(gemm(x, h->zpost, Ci, x.pk(h->proj.pk.f), b, c.embed_dim, Ci, 1, h->v, c.embed_dim, nullptr, nullptr, nullptr, nullptr));
+    // join: the caller's stream continues after the branch; the logits kernel runs there (it reads caller-produced text features)
+    HIP_CHECK_RET(hipEventRecord(h->ev_join, x.s));
+    HIP_CHECK_RET(hipStreamWaitEvent(A, h->ev_join, 0));
     // cosine logits (clip.py:509-518)
     RUN(dist_k_logits_loss(h->v, text_features, h->logit_scale, nullptr, h->logits, vid_logits, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           b, c.embed_dim, c.num_classes, c.dtype, stream));
-    if (logits) HIP_CHECK_RET(hipMemcpyAsync(logits, h->logits, (size_t)b * c.num_classes * sizeof(float), hipMemcpyDeviceToDevice, x.s));
+                           b, c.embed_dim, c.num_classes, c.dtype, A));
+    if (logits) HIP_CHECK_RET(hipMemcpyAsync(logits, h->logits, (size_t)b * c.num_classes * sizeof(float), hipMemcpyDeviceToDevice, A));
     h->branch_b = b;
     h->text = text_features;
     return DIST_OK;
