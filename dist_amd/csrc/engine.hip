@@ -110,10 +110,10 @@ struct dist_handle {
     struct BwdSet { void *dMp, *dM, *dXp, *dp, *dXo, *dz, *dU, *dY, *dh2, *dh1, *dzf, *dNa, *dNb; } bs[2];
     void *dR, *dkv, *dkn;
     // weight-gradient side stream (created once per handle; host-side objects only)
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr, side2 = nullptr;
     std::vector<hipEvent_t> ev_a;              // chain -> side: "buffer produced"
     std::vector<hipEvent_t> ev_b_dr, ev_b_done; // side -> chain: per layer "dR consumed", "all weight gradients of the layer issued and done"
-    hipEvent_t ev_join = nullptr, ev_pre = nullptr;
+    hipEvent_t ev_join = nullptr, ev_pre = nullptr, ev_b2 = nullptr;
     std::vector<hipEvent_t> ev_feat;           // chain -> side: ViT layer i output (mid_feat[i]) is complete
     void *dv, *dzp, *dy, *du, *ds, *dc, *dzu, *dun, *do2, *dq2, *dkv2, *dqn2, *dkn2, *dzs, *dsn, *do_, *dq, *dqn;
     int fwd_b = 0, branch_b = 0;
@@ -497,7 +497,8 @@ extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
     build_tables(h);
     h->ws_bytes = layout_ws(h, nullptr);
     // side stream + events of the two-stream backward (host objects; no device memory)
-    bool ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking) == hipSuccess;
     auto mk = [&](hipEvent_t& e) { ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
     h->ev_a.resize(10 * c.layers + 4); h->ev_b_dr.resize(c.layers); h->ev_b_done.resize(c.layers);
     for (auto& e : h->ev_a) mk(e);
@@ -505,7 +506,7 @@ extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
     for (auto& e : h->ev_b_done) mk(e);
     h->ev_feat.resize(c.layers + 1);
     for (auto& e : h->ev_feat) mk(e);
-    mk(h->ev_join); mk(h->ev_pre);
+    mk(h->ev_join); mk(h->ev_pre); mk(h->ev_b2);
     if (!ok) { dist_destroy(h); return DIST_ERR_STATE; }
     *out = h;
     return DIST_OK;
@@ -519,7 +520,9 @@ extern "C" void dist_destroy(dist_handle* h) {
     for (hipEvent_t e : h->ev_feat) if (e) hipEventDestroy(e);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ev_pre) hipEventDestroy(h->ev_pre);
+    if (h->ev_b2) hipEventDestroy(h->ev_b2);
     if (h->side) hipStreamDestroy(h->side);
+    if (h->side2) hipStreamDestroy(h->side2);
     delete h;
 }
 extern "C" const char* dist_last_error(const dist_handle* h) { return h ? h->err : ""; }
@@ -828,12 +831,17 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
     // sequences share the CUs instead of one.  Hazards: (1) chain scratch is double-buffered by layer parity and A
     // waits for B's "layer i+2 done" event before reusing a set; (2) the two in-place updates of the single-stream
     // version are out-of-place here (dM = copy of dM' from the LayerNorm backward, dX_out = dp + LN'(dU)).
-    hipStream_t A = x.s, B = h->side;
-    Ctx xb{h, B, c.dtype};
+    hipStream_t A = x.s, B = h->side, B2 = h->side2;
+    Ctx xb{h, B, c.dtype}, xb2{h, B2, c.dtype};          // two weight-gradient streams: independent dW GEMMs also overlap each other
     int evn = 0;
-    auto fork = [&]() -> int {           // B waits for everything enqueued on A so far
+    auto fork = [&]() -> int {           // B and B2 wait for everything enqueued on A so far
         hipEvent_t e = h->ev_a[evn++];
-        if (hipEventRecord(e, A) != hipSuccess || hipStreamWaitEvent(B, e, 0) != hipSuccess) return DIST_ERR_STATE;
+        if (hipEventRecord(e, A) != hipSuccess || hipStreamWaitEvent(B, e, 0) != hipSuccess || hipStreamWaitEvent(B2, e, 0) != hipSuccess)
+            return DIST_ERR_STATE;
+        return DIST_OK;
+    };
+    auto merge_b2 = [&]() -> int {       // fold B2 into B so one event on B covers both
+        if (hipEventRecord(h->ev_b2, B2) != hipSuccess || hipStreamWaitEvent(B, h->ev_b2, 0) != hipSuccess) return DIST_ERR_STATE;
         return DIST_OK;
     };
     // the ada / head part above ran on A and produced dFz in h->dR; B must also see the zeroed gradient buffer
@@ -858,17 +866,18 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         // ---- IntegrationNetwork backward (dist.py:40-45) ----
         // B: dW/db of ffn.c_proj and temporal_ffn.c_proj read dR (produced before this layer started)
         RUN(wgrad(xb, l.ffn_proj, dR, Ci, w.hf, Ci, rowsS, RM(), RM(), 0, true));
-        RUN(wgrad(xb, l.tf_proj, dR, Ci, w.g2, C4, rowsS, RM(), RM(), 0, true));
+        RUN(wgrad(xb2, l.tf_proj, dR, Ci, w.g2, C4, rowsS, RM(), RM(), 0, true));
+        RUN(merge_b2());
         HIP_CHECK_RET(hipEventRecord(h->ev_b_dr[i], B));
         RUN(lin_dx(h, x, l.ffn_proj, dR, rowsS, q.dzf, w.zf));                            // dzf = (dR Wp) * g'(zf)
         RUN(lin_dx(h, x, l.tf_proj, dR, rowsS, q.dh2, w.h2));                             // dh2 = (dR W3) * g'(h2)
         RUN(fork());
         RUN(wgrad(xb, l.ffn_fc, q.dzf, Ci, w.Na, Ci, rowsS, RM(), RM(), 0, true));
-        RUN(wgrad(xb, l.tf_fc2, q.dh2, C4, w.h1, C4, rowsS, RM(), RM(DIST_RM_SHIFT, t * L, L, 1), 1, true));
+        RUN(wgrad(xb2, l.tf_fc2, q.dh2, C4, w.h1, C4, rowsS, RM(), RM(DIST_RM_SHIFT, t * L, L, 1), 1, true));
         RUN(gemm(x, q.dh2, C4, x.pk(l.tf_fc2.pk.b), rowsS, C4, C4, l.tf_fc2.taps, q.dh1, C4, nullptr, nullptr, nullptr, nullptr,
                  RM(DIST_RM_SHIFT, t * L, L, -1)));
         RUN(fork());
-        RUN(wgrad(xb, l.tf_fc1, q.dh1, C4, w.Nb, Ci, rowsS, RM(), RM(), 0, true));
+        RUN(wgrad(xb2, l.tf_fc1, q.dh1, C4, w.Nb, Ci, rowsS, RM(), RM(), 0, true));
         RUN(lin_dx(h, x, l.ffn_fc, q.dzf, rowsS, q.dNa));
         RUN(lin_dx(h, x, l.tf_fc1, q.dh1, rowsS, q.dNb));
         // dM' = LN'(dNa, dNb) (+ dFz for the last layer); a second copy becomes dM (updated in place by the I2T term)
@@ -876,7 +885,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         // ---- T2I backward (dist.py:81-86): M' = M + [cls_token ; conv_strided(X')] ----
         RUN(fork());
         RUN(dist_k_cls_rows_bwd(q.dMp, x.gr(l.cls_token), (int)bt, L, Ci, t, c.dtype, B));
-        RUN(wgrad(xb, l.t2i, q.dMp, Ci, w.Xp, Ct, rowsQ, RM(DIST_RM_SKIPCLS, N), RM(DIST_RM_STRIDED, al, N), 2, true));
+        RUN(wgrad(xb2, l.t2i, q.dMp, Ci, w.Xp, Ct, rowsQ, RM(DIST_RM_SKIPCLS, N), RM(DIST_RM_STRIDED, al, N), 2, true));
         // dX' = dX_next (identity, absent for the last layer) + conv^T(dQ): column block a of row (bj,n) -> frame bj*alpha+a
         RUN(gemm(x, q.dMp, Ci, x.pk(l.t2i.pk.b), rowsQ, al * Ct, Ci, 1, q.dXp, Ct, nullptr, last ? nullptr : dXn, nullptr, nullptr,
                  RM(DIST_RM_SKIPCLS, N), OM(DIST_OM_SPLITCOLS, al, N, Ct)));
@@ -888,7 +897,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
             dM = q.dM;
         }
         RUN(fork());
-        if (!last) RUN(wgrad(xb, l.i2t, q.dY, Ct, w.M, Ci, rowsQ, RM(), RM(DIST_RM_SKIPCLS, N), 0, true));
+        if (!last) RUN(wgrad(xb2, l.i2t, q.dY, Ct, w.M, Ci, rowsQ, RM(), RM(DIST_RM_SKIPCLS, N), 0, true));
         // ---- mid_feat = input_linear(F_i) + R_{i-1}: no dF_i (frozen ViT) ----
         RUN(wgrad(xb, l.in_lin, dM, Ci, h->feat[i], d, rowsS, RM(), RM(), 0, true));
         // ---- TemporalNet backward (dist.py:63-65): X' = g(p), p = X + conv3x3(V) + b, V = g(z), z = conv_t(U), U = LN(X) ----
@@ -896,7 +905,8 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         RUN(gemm(x, q.dp, Ct, x.pk(l.tn_fc2.pk.b), rowsX, Ct, Ct, 9, q.dz, Ct, nullptr, nullptr, w.z, nullptr, RM(DIST_RM_SPATIAL, h->G, 0, -1)));
         RUN(fork());
         RUN(wgrad(xb, l.tn_fc2, q.dp, Ct, w.V, Ct, rowsX, RM(), RM(DIST_RM_SPATIAL, h->G, 0, 1), 1, true));
-        RUN(wgrad(xb, l.tn_fc1, q.dz, Ct, w.U, Ct, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 1, true));
+        RUN(wgrad(xb2, l.tn_fc1, q.dz, Ct, w.U, Ct, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 1, true));
+        RUN(merge_b2());
         HIP_CHECK_RET(hipEventRecord(h->ev_b_done[i], B));
         RUN(gemm(x, q.dz, Ct, x.pk(l.tn_fc1.pk.b), rowsX, Ct, Ct, l.tn_fc1.taps, q.dU, Ct, nullptr, nullptr, nullptr, nullptr,
                  RM(DIST_RM_SHIFT, T * N, N, -1)));
@@ -907,6 +917,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
     // temporal stem (dist.py:178-181): no input gradient
     RUN(fork());
     RUN(wgrad(xb, h->stem, dXn, Ct, h->patches, h->Kp, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 3, true));
+    RUN(merge_b2());
     // join: the caller's stream continues only after every weight gradient is complete
     HIP_CHECK_RET(hipEventRecord(h->ev_join, B));
     HIP_CHECK_RET(hipStreamWaitEvent(A, h->ev_join, 0));
