@@ -646,27 +646,41 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
     HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_pre, 0));               // what preceded dist_vit_forward on the caller's stream
     HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_feat[nl], 0));          // patch rows
 
+    // Two streams inside the branch: the temporal chain (TemporalNet_i, I2T_i) on `xt`, the integration chain
+    // (input_linear_i, T2I_i, IntegrationNetwork_i) on `x`.  TemporalNet_{i+1} only needs X_{i+1} = X'_i + I2T(M_i),
+    // not R_i, so it runs underneath IntegrationNetwork_i; the two chains meet at M_i (-> I2T) and X'_i (-> T2I).
+    Ctx xt{h, h->side2, c.dtype};
+    HIP_CHECK_RET(hipStreamWaitEvent(xt.s, h->ev_pre, 0));
+    HIP_CHECK_RET(hipStreamWaitEvent(xt.s, h->ev_feat[nl], 0));
+    auto ev_xp = [&](int i) { return h->ev_a[i]; };
+    auto ev_m = [&](int i) { return h->ev_a[nl + i]; };
+
     // temporal stem: Conv3d k=(tp,P,P) as a 5-tap row-shifted GEMM over the shared patch rows (dist.py:178-181,225)
-    RUN(gemm(x, h->patches, h->Kp, x.pk(h->stem.pk.f), rowsX, Ct, h->Kp, h->stem.taps, h->lw[0].X, Ct, x.th(h->stem.bias), nullptr, nullptr, nullptr,
+    RUN(gemm(xt, h->patches, h->Kp, x.pk(h->stem.pk.f), rowsX, Ct, h->Kp, h->stem.taps, h->lw[0].X, Ct, x.th(h->stem.bias), nullptr, nullptr, nullptr,
              RM(DIST_RM_SHIFT, T * N, N, 1)));
     for (int i = 0; i < nl; ++i) {
         const DistLayer& l = h->dl[i];
         DistLayerWs& w = h->lw[i];
         void* Xnext = (i + 1 < nl) ? h->lw[i + 1].X : h->Xlast;
-        // TemporalNet (dist.py:48-65)
-        RUN(ln_fwd(x, h->theta, l.tn_ln, w.X, w.U, rowsX, w.tn_mean, w.tn_rstd));
-        RUN(gemm(x, w.U, Ct, x.pk(l.tn_fc1.pk.f), rowsX, Ct, Ct, l.tn_fc1.taps, w.z, Ct, x.th(l.tn_fc1.bias), nullptr, nullptr, w.V,
+        // ---- temporal chain: TemporalNet (dist.py:48-65)
+        RUN(ln_fwd(xt, h->theta, l.tn_ln, w.X, w.U, rowsX, w.tn_mean, w.tn_rstd));
+        RUN(gemm(xt, w.U, Ct, x.pk(l.tn_fc1.pk.f), rowsX, Ct, Ct, l.tn_fc1.taps, w.z, Ct, x.th(l.tn_fc1.bias), nullptr, nullptr, w.V,
                  RM(DIST_RM_SHIFT, T * N, N, 1)));
-        RUN(gemm(x, w.V, Ct, x.pk(l.tn_fc2.pk.f), rowsX, Ct, Ct, 9, w.p, Ct, x.th(l.tn_fc2.bias), w.X, nullptr, w.Xp, RM(DIST_RM_SPATIAL, h->G, 0, 1)));
-        // mid_feat = input_linear(F_i) + res_feat (dist.py:229)
+        RUN(gemm(xt, w.V, Ct, x.pk(l.tn_fc2.pk.f), rowsX, Ct, Ct, 9, w.p, Ct, x.th(l.tn_fc2.bias), w.X, nullptr, w.Xp, RM(DIST_RM_SPATIAL, h->G, 0, 1)));
+        HIP_CHECK_RET(hipEventRecord(ev_xp(i), xt.s));
+        // ---- integration chain: mid_feat = input_linear(F_i) + res_feat (dist.py:229)
         HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_feat[i], 0));
         RUN(gemm(x, h->feat[i], d, x.pk(l.in_lin.pk.f), rowsS, Ci, d, 1, w.M, Ci, x.th(l.in_lin.bias), i ? h->lw[i - 1].R : nullptr, nullptr, nullptr));
-        // I2T (dist.py:90-105,231): Linear on the non-cls rows, nearest-upsampled x alpha in T, + x_temporal.
+        HIP_CHECK_RET(hipEventRecord(ev_m(i), x.s));
+        // I2T (dist.py:90-105,231) on the temporal chain: Linear on the non-cls rows, nearest-upsampled x alpha in T, + x_temporal.
         // (the last layer's result is discarded by the reference, dist.py:235 -> skipped)
-        if (i + 1 < nl)
-            RUN(gemm(x, w.M, Ci, x.pk(l.i2t.pk.f), rowsQ, Ct, Ci, 1, Xnext, Ct, x.th(l.i2t.bias), w.Xp, nullptr, nullptr,
+        if (i + 1 < nl) {
+            HIP_CHECK_RET(hipStreamWaitEvent(xt.s, ev_m(i), 0));
+            RUN(gemm(xt, w.M, Ci, x.pk(l.i2t.pk.f), rowsQ, Ct, Ci, 1, Xnext, Ct, x.th(l.i2t.bias), w.Xp, nullptr, nullptr,
                      RM(DIST_RM_SKIPCLS, N), OM(DIST_OM_DUP, al, N)));
+        }
         // T2I (dist.py:68-86,232): strided temporal conv into the patch rows of M', learnable cls row
+        HIP_CHECK_RET(hipStreamWaitEvent(x.s, ev_xp(i), 0));
         RUN(gemm(x, w.Xp, Ct, x.pk(l.t2i.pk.f), rowsQ, Ci, Ct, al, w.Mp, Ci, x.th(l.t2i.bias), w.M, nullptr, nullptr,
                  RM(DIST_RM_STRIDED, al, N), OM(DIST_OM_INSERTCLS, N)));
         RUN(dist_k_cls_rows(w.Mp, w.M, x.th(l.cls_token), (int)bt, L, Ci, t, c.dtype, x.s));
