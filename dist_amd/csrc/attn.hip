@@ -15,16 +15,28 @@
 
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = 512;           // 8 waves: the per-q-tile softmax chain is latency-bound, more waves per SIMD hide it
 constexpr int HD = 64;           // head dim
 constexpr int KPAD = 8;
+
+// 4x16 block transpose reads: lane li of a 16-lane group passes the address of 4 contiguous bf16 of block row li>>2 and
+// receives column li of the block (rows = 4 consecutive keys); the second read is the block 16 keys further
+DEV void v_frag_tr(Frag<bf16_t>& f, const bf16_t* p0, int stride16) {
+    typedef s16x4 __attribute__((address_space(3))) * lds_v4;
+    union { s16x4 s[2]; bf16x8 v; } u;
+    u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p0));
+    u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p0 + stride16));
+    f.v = u.v;
+}
+DEV void v_frag_tr(Frag<float>&, const float*, int) {}
 
 template <typename T>
 __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int heads, int Lp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KLD = HD + KPAD, VLD = Lp + KPAD;
+    constexpr bool TRV = sizeof(T) == 2;         // bf16: V stays row-major and is gathered with LDS transpose reads
     T* Ks = reinterpret_cast<T*>(smem);          // [Lp][KLD]
-    T* Vt = Ks + Lp * KLD;                       // [HD][VLD]
+    T* Vt = Ks + Lp * KLD;                       // fp32: [HD][VLD] (transposed) | bf16: [Lp][KLD] (row-major)
 
     const int f = blockIdx.x / heads, h = blockIdx.x % heads;
     const int d = heads * HD, ld = 3 * d;
@@ -40,88 +52,123 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
         if (key < L) frag_load(fr, base + (long)key * ld + d + h * HD + dv * 8);
         frag_store(fr, Ks + key * KLD + dv * 8);
     }
-    // V: transposed, key fastest (conflict-free LDS writes)
-    for (int v = tid; v < Lp * (HD / 8); v += NT) {
-        const int key = v % Lp, dv = v / Lp;
-        Frag<T> fr;
-        frag_zero(fr);
-        if (key < L) frag_load(fr, base + (long)key * ld + 2 * d + h * HD + dv * 8);
+    if (TRV) {
+        // V row-major like K (coalesced 16-B loads and stores); the PV fragments use ds_read_b64_tr_b16
+        for (int v = tid; v < Lp * (HD / 8); v += NT) {
+            const int key = v / (HD / 8), dv = v % (HD / 8);
+            Frag<T> fr;
+            frag_zero(fr);
+            if (key < L) frag_load(fr, base + (long)key * ld + 2 * d + h * HD + dv * 8);
+            frag_store(fr, Vt + key * KLD + dv * 8);
+        }
+    } else {
+        // V transposed, key fastest (conflict-free scalar LDS writes)
+        for (int v = tid; v < Lp * (HD / 8); v += NT) {
+            const int key = v % Lp, dv = v / Lp;
+            Frag<T> fr;
+            frag_zero(fr);
+            if (key < L) frag_load(fr, base + (long)key * ld + 2 * d + h * HD + dv * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) Vt[(dv * 8 + e) * VLD + key] = from_f<T>(frag_get(fr, e));
+            for (int e = 0; e < 8; ++e) Vt[(dv * 8 + e) * VLD + key] = from_f<T>(frag_get(fr, e));
+        }
     }
     __syncthreads();
 
     const int nq = (L + 15) / 16, nslab = Lp / 32;
-    for (int qt = wid; qt < nq; qt += 4) {
-        const int q = qt * 16 + li;
-        Frag<T> fq[2];
-        frag_zero(fq[0]); frag_zero(fq[1]);
-        if (q < L) {
-            frag_load(fq[0], base + (long)q * ld + h * HD + lg * 8);
-            frag_load(fq[1], base + (long)q * ld + h * HD + 32 + lg * 8);
-        }
-        f32x4 o[4];
+    constexpr int NW = NT / 64;
+    // each wave walks TWO 16-query tiles at once (qt, qt + NW): two independent score -> softmax -> PV dependency
+    // chains per wave, so the shuffle / exp / MFMA latencies of one tile are covered by the other
+    for (int qt0 = wid; qt0 < nq; qt0 += 2 * NW) {
+        int qrow[2];
+        Frag<T> fq[2][2];
+        f32x4 o[2][4];
+        float mrun[2], lrun[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float mrun = -1e30f, lrun = 0.f;
+        for (int u = 0; u < 2; ++u) {
+            const int qt = qt0 + u * NW;
+            qrow[u] = qt < nq ? qt * 16 + li : L;          // L = "no query" (nothing loaded, nothing stored)
+            frag_zero(fq[u][0]); frag_zero(fq[u][1]);
+            if (qrow[u] < L) {
+                frag_load(fq[u][0], base + (long)qrow[u] * ld + h * HD + lg * 8);
+                frag_load(fq[u][1], base + (long)qrow[u] * ld + h * HD + 32 + lg * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mrun[u] = -1e30f; lrun[u] = 0.f;
+        }
+        const bool two = qt0 + NW < nq;                   // wave-uniform
 
         for (int s = 0; s < nslab; ++s) {
-            f32x4 st[2];
+            Frag<T> fk[2][2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 const T* kp = Ks + (s * 32 + t * 16 + li) * KLD + lg * 8;
-                Frag<T> fk;
-                frag_load(fk, kp);
-                mma16(fk, fq[0], st[t]);
-                frag_load(fk, kp + 32);
-                mma16(fk, fq[1], st[t]);
+                frag_load(fk[t][0], kp);
+                frag_load(fk[t][1], kp + 32);
             }
-            float mx = -1e30f;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = s * 32 + t * 16 + lg * 4 + r;
-                    st[t][r] = key < L ? st[t][r] * 0.125f : -1e30f;
-                    mx = fmaxf(mx, st[t][r]);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mnew = fmaxf(mrun, mx);
-            const float scale = __expf(mrun - mnew);
-            mrun = mnew;
-            Frag<T> fp;
-            float ps = 0.f;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = s * 32 + t * 16 + lg * 4 + r;
-                    const float pv = key < L ? __expf(st[t][r] - mnew) : 0.f;
-                    ps += pv;
-                    frag_set(fp, t * 4 + r, pv);
-                }
-            lrun = lrun * scale + ps;
+            Frag<T> fv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[j][r] *= scale;
                 // V^T fragment: row = dcol j*16+li, k-slots = keys (s*32 + 4lg + e | +16)
-                const T* vp = Vt + (j * 16 + li) * VLD + s * 32 + lg * 4;
-                Frag<T> fv;
-                frag_load44(fv, vp, vp + 16);
-                mma16(fv, fp, o[j]);
+                if (TRV) v_frag_tr(fv[j], Vt + (s * 32 + 4 * lg + (li >> 2)) * KLD + j * 16 + (li & 3) * 4, 16 * KLD);
+                else { const T* vp = Vt + (j * 16 + li) * VLD + s * 32 + lg * 4; frag_load44(fv[j], vp, vp + 16); }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !two) continue;
+                f32x4 st[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    mma16(fk[t][0], fq[u][0], st[t]);
+                    mma16(fk[t][1], fq[u][1], st[t]);
+                }
+                float mx = -1e30f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = s * 32 + t * 16 + lg * 4 + r;
+                        st[t][r] = key < L ? st[t][r] * 0.125f : -1e30f;
+                        mx = fmaxf(mx, st[t][r]);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mnew = fmaxf(mrun[u], mx);
+                const float scale = __expf(mrun[u] - mnew);
+                mrun[u] = mnew;
+                Frag<T> fp;
+                float ps = 0.f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = s * 32 + t * 16 + lg * 4 + r;
+                        const float pv = key < L ? __expf(st[t][r] - mnew) : 0.f;
+                        ps += pv;
+                        frag_set(fp, t * 4 + r, pv);
+                    }
+                lrun[u] = lrun[u] * scale + ps;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[u][j][r] *= scale;
+                    mma16(fv[j], fp, o[u][j]);
+                }
             }
         }
-        lrun += __shfl_xor(lrun, 16, 64);
-        lrun += __shfl_xor(lrun, 32, 64);
-        const float inv = 1.f / lrun;
-        if (q < L) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v4[4] = {o[j][0] * inv, o[j][1] * inv, o[j][2] * inv, o[j][3] * inv};
-                store4(out + ((long)f * L + q) * d + h * HD + j * 16 + lg * 4, v4);
+        for (int u = 0; u < 2; ++u) {
+            float l = lrun[u];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            const float inv = 1.f / l;
+            if (qrow[u] < L) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v4[4] = {o[u][j][0] * inv, o[u][j][1] * inv, o[u][j][2] * inv, o[u][j][3] * inv};
+                    store4(out + ((long)f * L + qrow[u]) * d + h * HD + j * 16 + lg * 4, v4);
+                }
             }
         }
     }
@@ -202,7 +249,8 @@ __global__ __launch_bounds__(64) void xattn1q_bwd(const T* __restrict__ q, const
 template <typename T>
 int launch_attn(const void* qkv, void* out, int frames, int L, int heads, hipStream_t s) {
     const int Lp = (L + 31) / 32 * 32;
-    const size_t smem = ((size_t)Lp * (HD + KPAD) + (size_t)HD * (Lp + KPAD)) * sizeof(T);
+    const size_t smem = sizeof(T) == 2 ? (size_t)2 * Lp * (HD + KPAD) * sizeof(T)
+                                       : ((size_t)Lp * (HD + KPAD) + (size_t)HD * (Lp + KPAD)) * sizeof(T);
     if (smem > 160 * 1024) return DIST_ERR_ARG;
     static size_t attr_smem = 0;
     if (smem > attr_smem) {
