@@ -109,6 +109,8 @@ struct dist_handle {
     // layer-loop scratch, double-buffered by layer parity (the weight-gradient stream lags the data-gradient chain)
     struct BwdSet { void *dMp, *dM, *dXp, *dp, *dXo, *dz, *dU, *dY, *dh2, *dh1, *dzf, *dNa, *dNb; } bs[2];
     void *dR, *dkv, *dkn;
+    float* tn_partial[3] = {nullptr, nullptr, nullptr};   // two-phase dW reduction scratch, one per stream that launches dW GEMMs
+    long tn_partial_elems = 0;
     // weight-gradient side stream (created once per handle; host-side objects only)
     hipStream_t side = nullptr, side2 = nullptr;
     std::vector<hipEvent_t> ev_a;              // chain -> side: "buffer produced"
@@ -371,6 +373,8 @@ size_t layout_ws(dist_handle* h, char* base) {
     h->y_mean = F_(b); h->y_rstd = F_(b); h->logits = F_(b * c.num_classes); h->dlogits = F_(b * c.num_classes); h->loss = F_(4);
     // backward scratch
     h->dR = T_(rowsS, Ci); h->dkv = T_(rowsS, 2 * Ci); h->dkn = T_(rowsS, Ci);
+    h->tn_partial_elems = 8l << 20;                          // 32 MB each: >= 384 partial tiles of 128 x 128
+    for (int k = 0; k < 3; ++k) h->tn_partial[k] = F_(h->tn_partial_elems);
     for (int k = 0; k < 2; ++k) {
         dist_handle::BwdSet& q = h->bs[k];
         q.dMp = T_(rowsS, Ci); q.dM = T_(rowsS, Ci); q.dXp = T_(rowsX, Ct); q.dp = T_(rowsX, Ct); q.dXo = T_(rowsX, Ct);
@@ -435,6 +439,11 @@ int wgrad(const Ctx& c, const Lin& l, const void* dY, int ld_dy, const void* X, 
     else { const int PP3 = c.h->PP3, PP = PP3 / 3; g.K = PP3; g.so_i = (long)PP3 * l.taps; g.so_tap = PP; g.so_outer = (long)PP * l.taps; g.inner = PP; }
     g.dtype = c.dtype; g.use_tr = c.h->cfg.use_tr;
     g.colsum = (with_bias && l.bias >= 0) ? c.gr(l.bias) : nullptr;       // db fused into the same pass over dY
+    {   // two-phase reduction scratch of the stream this launch goes to
+        dist_handle* h = c.h;
+        const int k = c.s == h->side ? 1 : (c.s == h->side2 ? 2 : 0);
+        g.partial = h->tn_partial[k]; g.partial_elems = h->tn_partial_elems;
+    }
     return dist_op_gemm_tn(&g, c.s);
 }
 int bgrad(const Ctx& c, long bias_off, const void* dY, long rows, int C, dist_rowmap m = RM()) {

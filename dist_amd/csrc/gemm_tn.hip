@@ -96,6 +96,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
     const T* __restrict__ A = static_cast<const T*>(p.A);
     const T* __restrict__ B = static_cast<const T*>(p.B);
 
+    const int kvec_last = (p.K + 7) / 8 * 8 - 8;           // last 8-wide column vector that stays inside a row of B
     // fused bias gradient: the blocks of the first column tile also sum the columns of their A rows
     const bool do_colsum = p.colsum != nullptr && tc == 0 && tap == 0;
     float csum[I_IT][8];
@@ -104,47 +105,51 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) csum[i][e] = 0.f;
 
-    Frag<T> ra[I_IT], rb[J_IT];
-    auto gload = [&](int mb) {
+    // Two register sets: the global loads of step s+2 are issued as soon as set (s & 1) has been written to LDS, so two
+    // 64-row tiles are in flight per block (the reduction is cold-HBM latency-bound: one tile of prefetch left the waves
+    // parked on s_waitcnt for most of a step).
+    // Loads are UNCONDITIONAL (addresses clamped into the matrices, validity kept as a flag and applied when the tile
+    // is written to LDS): with a branch around each load hipcc loses its load counting and waits vmcnt(0) before the LDS
+    // writes, which drains the set that was just requested and defeats the 2-deep prefetch.
+    static_assert((BR * VI) % NT == 0 && (BR * VJ) % NT == 0, "whole vectors per thread");
+    struct Regs { Frag<T> a[I_IT], b[J_IT]; unsigned oka, okb; };
+    auto gload = [&](Regs& R, int mb) __attribute__((always_inline)) {
+        R.oka = 0; R.okb = 0;
 #pragma unroll
         for (int i = 0; i < I_IT; ++i) {
             const int v = tid + i * NT;
-            frag_zero(ra[i]);
-            if (v < BR * VI) {
-                const int m = mb + v / VI, col = i0 + (v % VI) * 8;
-                if (m < mend && col < p.NI) {
-                    const int src = PLAIN ? m : rowmap_src(p.amap, m, 0, 1);
-                    if (src >= 0) frag_load(ra[i], A + (long)src * p.lda + col);
-                }
-            }
-            if (do_colsum) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) csum[i][e] += frag_get(ra[i], e);
-            }
+            const int m = mb + v / VI, col = i0 + (v % VI) * 8;
+            const int mm = min(m, mend - 1), cc = min(col, p.NI - 8);
+            const int src = PLAIN ? mm : rowmap_src(p.amap, mm, 0, 1);
+            if (m < mend && col < p.NI && src >= 0) R.oka |= 1u << i;
+            frag_load(R.a[i], A + (long)max(src, 0) * p.lda + cc);
         }
 #pragma unroll
         for (int i = 0; i < J_IT; ++i) {
             const int v = tid + i * NT;
-            frag_zero(rb[i]);
-            if (v < BR * VJ) {
-                const int m = mb + v / VJ, col = c0 + (v % VJ) * 8;
-                if (m < mend && col < p.K) {
-                    const int src = PLAIN ? m : rowmap_src(p.bmap, m, tap, p.taps);
-                    if (src >= 0) frag_load(rb[i], B + (long)src * p.ldb + col);
-                }
-            }
+            const int m = mb + v / VJ, col = c0 + (v % VJ) * 8;
+            const int mm = min(m, mend - 1), cc = min(col, kvec_last);
+            const int src = PLAIN ? mm : rowmap_src(p.bmap, mm, tap, p.taps);
+            if (m < mend && col < p.K && src >= 0) R.okb |= 1u << i;
+            frag_load(R.b[i], B + (long)max(src, 0) * p.ldb + cc);
         }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](Regs& R, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < I_IT; ++i) {
             const int v = tid + i * NT;
-            if (v < BR * VI) frag_store(ra[i], Ys + (buf * BR + v / VI) * LDI + (v % VI) * 8);
+            if (!((R.oka >> i) & 1u)) frag_zero(R.a[i]);
+            frag_store(R.a[i], Ys + (buf * BR + v / VI) * LDI + (v % VI) * 8);
+            if (do_colsum) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) csum[i][e] += frag_get(R.a[i], e);
+            }
         }
 #pragma unroll
         for (int i = 0; i < J_IT; ++i) {
             const int v = tid + i * NT;
-            if (v < BR * VJ) frag_store(rb[i], Xs + (buf * BR + v / VJ) * LDJ + (v % VJ) * 8);
+            if (!((R.okb >> i) & 1u)) frag_zero(R.b[i]);
+            frag_store(R.b[i], Xs + (buf * BR + v / VJ) * LDJ + (v % VJ) * 8);
         }
     };
 
@@ -154,14 +159,14 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
 #pragma unroll
         for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    gload(mbeg);
-    sstore(0);
-    __syncthreads();
-    int cur = 0;
-    for (int mb = mbeg; mb < mend; mb += BR) {
-        if (mb + BR < mend) gload(mb + BR);
-        const T* ys = Ys + cur * BR * LDI;
-        const T* xs = Xs + cur * BR * LDJ;
+    const int nsteps = (mend - mbeg + BR - 1) / BR;
+    auto body = [&](Regs& R, int st) __attribute__((always_inline)) {
+        const int buf = st & 1;
+        sstore(R, buf);                                   // waits for this set's loads only
+        __syncthreads();                                  // tile st visible; buffer (st+1)&1 no longer read by anyone
+        if (st + 2 < nsteps) gload(R, mbeg + (st + 2) * BR);
+        const T* ys = Ys + buf * BR * LDI;
+        const T* xs = Xs + buf * BR * LDJ;
 #pragma unroll
         for (int kb = 0; kb < BR / 32; ++kb) {
             Frag<T> fa[FI], fb[FJ];
@@ -174,10 +179,15 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) mma16(fa[i], fb[j], acc[i][j]);     // D[i][c]: row = 4*lg + r, col = li
         }
-        if (mb + BR < mend) sstore(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+    };
+    Regs r0, r1;
+    gload(r0, mbeg);
+    if (nsteps > 1) gload(r1, mbeg + BR);
+    for (int st = 0; st < nsteps; st += 2) {
+        body(r0, st);
+        if (st + 1 < nsteps) body(r1, st + 1);
     }
+    __syncthreads();                                      // the tiles are dead: LDS is reused by the bias-gradient reduction
 
     if (do_colsum) {
         // (tid, i) always maps to the same column vector: v % VI with v = tid + i*NT
@@ -197,19 +207,56 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
             if (i0 + i < p.NI) atomicAdd(p.colsum + i0 + i, red[i]);
     }
 
+    // ---- epilogue: fp32 atomics into the parameter-layout gradient.  The MFMA layout gives a lane 4 rows x 1 column per
+    // fragment (a wave instruction would touch 4 x 64-byte pieces); each wave stages its WTI x WTJ sub-tile in LDS and
+    // issues the atomics row by row instead, 64 consecutive columns per instruction.
+    __syncthreads();                                      // operand tiles / bias scratch are dead
+    {
+        constexpr int SLD = WTJ + 1;                      // +1 float: conflict-free column writes
+        float* st = reinterpret_cast<float*>(smem) + wid * (WTI * SLD);
+        static_assert(4 * WTI * SLD * 4 <= 2 * BR * (LDI + LDJ) * (int)sizeof(T), "atomic staging fits in the operand buffers");
 #pragma unroll
-    for (int j = 0; j < FJ; ++j) {
-        const int c = c0 + wj * WTJ + j * 16 + li;
-        if (c >= p.K) continue;
-        const long jo = (long)tap * p.so_tap + (long)(c / p.inner) * p.so_outer + (c % p.inner);
+        for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int i = 0; i < FI; ++i) {
+            for (int j = 0; j < FJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ii = i0 + wi * WTI + i * 16 + lg * 4 + r;
-                if (ii < p.NI) atomicAdd(p.out + (long)ii * p.so_i + jo, acc[i][j][r]);
+                for (int r = 0; r < 4; ++r) st[(i * 16 + lg * 4 + r) * SLD + j * 16 + li] = acc[i][j][r];
+        // wave-local: the LDS unit executes one wave's accesses in order, no barrier needed
+        if (p.partial) {
+            // two-phase reduction: plain coalesced stores of this block's partial tile; tn_reduce_kernel sums the row splits
+            float* pt = p.partial + ((long)ms * tiles_ij + (bid % tiles_ij)) * (BI * BJ);
+            for (int v = lane; v < WTI * WTJ; v += 64) {
+                const int row = v / WTJ, col = v - row * WTJ;
+                pt[(wi * WTI + row) * BJ + wj * WTJ + col] = st[row * SLD + col];
+            }
+        } else {
+            for (int v = lane; v < WTI * WTJ; v += 64) {
+                const int row = v / WTJ, col = v - row * WTJ;
+                const int ii = i0 + wi * WTI + row, c = c0 + wj * WTJ + col;
+                if (ii < p.NI && c < p.K) {
+                    const long jo = (long)tap * p.so_tap + (long)(c / p.inner) * p.so_outer + (c % p.inner);
+                    atomicAdd(p.out + (long)ii * p.so_i + jo, st[row * SLD + col]);
+                }
             }
         }
+    }
+}
+
+// sums the row-split partial tiles and adds the result into the parameter-layout gradient
+template <int BI, int BJ>
+__global__ __launch_bounds__(NT) void tn_reduce_kernel(const dist_gemm_tn_args p, int msplit, int tiles_i, int tiles_c) {
+    const int tiles_ij = tiles_i * tiles_c * p.taps;
+    const long total = (long)tiles_ij * BI * BJ;
+    for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
+        const int t = (int)(e / (BI * BJ)), r = (int)(e % (BI * BJ));
+        const int row = r / BJ, col = r - row * BJ;
+        const int ti = t % tiles_i, tc = (t / tiles_i) % tiles_c, tap = t / (tiles_i * tiles_c);
+        const int ii = ti * BI + row, c = tc * BJ + col;
+        if (ii >= p.NI || c >= p.K) continue;
+        float acc = 0.f;
+        for (int s = 0; s < msplit; ++s) acc += p.partial[((long)s * tiles_ij + t) * (BI * BJ) + r];
+        const long jo = (long)tap * p.so_tap + (long)(c / p.inner) * p.so_outer + (c % p.inner);
+        atomicAdd(p.out + (long)ii * p.so_i + jo, acc);
     }
 }
 
@@ -224,17 +271,25 @@ int launch(const dist_gemm_tn_args& a, hipStream_t s) {
     }
     const int tiles_i = (a.NI + BI - 1) / BI, tiles_c = (a.K + BJ - 1) / BJ;
     const long tiles = (long)tiles_i * tiles_c * a.taps;
-    // split the reduction so that ~640 blocks are in flight, at least 512 rows per block (every block ends with
+    // split the reduction so that ~384 blocks are in flight, at least 512 rows per block (every block ends with
     // tile-size fp32 atomics: fewer, longer blocks keep that traffic down)
-    long msplit = (640 + tiles - 1) / tiles;
+    long msplit = (384 + tiles - 1) / tiles;
     const long max_split = (a.M + 511) / 512;
     if (msplit > max_split) msplit = max_split;
     if (msplit < 1) msplit = 1;
     int chunk = (int)((a.M + msplit - 1) / msplit);
     chunk = (chunk + BR - 1) / BR * BR;
     msplit = (a.M + chunk - 1) / chunk;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * msplit)), dim3(NT), smem, s, a, chunk, tiles_i, tiles_c);
+    dist_gemm_tn_args b = a;
+    const bool two_phase = a.partial != nullptr && msplit > 1 && tiles * msplit * (long)(BI * BJ) <= a.partial_elems;
+    if (!two_phase) b.partial = nullptr;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * msplit)), dim3(NT), smem, s, b, chunk, tiles_i, tiles_c);
     HIP_CHECK_RET(hipGetLastError());
+    if (two_phase) {
+        const long total = tiles * (long)(BI * BJ);
+        hipLaunchKernelGGL((tn_reduce_kernel<BI, BJ>), dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, s, b, (int)msplit, tiles_i, tiles_c);
+        HIP_CHECK_RET(hipGetLastError());
+    }
     return DIST_OK;
 }
 

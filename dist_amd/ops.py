@@ -58,7 +58,7 @@ def gemm_nt(A, B, M, N, K, *, taps=1, bias=None, res=None, aux=None, amap=None, 
     L.check(lib.dist_op_gemm_nt(C.byref(a), _stream()))
 
 
-def gemm_tn(A, B, out, M, NI, K, *, taps=1, amap=None, bmap=None, so_i=None, so_tap=None, so_outer=1, inner=1, use_tr=1, colsum=None):
+def gemm_tn(A, B, out, M, NI, K, *, taps=1, amap=None, bmap=None, so_i=None, so_tap=None, so_outer=1, inner=1, use_tr=1, colsum=None, partial=None):
     lib = L.load()
     a = L.GemmTnArgs()
     a.A, a.B, a.out = _p(A), _p(B), _p(out)
@@ -71,6 +71,8 @@ def gemm_tn(A, B, out, M, NI, K, *, taps=1, amap=None, bmap=None, so_i=None, so_
     a.so_outer, a.inner = so_outer, inner
     a.dtype, a.use_tr = _dt(A), use_tr
     a.colsum = _p(colsum)
+    a.partial = _p(partial)
+    a.partial_elems = partial.numel() if partial is not None else 0
     L.check(lib.dist_op_gemm_tn(C.byref(a), _stream()))
 
 

@@ -80,6 +80,9 @@ typedef struct dist_gemm_tn_args {
     int64_t so_i, so_tap, so_outer; int inner;
     int dtype; int use_tr;   /* use_tr: bf16 LDS transpose reads (ds_read_b64_tr_b16) */
     float* colsum;           /* optional: colsum[i] += sum_m A[amap(m)][i] (the bias gradient), fused into the same pass */
+    float* partial;          /* optional scratch (fp32): when large enough, row-split partial tiles are stored here with plain
+                                coalesced stores and summed by a second small kernel instead of per-block atomics */
+    int64_t partial_elems;
 } dist_gemm_tn_args;
 int dist_op_gemm_tn(const dist_gemm_tn_args* a, void* stream);
 

@@ -177,6 +177,11 @@ def test_gemm_tn_plain(gpu_lib, dtype, use_tr, M, NI, K):
     ref = A.double().t() @ B.double()
     torch.testing.assert_close(out.double(), ref, rtol=1e-4, atol=1e-4 * M ** 0.5)
     torch.testing.assert_close(cs.double(), A.double().sum(0), rtol=1e-4, atol=1e-4 * M ** 0.5)   # fused bias gradient
+    # two-phase reduction (partial tiles + reduce kernel) must give the same answer as the atomic epilogue
+    out2 = torch.zeros(NI, K, dtype=torch.float32, device="cuda")
+    part = torch.empty(8 << 20, dtype=torch.float32, device="cuda")
+    ops.gemm_tn(A, B, out2, M, NI, K, use_tr=use_tr, partial=part)
+    torch.testing.assert_close(out2.double(), ref, rtol=1e-4, atol=1e-4 * M ** 0.5)
 
 
 @pytest.mark.parametrize("dtype,use_tr", [(torch.float32, 0), (torch.bfloat16, 1)])
