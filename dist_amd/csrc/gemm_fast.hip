@@ -252,7 +252,7 @@ bool dist_k_gemm_fast_eligible(const dist_gemm_args* a) {
     if (a->omap.mode != DIST_OM_PLAIN && a->omap.mode != DIST_OM_INSERTCLS) return false;
     if (a->flags & DIST_EPI_MULG) return false;
     if (a->K % BK || a->K < 4 * BK || a->N % 64 || a->N < 256 || a->M < 1024) return false;
-    if (a->N % BN > 0 && a->N % BN < 128) return false;   // a mostly empty last column tile: leave it to the 128-wide kernel
+    if (a->N % BN > 0 && (a->N % BN < 128 || a->K < 768)) return false;   // a half-empty last column tile only pays for long K
     if (a->lda % 8 || a->ldb % 8 || a->ldc % 8 || a->ldc2 % 8 || a->ldres % 8) return false;
     return true;
 }

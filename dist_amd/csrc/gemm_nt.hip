@@ -58,42 +58,63 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const dist_gemm_args p) {
     const int total = ktp * taps;
 
     Frag<T> ra[A_IT], rb[B_IT];
-
-    auto gload = [&](int tt) {
+    // Per-thread tile coordinates are fixed for the whole K loop: rows (and their row-map image, recomputed only when
+    // the tap changes) are resolved outside the loads.  The loads themselves are UNCONDITIONAL with clamped addresses and
+    // the zero padding is applied when the tile is written to LDS: a branch around each load makes hipcc lose its
+    // load counting (vmcnt(0) everywhere) and the index arithmetic of the row maps is ~40 VALU per load.
+    int am[A_IT], asrc[A_IT], akk[A_IT], bkk[B_IT];
+    long boff[B_IT];
+    unsigned arow_ok = 0, brow_ok = 0, a_ok = 0, b_ok = 0;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int v = tid + i * NT;
+        const int row = min(v / KV, BM - 1);
+        akk[i] = (v % KV) * 8;
+        am[i] = min(m0 + row, M - 1);
+        asrc[i] = am[i];
+        if (v < BM * KV && m0 + row < M) arow_ok |= 1u << i;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int v = tid + i * NT;
+        const int row = min(v / KV, BN - 1);
+        bkk[i] = (v % KV) * 8;
+        boff[i] = (long)min(n0 + row, N - 1) * p.ldb;
+        if (v < BN * KV && n0 + row < N) brow_ok |= 1u << i;
+    }
+    int cur_tap = -1;
+    auto gload = [&](int tt) __attribute__((always_inline)) {
         const int tap = tt / ktp, k0 = (tt - tap * ktp) * BK;
+        if (GENERIC && tap != cur_tap) {                   // wave-uniform: the row images of this tap
+            cur_tap = tap;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) asrc[i] = rowmap_src(p.amap, am[i], tap, taps);
+        }
+        a_ok = 0; b_ok = 0;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const int v = tid + i * NT;
-            frag_zero(ra[i]);
-            if (v < BM * KV) {
-                const int row = v / KV, kk = k0 + (v % KV) * 8;
-                const int m = m0 + row;
-                if (m < M && kk < K) {
-                    const int src = GENERIC ? rowmap_src(p.amap, m, tap, taps) : m;
-                    if (src >= 0) frag_load(ra[i], A + (long)src * p.lda + kk);
-                }
-            }
+            const int kk = k0 + akk[i];
+            if (((arow_ok >> i) & 1u) && kk < K && asrc[i] >= 0) a_ok |= 1u << i;
+            frag_load(ra[i], A + (long)max(asrc[i], 0) * p.lda + min(kk, K - 8));
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const int v = tid + i * NT;
-            frag_zero(rb[i]);
-            if (v < BN * KV) {
-                const int row = v / KV, kk = k0 + (v % KV) * 8;
-                const int n = n0 + row;
-                if (n < N && kk < K) frag_load(rb[i], B + (long)n * p.ldb + (long)tap * K + kk);
-            }
+            const int kk = k0 + bkk[i];
+            if (((brow_ok >> i) & 1u) && kk < K) b_ok |= 1u << i;
+            frag_load(rb[i], B + boff[i] + (long)tap * K + min(kk, K - 8));
         }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int v = tid + i * NT;
+            if (!((a_ok >> i) & 1u)) frag_zero(ra[i]);
             if (v < BM * KV) frag_store(ra[i], As + (buf * BM + v / KV) * LD + (v % KV) * 8);
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int v = tid + i * NT;
+            if (!((b_ok >> i) & 1u)) frag_zero(rb[i]);
             if (v < BN * KV) frag_store(rb[i], Bs + (buf * BN + v / KV) * LD + (v % KV) * 8);
         }
     };

@@ -132,6 +132,7 @@ class GradReducer:
         self.overlap = overlap and world > 1 and torch.cuda.is_available()
         self.comm = torch.cuda.Stream() if self.overlap else None
         self._pending = None          # [begin, end) not yet sent (slices arrive in descending order)
+        self._sent = []
         self.n_collectives = 0
         if self.overlap:
             engine.set_grad_ready_hook(self._on_slice)
@@ -143,6 +144,7 @@ class GradReducer:
         with torch.cuda.stream(self.comm):
             dist.all_reduce(self.eng.grads[begin:end])
         self.n_collectives += 1
+        self._sent.append((begin, end))
 
     def _on_slice(self, begin, end):
         if self._pending is None:
@@ -158,6 +160,7 @@ class GradReducer:
 
     def backward_and_reduce(self, dlogits):
         self.n_collectives = 0
+        self._sent = []
         self.eng.backward(dlogits)
         if self.world <= 1:
             return
@@ -171,3 +174,6 @@ class GradReducer:
         done = torch.cuda.Event()
         done.record(self.comm)
         torch.cuda.current_stream().wait_event(done)      # AdamW waits for the last bucket
+        covered = sum(e - b for b, e in self._sent)
+        if covered != self.eng.grads.numel():              # must never happen: every element is reduced exactly once
+            raise RuntimeError(f"gradient buckets cover {covered} of {self.eng.grads.numel()} elements")
