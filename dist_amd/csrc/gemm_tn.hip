@@ -18,7 +18,7 @@
 namespace {
 
 constexpr int NT = 256;
-constexpr int PADT = 8;
+constexpr int PADT = 16;  // row stride = 8 banks mod 64: the 8 rows of a half-wave transpose read land on distinct banks
 constexpr int BR = 64;   // rows (reduction) per step = two 32-row MFMA k-blocks
 
 template <typename T, bool TR>
@@ -164,7 +164,11 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
         const int buf = st & 1;
         sstore(R, buf);                                   // waits for this set's loads only
         __syncthreads();                                  // tile st visible; buffer (st+1)&1 no longer read by anyone
-        if (st + 2 < nsteps) gload(R, mbeg + (st + 2) * BR);
+        // UNCONDITIONAL as well (past the end every row is flagged invalid and the addresses are clamped): with
+        // `if (st + 2 < nsteps)` around it the waitcnt pass merges the two paths conservatively and the sstore above
+        // waits vmcnt(7..0) instead of vmcnt(15..8), i.e. for BOTH sets - the measured step time was then
+        // load time + compute time instead of their maximum
+        gload(R, mbeg + (st + 2) * BR);
         const T* ys = Ys + buf * BR * LDI;
         const T* xs = Xs + buf * BR * LDJ;
 #pragma unroll
@@ -182,10 +186,10 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
     };
     Regs r0, r1;
     gload(r0, mbeg);
-    if (nsteps > 1) gload(r1, mbeg + BR);
-    for (int st = 0; st < nsteps; st += 2) {
+    gload(r1, mbeg + BR);
+    for (int st = 0; st < nsteps; st += 2) {              // an odd count runs one all-zero step at the end
         body(r0, st);
-        if (st + 1 < nsteps) body(r1, st + 1);
+        body(r1, st + 1);
     }
     __syncthreads();                                      // the tiles are dead: LDS is reused by the bias-gradient reduction
 
@@ -242,22 +246,34 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
     }
 }
 
-// sums the row-split partial tiles and adds the result into the parameter-layout gradient
+// sums the row-split partial tiles and adds the result into the parameter-layout gradient.  blockIdx.y owns a group of
+// `per` splits (small tiles are split hundreds of ways: one thread walking all of them serially was latency-bound and
+// cost more than the GEMM itself); four independent accumulators keep four loads in flight per thread.
 template <int BI, int BJ>
-__global__ __launch_bounds__(NT) void tn_reduce_kernel(const dist_gemm_tn_args p, int msplit, int tiles_i, int tiles_c) {
+__global__ __launch_bounds__(NT) void tn_reduce_kernel(const dist_gemm_tn_args p, int msplit, int tiles_i, int tiles_c, int per) {
     const int tiles_ij = tiles_i * tiles_c * p.taps;
     const long total = (long)tiles_ij * BI * BJ;
-    for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
-        const int t = (int)(e / (BI * BJ)), r = (int)(e % (BI * BJ));
-        const int row = r / BJ, col = r - row * BJ;
-        const int ti = t % tiles_i, tc = (t / tiles_i) % tiles_c, tap = t / (tiles_i * tiles_c);
-        const int ii = ti * BI + row, c = tc * BJ + col;
-        if (ii >= p.NI || c >= p.K) continue;
-        float acc = 0.f;
-        for (int s = 0; s < msplit; ++s) acc += p.partial[((long)s * tiles_ij + t) * (BI * BJ) + r];
-        const long jo = (long)tap * p.so_tap + (long)(c / p.inner) * p.so_outer + (c % p.inner);
-        atomicAdd(p.out + (long)ii * p.so_i + jo, acc);
+    const long e = (long)blockIdx.x * NT + threadIdx.x;
+    if (e >= total) return;
+    const int t = (int)(e / (BI * BJ)), r = (int)(e % (BI * BJ));
+    const int row = r / BJ, col = r - row * BJ;
+    const int ti = t % tiles_i, tc = (t / tiles_i) % tiles_c, tap = t / (tiles_i * tiles_c);
+    const int ii = ti * BI + row, c = tc * BJ + col;
+    if (ii >= p.NI || c >= p.K) return;
+    const int s0 = blockIdx.y * per, s1 = min(msplit, s0 + per);
+    const long stride = (long)tiles_ij * (BI * BJ);
+    const float* __restrict__ src = p.partial + (long)t * (BI * BJ) + r;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = s0;
+    for (; s + 3 < s1; s += 4) {
+        a0 += src[(long)s * stride];
+        a1 += src[(long)(s + 1) * stride];
+        a2 += src[(long)(s + 2) * stride];
+        a3 += src[(long)(s + 3) * stride];
     }
+    for (; s < s1; ++s) a0 += src[(long)s * stride];
+    const long jo = (long)tap * p.so_tap + (long)(c / p.inner) * p.so_outer + (c % p.inner);
+    atomicAdd(p.out + (long)ii * p.so_i + jo, (a0 + a1) + (a2 + a3));
 }
 
 template <typename T, int BI, int BJ, int WI, int WJ, bool TR, bool PLAIN>
@@ -287,7 +303,13 @@ int launch(const dist_gemm_tn_args& a, hipStream_t s) {
     HIP_CHECK_RET(hipGetLastError());
     if (two_phase) {
         const long total = tiles * (long)(BI * BJ);
-        hipLaunchKernelGGL((tn_reduce_kernel<BI, BJ>), dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, s, b, (int)msplit, tiles_i, tiles_c);
+        const long gx = (total + NT - 1) / NT;
+        long groups = (1024 + gx - 1) / gx;               // ~1024 blocks in flight ...
+        if (groups > msplit / 4) groups = msplit / 4;     // ... but at least 4 splits per thread
+        if (groups < 1) groups = 1;
+        const int per = (int)((msplit + groups - 1) / groups);
+        groups = (msplit + per - 1) / per;
+        hipLaunchKernelGGL((tn_reduce_kernel<BI, BJ>), dim3((unsigned)gx, (unsigned)groups), dim3(NT), 0, s, b, (int)msplit, tiles_i, tiles_c, per);
         HIP_CHECK_RET(hipGetLastError());
     }
     return DIST_OK;
