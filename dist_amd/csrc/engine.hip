@@ -373,7 +373,7 @@ size_t layout_ws(dist_handle* h, char* base) {
     h->y_mean = F_(b); h->y_rstd = F_(b); h->logits = F_(b * c.num_classes); h->dlogits = F_(b * c.num_classes); h->loss = F_(4);
     // backward scratch
     h->dR = T_(rowsS, Ci); h->dkv = T_(rowsS, 2 * Ci); h->dkn = T_(rowsS, Ci);
-    h->tn_partial_elems = 8l << 20;                          // 32 MB each: >= 384 partial tiles of 128 x 128
+    h->tn_partial_elems = 9l << 20;                          // 36 MB each: >= 512 partial tiles of 128 x 128 (+ slack)
     for (int k = 0; k < 3; ++k) h->tn_partial[k] = F_(h->tn_partial_elems);
     for (int k = 0; k < 2; ++k) {
         dist_handle::BwdSet& q = h->bs[k];

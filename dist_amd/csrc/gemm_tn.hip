@@ -194,21 +194,25 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
     __syncthreads();                                      // the tiles are dead: LDS is reused by the bias-gradient reduction
 
     if (do_colsum) {
-        // (tid, i) always maps to the same column vector: v % VI with v = tid + i*NT
+        // every (thread, i) owns one (tile row, column vector) cell: park the per-thread sums in a BR x BI fp32 matrix (plain
+        // stores, no two threads share a cell), then thread c adds up column c.  (LDS atomics on BI addresses serialised
+        // 8192 updates per block here and cost more than a separate column-sum pass over A.)
         float* red = reinterpret_cast<float*>(smem);          // the tiles are dead after the last barrier
-        for (int i = tid; i < BI; i += NT) red[i] = 0.f;
-        __syncthreads();
+        static_assert(BR * BI * 4 <= 2 * BR * (LDI + LDJ) * (int)sizeof(T), "bias-gradient scratch fits in the operand buffers");
 #pragma unroll
         for (int i = 0; i < I_IT; ++i) {
             const int v = tid + i * NT;
-            if (v < BR * VI) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) atomicAdd(&red[(v % VI) * 8 + e], csum[i][e]);
-            }
+            for (int e = 0; e < 8; ++e) red[(v / VI) * BI + (v % VI) * 8 + e] = csum[i][e];
         }
         __syncthreads();
-        for (int i = tid; i < BI; i += NT)
-            if (i0 + i < p.NI) atomicAdd(p.colsum + i0 + i, red[i]);
+        if (tid < BI && i0 + tid < p.NI) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < BR; r += 2) { a0 += red[r * BI + tid]; a1 += red[(r + 1) * BI + tid]; }
+            if (p.partial) p.partial[(long)gridDim.x * (BI * BJ) + ((long)ms * tiles_i + ti) * BI + tid] = a0 + a1;   // after the partial tiles
+            else atomicAdd(p.colsum + i0 + tid, a0 + a1);
+        }
     }
 
     // ---- epilogue: fp32 atomics into the parameter-layout gradient.  The MFMA layout gives a lane 4 rows x 1 column per
@@ -254,13 +258,21 @@ __global__ __launch_bounds__(NT) void tn_reduce_kernel(const dist_gemm_tn_args p
     const int tiles_ij = tiles_i * tiles_c * p.taps;
     const long total = (long)tiles_ij * BI * BJ;
     const long e = (long)blockIdx.x * NT + threadIdx.x;
-    if (e >= total) return;
+    const int s0 = blockIdx.y * per, s1 = min(msplit, s0 + per);
+    if (e >= total) {                                     // trailing blocks: the bias-gradient partials (tiles_i * BI per split)
+        const long c = e - total;
+        if (!p.colsum || c >= p.NI) return;
+        const float* __restrict__ cp = p.partial + (long)msplit * total + c;
+        float a = 0.f;
+        for (int s = s0; s < s1; ++s) a += cp[(long)s * tiles_i * BI];
+        atomicAdd(p.colsum + c, a);
+        return;
+    }
     const int t = (int)(e / (BI * BJ)), r = (int)(e % (BI * BJ));
     const int row = r / BJ, col = r - row * BJ;
     const int ti = t % tiles_i, tc = (t / tiles_i) % tiles_c, tap = t / (tiles_i * tiles_c);
     const int ii = ti * BI + row, c = tc * BJ + col;
     if (ii >= p.NI || c >= p.K) return;
-    const int s0 = blockIdx.y * per, s1 = min(msplit, s0 + per);
     const long stride = (long)tiles_ij * (BI * BJ);
     const float* __restrict__ src = p.partial + (long)t * (BI * BJ) + r;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -287,9 +299,9 @@ int launch(const dist_gemm_tn_args& a, hipStream_t s) {
     }
     const int tiles_i = (a.NI + BI - 1) / BI, tiles_c = (a.K + BJ - 1) / BJ;
     const long tiles = (long)tiles_i * tiles_c * a.taps;
-    // split the reduction so that ~384 blocks are in flight, at least 512 rows per block (every block ends with
-    // tile-size fp32 atomics: fewer, longer blocks keep that traffic down)
-    long msplit = (384 + tiles - 1) / tiles;
+    // split the reduction so that at most 512 blocks exist: two are co-resident per CU (LDS), so every CU gets the same
+    // share; at least 512 rows per block (every block ends with a tile-size partial store)
+    long msplit = 512 / tiles;
     const long max_split = (a.M + 511) / 512;
     if (msplit > max_split) msplit = max_split;
     if (msplit < 1) msplit = 1;
@@ -297,13 +309,13 @@ int launch(const dist_gemm_tn_args& a, hipStream_t s) {
     chunk = (chunk + BR - 1) / BR * BR;
     msplit = (a.M + chunk - 1) / chunk;
     dist_gemm_tn_args b = a;
-    const bool two_phase = a.partial != nullptr && msplit > 1 && tiles * msplit * (long)(BI * BJ) <= a.partial_elems;
+    const bool two_phase = a.partial != nullptr && msplit > 1 && tiles * msplit * (long)(BI * BJ) + msplit * (long)tiles_i * BI <= a.partial_elems;
     if (!two_phase) b.partial = nullptr;
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * msplit)), dim3(NT), smem, s, b, chunk, tiles_i, tiles_c);
     HIP_CHECK_RET(hipGetLastError());
     if (two_phase) {
         const long total = tiles * (long)(BI * BJ);
-        const long gx = (total + NT - 1) / NT;
+        const long gx = (total + (a.colsum ? (long)tiles_i * BI : 0) + NT - 1) / NT;
         long groups = (1024 + gx - 1) / gx;               // ~1024 blocks in flight ...
         if (groups > msplit / 4) groups = msplit / 4;     // ... but at least 4 splits per thread
         if (groups < 1) groups = 1;

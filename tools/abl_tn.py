@@ -16,9 +16,10 @@ def mk(n, *shape): return [torch.randn(*shape, device="cuda").to(dt) for _ in ra
 for (M, NI, K) in [(201728, 384, 768), (50432, 384, 768), (50432, 384, 384), (50432, 384, 96), (200704, 96, 96), (50176, 96, 384)]:
     n = 4 if M > 100000 else 12
     As, Bs = mk(n, M, NI), mk(n, M, K)
-    out = torch.zeros(NI, K, device="cuda"); part = torch.empty(8 << 20, device="cuda")
-    for tag, tr in [("full", 1)]:
-        t = timeit_rot([(lambda a=a, b=b: ops.gemm_tn(a, b, out, M, NI, K, partial=part, use_tr=tr)) for a, b in zip(As, Bs)])
+    out = torch.zeros(NI, K, device="cuda"); part = torch.empty(9 << 20, device="cuda")
+    cs = torch.zeros(NI, device="cuda")
+    for tag, tr, c in [("full", 1, None), ("full+colsum", 1, cs), ("full", 1, None), ("full+colsum", 1, cs)]:
+        t = timeit_rot([(lambda a=a, b=b: ops.gemm_tn(a, b, out, M, NI, K, partial=part, use_tr=tr, colsum=c)) for a, b in zip(As, Bs)])
         print(f"M={M} NI={NI} K={K} {tag:20s}: {t*1e6:8.1f} us {2*M*NI*K/t/1e12:7.1f} TF", flush=True)
     t = timeit_rot([(lambda a=a, b=b: torch.mm(a.t(), b)) for a, b in zip(As, Bs)])
     print(f"M={M} NI={NI} K={K} torch.mm(A.t(),B)    : {t*1e6:8.1f} us {2*M*NI*K/t/1e12:7.1f} TF", flush=True)

@@ -24,7 +24,7 @@ for (M, NI, K, taps, mode, kw, tag) in [(100352, 96, 96, 9, L.RM_SPATIAL, (14, 0
                                         (50432, 384, 768, 1, 0, (0, 0), "dWi"), (50432, 384, 384, 1, 0, (0, 0), "dWffn"), (50432, 384, 96, 1, 0, (0,0), "dW3"),
                                         (50432, 96, 96, 3, L.RM_SHIFT, (8*197, 197), "tf_fc2")]:
     As, Bs = mk(M, NI), mk(M, K)
-    out = torch.zeros(NI, K * taps, device="cuda"); cs = torch.zeros(NI, device="cuda"); part = torch.empty(8 << 20, device="cuda")
+    out = torch.zeros(NI, K * taps, device="cuda"); cs = torch.zeros(NI, device="cuda"); part = torch.empty(9 << 20, device="cuda")
     fns = [(lambda a=a, b=b: ops.gemm_tn(a, b, out, M, NI, K, taps=taps, bmap=ops.rowmap(mode, kw[0], kw[1]), colsum=cs, partial=part)) for a, b in zip(As, Bs)]
     t = timeit_rot(fns)
     byts = (M * NI + M * K) * 2

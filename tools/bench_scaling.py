@@ -12,7 +12,7 @@ print("== TN: dWi tile shape (NI=384, K=768), M grows; blocks stay ~396 ==")
 for M in (6304, 12608, 25216, 50432, 100864, 201728):
     n = max(2, min(12, (1 << 30) // (M * (384 + 768) * 2)))
     As, Bs = mk(n, M, 384), mk(n, M, 768)
-    out = torch.zeros(384, 768, device="cuda"); part = torch.empty(8 << 20, device="cuda")
+    out = torch.zeros(384, 768, device="cuda"); part = torch.empty(9 << 20, device="cuda")
     t = timeit_rot([(lambda a=a, b=b: ops.gemm_tn(a, b, out, M, 384, 768, partial=part)) for a, b in zip(As, Bs)])
     print(f"M={M:7d}: {t*1e6:8.1f} us {2*M*384*768/t/1e12:7.1f} TF", flush=True)
     del As, Bs
@@ -20,7 +20,7 @@ print("== TN: NI=96,K=96 taps=1 plain ==")
 for M in (12544, 25088, 50176, 100352, 200704):
     n = 12
     As, Bs = mk(n, M, 96), mk(n, M, 96)
-    out = torch.zeros(96, 96, device="cuda"); part = torch.empty(8 << 20, device="cuda")
+    out = torch.zeros(96, 96, device="cuda"); part = torch.empty(9 << 20, device="cuda")
     t = timeit_rot([(lambda a=a, b=b: ops.gemm_tn(a, b, out, M, 96, 96, partial=part)) for a, b in zip(As, Bs)])
     print(f"M={M:7d}: {t*1e6:8.1f} us {2*M*96*96/t/1e12:7.1f} TF", flush=True)
     del As, Bs
