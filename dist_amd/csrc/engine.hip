@@ -12,6 +12,7 @@
 // launches on the caller's stream; it never allocates device memory and never syncs.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -113,6 +114,7 @@ struct dist_handle {
     long tn_partial_elems = 0;
     // weight-gradient side stream (created once per handle; host-side objects only)
     hipStream_t side = nullptr, side2 = nullptr;
+    int serial = 0;                            // DIST_AMD_SERIAL (measurement knob): bit 0 = branch forward, bit 1 = backward on the caller's stream only
     std::vector<hipEvent_t> ev_a;              // chain -> side: "buffer produced"
     std::vector<hipEvent_t> ev_b_dr, ev_b_done; // side -> chain: per layer "dR consumed", "all weight gradients of the layer issued and done"
     hipEvent_t ev_join = nullptr, ev_pre = nullptr, ev_b2 = nullptr;
@@ -506,6 +508,7 @@ extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
     build_tables(h);
     h->ws_bytes = layout_ws(h, nullptr);
     // side stream + events of the two-stream backward (host objects; no device memory)
+    if (const char* e = getenv("DIST_AMD_SERIAL")) h->serial = atoi(e);
     bool ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking) == hipSuccess;
     auto mk = [&](hipEvent_t& e) { ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
@@ -647,18 +650,19 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
     // remaining frozen-ViT layers still queued on the caller's stream (their LayerNorm / attention phases and the
     // tails of the GEMM rounds leave CUs idle); the caller's stream joins at the end.
     hipStream_t A = static_cast<hipStream_t>(stream);
-    Ctx x{h, h->side, c.dtype};
+    hipStream_t S1 = (h->serial & 1) ? A : h->side, S2 = (h->serial & 1) ? A : h->side2;
+    Ctx x{h, S1, c.dtype};
     const int d = c.width, Ci = c.integration_dim, Ct = c.temporal_dim, C4 = h->C4, N = h->N, L = h->L, T = c.frames, t = h->t, al = c.alpha;
     const long rowsX = (long)b * T * N, rowsS = (long)b * t * L, rowsQ = (long)b * t * N, bt = (long)b * t;
     const int nl = c.layers;
-    stream = h->side;
+    stream = S1;
     HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_pre, 0));               // what preceded dist_vit_forward on the caller's stream
     HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_feat[nl], 0));          // patch rows
 
     // Two streams inside the branch: the temporal chain (TemporalNet_i, I2T_i) on `xt`, the integration chain
     // (input_linear_i, T2I_i, IntegrationNetwork_i) on `x`.  TemporalNet_{i+1} only needs X_{i+1} = X'_i + I2T(M_i),
     // not R_i, so it runs underneath IntegrationNetwork_i; the two chains meet at M_i (-> I2T) and X'_i (-> T2I).
-    Ctx xt{h, h->side2, c.dtype};
+    Ctx xt{h, S2, c.dtype};
     HIP_CHECK_RET(hipStreamWaitEvent(xt.s, h->ev_pre, 0));
     HIP_CHECK_RET(hipStreamWaitEvent(xt.s, h->ev_feat[nl], 0));
     auto ev_xp = [&](int i) { return h->ev_a[i]; };
@@ -854,7 +858,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
     // sequences share the CUs instead of one.  Hazards: (1) chain scratch is double-buffered by layer parity and A
     // waits for B's "layer i+2 done" event before reusing a set; (2) the two in-place updates of the single-stream
     // version are out-of-place here (dM = copy of dM' from the LayerNorm backward, dX_out = dp + LN'(dU)).
-    hipStream_t A = x.s, B = h->side, B2 = h->side2;
+    hipStream_t A = x.s, B = (h->serial & 2) ? A : h->side, B2 = (h->serial & 2) ? A : h->side2;
     Ctx xb{h, B, c.dtype}, xb2{h, B2, c.dtype};          // two weight-gradient streams: independent dW GEMMs also overlap each other
     int evn = 0;
     auto fork = [&]() -> int {           // B and B2 wait for everything enqueued on A so far

@@ -15,16 +15,30 @@
 //    pair per SIMD); the MFMA is issued swapped so a lane holds 4 consecutive output columns;
 //  * epilogue through LDS: the residual tile is fetched and the result tile is written as full
 //    128-byte rows (16 B per lane), instead of 8-byte pieces at a row stride.
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 32, NT = 512;
-constexpr int STAGES = 4, AHEAD = 3;
-constexpr int STAGE_BYTES = (BM + BN) * BK * 2;          // 32 KB
+// Two shapes of the same kernel (NW = waves per block, every wave owns a 128 x 64 output sub-tile):
+//   NW = 8: 256 x 256 tile, 4-stage ring (128 KB), one block per CU;
+//   NW = 4: 256 x 128 tile, 3-stage ring (72 KB), TWO blocks per CU.  The two blocks run out of phase: one block's
+//           prologue (first DMA latency) and epilogue (residual fetch, 64 KB of stores) overlap the other's MFMA
+//           loop, and the barrier of one block no longer idles the SIMDs.  With one block per CU the fixed part of a
+//           block (13-18 us) was as long as its whole K = 768 loop.
+constexpr int BM = 256, BK = 32;
 constexpr int A_BYTES = BM * BK * 2;                      // 16 KB
 constexpr int EPI_BYTES = 128 * 64 * 2;                   // per-wave staging region: 128 rows x 128 B
+template <int NW> struct Shape {
+    static constexpr int WN = NW / 2;                     // waves along n (2 along m)
+    static constexpr int BN = 64 * WN;
+    static constexpr int NT = 64 * NW;
+    static constexpr int STAGES = NW == 8 ? 4 : 3, AHEAD = STAGES - 1;
+    static constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+    static constexpr int PA = 16 / NW, PB = 2, NP = PA + PB;   // 1-KB LDS-DMA pieces per wave per stage (A rows, B rows)
+    static constexpr int MINB = NW == 8 ? 1 : 2;
+};
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_ptr;
@@ -33,11 +47,14 @@ DEV int swz(int q) { return (4 - q) & 3; }               // f = {0,3,2,1}
 
 struct FragSet { bf16x8 a[8]; bf16x8 b[4]; };
 
-__global__ __launch_bounds__(NT) void gemm_fast_kernel(const dist_gemm_args p) {
+template <int NW>
+__global__ __launch_bounds__(Shape<NW>::NT, Shape<NW>::MINB) void gemm_fast_kernel(const dist_gemm_args p) {
+    using S = Shape<NW>;
+    constexpr int BN = S::BN, STAGES = S::STAGES, AHEAD = S::AHEAD, STAGE_BYTES = S::STAGE_BYTES, PA = S::PA, PB = S::PB, NP = S::NP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 2, wn = wid & 3;                // 2 x 4 waves
+    const int wm = wid / S::WN, wn = wid % S::WN;         // 2 x WN waves
     const int li = lane & 15, lg = lane >> 4;
 
     const int tiles_n = (p.N + BN - 1) / BN;
@@ -54,30 +71,36 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const dist_gemm_args p) {
     const bf16_t* __restrict__ A = static_cast<const bf16_t*>(p.A);
     const bf16_t* __restrict__ B = static_cast<const bf16_t*>(p.B);
 
-    // ---- LDS-DMA source addresses: each wave moves 2 x 1 KB of A and 2 x 1 KB of B per stage.
+    // ---- LDS-DMA source addresses: each wave moves PA x 1 KB of A and PB x 1 KB of B per stage.
     // 1 KB = 16 rows x 64 B; lane l lands at row (l>>2), physical chunk (l&3) and therefore fetches
     // logical chunk (l&3) ^ f((l>>4)&3) of that row.
     const int lrow = lane >> 2;
     const int lchunk = (lane & 3) ^ swz((lane >> 4) & 3);
-    const bf16_t* ga[2];
-    const bf16_t* gb[2];
+    // 32-bit byte offsets from the (wave-uniform) matrix bases: half the address registers of 64-bit pointers, and the
+    // loads take the scalar-base + vector-offset form (the launcher checks that both matrices are < 2 GB)
+    const char* Ab = reinterpret_cast<const char*>(A);
+    const char* Bb = reinterpret_cast<const char*>(B);
+    unsigned ga[PA], gb[PB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = (wid * 2 + j) * 16 + lrow;
-        ga[j] = A + (long)rowmap_src(p.amap, min(m0 + r, M - 1), 0, 1) * p.lda + lchunk * 8;   // plain / strided / skip-cls rows
-        gb[j] = B + (long)min(n0 + r, N - 1) * p.ldb + lchunk * 8;
+    for (int j = 0; j < PA; ++j) {
+        const int r = (wid * PA + j) * 16 + lrow;
+        ga[j] = ((unsigned)rowmap_src(p.amap, min(m0 + r, M - 1), 0, 1) * (unsigned)p.lda + lchunk * 8) * 2u;   // plain / strided / skip-cls rows
     }
-    // piece q of tile kt: q = 0,1 -> A rows of this wave's two 16-row groups, q = 2,3 -> B
-    auto dma_piece = [&](int kt, int q) {
-        char* sb = smem + (kt % STAGES) * STAGE_BYTES;
-        const int k0 = kt * BK, j = q & 1;
-        const int off = (wid * 2 + j) * 1024;
-        if (q < 2) __builtin_amdgcn_global_load_lds((gbl_ptr)(ga[j] + k0), (lds_ptr)(sb + off), 16, 0, 0);
-        else __builtin_amdgcn_global_load_lds((gbl_ptr)(gb[j] + k0), (lds_ptr)(sb + A_BYTES + off), 16, 0, 0);
-    };
-    auto stage_issue = [&](int kt) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dma_piece(kt, q);
+    for (int j = 0; j < PB; ++j) {
+        const int r = (wid * PB + j) * 16 + lrow;
+        gb[j] = ((unsigned)min(n0 + r, N - 1) * (unsigned)p.ldb + lchunk * 8) * 2u;
+    }
+    // piece q of tile kt: q < PA -> this wave's A row groups, then its B row groups
+    auto dma_piece = [&](int kt, int q) __attribute__((always_inline)) {
+        char* sb = smem + (kt % STAGES) * STAGE_BYTES;
+        const int k0 = kt * BK;
+        if (q < PA) __builtin_amdgcn_global_load_lds((gbl_ptr)(Ab + (ga[q] + (unsigned)k0 * 2u)), (lds_ptr)(sb + (wid * PA + q) * 1024), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((gbl_ptr)(Bb + (gb[q - PA] + (unsigned)k0 * 2u)), (lds_ptr)(sb + A_BYTES + (wid * PB + (q - PA)) * 1024), 16, 0, 0);
+    };
+    auto stage_issue = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) dma_piece(kt, q);
     };
 
     // fragment read offsets (bytes within a stage): row r, logical chunk lg
@@ -110,20 +133,23 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const dist_gemm_args p) {
     // `nxt`, and multiply tile kt in four groups of 8 MFMAs with ONE LDS-DMA piece of tile kt+3 issued
     // behind each group: the DMA issue cost (~60-180 cycles per piece) hides under the matrix pipe instead
     // of sitting between the barrier and the first MFMA.
-    auto step = [&](FragSet& cur, FragSet& nxt, int kt) {
+    auto step = [&](FragSet& cur, FragSet& nxt, int kt) __attribute__((always_inline)) {
         const bool more = kt + 1 < nk, refill = kt + AHEAD < nk;
         if (more) {
-            // DMA groups outstanding here: tiles kt+1 and kt+2 (4 pieces each); kt+1 must be complete
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            // DMA groups outstanding here: tiles kt+1 .. kt+AHEAD-1 (NP pieces each); kt+1 must be complete
+            if (AHEAD == 3 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                 // tile kt+1 landed for every wave; tile kt-1 no longer read by anyone
             frag_read(nxt, kt + 1);
         }
         __builtin_amdgcn_sched_barrier(0);
+        // 32 MFMAs in NP groups with ONE LDS-DMA piece of tile kt+AHEAD issued behind each group
+        // group g multiplies a-fragments [lo(g), lo(g+1)): 2,2,2,2 (NP = 4) or 2,2,1,1,1,1 (NP = 6)
+        auto lo = [](int g) { return NP == 4 ? 2 * g : (g < 2 ? 2 * g : g + 2); };
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < NP; ++g) {
 #pragma unroll
-            for (int i = 2 * g; i < 2 * g + 2; ++i)
+            for (int i = lo(g); i < lo(g + 1); ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.b[j], cur.a[i], acc[i][j], 0, 0, 0);   // swapped: D[n][m]
@@ -138,10 +164,11 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const dist_gemm_args p) {
                           "+v"(nxt.a[6]), "+v"(nxt.a[7]), "+v"(nxt.b[0]), "+v"(nxt.b[1]), "+v"(nxt.b[2]), "+v"(nxt.b[3]));
     };
 
-    stage_issue(0);
-    stage_issue(1);
-    stage_issue(2);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // tile 0 landed (this wave's share)
+#pragma unroll
+    for (int st = 0; st < AHEAD; ++st) stage_issue(st);
+    if (AHEAD == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // tile 0 landed (this wave's share)
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    static_assert((AHEAD == 3 && NP == 4) || (AHEAD == 2 && NP == 6), "the counted waits above are written for these two shapes");
     __builtin_amdgcn_s_barrier();
     FragSet f0, f1;
     frag_read(f0, 0);
@@ -246,29 +273,52 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const dist_gemm_args p) {
 
 }  // namespace
 
-bool dist_k_gemm_fast_eligible(const dist_gemm_args* a) {
+static bool fast_common_ok(const dist_gemm_args* a) {
     if (a->dtype != DIST_BF16 || a->taps != 1) return false;
     if (a->amap.mode != DIST_RM_PLAIN && a->amap.mode != DIST_RM_STRIDED && a->amap.mode != DIST_RM_SKIPCLS) return false;
     if (a->omap.mode != DIST_OM_PLAIN && a->omap.mode != DIST_OM_INSERTCLS) return false;
     if (a->flags & DIST_EPI_MULG) return false;
-    if (a->K % BK || a->K < 4 * BK || a->N % 64 || a->N < 256 || a->M < 1024) return false;
-    if (a->N % BN > 0 && (a->N % BN < 128 || a->K < 768)) return false;   // a half-empty last column tile only pays for long K
+    if (a->K % BK || a->K < 4 * BK || a->N % 64 || a->M < 1024) return false;
     if (a->lda % 8 || a->ldb % 8 || a->ldc % 8 || a->ldc2 % 8 || a->ldres % 8) return false;
+    const long a_rows = a->amap.mode == DIST_RM_PLAIN ? a->M : 2 * a->M + a->M / 64 + 64;   // generous bound for the strided / skip-cls images
+    if (a_rows * a->lda >= (1l << 30) || (long)a->N * a->ldb >= (1l << 30)) return false;     // 32-bit byte offsets
     return true;
+}
+
+// 0 = not eligible, 4 / 8 = waves of the variant that takes the shape
+static int fast_variant(const dist_gemm_args* a) {
+    if (!fast_common_ok(a)) return 0;
+    static const int forced = [] { const char* e = getenv("DIST_AMD_FAST_NW"); return e ? atoi(e) : 0; }();   // measurement knob
+    const bool ok8 = a->N >= 256 && !(a->N % 256 > 0 && (a->N % 256 < 128 || a->K < 768));
+    const bool ok4 = a->N >= 128 && a->N % 128 == 0;
+    // measured (tools/bench_fastk.py, profiles/r01_fast_gemm_shapes.md): the two-block shape hides ~40 % of the fixed
+    // per-block cost but its K loop is ~30 % slower (prefetch depth 2, 1.5x the LDS-DMA pieces per FLOP) - it loses on
+    // every ViT shape, so it only runs when asked for
+    if (forced == 4 && ok4) return 4;
+    return ok8 ? 8 : 0;
+}
+
+bool dist_k_gemm_fast_eligible(const dist_gemm_args* a) { return fast_variant(a) != 0; }
+
+template <int NW>
+static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
+    using S = Shape<NW>;
+    constexpr size_t smem = (size_t)S::STAGES * S::STAGE_BYTES;
+    static_assert(NW * EPI_BYTES <= S::STAGES * S::STAGE_BYTES, "epilogue staging fits in the operand ring");
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_done = true;
+    }
+    const long tiles = ((a->M + BM - 1) / BM) * ((a->N + S::BN - 1) / S::BN);
+    hipLaunchKernelGGL(gemm_fast_kernel<NW>, dim3((unsigned)tiles), dim3(S::NT), smem, s, *a);
+    HIP_CHECK_RET(hipGetLastError());
+    return 1;
 }
 
 // returns 1 if handled, 0 if the shape does not qualify (caller falls through), <0 on error
 int dist_k_gemm_fast(const dist_gemm_args* a, hipStream_t s) {
-    if (!dist_k_gemm_fast_eligible(a)) return 0;
-    constexpr size_t smem = (size_t)STAGES * STAGE_BYTES;
-    static_assert(8 * EPI_BYTES <= STAGES * STAGE_BYTES, "epilogue staging fits in the operand ring");
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_done = true;
-    }
-    const long tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
-    hipLaunchKernelGGL(gemm_fast_kernel, dim3((unsigned)tiles), dim3(NT), smem, s, *a);
-    HIP_CHECK_RET(hipGetLastError());
-    return 1;
+    const int v = fast_variant(a);
+    if (v == 0) return 0;
+    return v == 8 ? launch_fast<8>(a, s) : launch_fast<4>(a, s);
 }

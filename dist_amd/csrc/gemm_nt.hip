@@ -57,14 +57,16 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const dist_gemm_args p) {
     const int ktp = (K + BK - 1) / BK;          // K tiles per tap
     const int total = ktp * taps;
 
-    Frag<T> ra[A_IT], rb[B_IT];
+    // Two register sets: the loads of K-tile t+2 are issued as soon as set (t & 1) has been written to LDS, so two tiles
+    // are in flight per block (with one, every K-tile cost one full memory latency: the MFMAs of a tile take ~0.2 us).
     // Per-thread tile coordinates are fixed for the whole K loop: rows (and their row-map image, recomputed only when
-    // the tap changes) are resolved outside the loads.  The loads themselves are UNCONDITIONAL with clamped addresses and
-    // the zero padding is applied when the tile is written to LDS: a branch around each load makes hipcc lose its
-    // load counting (vmcnt(0) everywhere) and the index arithmetic of the row maps is ~40 VALU per load.
+    // the tap changes) are resolved outside the loads.  The loads themselves are UNCONDITIONAL with clamped addresses -
+    // also past the last tile - and the zero padding is applied when the tile is written to LDS: a branch around a load
+    // makes hipcc lose its load counting (vmcnt(0) everywhere, which drains both sets).
+    struct Regs { Frag<T> a[A_IT], b[B_IT]; unsigned oka, okb; };
     int am[A_IT], asrc[A_IT], akk[A_IT], bkk[B_IT];
     long boff[B_IT];
-    unsigned arow_ok = 0, brow_ok = 0, a_ok = 0, b_ok = 0;
+    unsigned arow_ok = 0, brow_ok = 0;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int v = tid + i * NT;
@@ -83,39 +85,40 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const dist_gemm_args p) {
         if (v < BN * KV && n0 + row < N) brow_ok |= 1u << i;
     }
     int cur_tap = -1;
-    auto gload = [&](int tt) __attribute__((always_inline)) {
+    auto gload = [&](Regs& R, int t_req) __attribute__((always_inline)) {
+        const int tt = min(t_req, total - 1);
         const int tap = tt / ktp, k0 = (tt - tap * ktp) * BK;
         if (GENERIC && tap != cur_tap) {                   // wave-uniform: the row images of this tap
             cur_tap = tap;
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) asrc[i] = rowmap_src(p.amap, am[i], tap, taps);
         }
-        a_ok = 0; b_ok = 0;
+        R.oka = 0; R.okb = 0;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int kk = k0 + akk[i];
-            if (((arow_ok >> i) & 1u) && kk < K && asrc[i] >= 0) a_ok |= 1u << i;
-            frag_load(ra[i], A + (long)max(asrc[i], 0) * p.lda + min(kk, K - 8));
+            if (((arow_ok >> i) & 1u) && kk < K && asrc[i] >= 0) R.oka |= 1u << i;
+            frag_load(R.a[i], A + (long)max(asrc[i], 0) * p.lda + min(kk, K - 8));
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int kk = k0 + bkk[i];
-            if (((brow_ok >> i) & 1u) && kk < K) b_ok |= 1u << i;
-            frag_load(rb[i], B + boff[i] + (long)tap * K + min(kk, K - 8));
+            if (((brow_ok >> i) & 1u) && kk < K) R.okb |= 1u << i;
+            frag_load(R.b[i], B + boff[i] + (long)tap * K + min(kk, K - 8));
         }
     };
-    auto sstore = [&](int buf) __attribute__((always_inline)) {
+    auto sstore = [&](Regs& R, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int v = tid + i * NT;
-            if (!((a_ok >> i) & 1u)) frag_zero(ra[i]);
-            if (v < BM * KV) frag_store(ra[i], As + (buf * BM + v / KV) * LD + (v % KV) * 8);
+            if (!((R.oka >> i) & 1u)) frag_zero(R.a[i]);
+            if (v < BM * KV) frag_store(R.a[i], As + (buf * BM + v / KV) * LD + (v % KV) * 8);
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int v = tid + i * NT;
-            if (!((b_ok >> i) & 1u)) frag_zero(rb[i]);
-            if (v < BN * KV) frag_store(rb[i], Bs + (buf * BN + v / KV) * LD + (v % KV) * 8);
+            if (!((R.okb >> i) & 1u)) frag_zero(R.b[i]);
+            if (v < BN * KV) frag_store(R.b[i], Bs + (buf * BN + v / KV) * LD + (v % KV) * 8);
         }
     };
 
@@ -125,14 +128,13 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const dist_gemm_args p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    gload(0);
-    sstore(0);
-    __syncthreads();
-    int cur = 0;
-    for (int tt = 0; tt < total; ++tt) {
-        if (tt + 1 < total) gload(tt + 1);
-        const T* as = As + (cur * BM + wm * WTM + li) * LD + lg * 8;
-        const T* bs = Bs + (cur * BN + wn * WTN + li) * LD + lg * 8;
+    auto body = [&](Regs& R, int tt) __attribute__((always_inline)) {
+        const int buf = tt & 1;
+        sstore(R, buf);                                     // waits for this set's loads only
+        __syncthreads();                                    // tile tt visible; buffer (tt+1)&1 no longer read by anyone
+        gload(R, tt + 2);
+        const T* as = As + (buf * BM + wm * WTM + li) * LD + lg * 8;
+        const T* bs = Bs + (buf * BN + wn * WTN + li) * LD + lg * 8;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
             Frag<T> fa[FM], fb[FN];
@@ -145,10 +147,16 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const dist_gemm_args p) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j) mma16(fb[j], fa[i], acc[i][j]);   // swapped: D[n][m]
         }
-        if (tt + 1 < total) sstore(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+    };
+    Regs r0, r1;
+    gload(r0, 0);
+    gload(r1, 1);
+    int tt = 0;
+    for (; tt + 1 < total; tt += 2) {
+        body(r0, tt);
+        body(r1, tt + 1);
     }
+    if (tt < total) body(r0, tt);
 
     // ---- epilogue through LDS.  A lane holds, per fragment, row ..+li and 4 columns ..+4*lg+{0..3}; writing
     // those 8-byte pieces straight to HBM at a row stride (and fetching the residual the same way) ran at a
