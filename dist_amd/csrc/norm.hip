@@ -8,7 +8,18 @@
 namespace {
 
 constexpr int NT = 256;
-constexpr int MAXIT = 2;
+constexpr int MAXIT = 3;
+
+// lanes per row: the smallest of {4, 16, 32, 64} that leaves at most MAXIT 8-element vectors per lane, so every
+// lane has up to three independent loads in flight and the lanes of a row are evenly loaded (C = 768 -> 32 lanes x 3,
+// C = 384 -> 16 x 3, C = 96 -> 4 x 3, C = 1024 -> 64 x 2)
+inline int lanes_per_row(int C) {
+    const int nvec = C / 8;
+    if (nvec <= 4 * MAXIT) return 4;
+    if (nvec <= 16 * MAXIT) return 16;
+    if (nvec <= 32 * MAXIT) return 32;
+    return 64;
+}
 
 template <typename T, int LPR>
 __global__ __launch_bounds__(NT) void ln_fwd_kernel(const dist_ln_args p) {
@@ -20,20 +31,45 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const dist_ln_args p) {
     T* __restrict__ Y = static_cast<T*>(p.y);
     T* __restrict__ Y2 = static_cast<T*>(p.y2);
     const float invC = 1.f / (float)C;
+    const long stride = (long)gridDim.x * RPB;
 
-    for (long row = (long)blockIdx.x * RPB + slot; row < p.rows; row += (long)gridDim.x * RPB) {
+    // this lane's columns are the same for every row: affine parameters live in registers
+    float w[MAXIT][8], bb[MAXIT][8];
+    unsigned vok = 0;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int v = lr + it * LPR;
+        if (v < nvec) vok |= 1u << it;
+        const int vc = min(v, nvec - 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { w[it][e] = p.w[vc * 8 + e]; bb[it][e] = p.b[vc * 8 + e]; }
+    }
+    // software pipeline over this lane group's rows: the vectors of the next row are requested before the current row is
+    // reduced (unconditional, clamped: no branch around the loads)
+    long row = (long)blockIdx.x * RPB + slot;
+    Frag<T> nx[MAXIT];
+    {
+        const long r0 = min(row, p.rows - 1);
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) frag_load(nx[it], X + r0 * C + min(lr + it * LPR, nvec - 1) * 8);
+    }
+    for (; row < p.rows; row += stride) {
         float x[MAXIT][8];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[it][e] = frag_get(nx[it], e);
+        {
+            const long rn = min(row + stride, p.rows - 1);
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) frag_load(nx[it], X + rn * C + min(lr + it * LPR, nvec - 1) * 8);
+        }
         float s = 0.f;
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
-            const int v = lr + it * LPR;
-            if (v < nvec) {
-                Frag<T> f;
-                frag_load(f, X + row * C + v * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x[it][e] = frag_get(f, e);
+            if ((vok >> it) & 1u) {
                 if (p.addend) {
-                    const float* ad = p.addend + (row % p.addend_period) * C + v * 8;
+                    const float* ad = p.addend + (row % p.addend_period) * C + (lr + it * LPR) * 8;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) x[it][e] += ad[e];
                 }
@@ -45,8 +81,7 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const dist_ln_args p) {
         float q = 0.f;
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
-            const int v = lr + it * LPR;
-            if (v < nvec) {
+            if ((vok >> it) & 1u) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float d = x[it][e] - mean; q += d * d; }
             }
@@ -59,10 +94,10 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const dist_ln_args p) {
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int v = lr + it * LPR;
-            if (v < nvec) {
+            if ((vok >> it) & 1u) {
                 Frag<T> o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) frag_set(o, e, (x[it][e] - mean) * rstd * p.w[v * 8 + e] + p.b[v * 8 + e]);
+                for (int e = 0; e < 8; ++e) frag_set(o, e, (x[it][e] - mean) * rstd * w[it][e] + bb[it][e]);
                 frag_store(o, Y + row * C + v * 8);
                 if (Y2) {
 #pragma unroll
@@ -74,7 +109,7 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const dist_ln_args p) {
     }
 }
 
-template <typename T, int LPR>
+template <typename T, int LPR, bool DUAL>
 __global__ __launch_bounds__(NT) void ln_bwd_kernel(const dist_ln_bwd_args p) {
     constexpr int RPB = NT / LPR;
     __shared__ float red[4][1024];
@@ -85,45 +120,68 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const dist_ln_bwd_args p) {
     const T* __restrict__ DY = static_cast<const T*>(p.dy);
     const T* __restrict__ DY2 = static_cast<const T*>(p.dy2);
     T* __restrict__ DX = static_cast<T*>(p.dx);
-    const T* __restrict__ DXA = static_cast<const T*>(p.dx_add);
+    const T* __restrict__ DXA = p.dx_add ? static_cast<const T*>(p.dx_add) : (p.accumulate_dx ? static_cast<const T*>(p.dx) : nullptr);
     T* __restrict__ DXC = static_cast<T*>(p.dx_copy);
     const float invC = 1.f / (float)C;
     const bool want_w = p.dw || p.db || p.dw2 || p.db2;
 
-    for (int i = tid; i < 4 * 1024; i += NT) (&red[0][0])[i] = 0.f;
-    __syncthreads();
-
-    float aw[MAXIT][8], ab[MAXIT][8], aw2[MAXIT][8], ab2[MAXIT][8];
+    // this lane's columns are the same for every row: weights in registers; all vectors of a row are requested
+    // together (unconditional, clamped; validity as a mask) before the first one is consumed
+    float w[MAXIT][8];
+    int vcol[MAXIT];
+    unsigned vok = 0;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int v = lr + it * LPR;
+        if (v < nvec) vok |= 1u << it;
+        vcol[it] = min(v, nvec - 1) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[it][e] = p.w[vcol[it] + e];
+    }
+    float aw[MAXIT][8], ab[MAXIT][8], aw2[DUAL ? MAXIT : 1][8], ab2[DUAL ? MAXIT : 1][8];
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) aw[it][e] = ab[it][e] = aw2[it][e] = ab2[it][e] = 0.f;
+        for (int e = 0; e < 8; ++e) aw[it][e] = ab[it][e] = 0.f;
+#pragma unroll
+    for (int it = 0; it < (DUAL ? MAXIT : 1); ++it)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) aw2[it][e] = ab2[it][e] = 0.f;
 
     for (long row = (long)blockIdx.x * RPB + slot; row < p.rows; row += (long)gridDim.x * RPB) {
+        Frag<T> fx[MAXIT], fd[MAXIT], fd2[DUAL ? MAXIT : 1], fa[MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            frag_load(fx[it], X + row * C + vcol[it]);
+            frag_load(fd[it], DY + row * C + vcol[it]);
+            if (DUAL) frag_load(fd2[it], DY2 + row * C + vcol[it]);
+        }
+        if (DXA) {
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) frag_load(fa[it], DXA + row * C + vcol[it]);
+        } else {
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) frag_zero(fa[it]);
+        }
         const float mean = p.mean[row], rstd = p.rstd[row];
         float xh[MAXIT][8], g[MAXIT][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
-            const int v = lr + it * LPR;
-            if (v < nvec) {
-                Frag<T> fx, fd;
-                frag_load(fx, X + row * C + v * 8);
-                frag_load(fd, DY + row * C + v * 8);
+            if ((vok >> it) & 1u) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    xh[it][e] = (frag_get(fx, e) - mean) * rstd;
-                    const float dy = frag_get(fd, e);
-                    g[it][e] = dy * p.w[v * 8 + e];
+                    xh[it][e] = (frag_get(fx[it], e) - mean) * rstd;
+                    const float dy = frag_get(fd[it], e);
+                    g[it][e] = dy * w[it][e];
                     aw[it][e] += dy * xh[it][e];
                     ab[it][e] += dy;
                 }
-                if (DY2) {
-                    frag_load(fd, DY2 + row * C + v * 8);
+                if (DUAL) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float dy = frag_get(fd, e);
-                        g[it][e] += dy * p.w2[v * 8 + e];
+                        const float dy = frag_get(fd2[it], e);
+                        g[it][e] += dy * p.w2[vcol[it] + e];
                         aw2[it][e] += dy * xh[it][e];
                         ab2[it][e] += dy;
                     }
@@ -136,42 +194,51 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const dist_ln_bwd_args p) {
         if (DX) {
 #pragma unroll
             for (int it = 0; it < MAXIT; ++it) {
-                const int v = lr + it * LPR;
-                if (v < nvec) {
+                if ((vok >> it) & 1u) {
                     Frag<T> o;
-                    if (DXA) frag_load(o, DXA + row * C + v * 8);
-                    else if (p.accumulate_dx) frag_load(o, DX + row * C + v * 8);
-                    else frag_zero(o);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) frag_set(o, e, frag_get(o, e) + rstd * (g[it][e] - c1 - xh[it][e] * c2));
-                    frag_store(o, DX + row * C + v * 8);
-                    if (DXC) frag_store(o, DXC + row * C + v * 8);
+                    for (int e = 0; e < 8; ++e) frag_set(o, e, frag_get(fa[it], e) + rstd * (g[it][e] - c1 - xh[it][e] * c2));
+                    frag_store(o, DX + row * C + vcol[it]);
+                    if (DXC) frag_store(o, DXC + row * C + vcol[it]);
                 }
             }
         }
     }
     if (!want_w) return;
+    // block reduction of the per-lane parameter-gradient sums, one array at a time: lanes that own the same columns
+    // (same lr) are first summed inside the wave by shuffles, then across the 4 waves through a [4][C] LDS image
+    // (plain stores; LDS atomics on C addresses from every lane serialised thousands of updates per block)
+    auto reduce_out = [&](auto& a, float* __restrict__ dst) {
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-        const int v = lr + it * LPR;
-        if (v < nvec) {
+        for (int it = 0; it < MAXIT; ++it)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                atomicAdd(&red[0][v * 8 + e], aw[it][e]);
-                atomicAdd(&red[1][v * 8 + e], ab[it][e]);
-                if (DY2) {
-                    atomicAdd(&red[2][v * 8 + e], aw2[it][e]);
-                    atomicAdd(&red[3][v * 8 + e], ab2[it][e]);
+                float v = a[it][e];
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1)
+                    if (o >= LPR) v += __shfl_xor(v, o, 64);
+                a[it][e] = v;
+            }
+        const int wid = tid >> 6, lane = tid & 63;
+        if (lane < LPR) {
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int v = lr + it * LPR;
+                if (v < nvec) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) red[wid][v * 8 + e] = a[it][e];
                 }
             }
         }
-    }
-    __syncthreads();
-    for (int c = tid; c < C; c += NT) {
-        if (p.dw) atomicAdd(p.dw + c, red[0][c]);
-        if (p.db) atomicAdd(p.db + c, red[1][c]);
-        if (DY2 && p.dw2) atomicAdd(p.dw2 + c, red[2][c]);
-        if (DY2 && p.db2) atomicAdd(p.db2 + c, red[3][c]);
+        __syncthreads();
+        for (int c = tid; c < C; c += NT) atomicAdd(dst + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+        __syncthreads();
+    };
+    if (p.dw) reduce_out(aw, p.dw);
+    if (p.db) reduce_out(ab, p.db);
+    if constexpr (DUAL) {
+        if (p.dw2) reduce_out(aw2, p.dw2);
+        if (p.db2) reduce_out(ab2, p.db2);
     }
 }
 
@@ -183,22 +250,28 @@ int grid_for(long rows, int rpb) {
 
 }  // namespace
 
+template <typename T, typename A, typename K4, typename K16, typename K32, typename K64>
+void launch_by_lpr(int lpr, int grid, hipStream_t s, const A& a, K4 k4, K16 k16, K32 k32, K64 k64) {
+    switch (lpr) {
+        case 4: hipLaunchKernelGGL(k4, dim3(grid), dim3(NT), 0, s, a); break;
+        case 16: hipLaunchKernelGGL(k16, dim3(grid), dim3(NT), 0, s, a); break;
+        case 32: hipLaunchKernelGGL(k32, dim3(grid), dim3(NT), 0, s, a); break;
+        default: hipLaunchKernelGGL(k64, dim3(grid), dim3(NT), 0, s, a); break;
+    }
+}
+
 extern "C" int dist_op_layernorm(const dist_ln_args* a, void* stream) {
     if (!a || !a->x || !a->y || !a->w || !a->b || a->rows <= 0) return DIST_ERR_ARG;
     if (a->C % 8 || a->C > 1024 || a->C < 8) return DIST_ERR_ARG;
     if (a->y2 && (!a->w2 || !a->b2)) return DIST_ERR_ARG;
     if (a->addend && a->addend_period <= 0) return DIST_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool small = a->C <= 128;
-    const int rpb = small ? NT / 16 : NT / 64;
-    const int grid = grid_for(a->rows, rpb);
-    if (a->dtype == DIST_BF16) {
-        if (small) hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, 16>), dim3(grid), dim3(NT), 0, s, *a);
-        else hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, 64>), dim3(grid), dim3(NT), 0, s, *a);
-    } else {
-        if (small) hipLaunchKernelGGL((ln_fwd_kernel<float, 16>), dim3(grid), dim3(NT), 0, s, *a);
-        else hipLaunchKernelGGL((ln_fwd_kernel<float, 64>), dim3(grid), dim3(NT), 0, s, *a);
-    }
+    const int lpr = lanes_per_row(a->C);
+    const int grid = grid_for(a->rows, NT / lpr);
+    if (a->dtype == DIST_BF16)
+        launch_by_lpr<bf16_t>(lpr, grid, s, *a, ln_fwd_kernel<bf16_t, 4>, ln_fwd_kernel<bf16_t, 16>, ln_fwd_kernel<bf16_t, 32>, ln_fwd_kernel<bf16_t, 64>);
+    else
+        launch_by_lpr<float>(lpr, grid, s, *a, ln_fwd_kernel<float, 4>, ln_fwd_kernel<float, 16>, ln_fwd_kernel<float, 32>, ln_fwd_kernel<float, 64>);
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
 }
@@ -208,17 +281,18 @@ extern "C" int dist_op_layernorm_bwd(const dist_ln_bwd_args* a, void* stream) {
     if (a->C % 8 || a->C > 1024 || a->C < 8) return DIST_ERR_ARG;
     if (a->dy2 && !a->w2) return DIST_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool small = a->C <= 128;
-    const int rpb = small ? NT / 16 : NT / 64;
+    const int lpr = lanes_per_row(a->C);
+    const int rpb = NT / lpr;
     long g = (a->rows + rpb - 1) / rpb;
-    if (g > 512) g = 512;          // few blocks: each ends with C x 4 global atomics
+    if (g > 768) g = 768;          // 3 blocks per CU; each ends with C x 2..4 global atomics
     const int grid = (int)g;
+    const bool dual = a->dy2 != nullptr;
     if (a->dtype == DIST_BF16) {
-        if (small) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 16>), dim3(grid), dim3(NT), 0, s, *a);
-        else hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 64>), dim3(grid), dim3(NT), 0, s, *a);
+        if (dual) launch_by_lpr<bf16_t>(lpr, grid, s, *a, ln_bwd_kernel<bf16_t, 4, true>, ln_bwd_kernel<bf16_t, 16, true>, ln_bwd_kernel<bf16_t, 32, true>, ln_bwd_kernel<bf16_t, 64, true>);
+        else launch_by_lpr<bf16_t>(lpr, grid, s, *a, ln_bwd_kernel<bf16_t, 4, false>, ln_bwd_kernel<bf16_t, 16, false>, ln_bwd_kernel<bf16_t, 32, false>, ln_bwd_kernel<bf16_t, 64, false>);
     } else {
-        if (small) hipLaunchKernelGGL((ln_bwd_kernel<float, 16>), dim3(grid), dim3(NT), 0, s, *a);
-        else hipLaunchKernelGGL((ln_bwd_kernel<float, 64>), dim3(grid), dim3(NT), 0, s, *a);
+        if (dual) launch_by_lpr<float>(lpr, grid, s, *a, ln_bwd_kernel<float, 4, true>, ln_bwd_kernel<float, 16, true>, ln_bwd_kernel<float, 32, true>, ln_bwd_kernel<float, 64, true>);
+        else launch_by_lpr<float>(lpr, grid, s, *a, ln_bwd_kernel<float, 4, false>, ln_bwd_kernel<float, 16, false>, ln_bwd_kernel<float, 32, false>, ln_bwd_kernel<float, 64, false>);
     }
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
