@@ -135,8 +135,16 @@ def main():
             step()
         ms, flops, launches = eng.profile_end()
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # HBM bytes per launch of this kernel: PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes, corrected
+        # as MI355X_MICROARCH.md prescribes), collected offline by tools/pmc_pass.sh and committed; null when the file is absent
+        traffic = None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_fast_gemm.json")
+        if args.config == "b16_8+16f" and os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f).get("traffic_bytes_per_launch_avg")
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "traffic_note": "bytes per launch, mean of the four ViT GEMM shapes (48 of the launches), profiles/r01_pmc_fast_gemm.json",
                 "kernel": "gemm_fast_kernel 256x256x32 LDS-DMA (ViT QKV/out/MLP + large DiST Linears)", "launches_per_step": launches // max(nprof, 1),
                 "avg_launch_us": round(ms * 1e3 / max(launches, 1), 1)}
 
