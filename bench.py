@@ -78,7 +78,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP library is the only implementation of the path)")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count() if os.environ.get("DIST_AMD_BACKEND") == "gloo" else local_rank)
 
     from dist_amd import synth
     from dist_amd import distributed as du

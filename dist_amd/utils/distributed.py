@@ -24,7 +24,9 @@ def init_process_group(rank, world, local_rank=0, backend=None, init_method=None
     """One process per GPU; backend 'nccl' IS RCCL on ROCm; gloo for the CPU tests."""
     global _LOCAL_WORLD, _LOCAL_RANK
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # DIST_AMD_BACKEND=gloo lets two ranks share ONE GPU (RCCL refuses duplicate devices): that is how the
+        # multi-rank path (hooks, buckets, streams) is exercised on a 1-GPU box (tests/test_ddp_gpu.py)
+        backend = os.environ.get("DIST_AMD_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if init_method is None:
         addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
         port = os.environ.get("MASTER_PORT", "29500")
