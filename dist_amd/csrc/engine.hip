@@ -507,8 +507,15 @@ extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
     h->PP3 = 3 * c.patch * c.patch; h->Kp = (h->PP3 + 7) / 8 * 8;
     build_tables(h);
     h->ws_bytes = layout_ws(h, nullptr);
-    // side stream + events of the two-stream backward (host objects; no device memory)
     if (const char* e = getenv("DIST_AMD_SERIAL")) h->serial = atoi(e);
+    *out = h;
+    return DIST_OK;
+}
+// side streams + events of the multi-stream forward / backward: created by dist_bind (the first call that needs a
+// device), so dist_create and the parameter tables stay host-only
+static int ensure_streams(dist_handle* h) {
+    if (h->side) return DIST_OK;
+    const dist_config& c = h->cfg;
     bool ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking) == hipSuccess;
     auto mk = [&](hipEvent_t& e) { ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
@@ -519,10 +526,9 @@ extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
     h->ev_feat.resize(c.layers + 1);
     for (auto& e : h->ev_feat) mk(e);
     mk(h->ev_join); mk(h->ev_pre); mk(h->ev_b2);
-    if (!ok) { dist_destroy(h); return DIST_ERR_STATE; }
-    *out = h;
-    return DIST_OK;
+    return ok ? DIST_OK : DIST_ERR_STATE;
 }
+
 extern "C" void dist_destroy(dist_handle* h) {
     if (!h) return;
     for (hipEvent_t e : h->prof_ev) hipEventDestroy(e);
@@ -557,6 +563,7 @@ extern "C" int dist_bind(dist_handle* h, float* theta, float* grads, const float
                          void* packed, void* workspace) {
     if (!h) return DIST_ERR_ARG;
     if (!theta || !visual || !logit_scale || !packed || !workspace) return fail(h, DIST_ERR_UNBOUND, "dist_bind: null buffer");
+    if (ensure_streams(h) != DIST_OK) return fail(h, DIST_ERR_STATE, "dist_bind: cannot create the side streams / events (no HIP device?)");
     h->theta = theta; h->grads = grads; h->visual = visual; h->logit_scale = logit_scale; h->dlogit_scale = dlogit_scale;
     h->packed = static_cast<char*>(packed); h->ws = static_cast<char*>(workspace);
     layout_ws(h, h->ws);
