@@ -36,6 +36,40 @@ __global__ __launch_bounds__(NT) void patchify_kernel(const float* __restrict__ 
         out[i] = from_f<T>(v);
     }
 }
+// P % 8 == 0 (ViT-B/16): one block per (clip, frame, patch row).  The 3 x P image rows of that band are read as whole
+// W-float lines (coalesced float4), parked in LDS in the output type, and the G patch rows are written as whole
+// Kp-element lines (16 B per lane): the element-wise version above reads 64-byte pieces and spends ~40 integer
+// operations per 2-byte output.
+template <typename T>
+__global__ __launch_bounds__(NT) void patchify_band_kernel(const float* __restrict__ video, T* __restrict__ out, int Tn, int H, int W, int P, int Kp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* band = reinterpret_cast<T*>(smem);                  // [3][P][W]
+    const int G = W / P, Gy = H / P;
+    const int gy = blockIdx.x % Gy;
+    const long bk = blockIdx.x / Gy;
+    const int k = (int)(bk % Tn), bi = (int)(bk / Tn);
+    const int W4 = W / 4, per_c = P * W4;
+    for (int v = threadIdx.x; v < 3 * per_c; v += NT) {
+        const int c = v / per_c, rem = v - c * per_c, py = rem / W4, x4 = rem - py * W4;
+        const float4 f = *reinterpret_cast<const float4*>(video + (((long)bi * 3 + c) * Tn + k) * H * W + (long)(gy * P + py) * W + x4 * 4);
+        T* d = band + (c * P + py) * W + x4 * 4;
+        d[0] = from_f<T>(f.x); d[1] = from_f<T>(f.y); d[2] = from_f<T>(f.z); d[3] = from_f<T>(f.w);
+    }
+    __syncthreads();
+    const int vpr = Kp / 8, vp = P / 8;                    // 8-element vectors per output row / per patch line
+    const long row0 = (bk * Gy + gy) * G;
+    for (int v = threadIdx.x; v < G * vpr; v += NT) {
+        const int gx = v / vpr, j = v - gx * vpr;
+        Frag<T> o;
+        if (j * 8 < 3 * P * P) {
+            const int c = j / (P * vp), rem = j - c * (P * vp), py = rem / vp, h = rem - py * vp;
+            frag_load(o, band + (c * P + py) * W + gx * P + h * 8);
+        } else {
+            frag_zero(o);
+        }
+        frag_store(o, out + (row0 + gx) * Kp + j * 8);
+    }
+}
 
 // ---- elementwise --------------------------------------------------------------------------
 template <typename T>
@@ -256,21 +290,54 @@ __global__ __launch_bounds__(NT) void logits_loss_kernel(const T* __restrict__ v
 }
 
 // ---- fused multi-tensor AdamW (torch.optim.AdamW single-tensor math) ---------------------------
+DEV void adamw_one(float& pp, float gr, float& mm, float& vv, const dist_adamw_seg& sg, float b1, float b2, float eps, float bc1, float bc2s) {
+    pp *= (1.f - sg.lr * sg.weight_decay);
+    mm = b1 * mm + (1.f - b1) * gr;
+    vv = b2 * vv + (1.f - b2) * gr * gr;
+    const float denom = sqrtf(vv) / bc2s + eps;
+    pp -= (sg.lr / bc1) * mm / denom;
+}
+constexpr int ADAMW_CHUNK = NT * 4 * 4;                   // elements per block: 4 float4 per thread
 __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    const dist_adamw_seg* __restrict__ segs, int nseg, long n,
                                                    float b1, float b2, float eps, float bc1, float bc2s, float gscale) {
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    // a block owns ADAMW_CHUNK consecutive elements; ONE binary search per block (segment of its first element), every
+    // thread then walks forward from there (segments are sorted, a chunk touches one or two of them) and works on
+    // float4s: the per-element search of the first version cost nine dependent loads per 4-byte element
+    __shared__ int s_first;
+    const long c0 = (long)blockIdx.x * ADAMW_CHUNK;
+    if (threadIdx.x == 0) {
         int lo = 0, hi = nseg - 1;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (segs[mid].end <= i) lo = mid + 1; else hi = mid; }
-        const dist_adamw_seg sg = segs[lo];
-        if (i < sg.begin || i >= sg.end) continue;
-        const float gr = g[i] * gscale;
-        float pp = p[i] * (1.f - sg.lr * sg.weight_decay);
-        const float mm = b1 * m[i] + (1.f - b1) * gr;
-        const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
-        const float denom = sqrtf(vv) / bc2s + eps;
-        pp -= (sg.lr / bc1) * mm / denom;
-        p[i] = pp; m[i] = mm; v[i] = vv;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (segs[mid].end <= c0) lo = mid + 1; else hi = mid; }
+        s_first = lo;
+    }
+    __syncthreads();
+    int si = s_first;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long i = c0 + ((long)k * NT + threadIdx.x) * 4;
+        if (i >= n) break;
+        while (si < nseg - 1 && segs[si].end <= i) ++si;
+        const dist_adamw_seg sg = segs[si];
+        if (i >= sg.begin && i + 4 <= sg.end && i + 4 <= n) {
+            float4 pp = *reinterpret_cast<float4*>(p + i), mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+            const float4 gg = *reinterpret_cast<const float4*>(g + i);
+            adamw_one(pp.x, gg.x * gscale, mm.x, vv.x, sg, b1, b2, eps, bc1, bc2s);
+            adamw_one(pp.y, gg.y * gscale, mm.y, vv.y, sg, b1, b2, eps, bc1, bc2s);
+            adamw_one(pp.z, gg.z * gscale, mm.z, vv.z, sg, b1, b2, eps, bc1, bc2s);
+            adamw_one(pp.w, gg.w * gscale, mm.w, vv.w, sg, b1, b2, eps, bc1, bc2s);
+            *reinterpret_cast<float4*>(p + i) = pp; *reinterpret_cast<float4*>(m + i) = mm; *reinterpret_cast<float4*>(v + i) = vv;
+        } else {                                            // a float4 that straddles a segment border (or a gap between segments)
+            int sj = si;
+            for (long e = i; e < i + 4 && e < n; ++e) {
+                while (sj < nseg - 1 && segs[sj].end <= e) ++sj;
+                const dist_adamw_seg se = segs[sj];
+                if (e < se.begin || e >= se.end) continue;
+                float pp = p[e], mm = m[e], vv = v[e];
+                adamw_one(pp, g[e] * gscale, mm, vv, se, b1, b2, eps, bc1, bc2s);
+                p[e] = pp; m[e] = mm; v[e] = vv;
+            }
+        }
     }
 }
 
@@ -306,6 +373,14 @@ extern "C" int dist_op_patchify(const float* video, void* patches, int b, int T,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int Kp = (3 * P * P + 7) / 8 * 8;
     const long total = (long)b * T * (H / P) * (W / P) * Kp;
+    const size_t band = (size_t)3 * P * W * (dtype == DIST_BF16 ? 2 : 4);
+    if (P % 8 == 0 && W % 4 == 0 && band <= 64 * 1024 && (3 * P * P) % 8 == 0) {
+        const unsigned grid = (unsigned)((long)b * T * (H / P));
+        if (dtype == DIST_BF16) hipLaunchKernelGGL(patchify_band_kernel<bf16_t>, dim3(grid), dim3(NT), band, s, video, (bf16_t*)patches, T, H, W, P, Kp);
+        else hipLaunchKernelGGL(patchify_band_kernel<float>, dim3(grid), dim3(NT), band, s, video, (float*)patches, T, H, W, P, Kp);
+        HIP_CHECK_RET(hipGetLastError());
+        return DIST_OK;
+    }
     if (dtype == DIST_BF16) hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid1d(total, NT * 8)), dim3(NT), 0, s, video, (bf16_t*)patches, b, T, H, W, P, Kp);
     else hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid1d(total, NT * 8)), dim3(NT), 0, s, video, (float*)patches, b, T, H, W, P, Kp);
     HIP_CHECK_RET(hipGetLastError());
@@ -372,7 +447,7 @@ extern "C" int dist_op_adamw(float* param, const float* grad, float* m, float* v
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid1d(n, NT * 4)), dim3(NT), 0, s, param, grad, m, v, segs_dev, nseg, (long)n, beta1, beta2, eps, bc1, bc2s, grad_scale);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + ADAMW_CHUNK - 1) / ADAMW_CHUNK)), dim3(NT), 0, s, param, grad, m, v, segs_dev, nseg, (long)n, beta1, beta2, eps, bc1, bc2s, grad_scale);
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
 }
