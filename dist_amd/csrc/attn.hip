@@ -15,7 +15,7 @@
 
 namespace {
 
-constexpr int NT = 512;           // 8 waves: the per-q-tile softmax chain is latency-bound, more waves per SIMD hide it
+constexpr int NT = 448;           // 7 waves x two 16-query tiles = 14 tile slots for the 13 tiles of L = 197 (8 waves left 3 of them half idle)
 constexpr int HD = 64;           // head dim
 constexpr int KPAD = 8;
 
@@ -44,24 +44,51 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
 
-    // K: row-major, 16-B vectors, d fastest
-    for (int v = tid; v < Lp * (HD / 8); v += NT) {
-        const int key = v / (HD / 8), dv = v % (HD / 8);
-        Frag<T> fr;
-        frag_zero(fr);
-        if (key < L) frag_load(fr, base + (long)key * ld + d + h * HD + dv * 8);
-        frag_store(fr, Ks + key * KLD + dv * 8);
-    }
-    if (TRV) {
-        // V row-major like K (coalesced 16-B loads and stores); the PV fragments use ds_read_b64_tr_b16
-        for (int v = tid; v < Lp * (HD / 8); v += NT) {
-            const int key = v / (HD / 8), dv = v % (HD / 8);
-            Frag<T> fr;
-            frag_zero(fr);
-            if (key < L) frag_load(fr, base + (long)key * ld + 2 * d + h * HD + dv * 8);
-            frag_store(fr, Vt + key * KLD + dv * 8);
+    const int nq = (L + 15) / 16, nslab = Lp / 32;
+    constexpr int NW = NT / 64;
+    // the query fragments of this wave's first tile pair are requested right behind the K / V staging stores: their
+    // latency hides behind the block barrier
+    auto load_q = [&](int qt0, int (&qrow)[2], Frag<T> (&fq)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int qt = qt0 + u * NW;
+            qrow[u] = qt < nq ? qt * 16 + li : L;          // L = "no query" (clamped load, nothing stored)
+            const T* qp = base + (long)min(qrow[u], L - 1) * ld + h * HD + lg * 8;
+            frag_load(fq[u][0], qp);
+            frag_load(fq[u][1], qp + 32);
         }
-    } else {
+    };
+    int qrow[2];
+    Frag<T> fq[2][2];
+
+    // K and V: row-major, 16-B vectors, d fastest.  All loads of a thread are issued back to back (unconditional, key
+    // clamped, padding rows zeroed at the LDS store): one memory latency for the whole staging phase instead of one
+    // per loop iteration
+    constexpr int KV_IT = 6;                                  // covers Lp * 8 vectors up to Lp = 336 (L = 257 -> Lp = 288)
+    const int n_it = (Lp * (HD / 8) + NT - 1) / NT;           // block-uniform
+    {
+        Frag<T> rk[KV_IT], rv[KV_IT];
+#pragma unroll
+        for (int it = 0; it < KV_IT; ++it) {
+            if (it < n_it) {
+                const int v = min(tid + it * NT, Lp * (HD / 8) - 1);
+                const int key = min(v / (HD / 8), L - 1), dv = v % (HD / 8);
+                frag_load(rk[it], base + (long)key * ld + d + h * HD + dv * 8);
+                if (TRV) frag_load(rv[it], base + (long)key * ld + 2 * d + h * HD + dv * 8);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < KV_IT; ++it) {
+            const int v = tid + it * NT;
+            if (it < n_it && v < Lp * (HD / 8)) {
+                const int key = v / (HD / 8), dv = v % (HD / 8);
+                if (key >= L) { frag_zero(rk[it]); if (TRV) frag_zero(rv[it]); }
+                frag_store(rk[it], Ks + key * KLD + dv * 8);
+                if (TRV) frag_store(rv[it], Vt + key * KLD + dv * 8);
+            }
+        }
+    }
+    if (!TRV) {
         // V transposed, key fastest (conflict-free scalar LDS writes)
         for (int v = tid; v < Lp * (HD / 8); v += NT) {
             const int key = v % Lp, dv = v / Lp;
@@ -72,26 +99,17 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
             for (int e = 0; e < 8; ++e) Vt[(dv * 8 + e) * VLD + key] = from_f<T>(frag_get(fr, e));
         }
     }
+    load_q(wid, qrow, fq);
     __syncthreads();
 
-    const int nq = (L + 15) / 16, nslab = Lp / 32;
-    constexpr int NW = NT / 64;
     // each wave walks TWO 16-query tiles at once (qt, qt + NW): two independent score -> softmax -> PV dependency
     // chains per wave, so the shuffle / exp / MFMA latencies of one tile are covered by the other
     for (int qt0 = wid; qt0 < nq; qt0 += 2 * NW) {
-        int qrow[2];
-        Frag<T> fq[2][2];
+        if (qt0 != wid) load_q(qt0, qrow, fq);
         f32x4 o[2][4];
         float mrun[2], lrun[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int qt = qt0 + u * NW;
-            qrow[u] = qt < nq ? qt * 16 + li : L;          // L = "no query" (nothing loaded, nothing stored)
-            frag_zero(fq[u][0]); frag_zero(fq[u][1]);
-            if (qrow[u] < L) {
-                frag_load(fq[u][0], base + (long)qrow[u] * ld + h * HD + lg * 8);
-                frag_load(fq[u][1], base + (long)qrow[u] * ld + h * HD + 32 + lg * 8);
-            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             mrun[u] = -1e30f; lrun[u] = 0.f;
@@ -163,7 +181,29 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
             l += __shfl_xor(l, 16, 64);
             l += __shfl_xor(l, 32, 64);
             const float inv = 1.f / l;
-            if (qrow[u] < L) {
+            if (TRV) {
+                // a lane holds 4 consecutive columns per 16-column fragment (8 bytes of bf16): lanes lg and lg ^ 1 swap
+                // two fragments each, so every lane ends up with 8 consecutive columns of two fragments and writes two
+                // 16-byte pieces instead of four 8-byte ones (the epilogue is store-issue-bound)
+                auto pk2 = [&](int j, int half) __attribute__((always_inline)) -> unsigned {
+                    union { bf16_t b[2]; unsigned w; } cv;
+                    cv.b[0] = (bf16_t)(o[u][j][2 * half] * inv); cv.b[1] = (bf16_t)(o[u][j][2 * half + 1] * inv);
+                    return cv.w;
+                };
+                // scalars, not an array: with an array hipcc turns the selects below into lane-indexed stack accesses
+                const unsigned a0 = pk2(0, 0), a1 = pk2(0, 1), b0 = pk2(1, 0), b1 = pk2(1, 1);
+                const unsigned c0 = pk2(2, 0), c1 = pk2(2, 1), d0 = pk2(3, 0), d1 = pk2(3, 1);
+                const bool odd = lg & 1;
+                // even lg keeps fragments 0, 1 and sends 2, 3; odd lg keeps 2, 3 and sends 0, 1
+                const unsigned r00 = __shfl_xor(odd ? a0 : c0, 16, 64), r01 = __shfl_xor(odd ? a1 : c1, 16, 64);
+                const unsigned r10 = __shfl_xor(odd ? b0 : d0, 16, 64), r11 = __shfl_xor(odd ? b1 : d1, 16, 64);
+                if (qrow[u] < L) {
+                    T* orow = out + ((long)f * L + qrow[u]) * d + h * HD + (odd ? 32 : 0) + (lg >> 1) * 8;
+                    const unsigned k00 = odd ? c0 : a0, k01 = odd ? c1 : a1, k10 = odd ? d0 : b0, k11 = odd ? d1 : b1;
+                    *reinterpret_cast<uint4*>(orow) = odd ? make_uint4(r00, r01, k00, k01) : make_uint4(k00, k01, r00, r01);
+                    *reinterpret_cast<uint4*>(orow + 16) = odd ? make_uint4(r10, r11, k10, k11) : make_uint4(k10, k11, r10, r11);
+                }
+            } else if (qrow[u] < L) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v4[4] = {o[u][j][0] * inv, o[u][j][1] * inv, o[u][j][2] * inv, o[u][j][3] * inv};
