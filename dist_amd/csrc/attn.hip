@@ -31,7 +31,7 @@ DEV void v_frag_tr(Frag<bf16_t>& f, const bf16_t* p0, int stride16) {
 DEV void v_frag_tr(Frag<float>&, const float*, int) {}
 
 template <typename T>
-__global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int heads, int Lp) {
+__global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int heads, int Lp, int hm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KLD = HD + KPAD, VLD = Lp + KPAD;
     constexpr bool TRV = sizeof(T) == 2;         // bf16: V stays row-major and is gathered with LDS transpose reads
@@ -39,8 +39,13 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
     T* Vt = Ks + Lp * KLD;                       // fp32: [HD][VLD] (transposed) | bf16: [Lp][KLD] (row-major)
 
     const int f = blockIdx.x / heads, h = blockIdx.x % heads;
-    const int d = heads * HD, ld = 3 * d;
-    const T* base = qkv + (long)f * L * ld;
+    const int d = heads * HD;
+    // rows layout: q/k/v of head h are 64-column slices of the packed [frames*L][3d] rows; head-major layout: three
+    // contiguous [L][64] blocks per (frame, head)
+    const int ld = hm ? HD : 3 * d;
+    const T* qb = hm ? qkv + ((long)(f * heads + h) * 3) * L * HD : qkv + (long)f * L * ld + h * HD;
+    const T* kb = hm ? qb + (long)L * HD : qb + d;
+    const T* vb = hm ? kb + (long)L * HD : kb + d;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
 
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
         for (int u = 0; u < 2; ++u) {
             const int qt = qt0 + u * NW;
             qrow[u] = qt < nq ? qt * 16 + li : L;          // L = "no query" (clamped load, nothing stored)
-            const T* qp = base + (long)min(qrow[u], L - 1) * ld + h * HD + lg * 8;
+            const T* qp = qb + (long)min(qrow[u], L - 1) * ld + lg * 8;
             frag_load(fq[u][0], qp);
             frag_load(fq[u][1], qp + 32);
         }
@@ -73,8 +78,8 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
             if (it < n_it) {
                 const int v = min(tid + it * NT, Lp * (HD / 8) - 1);
                 const int key = min(v / (HD / 8), L - 1), dv = v % (HD / 8);
-                frag_load(rk[it], base + (long)key * ld + d + h * HD + dv * 8);
-                if (TRV) frag_load(rv[it], base + (long)key * ld + 2 * d + h * HD + dv * 8);
+                frag_load(rk[it], kb + (long)key * ld + dv * 8);
+                if (TRV) frag_load(rv[it], vb + (long)key * ld + dv * 8);
             }
         }
 #pragma unroll
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
             const int key = v % Lp, dv = v / Lp;
             Frag<T> fr;
             frag_zero(fr);
-            if (key < L) frag_load(fr, base + (long)key * ld + 2 * d + h * HD + dv * 8);
+            if (key < L) frag_load(fr, vb + (long)key * ld + dv * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) Vt[(dv * 8 + e) * VLD + key] = from_f<T>(frag_get(fr, e));
         }
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(64) void xattn1q_bwd(const T* __restrict__ q, const
 }
 
 template <typename T>
-int launch_attn(const void* qkv, void* out, int frames, int L, int heads, hipStream_t s) {
+int launch_attn(const void* qkv, void* out, int frames, int L, int heads, int hm, hipStream_t s) {
     const int Lp = (L + 31) / 32 * 32;
     const size_t smem = sizeof(T) == 2 ? (size_t)2 * Lp * (HD + KPAD) * sizeof(T)
                                        : ((size_t)Lp * (HD + KPAD) + (size_t)HD * (Lp + KPAD)) * sizeof(T);
@@ -297,17 +302,18 @@ int launch_attn(const void* qkv, void* out, int frames, int L, int heads, hipStr
         HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_smem = smem;
     }
-    hipLaunchKernelGGL(attn_kernel<T>, dim3(frames * heads), dim3(NT), smem, s, static_cast<const T*>(qkv), static_cast<T*>(out), L, heads, Lp);
+    hipLaunchKernelGGL(attn_kernel<T>, dim3(frames * heads), dim3(NT), smem, s, static_cast<const T*>(qkv), static_cast<T*>(out), L, heads, Lp, hm);
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
 }
 
 }  // namespace
 
-extern "C" int dist_op_attention(const void* qkv, void* out, int frames, int L, int heads, int dtype, void* stream) {
+extern "C" int dist_op_attention(const void* qkv, void* out, int frames, int L, int heads, int qkv_layout, int dtype, void* stream) {
     if (!qkv || !out || frames <= 0 || L <= 0 || heads <= 0) return DIST_ERR_ARG;
+    if (qkv_layout != DIST_QKV_ROWS && qkv_layout != DIST_QKV_HEADS) return DIST_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return dtype == DIST_BF16 ? launch_attn<bf16_t>(qkv, out, frames, L, heads, s) : launch_attn<float>(qkv, out, frames, L, heads, s);
+    return dtype == DIST_BF16 ? launch_attn<bf16_t>(qkv, out, frames, L, heads, qkv_layout, s) : launch_attn<float>(qkv, out, frames, L, heads, qkv_layout, s);
 }
 
 extern "C" int dist_op_xattn1q(const void* q, const void* kv, void* o, float* probs, int B, int S, int C, int dtype, void* stream) {

@@ -486,7 +486,7 @@ extern "C" const char* dist_strerror(int code) {
         default: return code <= -1000 ? hipGetErrorString((hipError_t)(-code - 1000)) : "unknown error";
     }
 }
-extern "C" int dist_abi_version(void) { return 1; }
+extern "C" int dist_abi_version(void) { return 2; }
 
 extern "C" void dist_destroy(dist_handle* h);
 extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
@@ -620,8 +620,10 @@ extern "C" int dist_vit_forward(dist_handle* h, const float* video, int b, void*
     for (int i = 0; i < c.layers; ++i) {
         const VitLayer& v = h->vit[i];
         RUN(ln_fwd(x, h->visual, v.ln1, xin, h->hbuf, rowsS, nullptr, nullptr));
-        RUN(gemm(x, h->hbuf, d, x.pk(v.qkv.pk.f), rowsS, 3 * d, d, 1, h->qkv, 3 * d, x.vs(v.qkv.bias), nullptr, nullptr, nullptr));
-        RUN(dist_op_attention(h->qkv, h->att, b * h->t, L, h->heads, c.dtype, stream));
+        // the QKV GEMM writes [frame][head][q|k|v][L][64] (DIST_OM_HEADS, leading dimension 64): every (frame, head) operand of
+        // the attention kernel is one contiguous block instead of 128-byte pieces at a 3d row stride
+        RUN(gemm(x, h->hbuf, d, x.pk(v.qkv.pk.f), rowsS, 3 * d, d, 1, h->qkv, 64, x.vs(v.qkv.bias), nullptr, nullptr, nullptr, RM(), OM(DIST_OM_HEADS, L, h->heads)));
+        RUN(dist_op_attention(h->qkv, h->att, b * h->t, L, h->heads, DIST_QKV_HEADS, c.dtype, stream));
         RUN(gemm(x, h->att, d, x.pk(v.out.pk.f), rowsS, d, d, 1, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr));
         RUN(ln_fwd(x, h->visual, v.ln2, h->xa, h->hbuf, rowsS, nullptr, nullptr));
         RUN(gemm(x, h->hbuf, d, x.pk(v.fc.pk.f), rowsS, 4 * d, d, 1, nullptr, 4 * d, x.vs(v.fc.bias), nullptr, nullptr, h->mlp));

@@ -192,6 +192,10 @@ __global__ __launch_bounds__(Shape<NW>::NT, Shape<NW>::MINB) void gemm_fast_kern
     const int crow = lane >> 3, cchunk = lane & 7;        // coalesced pass: 8 lanes cover one 128-B row
     const int icls = p.omap.mode == DIST_OM_INSERTCLS ? p.omap.p0 : 0;
     auto dest_row = [&](int m) -> long { return icls ? (long)(m / icls) * (icls + 1) + 1 + m % icls : (long)m; };
+    // DIST_OM_HEADS: this wave's 64 columns are exactly one (q|k|v, head) slice; row (frame, token) goes to
+    // [frame][head][part][token][64], so the 8 rows of a store instruction are 1 KB contiguous
+    const bool heads_om = p.omap.mode == DIST_OM_HEADS;
+    const int hp_part = (nw >> 6) / max(p.omap.p1, 1), hp_head = (nw >> 6) - hp_part * max(p.omap.p1, 1);
 
     if (flags & DIST_EPI_RES) {
         // all 16 row-pieces of the residual tile are requested back to back (the operand fragment registers are
@@ -245,7 +249,14 @@ __global__ __launch_bounds__(Shape<NW>::NT, Shape<NW>::MINB) void gemm_fast_kern
             const int r = it * 8 + crow;
             const int m = mw + r, n = nw + cchunk * 8;
             const uint4 v = *reinterpret_cast<const uint4*>(ew + r * 128 + ((cchunk ^ (r & 7)) << 4));
-            if (m < M && n < N) *reinterpret_cast<uint4*>(dst + dest_row(m) * ld + n) = v;
+            if (m < M && n < N) {
+                if (heads_om) {
+                    const int fr = m / p.omap.p0, tok = m - fr * p.omap.p0;
+                    *reinterpret_cast<uint4*>(dst + ((((long)fr * p.omap.p1 + hp_head) * 3 + hp_part) * p.omap.p0 + tok) * 64 + cchunk * 8) = v;
+                } else {
+                    *reinterpret_cast<uint4*>(dst + dest_row(m) * ld + n) = v;
+                }
+            }
         }
     };
     if (act_only) {
@@ -276,10 +287,11 @@ __global__ __launch_bounds__(Shape<NW>::NT, Shape<NW>::MINB) void gemm_fast_kern
 static bool fast_common_ok(const dist_gemm_args* a) {
     if (a->dtype != DIST_BF16 || a->taps != 1) return false;
     if (a->amap.mode != DIST_RM_PLAIN && a->amap.mode != DIST_RM_STRIDED && a->amap.mode != DIST_RM_SKIPCLS) return false;
-    if (a->omap.mode != DIST_OM_PLAIN && a->omap.mode != DIST_OM_INSERTCLS) return false;
+    if (a->omap.mode != DIST_OM_PLAIN && a->omap.mode != DIST_OM_INSERTCLS && a->omap.mode != DIST_OM_HEADS) return false;
     if (a->flags & DIST_EPI_MULG) return false;
     if (a->K % BK || a->K < 4 * BK || a->N % 64 || a->M < 1024) return false;
     if (a->lda % 8 || a->ldb % 8 || a->ldc % 8 || a->ldc2 % 8 || a->ldres % 8) return false;
+    if (a->omap.mode == DIST_OM_HEADS && (a->flags & (DIST_EPI_RES | DIST_EPI_ACT2))) return false;
     const long a_rows = a->amap.mode == DIST_RM_PLAIN ? a->M : 2 * a->M + a->M / 64 + 64;   // generous bound for the strided / skip-cls images
     if (a_rows * a->lda >= (1l << 30) || (long)a->N * a->ldb >= (1l << 30)) return false;     // 32-bit byte offsets
     return true;

@@ -183,6 +183,11 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const dist_gemm_args p) {
         ncol = n;
         if (om == DIST_OM_PLAIN) return m;
         if (om == DIST_OM_INSERTCLS) return (long)(m / op0) * (op0 + 1) + 1 + m % op0;
+        if (om == DIST_OM_HEADS) {                           // [frame][head][q|k|v][token][64]; the leading dimension is 64
+            const int hd = n >> 6, part = hd / op1, hh = hd - part * op1;
+            ncol = n & 63;
+            return ((long)((m / op0) * op1 + hh) * 3 + part) * op0 + m % op0;
+        }
         const int bj = m / op1, nn = m % op1;
         if (om == DIST_OM_SPLITCOLS) { a = n / op2; ncol = n - a * op2; }
         return ((long)bj * op0 + a) * op1 + nn;
@@ -317,6 +322,8 @@ extern "C" int dist_op_gemm_nt(const dist_gemm_args* a, void* stream) {
     if ((a->flags & DIST_EPI_RES) && !a->res) return DIST_ERR_ARG;
     if ((a->flags & DIST_EPI_MULG) && !a->aux) return DIST_ERR_ARG;
     if (a->omap.mode == DIST_OM_SPLITCOLS && (a->omap.p2 % 4 || a->N != a->omap.p0 * a->omap.p2)) return DIST_ERR_ARG;
+    if (a->omap.mode == DIST_OM_HEADS && (a->omap.p0 <= 0 || a->omap.p1 <= 0 || a->N != 3 * 64 * a->omap.p1 || a->ldc != 64 ||
+                                          (a->flags & (DIST_EPI_RES | DIST_EPI_MULG | DIST_EPI_ACT2)) || !a->C)) return DIST_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int fast = dist_k_gemm_fast(a, s);              // large plain bf16 GEMMs (frozen ViT): LDS-DMA 256x256 kernel
     if (fast != 0) return fast < 0 ? fast : DIST_OK;

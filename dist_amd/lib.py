@@ -8,7 +8,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libdist_amd.so")
 
 F32, BF16 = 0, 1
 RM_PLAIN, RM_SHIFT, RM_SPATIAL, RM_STRIDED, RM_SKIPCLS = range(5)
-OM_PLAIN, OM_DUP, OM_INSERTCLS, OM_SPLITCOLS = range(4)
+OM_PLAIN, OM_DUP, OM_INSERTCLS, OM_SPLITCOLS, OM_HEADS = range(5)
+QKV_ROWS, QKV_HEADS = 0, 1
 EPI_BIAS, EPI_MULG, EPI_RES, EPI_ACT2 = 1, 2, 4, 8
 
 
@@ -131,7 +132,7 @@ def load():
     _sig(lib, "dist_op_gemm_tn", argtypes=[C.POINTER(GemmTnArgs), C.c_void_p])
     _sig(lib, "dist_op_layernorm", argtypes=[C.POINTER(LnArgs), C.c_void_p])
     _sig(lib, "dist_op_layernorm_bwd", argtypes=[C.POINTER(LnBwdArgs), C.c_void_p])
-    _sig(lib, "dist_op_attention", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p])
+    _sig(lib, "dist_op_attention", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p])
     _sig(lib, "dist_op_xattn1q", argtypes=[C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p])
     _sig(lib, "dist_op_xattn1q_bwd", argtypes=[C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p])
     _sig(lib, "dist_op_patchify", argtypes=[C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p])

@@ -104,10 +104,11 @@ def layernorm_bwd(x, mean, rstd, dy, w, *, dy2=None, w2=None, dx=None, accumulat
     L.check(lib.dist_op_layernorm_bwd(C.byref(a), _stream()))
 
 
-def attention(qkv, frames, Ltok, heads):
+def attention(qkv, frames, Ltok, heads, layout=L.QKV_ROWS):
+    """layout QKV_ROWS: qkv is [frames*L, 3d]; QKV_HEADS: qkv holds [frame][head][q|k|v][L][64] (any shape, same size)."""
     lib = L.load()
-    out = torch.empty(qkv.shape[0], qkv.shape[1] // 3, dtype=qkv.dtype, device=qkv.device)
-    L.check(lib.dist_op_attention(_p(qkv), _p(out), frames, Ltok, heads, _dt(qkv), _stream()))
+    out = torch.empty(frames * Ltok, heads * 64, dtype=qkv.dtype, device=qkv.device)
+    L.check(lib.dist_op_attention(_p(qkv), _p(out), frames, Ltok, heads, layout, _dt(qkv), _stream()))
     return out
 
 

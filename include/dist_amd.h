@@ -47,7 +47,7 @@ int dist_abi_version(void);
 /* logical-row -> source-row maps: conv taps and token re-layouts without im2col */
 enum { DIST_RM_PLAIN = 0, DIST_RM_SHIFT = 1, DIST_RM_SPATIAL = 2, DIST_RM_STRIDED = 3, DIST_RM_SKIPCLS = 4 };
 typedef struct dist_rowmap { int mode, p0, p1, sign; } dist_rowmap;
-enum { DIST_OM_PLAIN = 0, DIST_OM_DUP = 1, DIST_OM_INSERTCLS = 2, DIST_OM_SPLITCOLS = 3 };
+enum { DIST_OM_PLAIN = 0, DIST_OM_DUP = 1, DIST_OM_INSERTCLS = 2, DIST_OM_SPLITCOLS = 3, DIST_OM_HEADS = 4 };
 typedef struct dist_outmap { int mode, p0, p1, p2; } dist_outmap;
 
 enum {
@@ -110,9 +110,13 @@ typedef struct dist_ln_bwd_args {
 } dist_ln_bwd_args;
 int dist_op_layernorm_bwd(const dist_ln_bwd_args* a, void* stream);
 
-/* per-frame multi-head self-attention on packed qkv [frames*L, 3*d] -> [frames*L, d]
- * (nn.MultiheadAttention inside ResidualAttentionBlockMid, clip.py:155,166-168) */
-int dist_op_attention(const void* qkv, void* out, int frames, int L, int heads, int dtype, void* stream);
+/* per-frame multi-head self-attention -> [frames*L, d]
+ * (nn.MultiheadAttention inside ResidualAttentionBlockMid, clip.py:155,166-168).
+ * qkv_layout DIST_QKV_ROWS:  packed rows [frames*L, 3*d] (the in_proj output as torch lays it out);
+ *            DIST_QKV_HEADS: [frame][head][q|k|v][L][64], what dist_op_gemm_nt writes with omap DIST_OM_HEADS - every
+ *            (frame, head) operand is one contiguous 25 KB block instead of 128-byte pieces at a 3*d row stride. */
+enum { DIST_QKV_ROWS = 0, DIST_QKV_HEADS = 1 };
+int dist_op_attention(const void* qkv, void* out, int frames, int L, int heads, int qkv_layout, int dtype, void* stream);
 
 /* one-query cross attention (CrossAttentionBlockGenral, clip.py:139-147; dist.py:144,158):
  * q [B, C], kv [B*S, 2C] -> o [B, C], probs [B, H, S] (fp32, saved for backward) */

@@ -22,7 +22,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert len(syms) >= 30
     for s in syms:
         assert hasattr(l, s), s
-    assert l.dist_abi_version() == 1
+    assert l.dist_abi_version() == 2
     assert l.dist_strerror(-1).decode().startswith("invalid argument")
 
 

@@ -273,6 +273,36 @@ def test_vit_attention(gpu_lib, dtype, frames, L_, heads):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("frames,L_,heads", [(6, 197, 12), (3, 257, 16), (5, 17, 2)])
+def test_vit_attention_head_major(gpu_lib, dtype, frames, L_, heads):
+    """same attention on the [frame][head][q|k|v][L][64] layout the QKV GEMM writes with DIST_OM_HEADS"""
+    from dist_amd import ops, lib as L
+    d = heads * 64
+    qkv = rnd((frames * L_, 3 * d), dtype, 1)
+    hm = qkv.reshape(frames, L_, 3, heads, 64).permute(0, 3, 2, 1, 4).contiguous()
+    out = ops.attention(hm, frames, L_, heads, layout=L.QKV_HEADS)
+    ref = ops.attention(qkv, frames, L_, heads)
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("frames,L_,heads,K", [(7, 197, 12, 768), (26, 197, 4, 256), (3, 17, 2, 64), (5, 50, 6, 128)])
+def test_gemm_heads_outmap(gpu_lib, dtype, frames, L_, heads, K):
+    """QKV projection written head-major (both the 256x256 LDS-DMA kernel and the generic kernel take this out-map)"""
+    from dist_amd import ops, lib as L
+    M, N = frames * L_, 3 * heads * 64
+    A = rnd((M, K), dtype, 1)
+    W = (rnd((N, K), torch.float32, 2) * K ** -0.5).to(dtype)
+    bias = rnd((N,), torch.float32, 3)
+    plain = torch.empty(M, N, dtype=dtype, device="cuda")
+    ops.gemm_nt(A, W, M, N, K, bias=bias, C_out=plain)
+    hm = torch.full((frames, heads, 3, L_, 64), float("nan"), dtype=dtype, device="cuda")
+    ops.gemm_nt(A, W, M, N, K, bias=bias, C_out=hm, ldc=64, omap=ops.outmap(L.OM_HEADS, L_, heads))
+    ref = plain.reshape(frames, L_, 3, heads, 64).permute(0, 3, 2, 1, 4)
+    assert torch.equal(hm, ref)
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("B,S,C", [(16, 197, 384), (4, 8, 384), (6, 10, 128)])
 def test_xattn1q(gpu_lib, dtype, B, S, C):
     from dist_amd import ops

@@ -53,4 +53,6 @@ print(f"layernorm 50432x768: {t*1e6:8.1f} us {2*xs[0].numel()*2/t/1e9:7.0f} GB/s
 del xs, ys
 qs = mk(256 * 197, 2304)
 t = timeit_rot([(lambda q=q: ops.attention(q, 256, 197, 12)) for q in qs])
-print(f"attention: {t*1e6:8.1f} us {4*256*12*197*197*64/t/1e12:7.1f} TF")
+print(f"attention (rows layout): {t*1e6:8.1f} us {4*256*12*197*197*64/t/1e12:7.1f} TF")
+t = timeit_rot([(lambda q=q: ops.attention(q, 256, 197, 12, layout=L.QKV_HEADS)) for q in qs])
+print(f"attention (head-major):  {t*1e6:8.1f} us {4*256*12*197*197*64/t/1e12:7.1f} TF")
