@@ -205,8 +205,8 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
                 if (qrow[u] < L) {
                     T* orow = out + ((long)f * L + qrow[u]) * d + h * HD + (odd ? 32 : 0) + (lg >> 1) * 8;
                     const unsigned k00 = odd ? c0 : a0, k01 = odd ? c1 : a1, k10 = odd ? d0 : b0, k11 = odd ? d1 : b1;
-                    *reinterpret_cast<uint4*>(orow) = odd ? make_uint4(r00, r01, k00, k01) : make_uint4(k00, k01, r00, r01);
-                    *reinterpret_cast<uint4*>(orow + 16) = odd ? make_uint4(r10, r11, k10, k11) : make_uint4(k10, k11, r10, r11);
+                    store16_nt(orow, odd ? make_uint4(r00, r01, k00, k01) : make_uint4(k00, k01, r00, r01));
+                    store16_nt(orow + 16, odd ? make_uint4(r10, r11, k10, k11) : make_uint4(k10, k11, r10, r11));
                 }
             } else if (qrow[u] < L) {
 #pragma unroll

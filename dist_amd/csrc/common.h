@@ -43,6 +43,20 @@ DEV void frag_store(const Frag<float>& f, float* p) {
     reinterpret_cast<float4*>(p)[0] = make_float4(f.v[0], f.v[1], f.v[2], f.v[3]);
     reinterpret_cast<float4*>(p)[1] = make_float4(f.v[4], f.v[5], f.v[6], f.v[7]);
 }
+// Streaming (non-temporal) stores for tensors that are written once and read by a LATER kernel (every activation is
+// far larger than the 4 MB L2 of an XCD): they do not evict the operand panels other workgroups are re-reading.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4v_t __attribute__((ext_vector_type(4)));
+DEV void store16_nt(void* p, const uint4& v) {
+    u32x4_t x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<u32x4_t*>(p));
+}
+DEV void frag_store_nt(const Frag<bf16_t>& f, bf16_t* p) { __builtin_nontemporal_store(f.v, reinterpret_cast<bf16x8*>(p)); }
+DEV void frag_store_nt(const Frag<float>& f, float* p) {
+    f32x4v_t a = {f.v[0], f.v[1], f.v[2], f.v[3]}, b = {f.v[4], f.v[5], f.v[6], f.v[7]};
+    __builtin_nontemporal_store(a, reinterpret_cast<f32x4v_t*>(p));
+    __builtin_nontemporal_store(b, reinterpret_cast<f32x4v_t*>(p) + 1);
+}
 // two groups of 4 contiguous elements (8-byte / 16-byte aligned) -> slots 0..3 and 4..7
 DEV void frag_load44(Frag<bf16_t>& f, const bf16_t* p0, const bf16_t* p1) {
     const bf16x4 a = *reinterpret_cast<const bf16x4*>(p0);

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const dist_gemm_args p) {
             const int m = mw + row, n = nw + vec * EPV;
             if (m < M && n < N) {
                 int nc; const long d = dest_of(m, n, a, nc);
-                *reinterpret_cast<uint4*>(dst + d * ld + nc) = *reinterpret_cast<const uint4*>(ew + row * ROWB + vec * 16);
+                store16_nt(dst + d * ld + nc, *reinterpret_cast<const uint4*>(ew + row * ROWB + vec * 16));
             }
         }
     };

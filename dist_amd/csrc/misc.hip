@@ -67,7 +67,7 @@ __global__ __launch_bounds__(NT) void patchify_band_kernel(const float* __restri
         } else {
             frag_zero(o);
         }
-        frag_store(o, out + (row0 + gx) * Kp + j * 8);
+        frag_store_nt(o, out + (row0 + gx) * Kp + j * 8);
     }
 }
 
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(NT) void gelu_bwd_kernel(const T* __restrict__ dy, 
         frag_load(x, dy + i * 8); frag_load(y, pre + i * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) frag_set(x, e, frag_get(x, e) * qgelu_grad(frag_get(y, e)));
-        frag_store(x, dx + i * 8);
+        frag_store_nt(x, dx + i * 8);
     }
 }
 

@@ -98,11 +98,11 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const dist_ln_args p) {
                 Frag<T> o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) frag_set(o, e, (x[it][e] - mean) * rstd * w[it][e] + bb[it][e]);
-                frag_store(o, Y + row * C + v * 8);
+                frag_store_nt(o, Y + row * C + v * 8);
                 if (Y2) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) frag_set(o, e, (x[it][e] - mean) * rstd * p.w2[v * 8 + e] + p.b2[v * 8 + e]);
-                    frag_store(o, Y2 + row * C + v * 8);
+                    frag_store_nt(o, Y2 + row * C + v * 8);
                 }
             }
         }
@@ -198,8 +198,8 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const dist_ln_bwd_args p) {
                     Frag<T> o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) frag_set(o, e, frag_get(fa[it], e) + rstd * (g[it][e] - c1 - xh[it][e] * c2));
-                    frag_store(o, DX + row * C + vcol[it]);
-                    if (DXC) frag_store(o, DXC + row * C + vcol[it]);
+                    frag_store_nt(o, DX + row * C + vcol[it]);
+                    if (DXC) frag_store_nt(o, DXC + row * C + vcol[it]);
                 }
             }
         }
