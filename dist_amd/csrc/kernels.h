@@ -32,4 +32,6 @@ int dist_k_logits_loss(const void* v, const float* text, const float* logit_scal
 // 256x256x32 LDS-DMA GEMM (gemm_fast.hip): 1 = launched, 0 = shape not eligible, <0 = error
 bool dist_k_gemm_fast_eligible(const dist_gemm_args* a);
 int dist_k_gemm_fast(const dist_gemm_args* a, hipStream_t s);
+int dist_k_gemm_small(const dist_gemm_args* a, hipStream_t s);       // M < 1024 (gemm_small.hip)
+int dist_k_gemm_small(const dist_gemm_args* a, hipStream_t s);       // M < 1024 (gemm_small.hip)
 

@@ -299,7 +299,9 @@ def test_gemm_heads_outmap(gpu_lib, dtype, frames, L_, heads, K):
     hm = torch.full((frames, heads, 3, L_, 64), float("nan"), dtype=dtype, device="cuda")
     ops.gemm_nt(A, W, M, N, K, bias=bias, C_out=hm, ldc=64, omap=ops.outmap(L.OM_HEADS, L_, heads))
     ref = plain.reshape(frames, L_, 3, heads, 64).permute(0, 3, 2, 1, 4)
-    assert torch.equal(hm, ref)
+    # the plain call may take another kernel (small-M split-K) with a different summation order: one rounding apart
+    torch.testing.assert_close(hm.float(), ref.float(), **(dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)))
+    assert not torch.isnan(hm.float()).any()
 
 
 @pytest.mark.parametrize("dtype", DT)
