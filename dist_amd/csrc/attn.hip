@@ -221,25 +221,50 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
 
 // ---- one-query cross attention ---------------------------------------------------------
 // q [B, C], kv [B*S, 2C] (k = cols [0,C), v = cols [C,2C)), heads = C/64; one wave per (B, head)
+// Lane map of both kernels: lane = 8 * kg + vec; key group kg (0..7) walks keys kg, kg + 8, ... and lane `vec` owns the
+// 8-element (16 B bf16) vector `vec` of the 64-wide head slice, so every key / value row is one coalesced 128-byte
+// access and a wave moves 8 rows per instruction (the first version read 2 bytes per lane and instruction).
+template <typename T>
+DEV float dot8(const Frag<T>& a, const float (&b)[8]) {
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += frag_get(a, e) * b[e];
+    return acc;
+}
+DEV float sum_vec_lanes(float v) {            // over the 8 lanes (vec) of a key group
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    return v;
+}
+DEV float sum_key_groups(float v) {           // over the 8 key groups (same vec)
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
 template <typename T>
 __global__ __launch_bounds__(64) void xattn1q_fwd(const T* __restrict__ q, const T* __restrict__ kv, T* __restrict__ o,
                                                   float* __restrict__ probs, int S, int C) {
     extern __shared__ float sp[];      // [S]
     const int H = C / HD;
     const int bi = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
-    const T* qp = q + (long)bi * C + h * HD;
-    const T* kvb = kv + (long)bi * S * 2 * C;
+    const int kg = lane >> 3, vec = lane & 7;
+    const T* kvb = kv + (long)bi * S * 2 * C + h * HD + vec * 8;
+    float qv[8];
+    {
+        Frag<T> fq;
+        frag_load(fq, q + (long)bi * C + h * HD + vec * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = frag_get(fq, e) * 0.125f;
+    }
     float mx = -1e30f;
-    for (int s = lane; s < S; s += 64) {
-        const T* kp = kvb + (long)s * 2 * C + h * HD;
-        float acc = 0.f;
-#pragma unroll 8
-        for (int e = 0; e < HD; ++e) acc += to_f(qp[e]) * to_f(kp[e]);
-        acc *= 0.125f;
-        sp[s] = acc;
-        mx = fmaxf(mx, acc);
+    for (int s = kg; s < S; s += 8) {
+        Frag<T> fk;
+        frag_load(fk, kvb + (long)s * 2 * C);
+        const float sc = sum_vec_lanes(dot8(fk, qv));
+        if (vec == 0) sp[s] = sc;
+        mx = fmaxf(mx, sc);
     }
     mx = wave_max(mx, 64);
+    __syncthreads();
     float sum = 0.f;
     for (int s = lane; s < S; s += 64) { const float e = __expf(sp[s] - mx); sp[s] = e; sum += e; }
     sum = wave_sum(sum, 64);
@@ -248,9 +273,20 @@ __global__ __launch_bounds__(64) void xattn1q_fwd(const T* __restrict__ q, const
     float* pr = probs + ((long)bi * H + h) * S;
     for (int s = lane; s < S; s += 64) { const float pv = sp[s] * inv; sp[s] = pv; pr[s] = pv; }
     __syncthreads();
-    float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += sp[s] * to_f(kvb[(long)s * 2 * C + C + h * HD + lane]);
-    o[(long)bi * C + h * HD + lane] = from_f<T>(acc);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int s = kg; s < S; s += 8) {
+        Frag<T> fv;
+        frag_load(fv, kvb + (long)s * 2 * C + C);
+        const float pv = sp[s];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += pv * frag_get(fv, e);
+    }
+    Frag<T> fo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) frag_set(fo, e, sum_key_groups(acc[e]));
+    if (kg == 0) frag_store(fo, o + (long)bi * C + h * HD + vec * 8);
 }
 
 template <typename T>
@@ -260,35 +296,52 @@ __global__ __launch_bounds__(64) void xattn1q_bwd(const T* __restrict__ q, const
     float* sds = sp + S;
     const int H = C / HD;
     const int bi = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
-    const T* kvb = kv + (long)bi * S * 2 * C;
-    T* dkvb = dkv + (long)bi * S * 2 * C;
+    const int kg = lane >> 3, vec = lane & 7;
+    const T* kvb = kv + (long)bi * S * 2 * C + h * HD + vec * 8;
+    T* dkvb = dkv + (long)bi * S * 2 * C + h * HD + vec * 8;
     const float* pr = probs + ((long)bi * H + h) * S;
-    const T* dop = d_o + (long)bi * C + h * HD;
+    float dov[8], qv[8];
+    {
+        Frag<T> f;
+        frag_load(f, d_o + (long)bi * C + h * HD + vec * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dov[e] = frag_get(f, e);
+        frag_load(f, q + (long)bi * C + h * HD + vec * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = frag_get(f, e);
+    }
     float dot = 0.f;
-    for (int s = lane; s < S; s += 64) {
-        const T* vp = kvb + (long)s * 2 * C + C + h * HD;
-        float acc = 0.f;
-#pragma unroll 8
-        for (int e = 0; e < HD; ++e) acc += to_f(dop[e]) * to_f(vp[e]);
+    for (int s = kg; s < S; s += 8) {
+        Frag<T> fv;
+        frag_load(fv, kvb + (long)s * 2 * C + C);
+        const float dp = sum_vec_lanes(dot8(fv, dov));
         const float pv = pr[s];
-        sp[s] = pv;
-        sds[s] = acc;              // dp
-        dot += pv * acc;
+        if (vec == 0) { sp[s] = pv; sds[s] = dp; dot += pv * dp; }
     }
     dot = wave_sum(dot, 64);
     __syncthreads();
     for (int s = lane; s < S; s += 64) sds[s] = sp[s] * (sds[s] - dot) * 0.125f;   // ds / sqrt(64)
     __syncthreads();
-    const float qd = to_f(q[(long)bi * C + h * HD + lane]);
-    const float dod = to_f(dop[lane]);
-    float acc = 0.f;
-    for (int s = 0; s < S; ++s) {
-        const long off = (long)s * 2 * C + h * HD + lane;
-        acc += sds[s] * to_f(kvb[off]);
-        dkvb[off] = from_f<T>(sds[s] * qd);
-        dkvb[off + C] = from_f<T>(sp[s] * dod);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int s = kg; s < S; s += 8) {
+        Frag<T> fk, dk, dv;
+        frag_load(fk, kvb + (long)s * 2 * C);
+        const float ds = sds[s], pv = sp[s];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            acc[e] += ds * frag_get(fk, e);
+            frag_set(dk, e, ds * qv[e]);
+            frag_set(dv, e, pv * dov[e]);
+        }
+        frag_store(dk, dkvb + (long)s * 2 * C);
+        frag_store(dv, dkvb + (long)s * 2 * C + C);
     }
-    dq[(long)bi * C + h * HD + lane] = from_f<T>(acc);
+    Frag<T> fo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) frag_set(fo, e, sum_key_groups(acc[e]));
+    if (kg == 0) frag_store(fo, dq + (long)bi * C + h * HD + vec * 8);
 }
 
 template <typename T>
