@@ -153,7 +153,8 @@ def main():
         value = clips / dt
         gf = GF_PER_CLIP.get(args.config, {}).get("fwd_bwd")
         out = {
-            "metric": "video clips/sec/node (train fwd+bwd), ViT-B/16 8+16f B=32/GPU",
+            "metric": "video clips/sec/node (train fwd+bwd), ViT-B/16 8+16f B=32/GPU" if (args.config == "b16_8+16f" and b == 32)
+                      else f"video clips/sec/node (train fwd+bwd), {args.config} B={b}/GPU",
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
