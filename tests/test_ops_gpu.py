@@ -117,6 +117,34 @@ def test_gemm_nt_rowmaps(gpu_lib, dtype, mode, kw, taps, N):
     torch.testing.assert_close(C.double(), ref, **tol(dtype))
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("grid,frames,sign", [(14, 5, 1), (14, 3, -1), (16, 3, 1)])
+def test_conv3x3_frame_epilogues(gpu_lib, dtype, grid, frames, sign):
+    """3x3 frame convolution, 96 channels (bf16: the frame-resident kernel of conv3x3.hip; fp32: the tiled kernel) with
+    every epilogue the TemporalNet uses: bias + residual + second activated output (forward), activation derivative (backward)."""
+    from dist_amd import ops
+    K = N = 96
+    M = grid * grid * frames
+    A = rnd((M, K), dtype, 1)
+    B = rnd((N, 9 * K), dtype, 2, (9 * K) ** -0.5)
+    bias = rnd((N,), torch.float32, 3)
+    res, aux = rnd((M, N), dtype, 4), rnd((M, N), dtype, 5)
+    amap = ops.rowmap(MODES["spatial"], grid, 0, sign)
+    conv = torch.zeros(M, N, dtype=torch.float64, device="cuda")
+    for tap in range(9):
+        conv += gather(A, "spatial", M, tap, 9, p0=grid, sign=sign) @ B.double()[:, tap * K:(tap + 1) * K].t()
+    C, C2 = torch.empty(M, N, dtype=dtype, device="cuda"), torch.empty(M, N, dtype=dtype, device="cuda")
+    ops.gemm_nt(A, B, M, N, K, taps=9, bias=bias, res=res, C_out=C, C2_out=C2, amap=amap)
+    torch.testing.assert_close(C.double(), conv + bias.double() + res.double(), **tol(dtype))
+    torch.testing.assert_close(C2.double(), qgelu(C.double()), **tol(dtype))
+    C3 = torch.empty(M, N, dtype=dtype, device="cuda")
+    ops.gemm_nt(A, B, M, N, K, taps=9, bias=bias, C2_out=C3, amap=amap)
+    torch.testing.assert_close(C3.double(), qgelu(conv + bias.double()), **tol(dtype))
+    C4 = torch.empty(M, N, dtype=dtype, device="cuda")
+    ops.gemm_nt(A, B, M, N, K, taps=9, aux=aux, C_out=C4, amap=amap)
+    torch.testing.assert_close(C4.double(), conv * qgelu_grad(aux.double()), **tol(dtype))
+
+
 def test_gemm_fast_patch_embed_maps(gpu_lib):
     """the ViT patch embedding as the 256x256 LDS-DMA kernel sees it: strided source rows (every alpha-th
     frame), rows inserted behind each frame's cls row, residual read at the destination."""
