@@ -516,8 +516,14 @@ extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
 static int ensure_streams(dist_handle* h) {
     if (h->side) return DIST_OK;
     const dist_config& c = h->cfg;
-    bool ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking) == hipSuccess;
+    // the side streams carry work that is off the critical path (branch forward beside the ViT, weight gradients beside the
+    // data-gradient chain): lowest priority, so the caller's stream gets freed CUs first (DIST_AMD_SIDE_PRIO=0: default priority)
+    int least = 0, greatest = 0;
+    hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const char* pe = getenv("DIST_AMD_SIDE_PRIO");
+    const int prio = (pe && atoi(pe) == 0) ? 0 : least;
+    bool ok = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio) == hipSuccess &&
+              hipStreamCreateWithPriority(&h->side2, hipStreamNonBlocking, prio) == hipSuccess;
     auto mk = [&](hipEvent_t& e) { ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
     h->ev_a.resize(10 * c.layers + 4); h->ev_b_dr.resize(c.layers); h->ev_b_done.resize(c.layers);
     for (auto& e : h->ev_a) mk(e);
