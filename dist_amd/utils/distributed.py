@@ -34,7 +34,19 @@ def init_process_group(rank, world, local_rank=0, backend=None, init_method=None
     kw = {}
     if backend == "nccl":
         kw["device_id"] = torch.device("cuda", local_rank)
-    dist.init_process_group(backend=backend, init_method=init_method, rank=rank, world_size=world, **kw)
+        try:
+            # the gradient all-reduce runs beside the backward kernels: RCCL's stream gets high priority so its few
+            # workgroups are scheduled as soon as a bucket is ready instead of queueing behind the compute grids
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = True
+            kw["pg_options"] = opts
+        except Exception:
+            pass
+    try:
+        dist.init_process_group(backend=backend, init_method=init_method, rank=rank, world_size=world, **kw)
+    except TypeError:
+        kw.pop("pg_options", None)
+        dist.init_process_group(backend=backend, init_method=init_method, rank=rank, world_size=world, **kw)
     _LOCAL_WORLD = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     _LOCAL_RANK = local_rank
 
@@ -132,7 +144,7 @@ class GradReducer:
         self.grad_scale = 1.0 / world
         self.bucket_elems = bucket_bytes // 4
         self.overlap = overlap and world > 1 and torch.cuda.is_available()
-        self.comm = torch.cuda.Stream() if self.overlap else None
+        self.comm = torch.cuda.Stream(priority=-1) if self.overlap else None   # high priority: buckets start as soon as they are ready
         self._pending = None          # [begin, end) not yet sent (slices arrive in descending order)
         self._sent = []
         self.n_collectives = 0
