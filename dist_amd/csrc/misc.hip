@@ -1,6 +1,7 @@
 // Small HBM-/latency-bound kernels of the DiST hot path: patch gather, elementwise ops,
 // column sums (bias gradients), token-row helpers, cosine-logits + soft-target CE
 // (forward and backward), fused multi-tensor AdamW, weight packing.
+#include <algorithm>
 #include "common.h"
 #include "kernels.h"
 
@@ -144,8 +145,8 @@ __global__ __launch_bounds__(NT) void cls_rows_bwd_kernel(const T* __restrict__ 
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         const int c = (int)(i % C);
         const int j = (int)(i / C);
-        float acc = 0.f;
-        for (long bj = j; bj < nbj; bj += period) acc += to_f(d[bj * L * C + c]);
+        float acc = 0.f;                                    // blockIdx.y: a slice of the clips (one thread walking all of them was pure latency)
+        for (long bj = j + (long)blockIdx.y * period; bj < nbj; bj += (long)period * gridDim.y) acc += to_f(d[bj * L * C + c]);
         atomicAdd(dtable + i, acc);
     }
 }
@@ -477,7 +478,7 @@ int dist_k_cls_rows(void* dst, const void* src, const float* table, int nbj, int
 int dist_k_cls_rows_bwd(const void* d, float* dtable, int nbj, int L, int C, int period, int dtype, hipStream_t s) {
     return with_type(dtype, [&](auto tag) {
         using T = decltype(tag);
-        hipLaunchKernelGGL(cls_rows_bwd_kernel<T>, dim3(grid1d((long)period * C, NT)), dim3(NT), 0, s, (const T*)d, dtable, nbj, L, C, period);
+        hipLaunchKernelGGL(cls_rows_bwd_kernel<T>, dim3(grid1d((long)period * C, NT), (unsigned)std::max(1, std::min(16, nbj / period / 2))), dim3(NT), 0, s, (const T*)d, dtable, nbj, L, C, period);
         HIP_CHECK_RET(hipGetLastError());
         return (int)DIST_OK;
     });
