@@ -319,8 +319,10 @@ void build_tables(dist_handle* h) {
     // ---- pack launch table: one block per PACK_PER_BLOCK destination elements ----
     for (size_t di = 0; di < h->descs.size(); ++di) {
         if ((int)di == ndesc_visual) h->nblk_visual = (int)h->blk_desc.size();
-        const long total = (long)h->descs[di].rows * h->descs[di].cols;
-        const int nb = (int)((total + PACK_PER_BLOCK - 1) / PACK_PER_BLOCK);
+        const PackDesc& pd = h->descs[di];
+        const long total = (long)pd.rows * pd.cols;
+        int nb = (int)((total + PACK_PER_BLOCK - 1) / PACK_PER_BLOCK);
+        if (pd.layout == PACK_B) { const int rpb = pack_b_rows(pd.cols); nb = (pd.rows + rpb - 1) / rpb; }   // whole rows per block
         h->blk_first.push_back((int)h->blk_desc.size());
         for (int b = 0; b < nb; ++b) h->blk_desc.push_back((int)di);
     }

@@ -6,6 +6,8 @@
 // weight packing: master fp32 tensors (reference layouts) -> GEMM-ready working copies
 enum { PACK_F = 0, PACK_B = 1, PACK_FT = 2 };
 constexpr int PACK_PER_BLOCK = 8192;
+constexpr int PACK_B_ELEMS = 12288;   // PACK_B blocks own whole destination rows: max(1, PACK_B_ELEMS / cols) of them (LDS transpose)
+__host__ __device__ inline int pack_b_rows(int cols) { const int r = PACK_B_ELEMS / cols; return r < 1 ? 1 : r; }
 struct PackDesc {
     long src_off;        // elements into theta (src_kind 0) or visual (src_kind 1)
     long dst_off;        // elements into the packed buffer (after its header)

@@ -352,13 +352,46 @@ __global__ __launch_bounds__(NT) void pack_kernel(const PackDesc* __restrict__ d
     const float* src = (d.src_kind ? src1 : src0) + d.src_off;
     T* dst = dst_base + d.dst_off;
     const long total = (long)d.rows * d.cols;
+    if (d.layout == PACK_B) {
+        // transposed layout dst[ci][tap*co + co] <- src[co][..ci..]: a block owns whole destination rows; the gather runs
+        // with consecutive lanes on consecutive ci (contiguous in the source for Linear weights), the tile is turned in
+        // LDS (odd dword row pitch: conflict-free column writes) and written out as whole rows.  (Element-wise, every
+        // lane read 4 bytes of a different source row: 16x the bytes through L2.)
+        extern __shared__ __attribute__((aligned(16))) char pk_smem[];
+        T* tile = reinterpret_cast<T*>(pk_smem);
+        const int rpb = pack_b_rows(d.cols);
+        const int r0 = (blk - blk_first[di]) * rpb, nr = min(rpb, d.rows - r0);
+        const int pitch = d.cols + (sizeof(T) == 2 ? 2 : 1);
+        const bool fits = (long)rpb * pitch <= PACK_B_ELEMS + 2 * rpb;
+        if (fits) {
+            for (int e = threadIdx.x; e < nr * d.cols; e += NT) {
+                const int cl = e % nr, c = e / nr;
+                const int ci = r0 + cl, tap = c / d.co, co = c % d.co;
+                float v = 0.f;
+                if (ci < d.kin) v = src[(long)co * d.s_co + (long)tap * d.s_tap + (long)(ci / d.inner) * d.s_outer + (ci % d.inner)];
+                tile[cl * pitch + c] = from_f<T>(v);
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < nr * d.cols; e += NT) {
+                const int cl = e / d.cols, c = e % d.cols;
+                dst[(long)(r0 + cl) * d.cols + c] = tile[cl * pitch + c];
+            }
+            return;
+        }
+        for (long i = (long)r0 * d.cols + threadIdx.x; i < (long)(r0 + nr) * d.cols; i += NT) {     // very wide rows: direct
+            const int ci = (int)(i / d.cols), c = (int)(i % d.cols), tap = c / d.co, co = c % d.co;
+            float v = 0.f;
+            if (ci < d.kin) v = src[(long)co * d.s_co + (long)tap * d.s_tap + (long)(ci / d.inner) * d.s_outer + (ci % d.inner)];
+            dst[i] = from_f<T>(v);
+        }
+        return;
+    }
     const long beg = (long)(blk - blk_first[di]) * PACK_PER_BLOCK;
     const long end = min(total, beg + PACK_PER_BLOCK);
     for (long i = beg + threadIdx.x; i < end; i += NT) {
         const int r = (int)(i / d.cols), c = (int)(i % d.cols);
         int co, tap, ci;
         if (d.layout == PACK_F) { co = r; tap = c / d.kpad; ci = c % d.kpad; }
-        else if (d.layout == PACK_B) { ci = r; tap = c / d.co; co = c % d.co; }
         else { tap = r / d.kpad; ci = r % d.kpad; co = c; }      // PACK_FT
         float v = 0.f;
         if (ci < d.kin) v = src[(long)co * d.s_co + (long)tap * d.s_tap + (long)(ci / d.inner) * d.s_outer + (ci % d.inner)];
@@ -462,7 +495,8 @@ int dist_k_pack(const PackDesc* descs_dev, const int* blk_desc_dev, const int* b
                 const float* theta, const float* visual, void* dst_base, int dtype, hipStream_t s) {
     return with_type(dtype, [&](auto tag) {
         using T = decltype(tag);
-        hipLaunchKernelGGL(pack_kernel<T>, dim3(nblocks), dim3(NT), 0, s, descs_dev, blk_desc_dev, blk_first_dev, first_block, theta, visual, (T*)dst_base);
+        const size_t smem = (size_t)(PACK_B_ELEMS + 2 * PACK_B_ELEMS / 8 + 64) * sizeof(T);   // rows * (cols + pad), cols >= 8
+        hipLaunchKernelGGL(pack_kernel<T>, dim3(nblocks), dim3(NT), smem, s, descs_dev, blk_desc_dev, blk_first_dev, first_block, theta, visual, (T*)dst_base);
         HIP_CHECK_RET(hipGetLastError());
         return (int)DIST_OK;
     });
