@@ -407,14 +407,14 @@ dist_outmap OM(int mode = DIST_OM_PLAIN, int p0 = 0, int p1 = 0, int p2 = 0) { r
 
 // C (and/or C2) = epi(A[amap] . W^T): thin positional wrapper over dist_op_gemm_nt
 int gemm(const Ctx& c, const void* A, int lda, const void* W, long M, int N, int K, int taps, void* C, int ldc,
-         const float* bias, const void* res, const void* aux, void* C2, dist_rowmap am = RM(), dist_outmap om = OM()) {
+         const float* bias, const void* res, const void* aux, void* C2, dist_rowmap am = RM(), dist_outmap om = OM(), int extra_flags = 0) {
     dist_gemm_args g;
     memset(&g, 0, sizeof(g));
     g.A = A; g.B = W; g.C = C; g.C2 = C2; g.bias = bias; g.res = res; g.aux = aux;
     g.M = M; g.N = N; g.K = K; g.taps = taps;
     g.lda = lda; g.ldb = taps * K; g.ldc = ldc; g.ldc2 = ldc; g.ldres = ldc; g.ldaux = ldc;
     g.amap = am; g.omap = om;
-    g.flags = (bias ? DIST_EPI_BIAS : 0) | (res ? DIST_EPI_RES : 0) | (aux ? DIST_EPI_MULG : 0) | (C2 ? DIST_EPI_ACT2 : 0);
+    g.flags = (bias ? DIST_EPI_BIAS : 0) | (res ? DIST_EPI_RES : 0) | (aux ? DIST_EPI_MULG : 0) | (C2 ? DIST_EPI_ACT2 : 0) | extra_flags;
     g.dtype = c.dtype;
     dist_handle* h = c.h;
     const bool dominant = h->prof_on && dist_k_gemm_fast_eligible(&g);
@@ -931,8 +931,10 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         RUN(dist_k_cls_rows_bwd(q.dMp, x.gr(l.cls_token), (int)bt, L, Ci, t, c.dtype, B));
         RUN(wgrad(xb2, l.t2i, q.dMp, Ci, w.Xp, Ct, rowsQ, RM(DIST_RM_SKIPCLS, N), RM(DIST_RM_STRIDED, al, N), 2, true));
         // dX' = dX_next (identity, absent for the last layer) + conv^T(dQ): column block a of row (bj,n) -> frame bj*alpha+a
-        RUN(gemm(x, q.dMp, Ci, x.pk(l.t2i.pk.b), rowsQ, al * Ct, Ci, 1, q.dXp, Ct, nullptr, last ? nullptr : dXn, nullptr, nullptr,
-                 RM(DIST_RM_SKIPCLS, N), OM(DIST_OM_SPLITCOLS, al, N, Ct)));
+        // ... and straight through X' = g(p): dp = (dX_next + conv^T(dQ)) * g'(p) in the same epilogue (no dX' tensor, no
+        // separate activation-backward pass)
+        RUN(gemm(x, q.dMp, Ci, x.pk(l.t2i.pk.b), rowsQ, al * Ct, Ci, 1, q.dp, Ct, nullptr, last ? nullptr : dXn, w.p, nullptr,
+                 RM(DIST_RM_SKIPCLS, N), OM(DIST_OM_SPLITCOLS, al, N, Ct), DIST_EPI_MULG_POST));
         // ---- I2T backward (dist.py:100-105): X_next = X' + upsample(Linear(M[1:])) ----
         const void* dM = q.dMp;            // last layer: no I2T path, dM = dM'
         if (!last) {
@@ -945,7 +947,6 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         // ---- mid_feat = input_linear(F_i) + R_{i-1}: no dF_i (frozen ViT) ----
         RUN(wgrad(xb, l.in_lin, dM, Ci, h->feat[i], d, rowsS, RM(), RM(), 0, true));
         // ---- TemporalNet backward (dist.py:63-65): X' = g(p), p = X + conv3x3(V) + b, V = g(z), z = conv_t(U), U = LN(X) ----
-        RUN(dist_op_gelu_bwd(q.dXp, w.p, q.dp, rowsX * Ct, c.dtype, stream));
         RUN(gemm(x, q.dp, Ct, x.pk(l.tn_fc2.pk.b), rowsX, Ct, Ct, 9, q.dz, Ct, nullptr, nullptr, w.z, nullptr, RM(DIST_RM_SPATIAL, h->G, 0, -1)));
         RUN(fork());
         RUN(wgrad(xb, l.tn_fc2, q.dp, Ct, w.V, Ct, rowsX, RM(), RM(DIST_RM_SPATIAL, h->G, 0, 1), 1, true));

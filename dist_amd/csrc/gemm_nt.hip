@@ -225,7 +225,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const dist_gemm_args p) {
             }
         }
     }
-    if (flags & DIST_EPI_MULG) {                            // v *= quickgelu'(aux[dest])   (never combined with DUP)
+    if ((flags & DIST_EPI_MULG) && !(flags & DIST_EPI_MULG_POST)) {   // v *= quickgelu'(aux[dest])   (never combined with DUP)
         stage_in(X, p.ldaux, 0);
 #pragma unroll
         for (int i = 0; i < FM; ++i)
@@ -251,12 +251,30 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const dist_gemm_args p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += x[r];
                 }
+                if (flags & DIST_EPI_MULG_POST) {            // keep the sum in the accumulators: the factor tile is staged next
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = v[r];
+                    continue;
+                }
                 if (act_only) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = qgelu(v[r]);
                 }
                 store4(slot(i, j), v);
             }
+        if (flags & DIST_EPI_MULG_POST) {                   // v = (acc + bias + res) * quickgelu'(aux[dest])
+            stage_in(X, p.ldaux, a);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    float x[4], v[4];
+                    load4(slot(i, j), x);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * qgelu_grad(x[r]);
+                    store4(slot(i, j), v);
+                }
+        }
         if (act_only) {
             flush(C2, p.ldc2, a);
         } else {
@@ -314,6 +332,7 @@ extern "C" int dist_op_gemm_nt(const dist_gemm_args* a, void* stream) {
             ((a->flags & DIST_EPI_MULG) && a->ldaux % epv)) return DIST_ERR_ARG;
         if (a->omap.mode == DIST_OM_SPLITCOLS && a->omap.p2 % epv) return DIST_ERR_ARG;
         if (a->omap.mode == DIST_OM_DUP && (a->flags & DIST_EPI_MULG)) return DIST_ERR_ARG;
+        if ((a->flags & DIST_EPI_MULG_POST) && (!(a->flags & DIST_EPI_MULG) || (a->flags & DIST_EPI_ACT2))) return DIST_ERR_ARG;
     }
     if (a->M > (1 << 30)) return DIST_ERR_ARG;
     if (!a->C && !(a->flags & DIST_EPI_ACT2)) return DIST_ERR_ARG;

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(NT) void gemm_small_kernel(const dist_gemm_args p) 
 // returns 1 if handled, 0 if the shape does not qualify (caller falls through), <0 on error
 int dist_k_gemm_small(const dist_gemm_args* a, hipStream_t s) {
     if (a->M >= 1024 || a->taps != 1 || a->amap.mode != DIST_RM_PLAIN || a->omap.mode != DIST_OM_PLAIN) return 0;
-    if (a->K % 32 || a->N % 8 || a->lda % 8 || a->ldb % 8) return 0;
+    if (a->K % 32 || a->N % 8 || a->lda % 8 || a->ldb % 8 || (a->flags & DIST_EPI_MULG_POST)) return 0;
     const int epv = 8;
     if ((a->C && a->ldc % epv) || ((a->flags & DIST_EPI_ACT2) && a->ldc2 % epv) || ((a->flags & DIST_EPI_RES) && a->ldres % epv) ||
         ((a->flags & DIST_EPI_MULG) && a->ldaux % epv)) return 0;

@@ -10,7 +10,7 @@ F32, BF16 = 0, 1
 RM_PLAIN, RM_SHIFT, RM_SPATIAL, RM_STRIDED, RM_SKIPCLS = range(5)
 OM_PLAIN, OM_DUP, OM_INSERTCLS, OM_SPLITCOLS, OM_HEADS = range(5)
 QKV_ROWS, QKV_HEADS = 0, 1
-EPI_BIAS, EPI_MULG, EPI_RES, EPI_ACT2 = 1, 2, 4, 8
+EPI_BIAS, EPI_MULG, EPI_RES, EPI_ACT2, EPI_MULG_POST = 1, 2, 4, 8, 16
 
 
 class RowMap(C.Structure):

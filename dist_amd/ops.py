@@ -36,7 +36,7 @@ def outmap(mode=L.OM_PLAIN, p0=0, p1=0, p2=0):
 
 
 def gemm_nt(A, B, M, N, K, *, taps=1, bias=None, res=None, aux=None, amap=None, omap=None,
-            C_out=None, C2_out=None, lda=None, ldc=None):
+            C_out=None, C2_out=None, lda=None, ldc=None, mulg_post=False):
     """C[omap(m)][n] = epi(sum_tap sum_k A[amap(m,tap)][k] B[n][tap*K+k]); returns None (writes C_out / C2_out)."""
     lib = L.load()
     a = L.GemmArgs()
@@ -53,7 +53,8 @@ def gemm_nt(A, B, M, N, K, *, taps=1, bias=None, res=None, aux=None, amap=None, 
     a.amap = amap or rowmap()
     a.omap = omap or outmap()
     a.flags = (L.EPI_BIAS if bias is not None else 0) | (L.EPI_RES if res is not None else 0) | \
-              (L.EPI_MULG if aux is not None else 0) | (L.EPI_ACT2 if C2_out is not None else 0)
+              (L.EPI_MULG if aux is not None else 0) | (L.EPI_ACT2 if C2_out is not None else 0) | \
+              (L.EPI_MULG_POST if mulg_post else 0)
     a.dtype = _dt(A)
     L.check(lib.dist_op_gemm_nt(C.byref(a), _stream()))
 

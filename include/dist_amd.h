@@ -54,7 +54,8 @@ enum {
     DIST_EPI_BIAS = 1,   /* v += bias[n] */
     DIST_EPI_MULG = 2,   /* v *= quickgelu'(aux[dest][n])   (backward through an activation) */
     DIST_EPI_RES = 4,    /* v += res[dest][n] */
-    DIST_EPI_ACT2 = 8    /* C2[dest][n] = quickgelu(v)  (C, if non-null, keeps the pre-activation) */
+    DIST_EPI_ACT2 = 8,   /* C2[dest][n] = quickgelu(v)  (C, if non-null, keeps the pre-activation) */
+    DIST_EPI_MULG_POST = 16  /* with MULG: the derivative factor is applied AFTER bias and residual: v = (acc + bias + res) * quickgelu'(aux) */
 };
 
 /* C[omap(m)][n] = epi( sum_tap sum_k A[amap(m,tap)][k] * B[n][tap*K + k] )

@@ -84,6 +84,10 @@ def test_gemm_nt_plain(gpu_lib, dtype, M, N, K):
     C4 = torch.empty(M, N, dtype=dtype, device="cuda")
     ops.gemm_nt(A, B, M, N, K, aux=aux, C_out=C4)
     torch.testing.assert_close(C4.double(), (A.double() @ B.double().t()) * qgelu_grad(aux.double()), **tol(dtype))
+    # derivative factor applied after bias and residual (backward through X' = g(p) fused into the producing GEMM)
+    C5 = torch.empty(M, N, dtype=dtype, device="cuda")
+    ops.gemm_nt(A, B, M, N, K, bias=bias, res=res, aux=aux, C_out=C5, mulg_post=True)
+    torch.testing.assert_close(C5.double(), (A.double() @ B.double().t() + bias.double() + res.double()) * qgelu_grad(aux.double()), **tol(dtype))
 
 
 @pytest.mark.parametrize("dtype", DT)
