@@ -644,15 +644,22 @@ extern "C" int dist_vit_forward(dist_handle* h, const float* video, int b, void*
     return DIST_OK;
 }
 
-// one-query cross attention block: s_out = s_in + out_proj(attn(q = W_q LN(s_in), kv = W_kv LN(keys)))
-static int xattn_fwd(dist_handle* h, const Ctx& x, const XAttn& A, const void* s_in, long nq, const void* keys, long nkeys_total, int S,
-                     void* kn, float* kn_mean, float* kn_rstd, void* kv, void* qn, float* qn_mean, float* qn_rstd, void* q, void* o,
-                     float* probs, void* s_out) {
+// one-query cross attention block: s_out = s_in + out_proj(attn(q = W_q LN(s_in), kv = W_kv LN(keys))).
+// The key side (LayerNorm + K/V projection of all keys: the only large kernels of the ada-pooling tail) does not depend
+// on the query, so it is a separate call: for the spatial blocks it runs on the second side stream for all ada layers at
+// once, beside the chain of small query-side kernels.
+static int xattn_keys(dist_handle* h, const Ctx& x, const XAttn& A, const void* keys, long nkeys_total, void* kn, float* kn_mean, float* kn_rstd, void* kv) {
     const int Ci = h->cfg.integration_dim;
     RUN(ln_fwd(x, h->theta, A.ln1, keys, kn, nkeys_total, kn_mean, kn_rstd));
     RUN(gemm(x, kn, Ci, x.pk(A.kv.pk.f), nkeys_total, 2 * Ci, Ci, 1, kv, 2 * Ci, x.th(A.kv.bias), nullptr, nullptr, nullptr));
+    return DIST_OK;
+}
+static int xattn_query(dist_handle* h, const Ctx& x, const XAttn& A, const void* s_in, long nq, int S, const void* kv, hipEvent_t kv_ready,
+                       void* qn, float* qn_mean, float* qn_rstd, void* q, void* o, float* probs, void* s_out) {
+    const int Ci = h->cfg.integration_dim;
     RUN(ln_fwd(x, h->theta, A.ln1, s_in, qn, nq, qn_mean, qn_rstd));
     RUN(gemm(x, qn, Ci, x.pk(A.q.pk.f), nq, Ci, Ci, 1, q, Ci, x.th(A.q.bias), nullptr, nullptr, nullptr));
+    if (kv_ready) HIP_CHECK_RET(hipStreamWaitEvent(x.s, kv_ready, 0));
     RUN(dist_op_xattn1q(q, kv, o, probs, (int)nq, S, Ci, x.dtype, x.s));
     RUN(gemm(x, o, Ci, x.pk(A.out.pk.f), nq, Ci, Ci, 1, s_out, Ci, x.th(A.out.bias), s_in, nullptr, nullptr));
     return DIST_OK;
@@ -725,19 +732,29 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
     }
     // current_layer_feat = res_feat + updated_mid_feat (dist.py:239)
     RUN(dist_op_add(h->lw[nl - 1].R, h->lw[nl - 1].Mp, h->Fz, rowsS * Ci, c.dtype, stream));
+    // key side of every spatial ada block on the (now idle) temporal stream: needs Fz only
+    hipEvent_t ev_fz = h->ev_a[2 * nl];
+    HIP_CHECK_RET(hipEventRecord(ev_fz, x.s));
+    HIP_CHECK_RET(hipStreamWaitEvent(xt.s, ev_fz, 0));
+    for (int a = 0; a < c.ada_layers; ++a) {
+        AdaWs& w = h->aw[a];
+        RUN(xattn_keys(h, xt, h->ada[a].sp, h->Fz, rowsS, w.kn, w.kn_mean, w.kn_rstd, w.kv));
+        HIP_CHECK_RET(hipEventRecord(h->ev_a[2 * nl + 1 + a], xt.s));
+    }
     RUN(dist_k_bcast_rows(x.th(h->agg_sp_cls), h->sbuf[0], bt, Ci, c.dtype, x.s));
     RUN(dist_k_bcast_rows(x.th(h->agg_cls), h->ubuf[0], b, Ci, c.dtype, x.s));
     for (int a = 0; a < c.ada_layers; ++a) {
         const AdaLayer& A = h->ada[a];
         AdaWs& w = h->aw[a];
         // spatial: per-frame cls query over the L tokens of its frame (dist.py:144-146)
-        RUN(xattn_fwd(h, x, A.sp, h->sbuf[a], bt, h->Fz, rowsS, L, w.kn, w.kn_mean, w.kn_rstd, w.kv, w.qn, w.qn_mean, w.qn_rstd, w.q, w.o, w.probs, w.s1));
+        RUN(xattn_query(h, x, A.sp, h->sbuf[a], bt, L, w.kv, h->ev_a[2 * nl + 1 + a], w.qn, w.qn_mean, w.qn_rstd, w.q, w.o, w.probs, w.s1));
         RUN(ln_fwd(x, h->theta, A.ln_sp, w.s1, w.sn, bt, w.s1_mean, w.s1_rstd));
         RUN(gemm(x, w.sn, Ci, x.pk(A.sp_fc.pk.f), bt, 4 * Ci, Ci, 1, w.zs, 4 * Ci, x.th(A.sp_fc.bias), nullptr, nullptr, w.hs));
         RUN(gemm(x, w.hs, 4 * Ci, x.pk(A.sp_proj.pk.f), bt, Ci, 4 * Ci, 1, h->sbuf[a + 1], Ci, x.th(A.sp_proj.bias), w.s1, nullptr, nullptr));
         // temporal: per-clip cls query over its t frame tokens (+ positional embedding) (dist.py:153-160)
         RUN(dist_k_add_table(h->sbuf[a + 1], x.th(A.pos), w.c, bt, Ci, t, c.dtype, x.s));
-        RUN(xattn_fwd(h, x, A.tm, h->ubuf[a], b, w.c, bt, t, w.kn2, w.kn2_mean, w.kn2_rstd, w.kv2, w.qn2, w.qn2_mean, w.qn2_rstd, w.q2, w.o2, w.probs2, w.u1));
+        RUN(xattn_keys(h, x, A.tm, w.c, bt, w.kn2, w.kn2_mean, w.kn2_rstd, w.kv2));
+        RUN(xattn_query(h, x, A.tm, h->ubuf[a], b, t, w.kv2, nullptr, w.qn2, w.qn2_mean, w.qn2_rstd, w.q2, w.o2, w.probs2, w.u1));
         RUN(ln_fwd(x, h->theta, A.ln_tm, w.u1, w.un, b, w.u1_mean, w.u1_rstd));
         RUN(gemm(x, w.un, Ci, x.pk(A.tm_fc.pk.f), b, 4 * Ci, Ci, 1, w.zu, 4 * Ci, x.th(A.tm_fc.bias), nullptr, nullptr, w.hu));
         RUN(gemm(x, w.hu, 4 * Ci, x.pk(A.tm_proj.pk.f), b, Ci, 4 * Ci, 1, h->ubuf[a + 1], Ci, x.th(A.tm_proj.bias), w.u1, nullptr, nullptr));
