@@ -111,6 +111,16 @@ DEV float qgelu_grad(float x) {
     const float s = 1.f / (1.f + __expf(-1.702f * x));
     return s * (1.f + 1.702f * x * (1.f - s));
 }
+// bf16 kernels: the sigmoid's reciprocal as one v_rcp_f32 (1 ulp of fp32, far below the bf16 rounding of the result) instead
+// of the IEEE division sequence (~12 VALU per element: 128 elements per lane in a 256x256 epilogue made the fc GEMM of
+// the ViT MLP 45 us slower than its FLOPs).  The fp32 parity kernels keep the exact division.
+template <typename T> DEV float qgelu_t(float x) { return qgelu(x); }
+template <> DEV float qgelu_t<bf16_t>(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * x)); }
+template <typename T> DEV float qgelu_grad_t(float x) { return qgelu_grad(x); }
+template <> DEV float qgelu_grad_t<bf16_t>(float x) {
+    const float s = __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * x));
+    return s * (1.f + 1.702f * x * (1.f - s));
+}
 
 DEV float wave_sum(float v, int width) {
 #pragma unroll

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(Shape<NW>::NT, Shape<NW>::MINB) void gemm_fast_kern
             }
             if (act_only) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = qgelu(v[q]);
+                for (int q = 0; q < 4; ++q) v[q] = qgelu_t<bf16_t>(v[q]);
             }
             store4(slot, v);
         }
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(Shape<NW>::NT, Shape<NW>::MINB) void gemm_fast_kern
                     float x[4];
                     load4(slot, x);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) x[q] = qgelu(x[q]);
+                    for (int q = 0; q < 4; ++q) x[q] = qgelu_t<bf16_t>(x[q]);
                     store4(slot, x);
                 }
             }

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const dist_gemm_args p) {
                 float x[4];
                 load4(slot(i, j), x);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] *= qgelu_grad(x[r]);
+                for (int r = 0; r < 4; ++r) acc[i][j][r] *= qgelu_grad_t<T>(x[r]);
             }
     }
     const bool act_only = (flags & DIST_EPI_ACT2) && !C;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const dist_gemm_args p) {
                 }
                 if (act_only) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = qgelu(v[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = qgelu_t<T>(v[r]);
                 }
                 store4(slot(i, j), v);
             }
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const dist_gemm_args p) {
                     float x[4], v[4];
                     load4(slot(i, j), x);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * qgelu_grad(x[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * qgelu_grad_t<T>(x[r]);
                     store4(slot(i, j), v);
                 }
         }
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const dist_gemm_args p) {
                         float x[4];
                         load4(slot(i, j), x);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) x[r] = qgelu(x[r]);
+                        for (int r = 0; r < 4; ++r) x[r] = qgelu_t<T>(x[r]);
                         store4(slot(i, j), x);
                     }
                 flush(C2, p.ldc2, a);

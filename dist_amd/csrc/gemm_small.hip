@@ -79,7 +79,7 @@ __global__ __launch_bounds__(NT) void gemm_small_kernel(const dist_gemm_args p) 
         Frag<T> x;
         frag_load(x, static_cast<const T*>(p.aux) + (long)m * p.ldaux + n);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= qgelu_grad(frag_get(x, e));
+        for (int e = 0; e < 8; ++e) v[e] *= qgelu_grad_t<T>(frag_get(x, e));
     }
     if (flags & DIST_EPI_RES) {
         Frag<T> x;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(NT) void gemm_small_kernel(const dist_gemm_args p) 
     Frag<T> o;
     if ((flags & DIST_EPI_ACT2) && !p.C) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) frag_set(o, e, qgelu(v[e]));
+        for (int e = 0; e < 8; ++e) frag_set(o, e, qgelu_t<T>(v[e]));
         frag_store(o, static_cast<T*>(p.C2) + (long)m * p.ldc2 + n);
         return;
     }
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(NT) void gemm_small_kernel(const dist_gemm_args p) 
     frag_store(o, static_cast<T*>(p.C) + (long)m * p.ldc + n);
     if (flags & DIST_EPI_ACT2) {                             // second output = quickgelu(stored value)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) frag_set(o, e, qgelu(frag_get(o, e)));
+        for (int e = 0; e < 8; ++e) frag_set(o, e, qgelu_t<T>(frag_get(o, e)));
         frag_store(o, static_cast<T*>(p.C2) + (long)m * p.ldc2 + n);
     }
 }

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(NT) void gelu_bwd_kernel(const T* __restrict__ dy, 
         Frag<T> x, y;
         frag_load(x, dy + i * 8); frag_load(y, pre + i * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) frag_set(x, e, frag_get(x, e) * qgelu_grad(frag_get(y, e)));
+        for (int e = 0; e < 8; ++e) frag_set(x, e, frag_get(x, e) * qgelu_grad_t<T>(frag_get(y, e)));
         frag_store_nt(x, dx + i * 8);
     }
 }
