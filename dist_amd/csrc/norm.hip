@@ -284,7 +284,12 @@ extern "C" int dist_op_layernorm_bwd(const dist_ln_bwd_args* a, void* stream) {
     const int lpr = lanes_per_row(a->C);
     const int rpb = NT / lpr;
     long g = (a->rows + rpb - 1) / rpb;
-    if (g > 768) g = 768;          // 3 blocks per CU; each ends with C x 2..4 global atomics
+    // every block ends with C x 2..4 global atomics on the SAME addresses: with parameter gradients requested the
+    // same-line atomic traffic, not HBM, sets the time, so fewer, longer blocks win (measured, tools/bench_ln2.py:
+    // dual-input 62 -> 52 us at 256 blocks, single-input 42 -> 33 us at 384); without them 1024 blocks stream best
+    const bool want_w = a->dw || a->db || a->dw2 || a->db2;
+    const long gcap = !want_w ? 1024 : (a->dy2 ? 256 : 384);
+    if (g > gcap) g = gcap;
     const int grid = (int)g;
     const bool dual = a->dy2 != nullptr;
     if (a->dtype == DIST_BF16) {
