@@ -47,6 +47,7 @@ struct DistLayer {
     LNp tn_ln; Lin tn_fc1, tn_fc2;           // TemporalNet
     Lin in_lin, i2t, t2i; long cls_token = -1;
     LNp in_ln, in_ln_t; Lin ffn_fc, ffn_proj, tf_fc1, tf_fc2, tf_proj;   // IntegrationNetwork
+    long pk_proj_f = -1, pk_proj_b = -1;     // the two c_proj weights side by side: [Ci][Ci+C4] forward, [Ci+C4][Ci] data-gradient
 };
 struct XAttn { LNp ln1; Lin q, kv, out; };   // CrossAttentionBlockGenral (in_proj split into q / kv rows)
 struct AdaLayer { long pos = -1; XAttn sp, tm; LNp ln_sp, ln_tm; Lin sp_fc, sp_proj, tm_fc, tm_proj; };
@@ -67,6 +68,7 @@ struct Arena {
 struct DistLayerWs {
     void *X, *U, *z, *V, *p, *Xp, *M, *Mp, *Na, *Nb, *zf, *hf, *h1, *h2, *g2, *R;
     float *tn_mean, *tn_rstd, *in_mean, *in_rstd;
+    float* bcat;     // ffn.c_proj.bias + temporal_ffn.c_proj.bias (refreshed by dist_pack_weights)
 };
 struct AdaWs {
     void *kn, *kv, *qn, *q, *o, *s1, *sn, *zs, *hs, *c, *kn2, *kv2, *qn2, *q2, *o2, *u1, *un, *zu, *hu;
@@ -289,6 +291,23 @@ void build_tables(dist_handle* h) {
         l.tf_fc1 = make_lin(h, 0, p + "temporal_ffn.c_fc1.", C4, Ci, 1, 0, true, {C4, Ci, 1, 1, 1});
         l.tf_fc2 = make_lin(h, 0, p + "temporal_ffn.c_fc2.", C4, C4, c.temporal_kernel, 1, true, {C4, C4, c.temporal_kernel, 1, 1});
         l.tf_proj = make_lin(h, 0, p + "temporal_ffn.c_proj.", Ci, C4, 1, 0, true, {Ci, C4, 1, 1, 1});
+        {   // R = [gelu(zf) | gelu(h2)] [W_ffn | W_tf]^T: the two projections are ONE GEMM over activations stored side by side
+            // (forward), one data-gradient GEMM and one weight-gradient GEMM (backward)
+            const int Cc = Ci + C4;
+            PackDesc d;
+            auto desc_of = [&](const Lin& lin, int layout) {
+                memset(&d, 0, sizeof(d));
+                d.src_off = lin.w; d.src_kind = 0; d.co = lin.N; d.kin = lin.K; d.kpad = lin.K; d.inner = 1;
+                d.s_co = lin.K; d.s_tap = 0; d.s_outer = 1; d.layout = layout;
+                if (layout == PACK_F) { d.rows = lin.N; d.cols = lin.K; } else { d.rows = lin.K; d.cols = lin.N; }
+            };
+            l.pk_proj_f = pk_alloc(h, (long)Ci * Cc);
+            desc_of(l.ffn_proj, PACK_F); d.dst_off = l.pk_proj_f; d.dpitch = Cc; h->descs.push_back(d);
+            desc_of(l.tf_proj, PACK_F); d.dst_off = l.pk_proj_f + Ci; d.dpitch = Cc; h->descs.push_back(d);
+            l.pk_proj_b = pk_alloc(h, (long)Cc * Ci);
+            desc_of(l.ffn_proj, PACK_FT); d.dst_off = l.pk_proj_b; h->descs.push_back(d);
+            desc_of(l.tf_proj, PACK_FT); d.dst_off = l.pk_proj_b + (long)Ci * Ci; h->descs.push_back(d);
+        }
         l.in_ln = make_ln(h, 0, p + "ln.", Ci);
         l.in_ln_t = make_ln(h, 0, p + "ln_temporal.", Ci);
         h->layer_end[i] = h->total[0];
@@ -356,8 +375,12 @@ size_t layout_ws(dist_handle* h, char* base) {
     for (int i = 0; i < c.layers; ++i) {
         DistLayerWs& w = h->lw[i];
         w.X = T_(rowsX, Ct); w.U = T_(rowsX, Ct); w.z = T_(rowsX, Ct); w.V = T_(rowsX, Ct); w.p = T_(rowsX, Ct); w.Xp = T_(rowsX, Ct);
-        w.M = T_(rowsS, Ci); w.Mp = T_(rowsS, Ci); w.Na = T_(rowsS, Ci); w.Nb = T_(rowsS, Ci); w.zf = T_(rowsS, Ci); w.hf = T_(rowsS, Ci);
-        w.h1 = T_(rowsS, C4); w.h2 = T_(rowsS, C4); w.g2 = T_(rowsS, C4); w.R = T_(rowsS, Ci);
+        w.M = T_(rowsS, Ci); w.Mp = T_(rowsS, Ci); w.Na = T_(rowsS, Ci); w.Nb = T_(rowsS, Ci);
+        // [zf | h2] and [hf | g2] = their activations live side by side in rows of Ci + C4 elements (see pk_proj_f)
+        w.zf = T_(rowsS, Ci + C4); w.hf = T_(rowsS, Ci + C4);
+        w.h2 = w.zf ? static_cast<char*>(w.zf) + (size_t)Ci * es : nullptr;
+        w.g2 = w.hf ? static_cast<char*>(w.hf) + (size_t)Ci * es : nullptr;
+        w.h1 = T_(rowsS, C4); w.R = T_(rowsS, Ci); w.bcat = F_(Ci);
         w.tn_mean = F_(rowsX); w.tn_rstd = F_(rowsX); w.in_mean = F_(rowsS); w.in_rstd = F_(rowsS);
     }
     h->Xlast = T_(rowsX, Ct);
@@ -382,8 +405,10 @@ size_t layout_ws(dist_handle* h, char* base) {
     for (int k = 0; k < 2; ++k) {
         dist_handle::BwdSet& q = h->bs[k];
         q.dMp = T_(rowsS, Ci); q.dM = T_(rowsS, Ci); q.dXp = T_(rowsX, Ct); q.dp = T_(rowsX, Ct); q.dXo = T_(rowsX, Ct);
-        q.dz = T_(rowsX, Ct); q.dU = T_(rowsX, Ct); q.dY = T_(rowsQ, Ct); q.dh2 = T_(rowsS, C4); q.dh1 = T_(rowsS, C4);
-        q.dzf = T_(rowsS, Ci); q.dNa = T_(rowsS, Ci); q.dNb = T_(rowsS, Ci);
+        q.dz = T_(rowsX, Ct); q.dU = T_(rowsX, Ct); q.dY = T_(rowsQ, Ct); q.dh1 = T_(rowsS, C4);
+        q.dzf = T_(rowsS, Ci + C4);                      // [dzf | dh2], same side-by-side rows
+        q.dh2 = q.dzf ? static_cast<char*>(q.dzf) + (size_t)Ci * es : nullptr;
+        q.dNa = T_(rowsS, Ci); q.dNb = T_(rowsS, Ci);
     }
     h->dv = T_(b, c.embed_dim); h->dzp = T_(b, Ci); h->dy = T_(b, Ci); h->du = T_(b, Ci); h->ds = T_(bt, Ci); h->dc = T_(bt, Ci);
     h->dzu = T_(bt, 4 * Ci); h->dun = T_(bt, Ci); h->do2 = T_(b, Ci); h->dq2 = T_(b, Ci); h->dkv2 = T_(bt, 2 * Ci); h->dqn2 = T_(b, Ci);
@@ -448,6 +473,22 @@ int wgrad(const Ctx& c, const Lin& l, const void* dY, int ld_dy, const void* X, 
         const int k = c.s == h->side ? 1 : (c.s == h->side2 ? 2 : 0);
         g.partial = h->tn_partial[k]; g.partial_elems = h->tn_partial_elems;
     }
+    return dist_op_gemm_tn(&g, c.s);
+}
+// weight (+ bias) gradients of two Linears that consume the SAME dY and whose inputs are stored side by side
+// ([X1 | X2], ldx = K1 + K2): one pass over dY, columns < K1 go to l1's weight, the rest to l2's; both biases get colsum(dY)
+int wgrad_pair(const Ctx& c, const Lin& l1, const Lin& l2, const void* dY, int ld_dy, const void* X12, int ldx, long M) {
+    dist_gemm_tn_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = dY; g.B = X12; g.out = c.gr(l1.w);
+    g.M = M; g.NI = l1.N; g.K = l1.K + l2.K; g.taps = 1; g.lda = ld_dy; g.ldb = ldx; g.amap = RM(); g.bmap = RM();
+    g.so_i = l1.K; g.so_tap = 0; g.so_outer = 1; g.inner = 1;
+    g.split_c = l1.K; g.out2 = c.gr(l2.w); g.so_i2 = l2.K;
+    g.dtype = c.dtype; g.use_tr = c.h->cfg.use_tr;
+    g.colsum = c.gr(l1.bias); g.colsum2 = c.gr(l2.bias);
+    dist_handle* h = c.h;
+    const int k = c.s == h->side ? 1 : (c.s == h->side2 ? 2 : 0);
+    g.partial = h->tn_partial[k]; g.partial_elems = h->tn_partial_elems;
     return dist_op_gemm_tn(&g, c.s);
 }
 int bgrad(const Ctx& c, long bias_off, const void* dY, long rows, int C, dist_rowmap m = RM()) {
@@ -602,6 +643,10 @@ extern "C" int dist_pack_weights(dist_handle* h, int what, void* stream) {
     else if (what == 2) { first = h->nblk_visual; count = nblk - h->nblk_visual; }
     else if (what != 3) return fail(h, DIST_ERR_ARG, "dist_pack_weights: what must be 1, 2 or 3");
     RUN(dist_k_pack(descs, blk_desc, blk_first, first, count, h->theta, h->visual, dst, h->cfg.dtype, s));
+    if ((what & 2) && h->ws) {                            // bias of the fused c_proj pair
+        for (int i = 0; i < h->cfg.layers; ++i)
+            RUN(dist_op_add(h->theta + h->dl[i].ffn_proj.bias, h->theta + h->dl[i].tf_proj.bias, h->lw[i].bcat, h->cfg.integration_dim, DIST_F32, s));
+    }
     return DIST_OK;
 }
 
@@ -723,12 +768,12 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
         RUN(dist_k_cls_rows(w.Mp, w.M, x.th(l.cls_token), (int)bt, L, Ci, t, c.dtype, x.s));
         // IntegrationNetwork (dist.py:16-45)
         RUN(ln_fwd(x, h->theta, l.in_ln, w.Mp, w.Na, rowsS, w.in_mean, w.in_rstd, &l.in_ln_t, w.Nb));
-        RUN(gemm(x, w.Na, Ci, x.pk(l.ffn_fc.pk.f), rowsS, Ci, Ci, 1, w.zf, Ci, x.th(l.ffn_fc.bias), nullptr, nullptr, w.hf));
+        RUN(gemm(x, w.Na, Ci, x.pk(l.ffn_fc.pk.f), rowsS, Ci, Ci, 1, w.zf, Ci + C4, x.th(l.ffn_fc.bias), nullptr, nullptr, w.hf));
         RUN(gemm(x, w.Nb, Ci, x.pk(l.tf_fc1.pk.f), rowsS, C4, Ci, 1, w.h1, C4, x.th(l.tf_fc1.bias), nullptr, nullptr, nullptr));
-        RUN(gemm(x, w.h1, C4, x.pk(l.tf_fc2.pk.f), rowsS, C4, C4, l.tf_fc2.taps, w.h2, C4, x.th(l.tf_fc2.bias), nullptr, nullptr, w.g2,
+        RUN(gemm(x, w.h1, C4, x.pk(l.tf_fc2.pk.f), rowsS, C4, C4, l.tf_fc2.taps, w.h2, Ci + C4, x.th(l.tf_fc2.bias), nullptr, nullptr, w.g2,
                  RM(DIST_RM_SHIFT, t * L, L, 1)));
-        RUN(gemm(x, w.hf, Ci, x.pk(l.ffn_proj.pk.f), rowsS, Ci, Ci, 1, w.R, Ci, x.th(l.ffn_proj.bias), nullptr, nullptr, nullptr));
-        RUN(gemm(x, w.g2, C4, x.pk(l.tf_proj.pk.f), rowsS, Ci, C4, 1, w.R, Ci, x.th(l.tf_proj.bias), w.R, nullptr, nullptr));
+        // R = ffn.c_proj(hf) + temporal_ffn.c_proj(g2): one GEMM over [hf | g2] (K = Ci + C4) with the two weights side by side
+        RUN(gemm(x, w.hf, Ci + C4, x.pk(l.pk_proj_f), rowsS, Ci, Ci + C4, 1, w.R, Ci, w.bcat, nullptr, nullptr, nullptr));
     }
     // current_layer_feat = res_feat + updated_mid_feat (dist.py:239)
     RUN(dist_op_add(h->lw[nl - 1].R, h->lw[nl - 1].Mp, h->Fz, rowsS * Ci, c.dtype, stream));
@@ -799,8 +844,8 @@ int lin_wb(dist_handle* h, const Ctx& x, const Lin& l, const void* dY, const voi
     return DIST_OK;
 }
 // dX = dY W (optionally * gelu'(aux), optionally accumulated through `res`)
-int lin_dx(dist_handle* h, const Ctx& x, const Lin& l, const void* dY, long rows, void* dX, const void* aux = nullptr, const void* res = nullptr) {
-    RUN(gemm(x, dY, l.N, x.pk(l.pk.b), rows, l.K, l.N, 1, dX, l.K, nullptr, res, aux, nullptr));
+int lin_dx(dist_handle* h, const Ctx& x, const Lin& l, const void* dY, long rows, void* dX, const void* aux = nullptr, const void* res = nullptr, int ld_dy = 0) {
+    RUN(gemm(x, dY, ld_dy ? ld_dy : l.N, x.pk(l.pk.b), rows, l.K, l.N, 1, dX, l.K, nullptr, res, aux, nullptr));
     return DIST_OK;
 }
 
@@ -926,20 +971,20 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
 
         // ---- IntegrationNetwork backward (dist.py:40-45) ----
         // B: dW/db of ffn.c_proj and temporal_ffn.c_proj read dR (produced before this layer started)
-        RUN(wgrad(xb, l.ffn_proj, dR, Ci, w.hf, Ci, rowsS, RM(), RM(), 0, true));
-        RUN(wgrad(xb2, l.tf_proj, dR, Ci, w.g2, C4, rowsS, RM(), RM(), 0, true));
+        const int Cc = Ci + C4;            // [zf | h2], [hf | g2], [dzf | dh2] rows
+        RUN(wgrad_pair(xb, l.ffn_proj, l.tf_proj, dR, Ci, w.hf, Cc, rowsS));
         RUN(merge_b2());
         HIP_CHECK_RET(hipEventRecord(h->ev_b_dr[i], B));
-        RUN(lin_dx(h, x, l.ffn_proj, dR, rowsS, q.dzf, w.zf));                            // dzf = (dR Wp) * g'(zf)
-        RUN(lin_dx(h, x, l.tf_proj, dR, rowsS, q.dh2, w.h2));                             // dh2 = (dR W3) * g'(h2)
+        // [dzf | dh2] = (dR [Wp ; W3]) * g'([zf | h2]): one data-gradient GEMM for the two projections
+        RUN(gemm(x, dR, Ci, x.pk(l.pk_proj_b), rowsS, Cc, Ci, 1, q.dzf, Cc, nullptr, nullptr, w.zf, nullptr));
         RUN(fork());
-        RUN(wgrad(xb, l.ffn_fc, q.dzf, Ci, w.Na, Ci, rowsS, RM(), RM(), 0, true));
-        RUN(wgrad(xb2, l.tf_fc2, q.dh2, C4, w.h1, C4, rowsS, RM(), RM(DIST_RM_SHIFT, t * L, L, 1), 1, true));
-        RUN(gemm(x, q.dh2, C4, x.pk(l.tf_fc2.pk.b), rowsS, C4, C4, l.tf_fc2.taps, q.dh1, C4, nullptr, nullptr, nullptr, nullptr,
+        RUN(wgrad(xb, l.ffn_fc, q.dzf, Cc, w.Na, Ci, rowsS, RM(), RM(), 0, true));
+        RUN(wgrad(xb2, l.tf_fc2, q.dh2, Cc, w.h1, C4, rowsS, RM(), RM(DIST_RM_SHIFT, t * L, L, 1), 1, true));
+        RUN(gemm(x, q.dh2, Cc, x.pk(l.tf_fc2.pk.b), rowsS, C4, C4, l.tf_fc2.taps, q.dh1, C4, nullptr, nullptr, nullptr, nullptr,
                  RM(DIST_RM_SHIFT, t * L, L, -1)));
         RUN(fork());
         RUN(wgrad(xb2, l.tf_fc1, q.dh1, C4, w.Nb, Ci, rowsS, RM(), RM(), 0, true));
-        RUN(lin_dx(h, x, l.ffn_fc, q.dzf, rowsS, q.dNa));
+        RUN(lin_dx(h, x, l.ffn_fc, q.dzf, rowsS, q.dNa, nullptr, nullptr, Cc));
         RUN(lin_dx(h, x, l.tf_fc1, q.dh1, rowsS, q.dNb));
         // dM' = LN'(dNa, dNb) (+ dFz for the last layer); a second copy becomes dM (updated in place by the I2T term)
         RUN(ln_bwd(x, l.in_ln, w.Mp, w.in_mean, w.in_rstd, q.dNa, q.dMp, false, rowsS, &l.in_ln_t, q.dNb, last ? dR : nullptr, last ? nullptr : q.dM));

@@ -21,6 +21,12 @@ constexpr int NT = 256;
 constexpr int PADT = 16;  // row stride = 8 banks mod 64: the 8 rows of a half-wave transpose read land on distinct banks
 constexpr int BR = 64;   // rows (reduction) per step = two 32-row MFMA k-blocks
 
+// destination of output element (i, c) of tap `tap`: the reference parameter layout, or the second tensor past split_c
+DEV float* tn_dst(const dist_gemm_tn_args& p, int ii, int c, int tap) {
+    if (p.out2 && c >= p.split_c) return p.out2 + (long)ii * p.so_i2 + (c - p.split_c);
+    return p.out + (long)ii * p.so_i + (long)tap * p.so_tap + (long)(c / p.inner) * p.so_outer + (c % p.inner);
+}
+
 template <typename T, bool TR>
 DEV void gather_frag(Frag<T>& f, const T* tile, int ld, int col0, int li, int lg);
 
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
 #pragma unroll 8
             for (int r = 0; r < BR; r += 2) { a0 += red[r * BI + tid]; a1 += red[(r + 1) * BI + tid]; }
             if (p.partial) p.partial[(long)gridDim.x * (BI * BJ) + ((long)ms * tiles_i + ti) * BI + tid] = a0 + a1;   // after the partial tiles
-            else atomicAdd(p.colsum + i0 + tid, a0 + a1);
+            else { atomicAdd(p.colsum + i0 + tid, a0 + a1); if (p.colsum2) atomicAdd(p.colsum2 + i0 + tid, a0 + a1); }
         }
     }
 
@@ -241,10 +247,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
             for (int v = lane; v < WTI * WTJ; v += 64) {
                 const int row = v / WTJ, col = v - row * WTJ;
                 const int ii = i0 + wi * WTI + row, c = c0 + wj * WTJ + col;
-                if (ii < p.NI && c < p.K) {
-                    const long jo = (long)tap * p.so_tap + (long)(c / p.inner) * p.so_outer + (c % p.inner);
-                    atomicAdd(p.out + (long)ii * p.so_i + jo, st[row * SLD + col]);
-                }
+                if (ii < p.NI && c < p.K) atomicAdd(tn_dst(p, ii, c, tap), st[row * SLD + col]);
             }
         }
     }
@@ -266,6 +269,7 @@ __global__ __launch_bounds__(NT) void tn_reduce_kernel(const dist_gemm_tn_args p
         float a = 0.f;
         for (int s = s0; s < s1; ++s) a += cp[(long)s * tiles_i * BI];
         atomicAdd(p.colsum + c, a);
+        if (p.colsum2) atomicAdd(p.colsum2 + c, a);
         return;
     }
     const int t = (int)(e / (BI * BJ)), r = (int)(e % (BI * BJ));
@@ -284,8 +288,7 @@ __global__ __launch_bounds__(NT) void tn_reduce_kernel(const dist_gemm_tn_args p
         a3 += src[(long)(s + 3) * stride];
     }
     for (; s < s1; ++s) a0 += src[(long)s * stride];
-    const long jo = (long)tap * p.so_tap + (long)(c / p.inner) * p.so_outer + (c % p.inner);
-    atomicAdd(p.out + (long)ii * p.so_i + jo, (a0 + a1) + (a2 + a3));
+    atomicAdd(tn_dst(p, ii, c, tap), (a0 + a1) + (a2 + a3));
 }
 
 template <typename T, int BI, int BJ, int WI, int WJ, bool TR, bool PLAIN>
@@ -349,6 +352,8 @@ extern "C" int dist_op_gemm_tn(const dist_gemm_tn_args* a, void* stream) {
     if (!a || !a->A || !a->B || !a->out || a->M <= 0 || a->NI <= 0 || a->K <= 0 || a->taps <= 0) return DIST_ERR_ARG;
     if (a->NI % 8 || a->lda % 8 || a->ldb % 8 || a->inner <= 0 || (a->K + 7) / 8 * 8 > a->ldb) return DIST_ERR_ARG;
     if (a->M > (1 << 30)) return DIST_ERR_ARG;
+    if (a->out2 && (a->taps != 1 || a->inner != 1 || a->so_outer != 1 || a->split_c <= 0 || a->split_c >= a->K)) return DIST_ERR_ARG;
+    if (a->colsum2 && !a->colsum) return DIST_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a->dtype == DIST_BF16) return a->use_tr ? dispatch<bf16_t, true>(*a, s) : dispatch<bf16_t, false>(*a, s);
     return dispatch<float, false>(*a, s);

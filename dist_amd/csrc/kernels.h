@@ -17,6 +17,7 @@ struct PackDesc {
     int co, kin, kpad;   // number of outputs, inputs per tap, padded inputs per tap
     int inner;           // source index = co*s_co + tap*s_tap + (ci/inner)*s_outer + ci%inner
     long s_co, s_tap, s_outer;
+    int dpitch;          // destination row pitch in elements (0 = cols): two weights packed side by side into one [N][K1+K2] matrix
 };
 
 int dist_k_pack(const PackDesc* descs_dev, const int* blk_desc_dev, const int* blk_first_dev, int first_block, int nblocks,

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(NT) void pack_kernel(const PackDesc* __restrict__ d
         else { tap = r / d.kpad; ci = r % d.kpad; co = c; }      // PACK_FT
         float v = 0.f;
         if (ci < d.kin) v = src[(long)co * d.s_co + (long)tap * d.s_tap + (long)(ci / d.inner) * d.s_outer + (ci % d.inner)];
-        dst[i] = from_f<T>(v);
+        dst[d.dpitch ? (long)r * d.dpitch + c : i] = from_f<T>(v);
     }
 }
 

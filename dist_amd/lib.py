@@ -34,7 +34,8 @@ class GemmTnArgs(C.Structure):
                 ("M", C.c_int64), ("NI", C.c_int), ("K", C.c_int), ("taps", C.c_int),
                 ("lda", C.c_int), ("ldb", C.c_int), ("amap", RowMap), ("bmap", RowMap),
                 ("so_i", C.c_int64), ("so_tap", C.c_int64), ("so_outer", C.c_int64), ("inner", C.c_int),
-                ("dtype", C.c_int), ("use_tr", C.c_int), ("colsum", C.c_void_p), ("partial", C.c_void_p), ("partial_elems", C.c_int64)]
+                ("dtype", C.c_int), ("use_tr", C.c_int), ("colsum", C.c_void_p), ("partial", C.c_void_p), ("partial_elems", C.c_int64),
+                ("split_c", C.c_int), ("out2", C.c_void_p), ("so_i2", C.c_int64), ("colsum2", C.c_void_p)]
 
 
 class LnArgs(C.Structure):

@@ -84,6 +84,10 @@ typedef struct dist_gemm_tn_args {
     float* partial;          /* optional scratch (fp32): when large enough, row-split partial tiles are stored here with plain
                                 coalesced stores and summed by a second small kernel instead of per-block atomics */
     int64_t partial_elems;
+    /* optional second destination (two weights that share the activation-gradient operand, e.g. a Linear pair whose inputs
+     * are stored side by side): columns c >= split_c go to out2[i*so_i2 + (c - split_c)], colsum is also added to colsum2.
+     * Plain layouts only (taps == 1, inner == 1, so_outer == 1). */
+    int split_c; float* out2; int64_t so_i2; float* colsum2;
 } dist_gemm_tn_args;
 int dist_op_gemm_tn(const dist_gemm_tn_args* a, void* stream);
 
