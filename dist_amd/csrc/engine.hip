@@ -529,7 +529,15 @@ extern "C" const char* dist_strerror(int code) {
         default: return code <= -1000 ? hipGetErrorString((hipError_t)(-code - 1000)) : "unknown error";
     }
 }
-extern "C" int dist_abi_version(void) { return 2; }
+extern "C" int dist_abi_version(void) { return 3; }
+extern "C" int dist_abi_sizeof(const char* n) {
+    if (!n) return -1;
+#define DIST_SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)
+    DIST_SZ(dist_gemm_args); DIST_SZ(dist_gemm_tn_args); DIST_SZ(dist_ln_args); DIST_SZ(dist_ln_bwd_args);
+    DIST_SZ(dist_adamw_seg); DIST_SZ(dist_config); DIST_SZ(dist_rowmap); DIST_SZ(dist_outmap);
+#undef DIST_SZ
+    return -1;
+}
 
 extern "C" void dist_destroy(dist_handle* h);
 extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {

@@ -100,6 +100,7 @@ def load():
     lib = C.CDLL(LIB_PATH)
     _sig(lib, "dist_strerror", restype=C.c_char_p)
     _sig(lib, "dist_strerror", argtypes=[C.c_int])
+    _sig(lib, "dist_abi_sizeof", argtypes=[C.c_char_p])
     _sig(lib, "dist_last_error", restype=C.c_char_p)
     _sig(lib, "dist_last_error", argtypes=[C.c_void_p])
     _sig(lib, "dist_param_name", restype=C.c_char_p)

@@ -39,6 +39,10 @@ enum {
 
 const char* dist_strerror(int code);
 int dist_abi_version(void);
+/* sizeof() of an argument struct of this header by name ("dist_gemm_args", "dist_gemm_tn_args", "dist_ln_args",
+ * "dist_ln_bwd_args", "dist_adamw_seg", "dist_config", "dist_rowmap", "dist_outmap"); -1 for an unknown name.
+ * Lets a foreign-language binding verify its mirror of the layout without a GPU. */
+int dist_abi_sizeof(const char* struct_name);
 
 /* ---------------------------------------------------------------------------------------
  * Operator level (also what the unit parity tests drive).

@@ -22,7 +22,13 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert len(syms) >= 30
     for s in syms:
         assert hasattr(l, s), s
-    assert l.dist_abi_version() == 2
+    assert l.dist_abi_version() == 3
+    # the ctypes mirrors of the argument structs have the library's layout size (checked without a GPU)
+    for cname, mirror in (("dist_gemm_args", lib.GemmArgs), ("dist_gemm_tn_args", lib.GemmTnArgs), ("dist_ln_args", lib.LnArgs),
+                          ("dist_ln_bwd_args", lib.LnBwdArgs), ("dist_adamw_seg", lib.AdamwSeg), ("dist_config", lib.Config),
+                          ("dist_rowmap", lib.RowMap), ("dist_outmap", lib.OutMap)):
+        assert l.dist_abi_sizeof(cname.encode()) == ctypes.sizeof(mirror), cname
+    assert l.dist_abi_sizeof(b"nope") == -1
     assert l.dist_strerror(-1).decode().startswith("invalid argument")
 
 
