@@ -68,7 +68,6 @@ struct Arena {
 struct DistLayerWs {
     void *X, *U, *z, *V, *p, *Xp, *M, *Mp, *Na, *Nb, *zf, *hf, *h1, *h2, *g2, *R;
     float *tn_mean, *tn_rstd, *in_mean, *in_rstd;
-    float* bcat;     // ffn.c_proj.bias + temporal_ffn.c_proj.bias (refreshed by dist_pack_weights)
 };
 struct AdaWs {
     void *kn, *kv, *qn, *q, *o, *s1, *sn, *zs, *hs, *c, *kn2, *kv2, *qn2, *q2, *o2, *u1, *un, *zu, *hu;
@@ -380,7 +379,7 @@ size_t layout_ws(dist_handle* h, char* base) {
         w.zf = T_(rowsS, Ci + C4); w.hf = T_(rowsS, Ci + C4);
         w.h2 = w.zf ? static_cast<char*>(w.zf) + (size_t)Ci * es : nullptr;
         w.g2 = w.hf ? static_cast<char*>(w.hf) + (size_t)Ci * es : nullptr;
-        w.h1 = T_(rowsS, C4); w.R = T_(rowsS, Ci); w.bcat = F_(Ci);
+        w.h1 = T_(rowsS, C4); w.R = T_(rowsS, Ci);
         w.tn_mean = F_(rowsX); w.tn_rstd = F_(rowsX); w.in_mean = F_(rowsS); w.in_rstd = F_(rowsS);
     }
     h->Xlast = T_(rowsX, Ct);
@@ -432,10 +431,10 @@ dist_outmap OM(int mode = DIST_OM_PLAIN, int p0 = 0, int p1 = 0, int p2 = 0) { r
 
 // C (and/or C2) = epi(A[amap] . W^T): thin positional wrapper over dist_op_gemm_nt
 int gemm(const Ctx& c, const void* A, int lda, const void* W, long M, int N, int K, int taps, void* C, int ldc,
-         const float* bias, const void* res, const void* aux, void* C2, dist_rowmap am = RM(), dist_outmap om = OM(), int extra_flags = 0) {
+         const float* bias, const void* res, const void* aux, void* C2, dist_rowmap am = RM(), dist_outmap om = OM(), int extra_flags = 0, const float* bias2 = nullptr) {
     dist_gemm_args g;
     memset(&g, 0, sizeof(g));
-    g.A = A; g.B = W; g.C = C; g.C2 = C2; g.bias = bias; g.res = res; g.aux = aux;
+    g.A = A; g.B = W; g.C = C; g.C2 = C2; g.bias = bias; g.bias2 = bias2; g.res = res; g.aux = aux;
     g.M = M; g.N = N; g.K = K; g.taps = taps;
     g.lda = lda; g.ldb = taps * K; g.ldc = ldc; g.ldc2 = ldc; g.ldres = ldc; g.ldaux = ldc;
     g.amap = am; g.omap = om;
@@ -651,10 +650,6 @@ extern "C" int dist_pack_weights(dist_handle* h, int what, void* stream) {
     else if (what == 2) { first = h->nblk_visual; count = nblk - h->nblk_visual; }
     else if (what != 3) return fail(h, DIST_ERR_ARG, "dist_pack_weights: what must be 1, 2 or 3");
     RUN(dist_k_pack(descs, blk_desc, blk_first, first, count, h->theta, h->visual, dst, h->cfg.dtype, s));
-    if ((what & 2) && h->ws) {                            // bias of the fused c_proj pair
-        for (int i = 0; i < h->cfg.layers; ++i)
-            RUN(dist_op_add(h->theta + h->dl[i].ffn_proj.bias, h->theta + h->dl[i].tf_proj.bias, h->lw[i].bcat, h->cfg.integration_dim, DIST_F32, s));
-    }
     return DIST_OK;
 }
 
@@ -781,7 +776,8 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
         RUN(gemm(x, w.h1, C4, x.pk(l.tf_fc2.pk.f), rowsS, C4, C4, l.tf_fc2.taps, w.h2, Ci + C4, x.th(l.tf_fc2.bias), nullptr, nullptr, w.g2,
                  RM(DIST_RM_SHIFT, t * L, L, 1)));
         // R = ffn.c_proj(hf) + temporal_ffn.c_proj(g2): one GEMM over [hf | g2] (K = Ci + C4) with the two weights side by side
-        RUN(gemm(x, w.hf, Ci + C4, x.pk(l.pk_proj_f), rowsS, Ci, Ci + C4, 1, w.R, Ci, w.bcat, nullptr, nullptr, nullptr));
+        RUN(gemm(x, w.hf, Ci + C4, x.pk(l.pk_proj_f), rowsS, Ci, Ci + C4, 1, w.R, Ci, x.th(l.ffn_proj.bias), nullptr, nullptr, nullptr,
+                 RM(), OM(), 0, x.th(l.tf_proj.bias)));
     }
     // current_layer_feat = res_feat + updated_mid_feat (dist.py:239)
     RUN(dist_op_add(h->lw[nl - 1].R, h->lw[nl - 1].Mp, h->Fz, rowsS * Ci, c.dtype, stream));

@@ -290,7 +290,7 @@ static bool fast_common_ok(const dist_gemm_args* a) {
     if (a->dtype != DIST_BF16 || a->taps != 1) return false;
     if (a->amap.mode != DIST_RM_PLAIN && a->amap.mode != DIST_RM_STRIDED && a->amap.mode != DIST_RM_SKIPCLS) return false;
     if (a->omap.mode != DIST_OM_PLAIN && a->omap.mode != DIST_OM_INSERTCLS && a->omap.mode != DIST_OM_HEADS) return false;
-    if (a->flags & DIST_EPI_MULG) return false;
+    if ((a->flags & DIST_EPI_MULG) || a->bias2) return false;
     if (a->K % BK || a->K < 4 * BK || a->N % 64 || a->M < 1024) return false;
     if (a->lda % 8 || a->ldb % 8 || a->ldc % 8 || a->ldc2 % 8 || a->ldres % 8) return false;
     if (a->omap.mode == DIST_OM_HEADS && (a->flags & (DIST_EPI_RES | DIST_EPI_ACT2))) return false;

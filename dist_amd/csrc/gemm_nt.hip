@@ -219,7 +219,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const dist_gemm_args p) {
             const int n = nw + j * 16 + lg * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float bv = (n + r < N) ? p.bias[n + r] : 0.f;
+                const float bv = (n + r < N) ? p.bias[n + r] + (p.bias2 ? p.bias2[n + r] : 0.f) : 0.f;
 #pragma unroll
                 for (int i = 0; i < FM; ++i) acc[i][j][r] += bv;
             }

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(NT) void gemm_small_kernel(const dist_gemm_args p) 
     const int flags = p.flags;
     if (flags & DIST_EPI_BIAS) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
+        for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e] + (p.bias2 ? p.bias2[n + e] : 0.f);
     }
     if (flags & DIST_EPI_MULG) {
         Frag<T> x;

@@ -26,7 +26,7 @@ class GemmArgs(C.Structure):
                 ("bias", C.c_void_p), ("res", C.c_void_p), ("aux", C.c_void_p),
                 ("M", C.c_int64), ("N", C.c_int), ("K", C.c_int), ("taps", C.c_int),
                 ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int), ("ldc2", C.c_int), ("ldres", C.c_int), ("ldaux", C.c_int),
-                ("amap", RowMap), ("omap", OutMap), ("flags", C.c_int), ("dtype", C.c_int)]
+                ("amap", RowMap), ("omap", OutMap), ("flags", C.c_int), ("dtype", C.c_int), ("bias2", C.c_void_p)]
 
 
 class GemmTnArgs(C.Structure):

@@ -72,6 +72,7 @@ typedef struct dist_gemm_args {
     int lda, ldb, ldc, ldc2, ldres, ldaux;
     dist_rowmap amap; dist_outmap omap;
     int flags; int dtype;
+    const float* bias2;   /* optional second bias, added with `bias` (two Linears evaluated as one GEMM over side-by-side inputs) */
 } dist_gemm_args;
 int dist_op_gemm_nt(const dist_gemm_args* a, void* stream);
 
