@@ -6,7 +6,12 @@ b=32 clips per GPU, bf16, synthetic frames, procedural random-init weights.
 A "step" = one pass of the hot path over one resident batch:
     frozen ViT forward -> DiST branch forward -> soft-target CE -> branch backward
     -> (N>1: RCCL all-reduce of the dist_net gradients only) -> fused AdamW + weight re-pack.
-Inputs are resident in HBM before the timed region.
+Inputs are resident in HBM before the timed region.  Two synthetic batches alternate.
+
+Default order = software pipelining over batches (dist_vit_prefetch / dist_vit_adopt): the ViT is frozen, so step n runs
+the ViT forward of batch n+1 on a low-priority stream beside branch forward / backward / AdamW of batch n (two feature
+slots in the workspace).  Every timed step still contains exactly one ViT forward and one branch forward + backward +
+AdamW; nothing is cached across steps.  `--no-pipeline` times the serial order of the same calls.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -69,6 +74,7 @@ def main():
     ap.add_argument("--config", default="b16_8+16f")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="serial order: ViT forward of a batch inside its own step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -92,22 +98,36 @@ def main():
     eng = Engine(config_from_geometry(g, b, torch.bfloat16))
     eng.load_state_dict(synth.state_dict(g))
     # clips are sharded per rank (independent units); every rank gets its own synthetic shard
-    video = torch.from_numpy(synth.video(g, b, seed=1 + rank)).cuda()
+    # two resident batches alternate (batch n+1 is a different tensor from batch n)
+    videos = [torch.from_numpy(synth.video(g, b, seed=1 + rank + 100 * k)).cuda() for k in range(2)]
     text = torch.from_numpy(synth.text_features(g)).cuda()
-    tgt = torch.from_numpy(synth.soft_target(g, b, seed=3 + rank)[0]).cuda()
+    tgts = [torch.from_numpy(synth.soft_target(g, b, seed=3 + rank + 100 * k)[0]).cuda() for k in range(2)]
     lr, wd, mult = 3.2e-5, 1e-4, 10.0      # configs/projects/dist/ssv2/vit-b16-8+16f.yaml:52-58
     reducer = du.GradReducer(eng, world) if world > 1 else None
+    pipelined = not args.no_pipeline
+    it = [0]
 
     def step():
-        eng.vit_forward(video)
+        n = it[0]
+        it[0] += 1
+        if pipelined:
+            eng.vit_prefetch(videos[(n + 1) % 2])      # frozen ViT of the NEXT batch, beside this batch's branch work
+        else:
+            eng.vit_forward(videos[n % 2])
         eng.branch_forward(text)
-        _, dlogits = eng.loss(tgt)
+        _, dlogits = eng.loss(tgts[n % 2])
         if reducer is not None:
             reducer.backward_and_reduce(dlogits)
         else:
             eng.backward(dlogits)
         eng.adamw_step(lr, wd, lr_mult=mult, grad_scale=1.0 / world)
+        if pipelined:
+            eng.vit_adopt()
 
+    if os.environ.get("DIST_AMD_MAIN_PRIO"):           # measurement knob: run the step on a torch stream of this priority
+        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["DIST_AMD_MAIN_PRIO"])))
+    if pipelined:
+        eng.vit_forward(videos[0])                     # pipeline prologue: features of batch 0
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -158,6 +178,8 @@ def main():
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "pipeline": ("frozen-ViT forward of batch n+1 on a low-priority stream beside branch fwd/bwd/AdamW of batch n "
+                         "(2 feature slots; one ViT forward per timed step)") if pipelined else "serial (--no-pipeline)",
             "config": {"workload": f"ViT-{args.config} bf16, synthetic 224^2 frames, batch={b}/GPU, fwd+bwd+AdamW, DP{world}",
                        "global_batch": b * world, "frames": f"{g.t}+{g.T}", "parallelism": f"dp{world}"},
         }

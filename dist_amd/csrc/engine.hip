@@ -102,6 +102,16 @@ struct dist_handle {
     // workspace
     void *patches, *x0, *xa, *hbuf, *qkv, *att, *mlp;
     std::vector<void*> feat;
+    // Two feature slots (patch rows + the 12 mid_feat tensors + their events): the frozen ViT of the NEXT batch can fill the
+    // spare slot (dist_vit_prefetch) while the branch forward / backward of the current batch read the other one.
+    // `patches`, `feat`, `ev_feat`, `ev_pre` above / below always alias slot[cur].
+    struct FeatSlot {
+        void* patches = nullptr; std::vector<void*> feat; std::vector<hipEvent_t> ev_feat; hipEvent_t ev_pre = nullptr;
+        int b = 0; bool prefetched = false;
+    } slot[2];
+    int cur = 0;
+    hipEvent_t ev_vit_done = nullptr, ev_after = nullptr, ev_bpre = nullptr; bool vit_ran = false;
+    void use_slot(int k) { cur = k; patches = slot[k].patches; feat = slot[k].feat; ev_feat = slot[k].ev_feat; ev_pre = slot[k].ev_pre; }
     std::vector<DistLayerWs> lw; std::vector<AdaWs> aw;
     void* Xlast;
     std::vector<void*> sbuf, ubuf;
@@ -114,7 +124,7 @@ struct dist_handle {
     float* tn_partial[3] = {nullptr, nullptr, nullptr};   // two-phase dW reduction scratch, one per stream that launches dW GEMMs
     long tn_partial_elems = 0;
     // weight-gradient side stream (created once per handle; host-side objects only)
-    hipStream_t side = nullptr, side2 = nullptr;
+    hipStream_t side = nullptr, side2 = nullptr, pf = nullptr;   // pf: the handle's own ViT prefetch stream
     int serial = 0;                            // DIST_AMD_SERIAL (measurement knob): bit 0 = branch forward, bit 1 = backward on the caller's stream only
     std::vector<hipEvent_t> ev_a;              // chain -> side: "buffer produced"
     std::vector<hipEvent_t> ev_b_dr, ev_b_done; // side -> chain: per layer "dR consumed", "all weight gradients of the layer issued and done"
@@ -365,11 +375,14 @@ size_t layout_ws(dist_handle* h, char* base) {
     const int d = c.width, Ci = c.integration_dim, Ct = c.temporal_dim, C4 = h->C4, H = h->iheads;
     auto T_ = [&](long rows, long cols) { return a.take((size_t)rows * cols * es); };
     auto F_ = [&](long n) { return static_cast<float*>(a.take((size_t)n * sizeof(float))); };
-    h->patches = T_(rowsX, h->Kp);
+    for (int k = 0; k < 2; ++k) h->slot[k].patches = T_(rowsX, h->Kp);
     h->x0 = T_(rowsS, d); h->xa = T_(rowsS, d); h->hbuf = T_(rowsS, d);
     h->qkv = T_(rowsS, 3 * d); h->att = T_(rowsS, d); h->mlp = T_(rowsS, 4 * d);
-    h->feat.resize(c.layers);
-    for (int i = 0; i < c.layers; ++i) h->feat[i] = T_(rowsS, d);
+    for (int k = 0; k < 2; ++k) {
+        h->slot[k].feat.resize(c.layers);
+        for (int i = 0; i < c.layers; ++i) h->slot[k].feat[i] = T_(rowsS, d);
+    }
+    h->patches = h->slot[h->cur].patches; h->feat = h->slot[h->cur].feat;
     h->lw.resize(c.layers);
     for (int i = 0; i < c.layers; ++i) {
         DistLayerWs& w = h->lw[i];
@@ -573,15 +586,20 @@ static int ensure_streams(dist_handle* h) {
     const char* pe = getenv("DIST_AMD_SIDE_PRIO");
     const int prio = (pe && atoi(pe) == 0) ? 0 : least;
     bool ok = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio) == hipSuccess &&
-              hipStreamCreateWithPriority(&h->side2, hipStreamNonBlocking, prio) == hipSuccess;
+              hipStreamCreateWithPriority(&h->side2, hipStreamNonBlocking, prio) == hipSuccess &&
+              hipStreamCreateWithPriority(&h->pf, hipStreamNonBlocking, least) == hipSuccess;
     auto mk = [&](hipEvent_t& e) { ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
     h->ev_a.resize(10 * c.layers + 4); h->ev_b_dr.resize(c.layers); h->ev_b_done.resize(c.layers);
     for (auto& e : h->ev_a) mk(e);
     for (auto& e : h->ev_b_dr) mk(e);
     for (auto& e : h->ev_b_done) mk(e);
-    h->ev_feat.resize(c.layers + 1);
-    for (auto& e : h->ev_feat) mk(e);
-    mk(h->ev_join); mk(h->ev_pre); mk(h->ev_b2);
+    for (int k = 0; k < 2; ++k) {
+        h->slot[k].ev_feat.resize(c.layers + 1);
+        for (auto& e : h->slot[k].ev_feat) mk(e);
+        mk(h->slot[k].ev_pre);
+    }
+    h->ev_feat = h->slot[h->cur].ev_feat; h->ev_pre = h->slot[h->cur].ev_pre;
+    mk(h->ev_join); mk(h->ev_b2); mk(h->ev_vit_done); mk(h->ev_after); mk(h->ev_bpre);
     return ok ? DIST_OK : DIST_ERR_STATE;
 }
 
@@ -591,12 +609,14 @@ extern "C" void dist_destroy(dist_handle* h) {
     for (hipEvent_t e : h->ev_a) if (e) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_b_dr) if (e) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_b_done) if (e) hipEventDestroy(e);
-    for (hipEvent_t e : h->ev_feat) if (e) hipEventDestroy(e);
-    if (h->ev_join) hipEventDestroy(h->ev_join);
-    if (h->ev_pre) hipEventDestroy(h->ev_pre);
-    if (h->ev_b2) hipEventDestroy(h->ev_b2);
+    for (int k = 0; k < 2; ++k) {
+        for (hipEvent_t e : h->slot[k].ev_feat) if (e) hipEventDestroy(e);
+        if (h->slot[k].ev_pre) hipEventDestroy(h->slot[k].ev_pre);
+    }
+    for (hipEvent_t e : {h->ev_join, h->ev_b2, h->ev_vit_done, h->ev_after, h->ev_bpre}) if (e) hipEventDestroy(e);
     if (h->side) hipStreamDestroy(h->side);
     if (h->side2) hipStreamDestroy(h->side2);
+    if (h->pf) hipStreamDestroy(h->pf);
     delete h;
 }
 extern "C" const char* dist_last_error(const dist_handle* h) { return h ? h->err : ""; }
@@ -631,6 +651,8 @@ extern "C" int dist_bind(dist_handle* h, float* theta, float* grads, const float
     off = (off + h->blk_desc.size() * sizeof(int) + 255) & ~(size_t)255;
     HIP_CHECK_RET(hipMemcpy(p + off, h->blk_first.data(), h->blk_first.size() * sizeof(int), hipMemcpyHostToDevice));
     h->fwd_b = h->branch_b = 0;
+    h->slot[0].b = h->slot[1].b = 0; h->slot[0].prefetched = h->slot[1].prefetched = false;
+    h->use_slot(0);
     return DIST_OK;
 }
 
@@ -654,21 +676,27 @@ extern "C" int dist_pack_weights(dist_handle* h, int what, void* stream) {
 }
 
 // -------------------------------------------------------------------------------------------------------------
-extern "C" int dist_vit_forward(dist_handle* h, const float* video, int b, void* stream) {
-    if (!h || !video) return DIST_ERR_ARG;
-    if (!h->ws) return fail(h, DIST_ERR_UNBOUND, "dist_vit_forward before dist_bind");
-    if (b <= 0 || b > h->cfg.batch) return fail(h, DIST_ERR_ARG, "batch %d outside (0, %d]", b, h->cfg.batch);
+// The frozen ViT of one batch into feature slot `k` on `stream`.  `after` (when ordered_after): a stream whose already queued work must
+// finish first (pipelined use: the backward of the batch that last used this slot, the weight re-pack).
+static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, void* stream, bool ordered_after, void* after) {
     const dist_config& c = h->cfg;
     Ctx x{h, static_cast<hipStream_t>(stream), c.dtype};
+    dist_handle::FeatSlot& S = h->slot[k];
     const int d = c.width, N = h->N, L = h->L;
     const long rowsS = (long)b * h->t * L, rowsQ = (long)b * h->t * N;
 
-    HIP_CHECK_RET(hipEventRecord(h->ev_pre, x.s));                      // everything queued before this step (re-pack, previous step)
-    RUN(dist_op_patchify(video, h->patches, b, c.frames, c.resolution, c.resolution, c.patch, c.dtype, stream));
-    HIP_CHECK_RET(hipEventRecord(h->ev_feat[c.layers], x.s));          // patch rows ready (temporal stem input)
+    if (ordered_after && after != stream) {
+        HIP_CHECK_RET(hipEventRecord(h->ev_after, static_cast<hipStream_t>(after)));
+        HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_after, 0));
+    }
+    // the ViT-internal scratch (x0, xa, hbuf, qkv, att, mlp) exists once: consecutive ViT passes are ordered, whatever their streams
+    if (h->vit_ran) HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_vit_done, 0));
+    HIP_CHECK_RET(hipEventRecord(S.ev_pre, x.s));                       // everything queued before this pass (re-pack, previous step)
+    RUN(dist_op_patchify(video, S.patches, b, c.frames, c.resolution, c.resolution, c.patch, c.dtype, stream));
+    HIP_CHECK_RET(hipEventRecord(S.ev_feat[c.layers], x.s));           // patch rows ready (temporal stem input)
     // patch embedding of the frames k = alpha*j only (the reference embeds all T frames and drops the
     // others at clip.py:284); rows land behind their frame's cls row
-    RUN(gemm(x, h->patches, h->Kp, x.pk(h->conv1.pk.f), rowsQ, d, h->Kp, 1, h->xa, d, nullptr, nullptr, nullptr, nullptr,
+    RUN(gemm(x, S.patches, h->Kp, x.pk(h->conv1.pk.f), rowsQ, d, h->Kp, 1, h->xa, d, nullptr, nullptr, nullptr, nullptr,
              RM(DIST_RM_STRIDED, c.alpha, N), OM(DIST_OM_INSERTCLS, N)));
     RUN(dist_k_cls_rows(h->xa, nullptr, x.vs(h->class_emb), b * h->t, L, d, 1, c.dtype, x.s));
     RUN(ln_fwd(x, h->visual, h->ln_pre, h->xa, h->x0, rowsS, nullptr, nullptr, nullptr, nullptr, x.vs(h->pos_emb), L));
@@ -683,11 +711,49 @@ extern "C" int dist_vit_forward(dist_handle* h, const float* video, int b, void*
         RUN(gemm(x, h->att, d, x.pk(v.out.pk.f), rowsS, d, d, 1, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr));
         RUN(ln_fwd(x, h->visual, v.ln2, h->xa, h->hbuf, rowsS, nullptr, nullptr));
         RUN(gemm(x, h->hbuf, d, x.pk(v.fc.pk.f), rowsS, 4 * d, d, 1, nullptr, 4 * d, x.vs(v.fc.bias), nullptr, nullptr, h->mlp));
-        RUN(gemm(x, h->mlp, 4 * d, x.pk(v.proj.pk.f), rowsS, d, 4 * d, 1, h->feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr));
-        HIP_CHECK_RET(hipEventRecord(h->ev_feat[i], x.s));              // mid_feat[i] complete: the branch may consume it
-        xin = h->feat[i];
+        RUN(gemm(x, h->mlp, 4 * d, x.pk(v.proj.pk.f), rowsS, d, 4 * d, 1, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr));
+        HIP_CHECK_RET(hipEventRecord(S.ev_feat[i], x.s));               // mid_feat[i] complete: the branch may consume it
+        xin = S.feat[i];
     }
+    HIP_CHECK_RET(hipEventRecord(h->ev_vit_done, x.s));
+    h->vit_ran = true;
+    S.b = b;
+    return DIST_OK;
+}
+
+static int vit_args_ok(dist_handle* h, const float* video, int b, const char* who) {
+    if (!h || !video) return DIST_ERR_ARG;
+    if (!h->ws) return fail(h, DIST_ERR_UNBOUND, "%s before dist_bind", who);
+    if (b <= 0 || b > h->cfg.batch) return fail(h, DIST_ERR_ARG, "batch %d outside (0, %d]", b, h->cfg.batch);
+    return DIST_OK;
+}
+
+extern "C" int dist_vit_forward(dist_handle* h, const float* video, int b, void* stream) {
+    RUN(vit_args_ok(h, video, b, "dist_vit_forward"));
+    h->slot[h->cur].prefetched = false;
+    RUN(vit_forward_slot(h, video, b, h->cur, stream, false, nullptr));
     h->fwd_b = b;
+    h->branch_b = 0;
+    return DIST_OK;
+}
+
+// Software pipelining over batches: the ViT is frozen, so its forward for batch n+1 does not depend on the optimizer step of
+// batch n.  dist_vit_prefetch runs it into the spare feature slot on its own (low-priority) stream while the branch
+// forward / backward / AdamW of batch n run on the caller's stream; dist_vit_adopt makes that slot the current one.
+extern "C" int dist_vit_prefetch(dist_handle* h, const float* video, int b, void* stream, void* after) {
+    RUN(vit_args_ok(h, video, b, "dist_vit_prefetch"));
+    const int k = h->cur ^ 1;
+    h->slot[k].prefetched = true;
+    h->slot[k].b = 0;
+    return vit_forward_slot(h, video, b, k, stream ? stream : h->pf, true, after);
+}
+extern "C" int dist_vit_adopt(dist_handle* h) {
+    if (!h) return DIST_ERR_ARG;
+    if (!h->ws) return fail(h, DIST_ERR_UNBOUND, "dist_vit_adopt before dist_bind");
+    const int k = h->cur ^ 1;
+    if (!h->slot[k].prefetched || h->slot[k].b <= 0) return fail(h, DIST_ERR_STATE, "dist_vit_adopt needs dist_vit_prefetch first");
+    h->use_slot(k);
+    h->fwd_b = h->slot[k].b;
     h->branch_b = 0;
     return DIST_OK;
 }
@@ -730,6 +796,12 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
     stream = S1;
     HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_pre, 0));               // what preceded dist_vit_forward on the caller's stream
     HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_feat[nl], 0));          // patch rows
+    const bool pref = h->slot[h->cur].prefetched && !(h->serial & 1);
+    if (pref) {                                                         // the features come from another stream: the side streams
+        HIP_CHECK_RET(hipEventRecord(h->ev_bpre, A));                   // must also follow the caller's stream (re-pack of the last step)
+        HIP_CHECK_RET(hipStreamWaitEvent(S1, h->ev_bpre, 0));
+        HIP_CHECK_RET(hipStreamWaitEvent(S2, h->ev_bpre, 0));
+    }
 
     // Two streams inside the branch: the temporal chain (TemporalNet_i, I2T_i) on `xt`, the integration chain
     // (input_linear_i, T2I_i, IntegrationNetwork_i) on `x`.  TemporalNet_{i+1} only needs X_{i+1} = X'_i + I2T(M_i),

@@ -60,6 +60,8 @@ class Engine:
         self._segs = None
         self._segs_key = None
         self._text = None
+        self._pf_video = None
+        self._cur_video = None
         self.b = 0
 
     def __del__(self):
@@ -138,6 +140,19 @@ class Engine:
         assert video.dtype == torch.float32 and video.is_contiguous() and video.is_cuda
         self.b = video.shape[0]
         L.check(self.lib.dist_vit_forward(self.h, video.data_ptr(), self.b, ops._stream()), self.h)
+
+    def vit_prefetch(self, video):
+        """Frozen ViT of the NEXT batch into the spare feature slot, on the handle's lowest-priority prefetch stream, behind
+        everything already queued on the current stream (dist_vit_prefetch).  `video` must stay alive until `vit_adopt`."""
+        assert video.dtype == torch.float32 and video.is_contiguous() and video.is_cuda
+        self._pf_video = video
+        L.check(self.lib.dist_vit_prefetch(self.h, video.data_ptr(), video.shape[0], None, ops._stream()), self.h)
+
+    def vit_adopt(self):
+        """The prefetched batch becomes the current one (as after `vit_forward` of it)."""
+        L.check(self.lib.dist_vit_adopt(self.h), self.h)
+        self.b = self._pf_video.shape[0]
+        self._cur_video, self._pf_video = self._pf_video, None
 
     def branch_forward(self, text_features):
         assert text_features.dtype == torch.float32 and text_features.is_contiguous()

@@ -211,6 +211,16 @@ int dist_pack_weights(dist_handle* h, int what, void* stream);
 /* VisionTransformer.forward under eval()+no_grad (clip.py:263-300,454-458): video [b,3,T,H,W] fp32
  * -> mid_feat kept inside the workspace ([layers][b,t,L,d]); optional copy-out pointer per layer. */
 int dist_vit_forward(dist_handle* h, const float* video, int b, void* stream);
+/* Software pipelining over batches.  The ViT is frozen (clip.py:454-458: eval() + no_grad), so its forward for batch n+1
+ * does not depend on the optimizer step of batch n.  The workspace holds TWO feature slots (patch rows + mid_feat):
+ * dist_vit_prefetch runs the ViT of the NEXT batch into the spare slot on `stream` (NULL = the handle's own lowest-priority
+ * prefetch stream) after everything already queued on `after` (the stream carrying the step - NULL is the null stream, as
+ * for every `stream` argument of this ABI: the backward that last read that slot and the weight re-pack are there);
+ * dist_vit_adopt (host only) makes
+ * the prefetched slot the current one, i.e. the state after dist_vit_forward of that batch.  The branch forward that
+ * follows waits on the slot's per-layer events, whatever stream produced them. */
+int dist_vit_prefetch(dist_handle* h, const float* video, int b, void* stream, void* after);
+int dist_vit_adopt(dist_handle* h);
 /* DiSTNetwork.forward + cosine logits (dist.py:222-247, clip.py:509-518): -> logits [b,K] fp32,
  * vid_logits [b,E] fp32 (L2-normalised video embedding) */
 int dist_branch_forward(dist_handle* h, const float* text_features, int b, float* logits, float* vid_logits, void* stream);

@@ -244,3 +244,59 @@ def test_grad_ready_hook_covers_the_flat_buffer_once(gpu_lib):
     assert all(slices[i][0] == slices[i + 1][1] for i in range(len(slices) - 1))
     for (b, e), snap in zip(slices, snaps):
         torch.testing.assert_close(snap, ref[b:e], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vit_prefetch_pipeline_equals_the_serial_order(gpu_lib, dtype):
+    """Software pipelining over batches (dist_vit_prefetch / dist_vit_adopt): the frozen ViT of batch n+1 runs into the
+    spare feature slot on the handle's prefetch stream while branch forward / backward / AdamW of batch n run on the
+    caller's stream.  Four training steps over alternating batches must give the same losses, logits and weights as
+    the serial order vit_forward -> branch -> backward -> AdamW (the ViT is frozen: nothing it reads changes)."""
+    from dist_amd import synth, lib as L
+    g, e1, sd, video, text, tgt = build("tiny", 2, dtype)
+    _, e2, *_ = build("tiny", 2, dtype)
+    vids = [video, torch.from_numpy(synth.video(g, 2, seed=7)).cuda()]
+    tgts = [tgt, torch.from_numpy(synth.soft_target(g, 2, seed=9)[0]).cuda()]
+    steps = 4
+
+    def train(eng, pipelined):
+        out = []
+        if pipelined:
+            with pytest.raises(L.DistError):
+                eng.vit_adopt()                                 # nothing prefetched yet
+            eng.vit_forward(vids[0])
+        for n in range(steps):
+            if pipelined:
+                eng.vit_prefetch(vids[(n + 1) % 2])
+            else:
+                eng.vit_forward(vids[n % 2])
+            logits, _ = eng.branch_forward(text)
+            loss, dl = eng.loss(tgts[n % 2])
+            eng.backward(dl)
+            eng.adamw_step(3.2e-4, 1e-4, lr_mult=1.0)
+            out.append((float(loss), logits.clone()))
+            if pipelined:
+                eng.vit_adopt()
+        torch.cuda.synchronize()
+        return out
+
+    a, b_ = train(e1, False), train(e2, True)
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    for (la, ga), (lb, gb) in zip(a, b_):
+        assert abs(la - lb) <= tol["atol"] + tol["rtol"] * abs(la), (la, lb)
+        torch.testing.assert_close(ga, gb, **tol)
+    # same kernels on the same data: only the atomics' summation order in the parameter gradients may differ.  Adam's update
+    # is ~lr*sign(g), so an element whose gradient is ~eps may flip: a handful may be off by up to 2*steps learning rates.
+    diff = (e1.theta - e2.theta).abs()
+    assert float(diff.max()) <= 2 * steps * 3.2e-4 * 1.05 + 1e-6, float(diff.max())
+    frac = float((diff > (2e-6 if dtype == torch.float32 else 1e-4) + 1e-4 * e1.theta.abs()).float().mean())
+    assert frac < (1e-3 if dtype == torch.float32 else 2e-2), frac
+    # the two slots really alternate: feat.0 of the current slot belongs to the batch adopted last
+    e2.vit_forward(vids[steps % 2])
+    ref = e2.debug("feat.0").clone()
+    e2.vit_prefetch(vids[(steps + 1) % 2]); e2.vit_adopt()
+    torch.cuda.synchronize()
+    assert not torch.equal(ref, e2.debug("feat.0"))
+    e2.vit_prefetch(vids[steps % 2]); e2.vit_adopt()
+    torch.cuda.synchronize()
+    torch.testing.assert_close(ref, e2.debug("feat.0"), rtol=0, atol=0)
