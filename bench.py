@@ -23,6 +23,10 @@ import os
 import sys
 import time
 
+# one hardware queue per HIP stream of a rank (caller's stream, two branch / weight-gradient streams, the ViT prefetch stream,
+# the gradient all-reduce stream, RCCL's own): with the default of 4 two of them would share a queue and serialise
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -106,16 +110,19 @@ def main():
     reducer = du.GradReducer(eng, world) if world > 1 else None
     pipelined = not args.no_pipeline
     it = [0]
+    split = int(os.environ.get("DIST_AMD_VIT_SPLIT", g.layers))   # ViT layers issued before the branch forward (the rest before the backward)
 
     def step():
         n = it[0]
         it[0] += 1
         if pipelined:
-            eng.vit_prefetch(videos[(n + 1) % 2])      # frozen ViT of the NEXT batch, beside this batch's branch work
+            eng.vit_prefetch(videos[(n + 1) % 2], layer_end=split)   # frozen ViT of the NEXT batch, beside this batch's branch work
         else:
             eng.vit_forward(videos[n % 2])
         eng.branch_forward(text)
         _, dlogits = eng.loss(tgts[n % 2])
+        if pipelined and split < g.layers:
+            eng.vit_prefetch_more()                    # the remaining ViT layers run beside the backward
         if reducer is not None:
             reducer.backward_and_reduce(dlogits)
         else:
@@ -146,15 +153,23 @@ def main():
         du.all_reduce_max(tt)
         dt = float(tt.item())
 
-    # dominant kernel (256x256x32 LDS-DMA MFMA GEMM of the frozen ViT), HIP events on its own stream
+    # dominant kernel (256x256x32 LDS-DMA MFMA GEMM of the frozen ViT), HIP events on its own stream.
+    #   roofline.achieved / frac : IN SITU, over steps of the timed loop's own schedule - the launch durations include the time the
+    #                              kernel's workgroups wait for CUs held by the branch / backward kernels of the other streams;
+    #   roofline.alone           : the same launches of one frozen-ViT pass with no other stream active (the kernel's own duration).
     roof = None
     if not args.no_roofline:
-        eng.profile_begin()
+        def measure(fn, reps):
+            eng.profile_begin()
+            for _ in range(reps):
+                fn()
+            ms, flops, launches = eng.profile_end()
+            ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            return ach, launches // max(reps, 1), ms * 1e3 / max(launches, 1)
         nprof = min(3, args.steps)
-        for _ in range(nprof):
-            step()
-        ms, flops, launches = eng.profile_end()
-        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        ach, lps, avg_us = measure(step, nprof)
+        torch.cuda.synchronize()
+        ach1, lps1, avg1 = measure(lambda: (eng.vit_forward(videos[0]), torch.cuda.synchronize()), 3)
         # HBM bytes per launch of this kernel: PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes, corrected
         # as MI355X_MICROARCH.md prescribes), collected offline by tools/pmc_pass.sh and committed; null when the file is absent
         traffic = None
@@ -165,8 +180,11 @@ def main():
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "traffic_note": "bytes per launch, mean of the four ViT GEMM shapes (48 of the launches), profiles/r01_pmc_fast_gemm.json",
-                "kernel": "gemm_fast_kernel 256x256x32 LDS-DMA (ViT QKV/out/MLP + large DiST Linears)", "launches_per_step": launches // max(nprof, 1),
-                "avg_launch_us": round(ms * 1e3 / max(launches, 1), 1)}
+                "kernel": "gemm_fast_kernel 256x256x32 LDS-DMA (ViT QKV/out/MLP + large DiST Linears)", "launches_per_step": lps,
+                "avg_launch_us": round(avg_us, 1),
+                "note": "in situ: launch durations while the kernels of the other streams share the CUs (the timed loop's schedule)",
+                "alone": {"achieved": round(ach1, 1), "frac": round(ach1 / PEAK_BF16_TFLOPS, 4), "launches": lps1, "avg_launch_us": round(avg1, 1),
+                          "note": "the launches of one frozen-ViT pass with no other stream active"}}
 
     if rank == 0:
         clips = world * b * args.steps

@@ -108,6 +108,7 @@ struct dist_handle {
     struct FeatSlot {
         void* patches = nullptr; std::vector<void*> feat; std::vector<hipEvent_t> ev_feat; hipEvent_t ev_pre = nullptr;
         int b = 0; bool prefetched = false;
+        int next_layer = 0, pending_b = 0;       // a prefetch pass issued in parts (dist_vit_prefetch_layers)
     } slot[2];
     int cur = 0;
     hipEvent_t ev_vit_done = nullptr, ev_after = nullptr, ev_bpre = nullptr; bool vit_ran = false;
@@ -678,7 +679,7 @@ extern "C" int dist_pack_weights(dist_handle* h, int what, void* stream) {
 // -------------------------------------------------------------------------------------------------------------
 // The frozen ViT of one batch into feature slot `k` on `stream`.  `after` (when ordered_after): a stream whose already queued work must
 // finish first (pipelined use: the backward of the batch that last used this slot, the weight re-pack).
-static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, void* stream, bool ordered_after, void* after) {
+static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, void* stream, bool ordered_after, void* after, int l0, int l1) {
     const dist_config& c = h->cfg;
     Ctx x{h, static_cast<hipStream_t>(stream), c.dtype};
     dist_handle::FeatSlot& S = h->slot[k];
@@ -689,19 +690,23 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
         HIP_CHECK_RET(hipEventRecord(h->ev_after, static_cast<hipStream_t>(after)));
         HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_after, 0));
     }
-    // the ViT-internal scratch (x0, xa, hbuf, qkv, att, mlp) exists once: consecutive ViT passes are ordered, whatever their streams
-    if (h->vit_ran) HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_vit_done, 0));
-    HIP_CHECK_RET(hipEventRecord(S.ev_pre, x.s));                       // everything queued before this pass (re-pack, previous step)
-    RUN(dist_op_patchify(video, S.patches, b, c.frames, c.resolution, c.resolution, c.patch, c.dtype, stream));
-    HIP_CHECK_RET(hipEventRecord(S.ev_feat[c.layers], x.s));           // patch rows ready (temporal stem input)
-    // patch embedding of the frames k = alpha*j only (the reference embeds all T frames and drops the
-    // others at clip.py:284); rows land behind their frame's cls row
-    RUN(gemm(x, S.patches, h->Kp, x.pk(h->conv1.pk.f), rowsQ, d, h->Kp, 1, h->xa, d, nullptr, nullptr, nullptr, nullptr,
-             RM(DIST_RM_STRIDED, c.alpha, N), OM(DIST_OM_INSERTCLS, N)));
-    RUN(dist_k_cls_rows(h->xa, nullptr, x.vs(h->class_emb), b * h->t, L, d, 1, c.dtype, x.s));
-    RUN(ln_fwd(x, h->visual, h->ln_pre, h->xa, h->x0, rowsS, nullptr, nullptr, nullptr, nullptr, x.vs(h->pos_emb), L));
     const void* xin = h->x0;
-    for (int i = 0; i < c.layers; ++i) {
+    if (l0 == 0) {
+        // the ViT-internal scratch (x0, xa, hbuf, qkv, att, mlp) exists once: consecutive ViT passes are ordered, whatever their streams
+        if (h->vit_ran) HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_vit_done, 0));
+        HIP_CHECK_RET(hipEventRecord(S.ev_pre, x.s));                   // everything queued before this pass (re-pack, previous step)
+        RUN(dist_op_patchify(video, S.patches, b, c.frames, c.resolution, c.resolution, c.patch, c.dtype, stream));
+        HIP_CHECK_RET(hipEventRecord(S.ev_feat[c.layers], x.s));       // patch rows ready (temporal stem input)
+        // patch embedding of the frames k = alpha*j only (the reference embeds all T frames and drops the
+        // others at clip.py:284); rows land behind their frame's cls row
+        RUN(gemm(x, S.patches, h->Kp, x.pk(h->conv1.pk.f), rowsQ, d, h->Kp, 1, h->xa, d, nullptr, nullptr, nullptr, nullptr,
+                 RM(DIST_RM_STRIDED, c.alpha, N), OM(DIST_OM_INSERTCLS, N)));
+        RUN(dist_k_cls_rows(h->xa, nullptr, x.vs(h->class_emb), b * h->t, L, d, 1, c.dtype, x.s));
+        RUN(ln_fwd(x, h->visual, h->ln_pre, h->xa, h->x0, rowsS, nullptr, nullptr, nullptr, nullptr, x.vs(h->pos_emb), L));
+    } else {
+        xin = S.feat[l0 - 1];
+    }
+    for (int i = l0; i < l1; ++i) {
         const VitLayer& v = h->vit[i];
         RUN(ln_fwd(x, h->visual, v.ln1, xin, h->hbuf, rowsS, nullptr, nullptr));
         // the QKV GEMM writes [frame][head][q|k|v][L][64] (DIST_OM_HEADS, leading dimension 64): every (frame, head) operand of
@@ -715,9 +720,13 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
         HIP_CHECK_RET(hipEventRecord(S.ev_feat[i], x.s));               // mid_feat[i] complete: the branch may consume it
         xin = S.feat[i];
     }
-    HIP_CHECK_RET(hipEventRecord(h->ev_vit_done, x.s));
-    h->vit_ran = true;
-    S.b = b;
+    S.next_layer = l1;
+    S.pending_b = b;
+    if (l1 == c.layers) {
+        HIP_CHECK_RET(hipEventRecord(h->ev_vit_done, x.s));
+        h->vit_ran = true;
+        S.b = b;
+    }
     return DIST_OK;
 }
 
@@ -731,7 +740,7 @@ static int vit_args_ok(dist_handle* h, const float* video, int b, const char* wh
 extern "C" int dist_vit_forward(dist_handle* h, const float* video, int b, void* stream) {
     RUN(vit_args_ok(h, video, b, "dist_vit_forward"));
     h->slot[h->cur].prefetched = false;
-    RUN(vit_forward_slot(h, video, b, h->cur, stream, false, nullptr));
+    RUN(vit_forward_slot(h, video, b, h->cur, stream, false, nullptr, 0, h->cfg.layers));
     h->fwd_b = b;
     h->branch_b = 0;
     return DIST_OK;
@@ -740,12 +749,28 @@ extern "C" int dist_vit_forward(dist_handle* h, const float* video, int b, void*
 // Software pipelining over batches: the ViT is frozen, so its forward for batch n+1 does not depend on the optimizer step of
 // batch n.  dist_vit_prefetch runs it into the spare feature slot on its own (low-priority) stream while the branch
 // forward / backward / AdamW of batch n run on the caller's stream; dist_vit_adopt makes that slot the current one.
-extern "C" int dist_vit_prefetch(dist_handle* h, const float* video, int b, void* stream, void* after) {
-    RUN(vit_args_ok(h, video, b, "dist_vit_prefetch"));
+extern "C" int dist_vit_prefetch_layers(dist_handle* h, const float* video, int b, int layer_end, void* stream, void* after) {
+    if (!h) return DIST_ERR_ARG;
     const int k = h->cur ^ 1;
-    h->slot[k].prefetched = true;
-    h->slot[k].b = 0;
-    return vit_forward_slot(h, video, b, k, stream ? stream : h->pf, true, after);
+    dist_handle::FeatSlot& S = h->slot[k];
+    int l0 = 0;
+    if (video) {                                       // a new pass into the spare slot
+        RUN(vit_args_ok(h, video, b, "dist_vit_prefetch"));
+        S.prefetched = true;
+        S.b = 0;
+    } else {                                           // continue the pass in flight
+        if (!h->ws) return fail(h, DIST_ERR_UNBOUND, "dist_vit_prefetch_layers before dist_bind");
+        if (!S.prefetched || S.b != 0 || S.pending_b <= 0) return fail(h, DIST_ERR_STATE, "dist_vit_prefetch_layers(video = NULL): no prefetch pass in flight");
+        l0 = S.next_layer;
+        b = S.pending_b;
+    }
+    if (layer_end < l0 || layer_end > h->cfg.layers) return fail(h, DIST_ERR_ARG, "layer_end %d outside [%d, %d]", layer_end, l0, h->cfg.layers);
+    if (!video && layer_end == l0) return DIST_OK;
+    return vit_forward_slot(h, video, b, k, stream ? stream : h->pf, true, after, l0, layer_end);
+}
+extern "C" int dist_vit_prefetch(dist_handle* h, const float* video, int b, void* stream, void* after) {
+    if (!h || !video) return DIST_ERR_ARG;
+    return dist_vit_prefetch_layers(h, video, b, h->cfg.layers, stream, after);
 }
 extern "C" int dist_vit_adopt(dist_handle* h) {
     if (!h) return DIST_ERR_ARG;

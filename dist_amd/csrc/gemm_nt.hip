@@ -5,7 +5,7 @@
 // GEMMs: the A loader resolves (row, tap) -> source row (or the zero padding) on the fly,
 // so no im2col buffer ever exists in HBM.
 //
-// Tile: BM x BN x BK, 256 threads = 4 waves (64-wide), each wave owns a (BM/WM) x (BN/WN)
+// Tile: BM x BN x BK, WM x WN = 4 or 8 waves (64-wide), each wave owns a (BM/WM) x (BN/WN)
 // sub-tile as 16x16 MFMA fragments.  Global -> registers -> LDS double buffer, one barrier
 // per K tile.  LDS rows are padded by 8 elements (16 B bf16) so the 16 rows a 16-lane
 // ds_read_b128 group touches land on 16 distinct 16-B slots of the 256-B bank row.
@@ -17,17 +17,17 @@
 
 namespace {
 
-constexpr int NT = 256;
 constexpr int PAD = 8;
 
 template <typename T, int BM, int BN, int BK, int WM, int WN, bool GENERIC>
-__global__ __launch_bounds__(NT) void gemm_nt_kernel(const dist_gemm_args p) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const dist_gemm_args p) {
+    constexpr int NT = WM * WN * 64;                    // 4 or 8 waves
     constexpr int LD = BK + PAD;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int FM = WTM / 16, FN = WTN / 16;
     constexpr int KV = BK / 8;
     constexpr int A_IT = (BM * KV + NT - 1) / NT, B_IT = (BN * KV + NT - 1) / NT;
-    static_assert(WM * WN == 4, "4 waves");
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* As = reinterpret_cast<T*>(smem);                 // [2][BM][LD]
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const dist_gemm_args p) {
     constexpr int ES = (int)sizeof(T);
     constexpr int ROWB = WTN * ES + 16;                     // padded staging row (bank spread)
     constexpr int VPR = WTN * ES / 16, EPV = 16 / ES;       // 16-byte vectors per row, elements per vector
-    static_assert(4 * WTM * ROWB <= 2 * (BM + BN) * LD * ES, "epilogue staging fits in the operand buffers");
+    static_assert(WM * WN * WTM * ROWB <= 2 * (BM + BN) * LD * ES, "epilogue staging fits in the operand buffers");
     char* ew = smem + wid * (WTM * ROWB);
     T* __restrict__ C = static_cast<T*>(p.C);
     T* __restrict__ C2 = static_cast<T*>(p.C2);
@@ -306,7 +306,7 @@ int launch(const dist_gemm_args& a, hipStream_t s) {
         attr_done = true;
     }
     const long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NT), smem, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(WM * WN * 64), smem, s, a);
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
 }
@@ -315,9 +315,14 @@ template <typename T>
 int dispatch(const dist_gemm_args& a, hipStream_t s) {
     const bool plain = a.amap.mode == DIST_RM_PLAIN && a.omap.mode == DIST_OM_PLAIN && a.taps == 1;
     const bool n96 = (a.N % 96 == 0) && (a.N % 128 != 0);
-    if (n96) return launch<T, 128, 96, 32, 4, 1, true>(a, s);
-    if (plain && a.K % 64 == 0) return launch<T, 128, 128, 64, 2, 2, false>(a, s);
-    return launch<T, 128, 128, 32, 2, 2, true>(a, s);
+    // 8 waves per block (the wave grid is 4x2 / 2x4): half the accumulators, fragments and staging registers per lane, so two
+    // 8-wave blocks (16 waves) share a CU where the 4-wave shapes had 2-3 blocks of 4 (conv3x3 69.6 -> 59.3 us, 384x384 Linear
+    // 48.6 -> 44.8 us, 384->96 Linear 18.3 -> 16.7 us alone; profiles/r01_nt_8wave.md).  DIST_AMD_NT_W8=0 restores the 4-wave shapes
+    // (measurement knob: bit 0 = N % 96 shapes, bit 1 = plain K % 64, bit 2 = generic).
+    static const int w8 = getenv("DIST_AMD_NT_W8") ? atoi(getenv("DIST_AMD_NT_W8")) : 7;
+    if (n96) return (w8 & 1) ? launch<T, 128, 96, 32, 4, 2, true>(a, s) : launch<T, 128, 96, 32, 4, 1, true>(a, s);
+    if (plain && a.K % 64 == 0) return (w8 & 2) ? launch<T, 128, 128, 64, 2, 4, false>(a, s) : launch<T, 128, 128, 64, 2, 2, false>(a, s);
+    return (w8 & 4) ? launch<T, 128, 128, 32, 2, 4, true>(a, s) : launch<T, 128, 128, 32, 2, 2, true>(a, s);
 }
 
 }  // namespace

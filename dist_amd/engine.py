@@ -141,12 +141,18 @@ class Engine:
         self.b = video.shape[0]
         L.check(self.lib.dist_vit_forward(self.h, video.data_ptr(), self.b, ops._stream()), self.h)
 
-    def vit_prefetch(self, video):
+    def vit_prefetch(self, video, layer_end=None):
         """Frozen ViT of the NEXT batch into the spare feature slot, on the handle's lowest-priority prefetch stream, behind
-        everything already queued on the current stream (dist_vit_prefetch).  `video` must stay alive until `vit_adopt`."""
+        everything already queued on the current stream (dist_vit_prefetch).  `video` must stay alive until `vit_adopt`.
+        layer_end < layers issues only the first layers; `vit_prefetch_more` continues the pass later in the step."""
         assert video.dtype == torch.float32 and video.is_contiguous() and video.is_cuda
         self._pf_video = video
-        L.check(self.lib.dist_vit_prefetch(self.h, video.data_ptr(), video.shape[0], None, ops._stream()), self.h)
+        le = self.cfg.layers if layer_end is None else int(layer_end)
+        L.check(self.lib.dist_vit_prefetch_layers(self.h, video.data_ptr(), video.shape[0], le, None, ops._stream()), self.h)
+
+    def vit_prefetch_more(self, layer_end=None):
+        le = self.cfg.layers if layer_end is None else int(layer_end)
+        L.check(self.lib.dist_vit_prefetch_layers(self.h, None, 0, le, None, ops._stream()), self.h)
 
     def vit_adopt(self):
         """The prefetched batch becomes the current one (as after `vit_forward` of it)."""

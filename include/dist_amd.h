@@ -220,6 +220,11 @@ int dist_vit_forward(dist_handle* h, const float* video, int b, void* stream);
  * the prefetched slot the current one, i.e. the state after dist_vit_forward of that batch.  The branch forward that
  * follows waits on the slot's per-layer events, whatever stream produced them. */
 int dist_vit_prefetch(dist_handle* h, const float* video, int b, void* stream, void* after);
+/* The same pass issued in parts, so the caller can spread it over its step (e.g. half beside the branch forward, the rest
+ * beside the backward): video != NULL starts a new pass (patch rows + ViT layers [0, layer_end)); video == NULL continues
+ * the pass in flight up to layer_end, again behind what is queued on `after` at the time of the call.  The pass is
+ * adoptable once layer_end == cfg.layers was reached. */
+int dist_vit_prefetch_layers(dist_handle* h, const float* video, int b, int layer_end, void* stream, void* after);
 int dist_vit_adopt(dist_handle* h);
 /* DiSTNetwork.forward + cosine logits (dist.py:222-247, clip.py:509-518): -> logits [b,K] fp32,
  * vid_logits [b,E] fp32 (L2-normalised video embedding) */

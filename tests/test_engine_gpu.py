@@ -266,12 +266,18 @@ def test_vit_prefetch_pipeline_equals_the_serial_order(gpu_lib, dtype):
                 eng.vit_adopt()                                 # nothing prefetched yet
             eng.vit_forward(vids[0])
         for n in range(steps):
+            split = (n % 2 == 1)                                # odd steps issue the pass in two parts (dist_vit_prefetch_layers)
             if pipelined:
-                eng.vit_prefetch(vids[(n + 1) % 2])
+                eng.vit_prefetch(vids[(n + 1) % 2], layer_end=1 if split else None)
+                if split:
+                    with pytest.raises(L.DistError):
+                        eng.vit_adopt()                             # the pass is not complete yet
             else:
                 eng.vit_forward(vids[n % 2])
             logits, _ = eng.branch_forward(text)
             loss, dl = eng.loss(tgts[n % 2])
+            if pipelined and split:
+                eng.vit_prefetch_more()                         # remaining layers beside the backward
             eng.backward(dl)
             eng.adamw_step(3.2e-4, 1e-4, lr_mult=1.0)
             out.append((float(loss), logits.clone()))
