@@ -62,6 +62,7 @@ class Engine:
         self._text = None
         self._pf_video = None
         self._cur_video = None
+        self._cur_ver = self._pf_ver = -1
         self.b = 0
 
     def __del__(self):
@@ -140,13 +141,19 @@ class Engine:
         assert video.dtype == torch.float32 and video.is_contiguous() and video.is_cuda
         self.b = video.shape[0]
         L.check(self.lib.dist_vit_forward(self.h, video.data_ptr(), self.b, ops._stream()), self.h)
+        self._cur_video, self._cur_ver = video, video._version
+
+    def has_features_for(self, video):
+        """True when the current feature slot already holds the frozen-ViT pass of exactly this tensor (same object,
+        not written since): it was prefetched during the previous step and adopted."""
+        return self._cur_video is video and video._version == self._cur_ver
 
     def vit_prefetch(self, video, layer_end=None):
         """Frozen ViT of the NEXT batch into the spare feature slot, on the handle's lowest-priority prefetch stream, behind
         everything already queued on the current stream (dist_vit_prefetch).  `video` must stay alive until `vit_adopt`.
         layer_end < layers issues only the first layers; `vit_prefetch_more` continues the pass later in the step."""
         assert video.dtype == torch.float32 and video.is_contiguous() and video.is_cuda
-        self._pf_video = video
+        self._pf_video, self._pf_ver = video, video._version
         le = self.cfg.layers if layer_end is None else int(layer_end)
         L.check(self.lib.dist_vit_prefetch_layers(self.h, video.data_ptr(), video.shape[0], le, None, ops._stream()), self.h)
 
@@ -158,7 +165,7 @@ class Engine:
         """The prefetched batch becomes the current one (as after `vit_forward` of it)."""
         L.check(self.lib.dist_vit_adopt(self.h), self.h)
         self.b = self._pf_video.shape[0]
-        self._cur_video, self._pf_video = self._pf_video, None
+        self._cur_video, self._cur_ver, self._pf_video = self._pf_video, self._pf_ver, None
 
     def branch_forward(self, text_features):
         assert text_features.dtype == torch.float32 and text_features.is_contiguous()

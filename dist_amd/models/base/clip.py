@@ -107,7 +107,8 @@ class _DistFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, video, text_features, logit_scale, *dist_params):
         engine.sync_packed(sum(p._version for p in dist_params))
-        engine.vit_forward(video)
+        if not engine.has_features_for(video):            # not prefetched during the previous step (CLIP.prefetch_video)
+            engine.vit_forward(video)
         logits, vid = engine.branch_forward(text_features)
         ctx.engine = engine
         ctx.n = len(dist_params)
@@ -200,9 +201,23 @@ class CLIP(nn.Module):
             image = image.view(bt // self.num_frames, self.num_frames, c, h, w).permute(0, 2, 1, 3, 4)
         return self.forward_video(image, text, others)
 
+    def prefetch_video(self, video):
+        """Software pipelining over batches (dist_vit_prefetch): the ViT is frozen, so the pass over the NEXT batch can run on
+        the engine's low-priority stream beside this batch's branch forward / backward / optimizer step.  Call with the
+        next batch's (already augmented) clip before `forward` of the current one, then `adopt_prefetched()` after the
+        optimizer step; `forward` of that clip then skips its ViT pass.  The tensor must not be written in between."""
+        conv = video.contiguous().float()
+        self.engine.vit_prefetch(conv)
+        self._pf_pair = (video, conv)
+
+    def adopt_prefetched(self):
+        self.engine.vit_adopt()
+        self._cur_pair, self._pf_pair = self._pf_pair, None
+
     def forward_video(self, video, text, others=None):
         text_features, _, others = self.cache_text(text, others)
-        video = video.contiguous().float()
+        pair = getattr(self, "_cur_pair", None)
+        video = pair[1] if (pair is not None and pair[0] is video) else video.contiguous().float()
         logits, vid = _DistFunction.apply(self.engine, video, text_features, self.logit_scale, *self._dist_params)
         return {"logits_per_image": logits, "logits_per_text": logits.t(), "img_logits": None, "vid_logits": vid[:, None, :]}
 

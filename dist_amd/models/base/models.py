@@ -17,3 +17,10 @@ class BaseVideoModel(nn.Module):
 
     def forward(self, x):
         return self.head(self.backbone(x))
+
+    # software pipelining over batches (runs/train.py): frozen-ViT pass of the next batch beside this batch's step
+    def prefetch(self, x_next):
+        self.backbone.base_encoder.prefetch_video(x_next["video"])
+
+    def adopt(self):
+        self.backbone.base_encoder.adopt_prefetched()

@@ -25,9 +25,25 @@ def train_epoch(train_loader, model, model_ema, optimizer, cur_epoch, mixup_fn, 
     data_size = len(train_loader)
     t0 = time.time()
     stats = {}
-    for cur_iter, (inputs, labels, _, meta) in enumerate(train_loader):
-        if mixup_fn is not None:
-            inputs["video"], labels["supervised"] = mixup_fn(inputs["video"], labels["supervised"])
+    # One batch of look-ahead: the loader's next batch is fetched (and mixed) before this batch's step, so the frozen-ViT pass
+    # over it runs beside this step (TRAIN.PIPELINE_VIT, default on; the order of loader / mixup draws is unchanged).
+    pipe = bool(getattr(cfg.TRAIN, "PIPELINE_VIT", True)) and hasattr(model, "prefetch")
+    it = iter(train_loader)
+
+    def fetch():
+        item = next(it, None)
+        if item is not None and mixup_fn is not None:
+            item[0]["video"], item[1]["supervised"] = mixup_fn(item[0]["video"], item[1]["supervised"])
+        return item
+
+    nxt = fetch()
+    cur_iter = -1
+    while nxt is not None:
+        cur_iter += 1
+        inputs, labels, _, meta = nxt
+        nxt = fetch()
+        if pipe and nxt is not None:
+            model.prefetch(nxt[0])
         inputs["texts"] = texts
         lr = optim.get_epoch_lr(cur_epoch + cfg.TRAIN.NUM_FOLDS * float(cur_iter) / data_size, cfg)
         optim.set_lr(optimizer, lr)
@@ -37,6 +53,8 @@ def train_epoch(train_loader, model, model_ema, optimizer, cur_epoch, mixup_fn, 
         loss.backward()
         model.grad_sync.reduce()
         optimizer.step()
+        if pipe and nxt is not None:
+            model.adopt()
         hard = labels["supervised"].argmax(dim=1) if labels["supervised"].dim() == 2 else labels["supervised"]
         top1, top5 = metrics.topk_errors(preds.detach(), hard, (1, 5))
         loss_r, top1, top5 = du.all_reduce([loss.detach(), top1, top5])          # one packed collective, one host sync

@@ -121,3 +121,31 @@ def test_runs_entry_point_trains_and_tests(gpu_lib, tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "top1_acc" in out.stdout and "Finish running" in out.stdout
     assert os.path.isdir(os.path.join(str(tmp_path), "checkpoints"))
+
+
+def test_train_loop_pipelines_the_frozen_vit_without_changing_results(gpu_lib):
+    """runs/train.py with TRAIN.PIPELINE_VIT (look-ahead of one batch: the frozen-ViT pass of batch n+1 runs beside the step
+    of batch n through CLIP.prefetch_video / adopt_prefetched) gives the per-iteration statistics of the serial loop."""
+    sys.path.insert(0, ROOT)
+    from runs import train as T
+
+    def run(pipe):
+        cfg = tiny_cfg("TRAIN.FP32_PARITY", "true", "TRAIN.PIPELINE_VIT", "true" if pipe else "false", "TRAIN.EVAL_PERIOD", "0",
+                       "TRAIN.CHECKPOINT_PERIOD", "0", "OPTIMIZER.MAX_EPOCH", "1")
+        logs = []
+        orig = T.train_epoch
+
+        def spy(*a, **k):
+            return orig(*a, **k, log=logs.append)
+        T.train_epoch = spy
+        try:
+            T.train(cfg)
+        finally:
+            T.train_epoch = orig
+        return logs
+
+    a, b = run(False), run(True)
+    assert len(a) == len(b) == 4
+    for x, y in zip(a, b):
+        assert abs(x["loss"] - y["loss"]) < 1e-4 * max(1.0, abs(x["loss"])), (x, y)
+        assert x["top1_err"] == y["top1_err"] and x["lr"] == y["lr"]
