@@ -302,9 +302,13 @@ int launch(const dist_gemm_tn_args& a, hipStream_t s) {
     }
     const int tiles_i = (a.NI + BI - 1) / BI, tiles_c = (a.K + BJ - 1) / BJ;
     const long tiles = (long)tiles_i * tiles_c * a.taps;
-    // split the reduction so that at most 512 blocks exist: two are co-resident per CU (LDS), so every CU gets the same
-    // share; at least 512 rows per block (every block ends with a tile-size partial store)
-    long msplit = 512 / tiles;
+    // split the reduction so that at most 256 blocks exist (one per CU); at least 512 rows per block (every block ends with a
+    // tile-size partial store).  512 blocks (two co-resident per CU) are 5-10 % faster per launch ALONE, but every split adds a
+    // partial tile that is written and read again (33 MB each way for the 384x768 gradient at 28 splits, against 116 MB of
+    // operands): in the step, where the other streams fill the CUs anyway, 256 blocks are 0.25 ms faster (22.77 / 22.79 ->
+    // 22.52 / 22.53 ms; 384: 22.69, 128: 22.85).
+    static const int max_blocks = getenv("DIST_AMD_TN_BLOCKS") ? atoi(getenv("DIST_AMD_TN_BLOCKS")) : 256;   // measurement knob
+    long msplit = max_blocks / tiles;
     const long max_split = (a.M + 511) / 512;
     if (msplit > max_split) msplit = max_split;
     if (msplit < 1) msplit = 1;
