@@ -48,7 +48,7 @@ DEV int swz(int q) { return (4 - q) & 3; }               // f = {0,3,2,1}
 struct FragSet { bf16x8 a[8]; bf16x8 b[4]; };
 
 template <int NW>
-__global__ __launch_bounds__(Shape<NW>::NT, Shape<NW>::MINB) void gemm_fast_kernel(const dist_gemm_args p) {
+__global__ __launch_bounds__(Shape<NW>::NT, Shape<NW>::MINB) void gemm_fast_kernel(const dist_gemm_args p, const int ngroups) {
     using S = Shape<NW>;
     constexpr int BN = S::BN, STAGES = S::STAGES, AHEAD = S::AHEAD, STAGE_BYTES = S::STAGE_BYTES, PA = S::PA, PB = S::PB, NP = S::NP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -65,7 +65,20 @@ __global__ __launch_bounds__(Shape<NW>::NT, Shape<NW>::MINB) void gemm_fast_kern
         const int q = nblk / 8, r = nblk % 8, x = bid % 8, y = bid / 8;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
     }
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    // Tile order: column tiles in `ngroups` groups, all row tiles of a group before the next group, the group's column tiles
+    // fastest.  With the contiguous XCD ranges above an XCD then works on ONE group for (nearly) its whole share: the group's
+    // weight rows (<= ~2.4 MB) stay in its 4 MB L2 while the activation panels stream through, instead of all of W (3.5 - 4.7 MB
+    // for the QKV / MLP GEMMs) being evicted and re-fetched for every batch of row tiles.
+    int tm, tn;
+    if (ngroups <= 1) { tm = bid / tiles_n; tn = bid % tiles_n; }
+    else {
+        const int gq = tiles_n / ngroups, gr = tiles_n % ngroups;      // the first gr groups hold gq + 1 column tiles
+        const int big = tiles_m * (gq + 1);
+        int g, idg, gsz, g0;
+        if (bid < gr * big) { g = bid / big; idg = bid - g * big; gsz = gq + 1; g0 = g * (gq + 1); }
+        else { const int b2 = bid - gr * big; g = b2 / (tiles_m * gq); idg = b2 - g * (tiles_m * gq); gsz = gq; g0 = gr * (gq + 1) + g * gq; }
+        tm = idg / gsz; tn = g0 + idg % gsz;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int M = (int)p.M, N = p.N, K = p.K;
     const bf16_t* __restrict__ A = static_cast<const bf16_t*>(p.A);
@@ -325,7 +338,25 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
         attr_done = true;
     }
     const long tiles = ((a->M + BM - 1) / BM) * ((a->N + S::BN - 1) / S::BN);
-    hipLaunchKernelGGL(gemm_fast_kernel<NW>, dim3((unsigned)tiles), dim3(S::NT), smem, s, *a);
+    // column-tile groups: as few groups as keep one group's weight rows under ~2.5 MB (DIST_AMD_FAST_NG forces a count; 1 = off)
+    static const int forced_ng = [] { const char* e = getenv("DIST_AMD_FAST_NG"); return e ? atoi(e) : 0; }();
+    const int tiles_n = (a->N + S::BN - 1) / S::BN;
+    int ng = forced_ng > 0 ? forced_ng : 1;
+    if (forced_ng == 0) {
+        // fabric bytes of the launch ~ ng x (activation bytes) + 8 XCDs x (weight bytes) when a group's weight rows stay in L2,
+        // and ~7 re-fetches of W per XCD when they do not (QKV measured: 276 MB = 77 + 8 x 7 x 3.5, profiles/r01_pmc_fast_gemm.md)
+        const double A = (double)a->M * a->K * 2.0, W = (double)a->N * a->K * 2.0;
+        double best = A + 8.0 * W * (W <= 2.5e6 ? 1.0 : 7.0);
+        for (int g = 2; g <= 4 && g <= tiles_n; ++g) {
+            const double wg = (double)((tiles_n + g - 1) / g) * S::BN * a->K * 2.0;
+            if (wg > 2.5e6) continue;
+            const double cost = g * A + 8.0 * W;
+            if (cost < 0.85 * best) { best = cost; ng = g; }
+        }
+    }
+    if (ng > tiles_n) ng = tiles_n;
+    if (ng < 1) ng = 1;
+    hipLaunchKernelGGL(gemm_fast_kernel<NW>, dim3((unsigned)tiles), dim3(S::NT), smem, s, *a, ng);
     HIP_CHECK_RET(hipGetLastError());
     return 1;
 }

@@ -65,13 +65,14 @@ DEV void gather_frag<bf16_t, true>(Frag<bf16_t>& f, const bf16_t* tile, int ld, 
 }
 
 template <typename T, int BI, int BJ, int WI, int WJ, bool TR, bool PLAIN>
-__global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, int chunk, int tiles_i, int tiles_c) {
+__global__ __launch_bounds__(WI * WJ * 64) void gemm_tn_kernel(const dist_gemm_tn_args p, int chunk, int tiles_i, int tiles_c) {
+    constexpr int NT = WI * WJ * 64;             // 4, 6 or 8 waves (shadows the namespace constant used by tn_reduce_kernel)
     constexpr int LDI = BI + PADT, LDJ = BJ + PADT;
     constexpr int WTI = BI / WI, WTJ = BJ / WJ;
     constexpr int FI = WTI / 16, FJ = WTJ / 16;
     constexpr int VI = BI / 8, VJ = BJ / 8;
     constexpr int I_IT = (BR * VI + NT - 1) / NT, J_IT = (BR * VJ + NT - 1) / NT;
-    static_assert(WI * WJ == 4, "4 waves");
+    static_assert(WTI % 16 == 0 && WTJ % 16 == 0, "whole 16x16 fragments per wave");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* Ys = reinterpret_cast<T*>(smem);          // [2][BR][LDI]
@@ -117,13 +118,13 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
     // Loads are UNCONDITIONAL (addresses clamped into the matrices, validity kept as a flag and applied when the tile
     // is written to LDS): with a branch around each load hipcc loses its load counting and waits vmcnt(0) before the LDS
     // writes, which drains the set that was just requested and defeats the 2-deep prefetch.
-    static_assert((BR * VI) % NT == 0 && (BR * VJ) % NT == 0, "whole vectors per thread");
+    // (thread, i) cells past the tile (BR * VI not a multiple of the block size) load a clamped address and are never stored
     struct Regs { Frag<T> a[I_IT], b[J_IT]; unsigned oka, okb; };
     auto gload = [&](Regs& R, int mb) __attribute__((always_inline)) {
         R.oka = 0; R.okb = 0;
 #pragma unroll
         for (int i = 0; i < I_IT; ++i) {
-            const int v = tid + i * NT;
+            const int v = min(tid + i * NT, BR * VI - 1);
             const int m = mb + v / VI, col = i0 + (v % VI) * 8;
             const int mm = min(m, mend - 1), cc = min(col, p.NI - 8);
             const int src = PLAIN ? mm : rowmap_src(p.amap, mm, 0, 1);
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
         }
 #pragma unroll
         for (int i = 0; i < J_IT; ++i) {
-            const int v = tid + i * NT;
+            const int v = min(tid + i * NT, BR * VJ - 1);
             const int m = mb + v / VJ, col = c0 + (v % VJ) * 8;
             const int mm = min(m, mend - 1), cc = min(col, kvec_last);
             const int src = PLAIN ? mm : rowmap_src(p.bmap, mm, tap, p.taps);
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
         for (int i = 0; i < I_IT; ++i) {
             const int v = tid + i * NT;
             if (!((R.oka >> i) & 1u)) frag_zero(R.a[i]);
+            if ((BR * VI) % NT != 0 && v >= BR * VI) continue;
             frag_store(R.a[i], Ys + (buf * BR + v / VI) * LDI + (v % VI) * 8);
             if (do_colsum) {
 #pragma unroll
@@ -155,6 +157,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
         for (int i = 0; i < J_IT; ++i) {
             const int v = tid + i * NT;
             if (!((R.okb >> i) & 1u)) frag_zero(R.b[i]);
+            if ((BR * VJ) % NT != 0 && v >= BR * VJ) continue;
             frag_store(R.b[i], Xs + (buf * BR + v / VJ) * LDJ + (v % VJ) * 8);
         }
     };
@@ -208,6 +211,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
 #pragma unroll
         for (int i = 0; i < I_IT; ++i) {
             const int v = tid + i * NT;
+            if ((BR * VI) % NT != 0 && v >= BR * VI) continue;
 #pragma unroll
             for (int e = 0; e < 8; ++e) red[(v / VI) * BI + (v % VI) * 8 + e] = csum[i][e];
         }
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(const dist_gemm_tn_args p, 
     {
         constexpr int SLD = WTJ + 1;                      // +1 float: conflict-free column writes
         float* st = reinterpret_cast<float*>(smem) + wid * (WTI * SLD);
-        static_assert(4 * WTI * SLD * 4 <= 2 * BR * (LDI + LDJ) * (int)sizeof(T), "atomic staging fits in the operand buffers");
+        static_assert(WI * WJ * WTI * SLD * 4 <= 2 * BR * (LDI + LDJ) * (int)sizeof(T), "atomic staging fits in the operand buffers");
 #pragma unroll
         for (int i = 0; i < FI; ++i)
 #pragma unroll
@@ -318,7 +322,7 @@ int launch(const dist_gemm_tn_args& a, hipStream_t s) {
     dist_gemm_tn_args b = a;
     const bool two_phase = a.partial != nullptr && msplit > 1 && tiles * msplit * (long)(BI * BJ) + msplit * (long)tiles_i * BI <= a.partial_elems;
     if (!two_phase) b.partial = nullptr;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * msplit)), dim3(NT), smem, s, b, chunk, tiles_i, tiles_c);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * msplit)), dim3(WI * WJ * 64), smem, s, b, chunk, tiles_i, tiles_c);
     HIP_CHECK_RET(hipGetLastError());
     if (two_phase) {
         const long total = tiles * (long)(BI * BJ);
@@ -338,6 +342,17 @@ template <typename T, bool TR, bool PLAIN>
 int dispatch2(const dist_gemm_tn_args& a, hipStream_t s) {
     const bool i96 = (a.NI % 96 == 0) && (a.NI % 128 != 0);
     const bool j96 = (a.K % 96 == 0) && (a.K % 128 != 0);
+    // 8 (6 for 96 x 96) waves per tile: half the accumulators / fragments / staging registers per lane of the 4-wave shapes
+    // (216-280 registers: 1-2 blocks of 4 waves per CU; now 119-152: 8 waves per CU in one block).  10-20 % faster per launch
+    // alone (conv3x3 dW 95.5 -> 77.4 us, 384x768 dW 71.9 -> 62.0 us); capping the registers at 128 for two 8-wave blocks spills
+    // and loses (92 us).  DIST_AMD_TN_W8=0: the 4-wave shapes (measurement knob).
+    static const int w8 = getenv("DIST_AMD_TN_W8") ? atoi(getenv("DIST_AMD_TN_W8")) : 1;
+    if (w8) {
+        if (i96 && j96) return launch<T, 96, 96, 3, 2, TR, PLAIN>(a, s);
+        if (i96) return launch<T, 96, 128, 2, 4, TR, PLAIN>(a, s);
+        if (j96) return launch<T, 128, 96, 4, 2, TR, PLAIN>(a, s);
+        return launch<T, 128, 128, 2, 4, TR, PLAIN>(a, s);
+    }
     if (i96 && j96) return launch<T, 96, 96, 2, 2, TR, PLAIN>(a, s);
     if (i96) return launch<T, 96, 128, 2, 2, TR, PLAIN>(a, s);
     if (j96) return launch<T, 128, 96, 2, 2, TR, PLAIN>(a, s);

@@ -35,7 +35,8 @@ print("== NT cold ==")
 for (M, N, K, taps, mode, kw, tag, extra) in [(100352, 96, 96, 9, L.RM_SPATIAL, (14, 0), "conv3x3", "res+act"), (100352, 96, 96, 3, L.RM_SHIFT, (16*196, 196), "conv_t", "act"),
                                                (50432, 384, 768, 1, 0, (0, 0), "in_lin", "res"), (50432, 384, 384, 1, 0, (0, 0), "ffn_fc", "act"),
                                                (50432, 96, 384, 1, 0, (0, 0), "tf_fc1", ""), (50432, 384, 96, 1, 0, (0, 0), "tf_proj", "res"),
-                                               (50432, 768, 768, 1, 0, (0, 0), "vit_out", "res"), (50432, 2304, 768, 1, 0, (0, 0), "vit_qkv", "")]:
+                                               (50432, 768, 768, 1, 0, (0, 0), "vit_out", "res"), (50432, 2304, 768, 1, 0, (0, 0), "vit_qkv", ""),
+                                               (50432, 3072, 768, 1, 0, (0, 0), "vit_fc", "act"), (50432, 768, 3072, 1, 0, (0, 0), "vit_proj", "res")]:
     As = mk(M, K); W = (torch.randn(N, taps * K, device="cuda") * (taps * K) ** -0.5).to(dt)
     Cs, C2s, Rs = mk(M, N), mk(M, N) if "act" in extra else [None] * NSET, mk(M, N) if "res" in extra else [None] * NSET
     bias = torch.randn(N, device="cuda")
