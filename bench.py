@@ -23,10 +23,6 @@ import os
 import sys
 import time
 
-# one hardware queue per HIP stream of a rank (caller's stream, two branch / weight-gradient streams, the ViT prefetch stream,
-# the gradient all-reduce stream, RCCL's own): with the default of 4 two of them would share a queue and serialise
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -94,7 +90,8 @@ def main():
     from dist_amd import distributed as du
     from dist_amd.engine import Engine, config_from_geometry
 
-    if world > 1:
+    force_reducer = bool(os.environ.get("DIST_AMD_FORCE_REDUCER"))    # measurement knob: RCCL group + gradient reducer at world size 1
+    if world > 1 or force_reducer:
         du.init_process_group(rank, world, local_rank)
 
     g = synth.geometry(args.config)
@@ -107,7 +104,7 @@ def main():
     text = torch.from_numpy(synth.text_features(g)).cuda()
     tgts = [torch.from_numpy(synth.soft_target(g, b, seed=3 + rank + 100 * k)[0]).cuda() for k in range(2)]
     lr, wd, mult = 3.2e-5, 1e-4, 10.0      # configs/projects/dist/ssv2/vit-b16-8+16f.yaml:52-58
-    reducer = du.GradReducer(eng, world) if world > 1 else None
+    reducer = du.GradReducer(eng, world) if (world > 1 or force_reducer) else None
     pipelined = not args.no_pipeline
     it = [0]
     split = int(os.environ.get("DIST_AMD_VIT_SPLIT", g.layers))   # ViT layers issued before the branch forward (the rest before the backward)
@@ -209,7 +206,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_reducer:
         du.destroy()
 
 

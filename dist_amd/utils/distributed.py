@@ -34,14 +34,8 @@ def init_process_group(rank, world, local_rank=0, backend=None, init_method=None
     kw = {}
     if backend == "nccl":
         kw["device_id"] = torch.device("cuda", local_rank)
-        try:
-            # the gradient all-reduce runs beside the backward kernels: RCCL's stream gets high priority so its few
-            # workgroups are scheduled as soon as a bucket is ready instead of queueing behind the compute grids
-            opts = dist.ProcessGroupNCCL.Options()
-            opts.is_high_priority_stream = True
-            kw["pg_options"] = opts
-        except Exception:
-            pass
+        # RCCL's internal stream stays at default priority (see GradReducer: a high-priority stream beside the engine's streams
+        # slows the whole step down)
     try:
         dist.init_process_group(backend=backend, init_method=init_method, rank=rank, world_size=world, **kw)
     except TypeError:
@@ -143,8 +137,16 @@ class GradReducer:
         self.world = world
         self.grad_scale = 1.0 / world
         self.bucket_elems = bucket_bytes // 4
-        self.overlap = overlap and world > 1 and torch.cuda.is_available()
-        self.comm = torch.cuda.Stream(priority=-1) if self.overlap else None   # high priority: buckets start as soon as they are ready
+        force = bool(os.environ.get("DIST_AMD_FORCE_REDUCER"))     # measurement knob: the reducer's streams / events at world size 1
+        self.force = force
+        self.overlap = overlap and (world > 1 or force) and torch.cuda.is_available()
+        self.mode = os.environ.get("DIST_AMD_REDUCER_MODE", "")      # measurement knob: noop / hiprio / sync
+        if self.mode == "sync":
+            self.overlap = False
+        # DEFAULT-priority stream.  A high-priority stream beside the engine's four (caller's, two side streams, ViT prefetch) costs
+        # 8-9 ms per step on MI355X (22.6 -> 31.3 ms with the reducer's streams / events alone, no collective issued): measured with
+        # DIST_AMD_FORCE_REDUCER=1 at world size 1, profiles/r01_streams_and_queues.md
+        self.comm = (torch.cuda.Stream(priority=-1) if self.mode == "hiprio" else torch.cuda.Stream()) if self.overlap else None
         self._pending = None          # [begin, end) not yet sent (slices arrive in descending order)
         self._sent = []
         self.n_collectives = 0
@@ -156,7 +158,8 @@ class GradReducer:
         ev.record(torch.cuda.current_stream())
         self.comm.wait_event(ev)
         with torch.cuda.stream(self.comm):
-            dist.all_reduce(self.eng.grads[begin:end])
+            if self.mode != "noop":
+                dist.all_reduce(self.eng.grads[begin:end])
         self.n_collectives += 1
         self._sent.append((begin, end))
 
@@ -176,7 +179,7 @@ class GradReducer:
         self.n_collectives = 0
         self._sent = []
         self.eng.backward(dlogits)
-        if self.world <= 1:
+        if self.world <= 1 and not self.force:
             return
         if not self.overlap:
             dist.all_reduce(self.eng.grads)
