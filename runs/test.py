@@ -41,9 +41,20 @@ class TestMeter:
 @torch.no_grad()
 def perform_test(test_loader, model, test_meter, cfg, texts):
     model.eval()
-    for inputs, labels, video_idx, _ in test_loader:
+    # one batch of look-ahead (TRAIN.PIPELINE_VIT): the frozen-ViT pass of the next batch runs beside the branch forward,
+    # the all-gather and the host-side meter update of this one (dist_vit_prefetch / dist_vit_adopt)
+    pipe = bool(getattr(cfg.TRAIN, "PIPELINE_VIT", True)) and hasattr(model, "prefetch")
+    it = iter(test_loader)
+    nxt = next(it, None)
+    while nxt is not None:
+        inputs, labels, video_idx, _ = nxt
+        nxt = next(it, None)
+        if pipe and nxt is not None:
+            model.prefetch(nxt[0])
         inputs["texts"] = texts
         preds, _ = model(inputs)
+        if pipe and nxt is not None:
+            model.adopt()
         preds, lab, idx = du.all_gather([preds, labels["supervised"], video_idx])
         test_meter.update_stats(preds.cpu(), lab.cpu(), idx.cpu())
     return test_meter.finalize_metrics()

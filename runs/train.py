@@ -71,9 +71,18 @@ def train_epoch(train_loader, model, model_ema, optimizer, cur_epoch, mixup_fn, 
 def eval_epoch(val_loader, model, cur_epoch, cfg, texts):
     model.eval()
     n, c1, c5 = 0, 0.0, 0.0
-    for inputs, labels, _, _ in val_loader:
+    pipe = bool(getattr(cfg.TRAIN, "PIPELINE_VIT", True)) and hasattr(model, "prefetch")
+    it = iter(val_loader)
+    nxt = next(it, None)
+    while nxt is not None:
+        inputs, labels, _, _ = nxt
+        nxt = next(it, None)
+        if pipe and nxt is not None:
+            model.prefetch(nxt[0])             # frozen ViT of the next batch beside this batch's branch forward
         inputs["texts"] = texts
         preds, _ = model(inputs)
+        if pipe and nxt is not None:
+            model.adopt()
         k1, k5 = metrics.topks_correct(preds, labels["supervised"], (1, 5))
         k1, k5 = du.all_reduce([k1, k5], average=False)
         c1 += float(k1); c5 += float(k5); n += preds.size(0) * du.get_world_size()
