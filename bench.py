@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="serial order: ViT forward of a batch inside its own step")
+    ap.add_argument("--no-serial-ref", action="store_true", help="skip the short serial-order reference run after the timed loop")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,6 +151,40 @@ def main():
         du.all_reduce_max(tt)
         dt = float(tt.item())
 
+    # the same calls in the serial order (ViT pass of a batch inside its own step), for reference next to `value`
+    serial = None
+    if pipelined and not args.no_serial_ref:
+        nser = max(1, min(10, args.steps))
+
+        def serial_step(n):
+            eng.vit_forward(videos[n % 2])
+            eng.branch_forward(text)
+            _, dl = eng.loss(tgts[n % 2])
+            if reducer is not None:
+                reducer.backward_and_reduce(dl)
+            else:
+                eng.backward(dl)
+            eng.adamw_step(lr, wd, lr_mult=mult, grad_scale=1.0 / world)
+        for n in range(2):
+            serial_step(n)
+        if world > 1:
+            du.barrier()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for n in range(nser):
+            serial_step(n)
+        torch.cuda.synchronize()
+        if world > 1:
+            du.barrier()
+        dts = time.perf_counter() - ts
+        if world > 1:
+            tt = torch.tensor([dts], device="cuda", dtype=torch.float64)
+            du.all_reduce_max(tt)
+            dts = float(tt.item())
+        serial = {"ms_per_step": round(dts / nser * 1e3, 3), "value": round(world * b * nser / dts, 2), "steps": nser,
+                  "note": "same kernels, ViT forward of a batch issued inside its own step (python bench.py --no-pipeline)"}
+        eng.vit_forward(videos[it[0] % 2])             # pipeline prologue again for the roofline steps below
+
     # dominant kernel (256x256x32 LDS-DMA MFMA GEMM of the frozen ViT), HIP events on its own stream.
     #   roofline.achieved / frac : IN SITU, over steps of the timed loop's own schedule - the launch durations include the time the
     #                              kernel's workgroups wait for CUs held by the branch / backward kernels of the other streams;
@@ -201,6 +236,8 @@ def main():
         if gf:
             out["path_tflops_per_gpu"] = round(value / world * gf / 1e3, 1)
             out["path_mfma_frac"] = round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4)
+        if serial:
+            out["serial_order"] = serial
         if roof:
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
