@@ -42,7 +42,12 @@ struct Lin {                                 // y = x W^T + bias, W [N][K] (opti
 };
 struct LNp { long w = -1, b = -1; int C = 0; };
 
-struct VitLayer { LNp ln1, ln2; Lin qkv, out, fc, proj; };
+struct VitLayer {
+    LNp ln1, ln2; Lin qkv, out, fc, proj;
+    // LayerNorm fold (DIST_EPI_LNFOLD): W diag(gamma) in bf16 (packed-buffer element offsets), column sums and folded biases
+    long pk_fold_qkv = -1, pk_fold_fc = -1;
+    float *cs_qkv = nullptr, *b_qkv = nullptr, *cs_fc = nullptr, *b_fc = nullptr;
+};
 struct DistLayer {
     LNp tn_ln; Lin tn_fc1, tn_fc2;           // TemporalNet
     Lin in_lin, i2t, t2i; long cls_token = -1;
@@ -101,6 +106,8 @@ struct dist_handle {
     size_t ws_bytes = 0;
     // workspace
     void *patches, *x0, *xa, *hbuf, *qkv, *att, *mlp;
+    float* lnstats = nullptr;                    // [2][rowsS] mean / rstd of the LayerNorm folded into the next ViT GEMM
+    bool vit_fold = false;                       // ln_1 -> in_proj and ln_2 -> c_fc folded (bf16, shapes the LDS-DMA GEMM takes)
     std::vector<void*> feat;
     // Two feature slots (patch rows + the 12 mid_feat tensors + their events): the frozen ViT of the NEXT batch can fill the
     // spare slot (dist_vit_prefetch) while the branch forward / backward of the current batch read the other one.
@@ -271,6 +278,10 @@ void build_tables(dist_handle* h) {
         v.ln2 = make_ln(h, 1, p + "ln_2.", d);
         v.fc = make_lin(h, 1, p + "mlp.c_fc.", 4 * d, d, 1, 0, false, {4 * d, d});
         v.proj = make_lin(h, 1, p + "mlp.c_proj.", d, 4 * d, 1, 0, false, {d, 4 * d});
+        if (c.dtype == DIST_BF16) {
+            v.pk_fold_qkv = pk_alloc(h, (long)3 * d * d);
+            v.pk_fold_fc = pk_alloc(h, (long)4 * d * d);
+        }
     }
     add_param(h, 1, "visual.ln_post.weight", {d});
     add_param(h, 1, "visual.ln_post.bias", {d});
@@ -379,6 +390,11 @@ size_t layout_ws(dist_handle* h, char* base) {
     for (int k = 0; k < 2; ++k) h->slot[k].patches = T_(rowsX, h->Kp);
     h->x0 = T_(rowsS, d); h->xa = T_(rowsS, d); h->hbuf = T_(rowsS, d);
     h->qkv = T_(rowsS, 3 * d); h->att = T_(rowsS, d); h->mlp = T_(rowsS, 4 * d);
+    h->lnstats = F_(2 * rowsS);
+    for (int i = 0; i < c.layers; ++i) {
+        VitLayer& v = h->vit[i];
+        v.cs_qkv = F_(3 * d); v.b_qkv = F_(3 * d); v.cs_fc = F_(4 * d); v.b_fc = F_(4 * d);
+    }
     for (int k = 0; k < 2; ++k) {
         h->slot[k].feat.resize(c.layers);
         for (int i = 0; i < c.layers; ++i) h->slot[k].feat[i] = T_(rowsS, d);
@@ -469,6 +485,35 @@ int gemm(const Ctx& c, const void* A, int lda, const void* W, long M, int N, int
 }
 
 // weight gradient of a Lin into the flat grads buffer, in the reference parameter layout
+// C = epi(LN(A) . W^T) with the LayerNorm folded into the GEMM (DIST_EPI_LNFOLD): A holds the RAW rows, Wf = W diag(gamma),
+// stats = [2][M] mean / rstd, colsum / biasf from dist_op_ln_fold.  Returns 1 when the LDS-DMA kernel took it, 0 when the shape
+// is not eligible (the caller runs LayerNorm + GEMM instead), < 0 on error.
+int gemm_lnfold(const Ctx& c, const void* A, int lda, const void* Wf, long M, int N, int K, void* C, int ldc, const float* biasf,
+                const float* stats, const float* colsum, void* C2, dist_outmap om = OM()) {
+    dist_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.B = Wf; g.C = C; g.C2 = C2; g.bias = biasf; g.bias2 = colsum; g.aux = stats;
+    g.M = M; g.N = N; g.K = K; g.taps = 1;
+    g.lda = lda; g.ldb = K; g.ldc = ldc; g.ldc2 = ldc; g.ldres = ldc; g.ldaux = ldc;
+    g.amap = RM(); g.omap = om;
+    g.flags = DIST_EPI_BIAS | DIST_EPI_LNFOLD | (C2 ? DIST_EPI_ACT2 : 0);
+    g.dtype = c.dtype;
+    if (!dist_k_gemm_fast_eligible(&g)) return 0;
+    dist_handle* h = c.h;
+    if (h->prof_on) {
+        if (h->prof_n + 2 > (int)h->prof_ev.size()) {
+            for (int i = 0; i < 256; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return DIST_ERR_STATE; h->prof_ev.push_back(e); }
+        }
+        hipEventRecord(h->prof_ev[h->prof_n], c.s);
+    }
+    const int rc = dist_op_gemm_nt(&g, c.s);
+    if (h->prof_on) {
+        hipEventRecord(h->prof_ev[h->prof_n + 1], c.s);
+        h->prof_n += 2;
+        h->prof_flops += 2.0 * (double)M * N * K;
+    }
+    return rc < 0 ? rc : 1;
+}
 int wgrad(const Ctx& c, const Lin& l, const void* dY, int ld_dy, const void* X, int ldx, long M,
           dist_rowmap am = RM(), dist_rowmap bm = RM(), int style = 0, bool with_bias = false) {
     dist_gemm_tn_args g;
@@ -673,6 +718,20 @@ extern "C" int dist_pack_weights(dist_handle* h, int what, void* stream) {
     else if (what == 2) { first = h->nblk_visual; count = nblk - h->nblk_visual; }
     else if (what != 3) return fail(h, DIST_ERR_ARG, "dist_pack_weights: what must be 1, 2 or 3");
     RUN(dist_k_pack(descs, blk_desc, blk_first, first, count, h->theta, h->visual, dst, h->cfg.dtype, s));
+    // frozen ViT: ln_1 -> attn.in_proj and ln_2 -> mlp.c_fc folded (W diag(gamma), column sums, folded biases); DIST_AMD_LNFOLD=0: off
+    static const bool fold_on = !(getenv("DIST_AMD_LNFOLD") && atoi(getenv("DIST_AMD_LNFOLD")) == 0);
+    h->vit_fold = false;
+    if ((what & 1) && h->cfg.dtype == DIST_BF16 && fold_on && h->vit.size() && h->vit[0].cs_qkv) {
+        const int d = h->cfg.width;
+        for (VitLayer& v : h->vit) {
+            char* base = h->packed + h->packed_hdr;
+            RUN(dist_op_ln_fold(h->visual + v.qkv.w, h->visual + v.qkv.bias, h->visual + v.ln1.w, h->visual + v.ln1.b,
+                                base + (size_t)v.pk_fold_qkv * h->es, v.cs_qkv, v.b_qkv, 3 * d, d, s));
+            RUN(dist_op_ln_fold(h->visual + v.fc.w, h->visual + v.fc.bias, h->visual + v.ln2.w, h->visual + v.ln2.b,
+                                base + (size_t)v.pk_fold_fc * h->es, v.cs_fc, v.b_fc, 4 * d, d, s));
+        }
+        h->vit_fold = true;
+    }
     return DIST_OK;
 }
 
@@ -708,14 +767,32 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
     }
     for (int i = l0; i < l1; ++i) {
         const VitLayer& v = h->vit[i];
-        RUN(ln_fwd(x, h->visual, v.ln1, xin, h->hbuf, rowsS, nullptr, nullptr));
         // the QKV GEMM writes [frame][head][q|k|v][L][64] (DIST_OM_HEADS, leading dimension 64): every (frame, head) operand of
-        // the attention kernel is one contiguous block instead of 128-byte pieces at a 3d row stride
-        RUN(gemm(x, h->hbuf, d, x.pk(v.qkv.pk.f), rowsS, 3 * d, d, 1, h->qkv, 64, x.vs(v.qkv.bias), nullptr, nullptr, nullptr, RM(), OM(DIST_OM_HEADS, L, h->heads)));
+        // the attention kernel is one contiguous block instead of 128-byte pieces at a 3d row stride.
+        // LayerNorm fold: ln_1 only computes the row statistics (reads 77 MB, writes 0.4 MB); the GEMM consumes the raw rows with
+        // W diag(gamma) and normalises in its epilogue - the normalised tensor is never written or read back.
+        int folded = 0;
+        if (h->vit_fold) {
+            RUN(ln_fwd(x, h->visual, v.ln1, xin, nullptr, rowsS, h->lnstats, h->lnstats + rowsS));
+            folded = gemm_lnfold(x, xin, d, x.pk(v.pk_fold_qkv), rowsS, 3 * d, d, h->qkv, 64, v.b_qkv, h->lnstats, v.cs_qkv, nullptr, OM(DIST_OM_HEADS, L, h->heads));
+            if (folded < 0) return fail(h, folded, "folded QKV GEMM failed");
+        }
+        if (!folded) {
+            RUN(ln_fwd(x, h->visual, v.ln1, xin, h->hbuf, rowsS, nullptr, nullptr));
+            RUN(gemm(x, h->hbuf, d, x.pk(v.qkv.pk.f), rowsS, 3 * d, d, 1, h->qkv, 64, x.vs(v.qkv.bias), nullptr, nullptr, nullptr, RM(), OM(DIST_OM_HEADS, L, h->heads)));
+        }
         RUN(dist_op_attention(h->qkv, h->att, b * h->t, L, h->heads, DIST_QKV_HEADS, c.dtype, stream));
         RUN(gemm(x, h->att, d, x.pk(v.out.pk.f), rowsS, d, d, 1, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr));
-        RUN(ln_fwd(x, h->visual, v.ln2, h->xa, h->hbuf, rowsS, nullptr, nullptr));
-        RUN(gemm(x, h->hbuf, d, x.pk(v.fc.pk.f), rowsS, 4 * d, d, 1, nullptr, 4 * d, x.vs(v.fc.bias), nullptr, nullptr, h->mlp));
+        folded = 0;
+        if (h->vit_fold) {
+            RUN(ln_fwd(x, h->visual, v.ln2, h->xa, nullptr, rowsS, h->lnstats, h->lnstats + rowsS));
+            folded = gemm_lnfold(x, h->xa, d, x.pk(v.pk_fold_fc), rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, h->lnstats, v.cs_fc, h->mlp);
+            if (folded < 0) return fail(h, folded, "folded MLP GEMM failed");
+        }
+        if (!folded) {
+            RUN(ln_fwd(x, h->visual, v.ln2, h->xa, h->hbuf, rowsS, nullptr, nullptr));
+            RUN(gemm(x, h->hbuf, d, x.pk(v.fc.pk.f), rowsS, 4 * d, d, 1, nullptr, 4 * d, x.vs(v.fc.bias), nullptr, nullptr, h->mlp));
+        }
         RUN(gemm(x, h->mlp, 4 * d, x.pk(v.proj.pk.f), rowsS, d, 4 * d, 1, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr));
         HIP_CHECK_RET(hipEventRecord(S.ev_feat[i], x.s));               // mid_feat[i] complete: the branch may consume it
         xin = S.feat[i];

@@ -235,6 +235,27 @@ __global__ __launch_bounds__(Shape<NW>::NT, Shape<NW>::MINB) void gemm_fast_kern
             const int n = nw + j * 16 + lg * 4 + r;
             bias4[j][r] = ((flags & DIST_EPI_BIAS) && n < N) ? p.bias[n] : 0.f;
         }
+    if (flags & DIST_EPI_LNFOLD) {
+        // LayerNorm folded into this GEMM: A held the raw rows, B = W diag(gamma); v = rstd[m] * (acc - mean[m] * colsum[n]) (+ bias')
+        const float* __restrict__ st = static_cast<const float*>(p.aux);     // [2][M]: mean, rstd
+        float cs4[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = nw + j * 16 + lg * 4 + r;
+                cs4[j][r] = n < N ? p.bias2[n] : 0.f;
+            }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = min(mw + i * 16 + li, M - 1);
+            const float mean = st[m], rstd = st[(long)M + m];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = rstd * (acc[i][j][r] - mean * cs4[j][r]);
+        }
+    }
     const bool act_only = (flags & DIST_EPI_ACT2) && !C;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -303,7 +324,9 @@ static bool fast_common_ok(const dist_gemm_args* a) {
     if (a->dtype != DIST_BF16 || a->taps != 1) return false;
     if (a->amap.mode != DIST_RM_PLAIN && a->amap.mode != DIST_RM_STRIDED && a->amap.mode != DIST_RM_SKIPCLS) return false;
     if (a->omap.mode != DIST_OM_PLAIN && a->omap.mode != DIST_OM_INSERTCLS && a->omap.mode != DIST_OM_HEADS) return false;
-    if ((a->flags & DIST_EPI_MULG) || a->bias2) return false;
+    if (a->flags & DIST_EPI_MULG) return false;
+    if (a->flags & DIST_EPI_LNFOLD) { if (!a->aux || !a->bias2 || a->amap.mode != DIST_RM_PLAIN) return false; }
+    else if (a->bias2) return false;
     if (a->K % BK || a->K < 4 * BK || a->N % 64 || a->M < 1024) return false;
     if (a->lda % 8 || a->ldb % 8 || a->ldc % 8 || a->ldc2 % 8 || a->ldres % 8) return false;
     if (a->omap.mode == DIST_OM_HEADS && (a->flags & (DIST_EPI_RES | DIST_EPI_ACT2))) return false;

@@ -549,3 +549,37 @@ int dist_k_bcast_rows(const float* table, void* out, long rows, int C, int dtype
         return (int)DIST_OK;
     });
 }
+
+// ---- LayerNorm -> Linear fold (DIST_EPI_LNFOLD): one block per output row n ----------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, bf16_t* __restrict__ Wp, float* __restrict__ colsum,
+                                                      float* __restrict__ bias_out, int K) {
+    __shared__ float red[2][4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    float s = 0.f, b = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        const float w = W[(long)n * K + k];
+        const bf16_t wp = (bf16_t)(w * gamma[k]);
+        Wp[(long)n * K + k] = wp;
+        s += (float)wp;                                     // the sum of what the MFMA will actually multiply
+        b += w * beta[k];
+    }
+    s = wave_sum(s, 64); b = wave_sum(b, 64);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = b; }
+    __syncthreads();
+    if (tid == 0) {
+        colsum[n] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        bias_out[n] = (bias ? bias[n] : 0.f) + (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+}  // namespace
+
+extern "C" int dist_op_ln_fold(const float* W, const float* bias, const float* gamma, const float* beta, void* Wp, float* colsum, float* bias_out,
+                               int N, int K, void* stream) {
+    if (!W || !gamma || !beta || !Wp || !colsum || !bias_out || N <= 0 || K <= 0) return DIST_ERR_ARG;
+    hipLaunchKernelGGL(ln_fold_kernel, dim3(N), dim3(256), 0, static_cast<hipStream_t>(stream), W, bias, gamma, beta,
+                       static_cast<bf16_t*>(Wp), colsum, bias_out, K);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const dist_ln_args p) {
             if (p.mean) p.mean[row] = mean;
             if (p.rstd) p.rstd[row] = rstd;
         }
+        if (!Y) continue;                                   // statistics only (the consumer GEMM normalises: DIST_EPI_LNFOLD)
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int v = lr + it * LPR;
@@ -261,7 +262,8 @@ void launch_by_lpr(int lpr, int grid, hipStream_t s, const A& a, K4 k4, K16 k16,
 }
 
 extern "C" int dist_op_layernorm(const dist_ln_args* a, void* stream) {
-    if (!a || !a->x || !a->y || !a->w || !a->b || a->rows <= 0) return DIST_ERR_ARG;
+    if (!a || !a->x || !a->w || !a->b || a->rows <= 0) return DIST_ERR_ARG;
+    if (!a->y && (!a->mean || !a->rstd || a->y2)) return DIST_ERR_ARG;      // y == NULL: statistics only
     if (a->C % 8 || a->C > 1024 || a->C < 8) return DIST_ERR_ARG;
     if (a->y2 && (!a->w2 || !a->b2)) return DIST_ERR_ARG;
     if (a->addend && a->addend_period <= 0) return DIST_ERR_ARG;

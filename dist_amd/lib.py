@@ -10,7 +10,7 @@ F32, BF16 = 0, 1
 RM_PLAIN, RM_SHIFT, RM_SPATIAL, RM_STRIDED, RM_SKIPCLS = range(5)
 OM_PLAIN, OM_DUP, OM_INSERTCLS, OM_SPLITCOLS, OM_HEADS = range(5)
 QKV_ROWS, QKV_HEADS = 0, 1
-EPI_BIAS, EPI_MULG, EPI_RES, EPI_ACT2, EPI_MULG_POST = 1, 2, 4, 8, 16
+EPI_BIAS, EPI_MULG, EPI_RES, EPI_ACT2, EPI_MULG_POST, EPI_LNFOLD = 1, 2, 4, 8, 16, 32
 
 
 class RowMap(C.Structure):
@@ -134,6 +134,7 @@ def load():
     _sig(lib, "dist_profile_end", argtypes=[C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)])
     _sig(lib, "dist_debug_tensor", argtypes=[C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)])
     _sig(lib, "dist_op_gemm_nt", argtypes=[C.POINTER(GemmArgs), C.c_void_p])
+    _sig(lib, "dist_op_ln_fold", argtypes=[C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p])
     _sig(lib, "dist_op_gemm_tn", argtypes=[C.POINTER(GemmTnArgs), C.c_void_p])
     _sig(lib, "dist_op_layernorm", argtypes=[C.POINTER(LnArgs), C.c_void_p])
     _sig(lib, "dist_op_layernorm_bwd", argtypes=[C.POINTER(LnBwdArgs), C.c_void_p])

@@ -36,7 +36,7 @@ def outmap(mode=L.OM_PLAIN, p0=0, p1=0, p2=0):
 
 
 def gemm_nt(A, B, M, N, K, *, taps=1, bias=None, res=None, aux=None, amap=None, omap=None,
-            C_out=None, C2_out=None, lda=None, ldc=None, mulg_post=False):
+            C_out=None, C2_out=None, lda=None, ldc=None, mulg_post=False, lnfold=None):
     """C[omap(m)][n] = epi(sum_tap sum_k A[amap(m,tap)][k] B[n][tap*K+k]); returns None (writes C_out / C2_out)."""
     lib = L.load()
     a = L.GemmArgs()
@@ -55,8 +55,23 @@ def gemm_nt(A, B, M, N, K, *, taps=1, bias=None, res=None, aux=None, amap=None, 
     a.flags = (L.EPI_BIAS if bias is not None else 0) | (L.EPI_RES if res is not None else 0) | \
               (L.EPI_MULG if aux is not None else 0) | (L.EPI_ACT2 if C2_out is not None else 0) | \
               (L.EPI_MULG_POST if mulg_post else 0)
+    if lnfold is not None:          # (stats fp32 [2][M] = mean then rstd, colsum fp32 [N]): LayerNorm folded into the GEMM (EPI_LNFOLD)
+        stats, colsum = lnfold
+        a.aux, a.bias2 = _p(stats), _p(colsum)
+        a.flags |= L.EPI_LNFOLD
     a.dtype = _dt(A)
     L.check(lib.dist_op_gemm_nt(C.byref(a), _stream()))
+
+
+def ln_fold(W, bias, gamma, beta):
+    """LayerNorm -> Linear fold (dist_op_ln_fold): returns (Wp bf16 [N,K] = W*gamma, colsum fp32 [N], bias' fp32 [N])."""
+    lib = L.load()
+    N, K = W.shape
+    Wp = torch.empty(N, K, dtype=torch.bfloat16, device=W.device)
+    colsum = torch.empty(N, dtype=torch.float32, device=W.device)
+    bout = torch.empty(N, dtype=torch.float32, device=W.device)
+    L.check(lib.dist_op_ln_fold(_p(W), _p(bias), _p(gamma), _p(beta), _p(Wp), _p(colsum), _p(bout), N, K, _stream()))
+    return Wp, colsum, bout
 
 
 def gemm_tn(A, B, out, M, NI, K, *, taps=1, amap=None, bmap=None, so_i=None, so_tap=None, so_outer=1, inner=1, use_tr=1, colsum=None, partial=None):
@@ -80,7 +95,8 @@ def gemm_tn(A, B, out, M, NI, K, *, taps=1, amap=None, bmap=None, so_i=None, so_
 def layernorm(x, w, b, *, y=None, y2=None, w2=None, b2=None, addend=None, period=0, mean=None, rstd=None, eps=1e-5):
     lib = L.load()
     rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
-    y = torch.empty_like(x) if y is None else y
+    stats_only = y is False         # y=False: statistics only (mean / rstd), no normalised output
+    y = None if stats_only else (torch.empty_like(x) if y is None else y)
     a = L.LnArgs()
     a.x, a.y, a.y2 = _p(x), _p(y), _p(y2)
     a.w, a.b, a.w2, a.b2 = _p(w), _p(b), _p(w2), _p(b2)

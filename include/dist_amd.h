@@ -59,7 +59,14 @@ enum {
     DIST_EPI_MULG = 2,   /* v *= quickgelu'(aux[dest][n])   (backward through an activation) */
     DIST_EPI_RES = 4,    /* v += res[dest][n] */
     DIST_EPI_ACT2 = 8,   /* C2[dest][n] = quickgelu(v)  (C, if non-null, keeps the pre-activation) */
-    DIST_EPI_MULG_POST = 16  /* with MULG: the derivative factor is applied AFTER bias and residual: v = (acc + bias + res) * quickgelu'(aux) */
+    DIST_EPI_MULG_POST = 16, /* with MULG: the derivative factor is applied AFTER bias and residual: v = (acc + bias + res) * quickgelu'(aux) */
+    DIST_EPI_LNFOLD = 32     /* the GEMM consumes the RAW rows x of a LayerNorm-then-Linear pair (clip.py:160-176: ln_1 -> attn
+                              * in_proj, ln_2 -> mlp.c_fc) and normalises in the epilogue:
+                              *   v = rstd[m] * (acc - mean[m] * colsum[n]) + bias[n]
+                              * with B = W * diag(gamma) (bf16), colsum[n] = sum_k B[n][k], bias[n] = b[n] + sum_k W[n][k] beta[k]
+                              * (dist_op_ln_fold prepares all three).  `aux` carries the row statistics as fp32 [2][M] (mean, then
+                              * rstd: dist_op_layernorm with y = NULL), `bias2` carries colsum.  Large plain bf16 GEMMs only
+                              * (the 256x256 LDS-DMA kernel); not combinable with MULG. */
 };
 
 /* C[omap(m)][n] = epi( sum_tap sum_k A[amap(m,tap)][k] * B[n][tap*K + k] )
@@ -75,6 +82,10 @@ typedef struct dist_gemm_args {
     const float* bias2;   /* optional second bias, added with `bias` (two Linears evaluated as one GEMM over side-by-side inputs) */
 } dist_gemm_args;
 int dist_op_gemm_nt(const dist_gemm_args* a, void* stream);
+/* prepares a LayerNorm-then-Linear pair for DIST_EPI_LNFOLD: Wp[n][k] = bf16(W[n][k] * gamma[k]) (overwrites the packed
+ * forward-layout copy of W), colsum[n] = sum_k float(Wp[n][k]), bias_out[n] = bias[n] + sum_k W[n][k] * beta[k] */
+int dist_op_ln_fold(const float* W, const float* bias, const float* gamma, const float* beta, void* Wp, float* colsum, float* bias_out,
+                    int N, int K, void* stream);
 
 /* out[i*so_i + tap*so_tap + (c/inner)*so_outer + c%inner] += sum_m A[amap(m)][i] * B[bmap(m,tap)][c]
  * (fp32 atomics; weight gradients of every Linear / Conv3d on the path, autograd in the reference) */

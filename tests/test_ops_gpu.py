@@ -438,3 +438,40 @@ def test_adamw(gpu_lib):
         opt.step()
         ops.adamw(p, g, m, v, segs, step)
         torch.testing.assert_close(p, torch.cat([q.data for q in ps]), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(2048, 768, 768, False), (1500, 2304, 768, False), (1111, 1024, 256, True)])
+def test_layernorm_folded_into_gemm(gpu_lib, M, N, K, act):
+    """DIST_EPI_LNFOLD (reference clip.py:160-176: ln_1 -> attn in_proj, ln_2 -> mlp.c_fc): the GEMM consumes the RAW rows with
+    W diag(gamma) and normalises in its epilogue, v = rstd (acc - mean colsum) + (b + W beta); `dist_op_layernorm` with y = NULL
+    only produces the row statistics.  Checked against fp32 LayerNorm -> Linear (-> QuickGELU) on the same bf16 inputs."""
+    from dist_amd import ops, lib as L
+    torch.manual_seed(0)
+    dev = "cuda"
+    x = (torch.randn(M, K, device=dev) * 1.7 + 0.8 + 3.0 * torch.randn(1, K, device=dev)).to(torch.bfloat16)   # rows far from zero mean
+    W = torch.randn(N, K, device=dev) * K ** -0.5
+    bias = torch.randn(N, device=dev)
+    gamma = 1.0 + 0.3 * torch.randn(K, device=dev)
+    beta = 0.2 * torch.randn(K, device=dev)
+    Wp, cs, bf = ops.ln_fold(W, bias, gamma, beta)
+    torch.testing.assert_close(Wp.float(), (W * gamma).to(torch.bfloat16).float(), rtol=0, atol=0)
+    torch.testing.assert_close(cs, Wp.float().sum(1), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(bf, bias + W @ beta, rtol=1e-5, atol=1e-4)
+    stats = torch.empty(2 * M, device=dev)
+    assert ops.layernorm(x, gamma, beta, y=False, mean=stats[:M], rstd=stats[M:]) is None
+    xf = x.float()
+    mu, var = xf.mean(1), xf.var(1, unbiased=False)
+    torch.testing.assert_close(stats[:M], mu, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(stats[M:], torch.rsqrt(var + 1e-5), rtol=1e-4, atol=1e-5)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    out2 = torch.empty_like(out) if act else None
+    ops.gemm_nt(x, Wp, M, N, K, bias=bf, lnfold=(stats, cs), C_out=out, C2_out=out2)
+    ref = torch.nn.functional.layer_norm(xf, (K,), gamma, beta, 1e-5) @ W.t() + bias
+    scale = float(ref.abs().max())
+    assert float((out.float() - ref).abs().max()) < 1.5e-2 * scale, float((out.float() - ref).abs().max()) / scale
+    if act:
+        refa = ref * torch.sigmoid(1.702 * ref)
+        assert float((out2.float() - refa).abs().max()) < 1.5e-2 * scale
+    # not combinable with the activation-derivative epilogue, and only for shapes the LDS-DMA kernel takes
+    with pytest.raises(L.DistError):
+        ops.gemm_nt(x[:512], Wp, 512, N, K, bias=bf, lnfold=(stats, cs), C_out=out[:512])
