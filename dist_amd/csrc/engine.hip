@@ -106,6 +106,7 @@ struct dist_handle {
     size_t ws_bytes = 0;
     // workspace
     void *patches, *x0, *xa, *hbuf, *qkv, *att, *mlp;
+    float *lnstats2 = nullptr, *lnstats3 = nullptr; int dummy = 0, dummy_reps = 1;   // perturbation experiment (DIST_AMD_DUMMY)
     float* lnstats = nullptr;                    // [2][rowsS] mean / rstd of the LayerNorm folded into the next ViT GEMM
     bool vit_fold = false;                       // ln_1 -> in_proj and ln_2 -> c_fc folded (bf16, shapes the LDS-DMA GEMM takes)
     std::vector<void*> feat;
@@ -390,7 +391,7 @@ size_t layout_ws(dist_handle* h, char* base) {
     for (int k = 0; k < 2; ++k) h->slot[k].patches = T_(rowsX, h->Kp);
     h->x0 = T_(rowsS, d); h->xa = T_(rowsS, d); h->hbuf = T_(rowsS, d);
     h->qkv = T_(rowsS, 3 * d); h->att = T_(rowsS, d); h->mlp = T_(rowsS, 4 * d);
-    h->lnstats = F_(2 * rowsS);
+    h->lnstats = F_(2 * rowsS); h->lnstats2 = F_(2 * rowsS); h->lnstats3 = F_(2 * rowsS);
     for (int i = 0; i < c.layers; ++i) {
         VitLayer& v = h->vit[i];
         v.cs_qkv = F_(3 * d); v.b_qkv = F_(3 * d); v.cs_fc = F_(4 * d); v.b_fc = F_(4 * d);
@@ -617,6 +618,8 @@ extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
     build_tables(h);
     h->ws_bytes = layout_ws(h, nullptr);
     if (const char* e = getenv("DIST_AMD_SERIAL")) h->serial = atoi(e);
+    if (const char* e = getenv("DIST_AMD_DUMMY")) h->dummy = atoi(e);
+    if (const char* e = getenv("DIST_AMD_DUMMY_REPS")) h->dummy_reps = atoi(e);
     *out = h;
     return DIST_OK;
 }
@@ -795,6 +798,7 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
         }
         RUN(gemm(x, h->mlp, 4 * d, x.pk(v.proj.pk.f), rowsS, d, 4 * d, 1, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr));
         HIP_CHECK_RET(hipEventRecord(S.ev_feat[i], x.s));               // mid_feat[i] complete: the branch may consume it
+        if (h->dummy & 1) for (int r = 0; r < h->dummy_reps; ++r) RUN(ln_fwd(x, h->visual, v.ln1, S.feat[i], nullptr, rowsS, h->lnstats2, h->lnstats2 + rowsS));
         xin = S.feat[i];
     }
     S.next_layer = l1;
@@ -1193,6 +1197,8 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         RUN(wgrad(xb2, l.tn_fc1, q.dz, Ct, w.U, Ct, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 1, true));
         RUN(merge_b2());
         HIP_CHECK_RET(hipEventRecord(h->ev_b_done[i], B));
+        if (h->dummy & 2) for (int r = 0; r < h->dummy_reps; ++r) RUN(ln_fwd(x, h->visual, h->vit[0].ln1, h->feat[i], nullptr, rowsS, h->lnstats2, h->lnstats2 + rowsS));
+        if (h->dummy & 4) for (int r = 0; r < h->dummy_reps; ++r) RUN(ln_fwd(xb, h->visual, h->vit[0].ln1, h->feat[i], nullptr, rowsS, h->lnstats3, h->lnstats3 + rowsS));
         RUN(gemm(x, q.dz, Ct, x.pk(l.tn_fc1.pk.b), rowsX, Ct, Ct, l.tn_fc1.taps, q.dU, Ct, nullptr, nullptr, nullptr, nullptr,
                  RM(DIST_RM_SHIFT, T * N, N, -1)));
         RUN(ln_bwd(x, l.tn_ln, w.X, w.tn_mean, w.tn_rstd, q.dU, q.dXo, false, rowsX, nullptr, nullptr, q.dp));   // dX_i = dp + LN'(dU)
