@@ -236,6 +236,15 @@ def main():
         if gf:
             out["path_tflops_per_gpu"] = round(value / world * gf / 1e3, 1)
             out["path_mfma_frac"] = round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4)
+        # whole-step HBM-side traffic from the committed PMC passes (tools/pmc_step.sh: FETCH_SIZE x2 + WRITE_SIZE over every kernel of
+        # one step, Infinity-Cache hits included) against this run's step time; null when the file is absent or the config differs
+        tj = os.path.join(ROOT, "profiles", "r01_pmc_step_traffic.json")
+        if args.config == "b16_8+16f" and b == 32 and os.path.exists(tj):
+            with open(tj) as f:
+                tr = json.load(f)
+            gbps = tr["bytes_per_step"] / (dt / args.steps) / 1e9
+            out["hbm"] = {"bytes_per_step_per_gpu": tr["bytes_per_step"], "achieved_gbps_per_gpu": round(gbps, 1), "peak_gbps": 8000.0,
+                          "frac": round(gbps / 8000.0, 4), "source": "profiles/r01_pmc_step_traffic.{md,json}"}
         if serial:
             out["serial_order"] = serial
         if roof:

@@ -23,3 +23,9 @@ print(f"total HBM-side traffic {tot/1e3:.2f} GB per step (reads x2-corrected {su
 print("| MB/step | read MB | write MB | launches/step | MB/launch | kernel |\n|---|---|---|---|---|---|")
 for r in rows[:24]:
     print(f"| {r[0]:.0f} | {r[1]:.0f} | {r[2]:.0f} | {r[3]:.1f} | {r[0]/max(r[3],1e-9):.1f} | `{r[4]}` |")
+if len(sys.argv) > 4:
+    import json
+    json.dump({"bytes_per_step": round(tot * 1e6), "read_bytes_per_step": round(sum(r[1] for r in rows) * 1e6),
+               "write_bytes_per_step": round(sum(r[2] for r in rows) * 1e6), "steps": steps,
+               "note": "rocprofv3 --pmc FETCH_SIZE (x2: gfx950 tallies 128-byte requests at 64 B) and --pmc WRITE_SIZE, separate passes, all kernels of python3 bench.py --steps 2 --warmup 1 --no-pipeline; includes Infinity-Cache hits"},
+              open(sys.argv[4], "w"))
