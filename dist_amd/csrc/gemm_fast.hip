@@ -16,6 +16,7 @@
 //  * epilogue through LDS: the residual tile is fetched and the result tile is written as full
 //    128-byte rows (16 B per lane), instead of 8-byte pieces at a row stride.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -47,153 +48,12 @@ DEV int swz(int q) { return (4 - q) & 3; }               // f = {0,3,2,1}
 
 struct FragSet { bf16x8 a[8]; bf16x8 b[4]; };
 
-template <int NW>
-__global__ __launch_bounds__(Shape<NW>::NT, Shape<NW>::MINB) void gemm_fast_kernel(const dist_gemm_args p, const int ngroups) {
-    using S = Shape<NW>;
-    constexpr int BN = S::BN, STAGES = S::STAGES, AHEAD = S::AHEAD, STAGE_BYTES = S::STAGE_BYTES, PA = S::PA, PB = S::PB, NP = S::NP;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid / S::WN, wn = wid % S::WN;         // 2 x WN waves
+// Epilogue shared by the two main loops: accumulators -> (LayerNorm fold, bias, residual, QuickGELU) -> bf16 -> per-wave LDS
+// staging -> full 128-byte rows.  acc[i][j][r] is output row mw + i*16 + (lane & 15), column nw + j*16 + (lane >> 4)*4 + r.
+DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, const int wid, const int lane,
+                       const int m0, const int n0, const int wm, const int wn) {
     const int li = lane & 15, lg = lane >> 4;
-
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tiles_m = (int)((p.M + BM - 1) / BM);
-    const int nblk = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {   // bijective XCD remap: consecutive ids share an XCD (and its L2); n-tiles of one A panel adjacent
-        const int q = nblk / 8, r = nblk % 8, x = bid % 8, y = bid / 8;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
-    }
-    // Tile order: column tiles in `ngroups` groups, all row tiles of a group before the next group, the group's column tiles
-    // fastest.  With the contiguous XCD ranges above an XCD then works on ONE group for (nearly) its whole share: the group's
-    // weight rows (<= ~2.4 MB) stay in its 4 MB L2 while the activation panels stream through, instead of all of W (3.5 - 4.7 MB
-    // for the QKV / MLP GEMMs) being evicted and re-fetched for every batch of row tiles.
-    int tm, tn;
-    if (ngroups <= 1) { tm = bid / tiles_n; tn = bid % tiles_n; }
-    else {
-        const int gq = tiles_n / ngroups, gr = tiles_n % ngroups;      // the first gr groups hold gq + 1 column tiles
-        const int big = tiles_m * (gq + 1);
-        int g, idg, gsz, g0;
-        if (bid < gr * big) { g = bid / big; idg = bid - g * big; gsz = gq + 1; g0 = g * (gq + 1); }
-        else { const int b2 = bid - gr * big; g = b2 / (tiles_m * gq); idg = b2 - g * (tiles_m * gq); gsz = gq; g0 = gr * (gq + 1) + g * gq; }
-        tm = idg / gsz; tn = g0 + idg % gsz;
-    }
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int M = (int)p.M, N = p.N, K = p.K;
-    const bf16_t* __restrict__ A = static_cast<const bf16_t*>(p.A);
-    const bf16_t* __restrict__ B = static_cast<const bf16_t*>(p.B);
-
-    // ---- LDS-DMA source addresses: each wave moves PA x 1 KB of A and PB x 1 KB of B per stage.
-    // 1 KB = 16 rows x 64 B; lane l lands at row (l>>2), physical chunk (l&3) and therefore fetches
-    // logical chunk (l&3) ^ f((l>>4)&3) of that row.
-    const int lrow = lane >> 2;
-    const int lchunk = (lane & 3) ^ swz((lane >> 4) & 3);
-    // 32-bit byte offsets from the (wave-uniform) matrix bases: half the address registers of 64-bit pointers, and the
-    // loads take the scalar-base + vector-offset form (the launcher checks that both matrices are < 2 GB)
-    const char* Ab = reinterpret_cast<const char*>(A);
-    const char* Bb = reinterpret_cast<const char*>(B);
-    unsigned ga[PA], gb[PB];
-#pragma unroll
-    for (int j = 0; j < PA; ++j) {
-        const int r = (wid * PA + j) * 16 + lrow;
-        ga[j] = ((unsigned)rowmap_src(p.amap, min(m0 + r, M - 1), 0, 1) * (unsigned)p.lda + lchunk * 8) * 2u;   // plain / strided / skip-cls rows
-    }
-#pragma unroll
-    for (int j = 0; j < PB; ++j) {
-        const int r = (wid * PB + j) * 16 + lrow;
-        gb[j] = ((unsigned)min(n0 + r, N - 1) * (unsigned)p.ldb + lchunk * 8) * 2u;
-    }
-    // piece q of tile kt: q < PA -> this wave's A row groups, then its B row groups
-    auto dma_piece = [&](int kt, int q) __attribute__((always_inline)) {
-        char* sb = smem + (kt % STAGES) * STAGE_BYTES;
-        const int k0 = kt * BK;
-        if (q < PA) __builtin_amdgcn_global_load_lds((gbl_ptr)(Ab + (ga[q] + (unsigned)k0 * 2u)), (lds_ptr)(sb + (wid * PA + q) * 1024), 16, 0, 0);
-        else __builtin_amdgcn_global_load_lds((gbl_ptr)(Bb + (gb[q - PA] + (unsigned)k0 * 2u)), (lds_ptr)(sb + A_BYTES + (wid * PB + (q - PA)) * 1024), 16, 0, 0);
-    };
-    auto stage_issue = [&](int kt) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < NP; ++q) dma_piece(kt, q);
-    };
-
-    // fragment read offsets (bytes within a stage): row r, logical chunk lg
-    int a_off[8], b_off[4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int r = wm * 128 + i * 16 + li;
-        a_off[i] = r * 64 + ((lg ^ swz((r >> 2) & 3)) << 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = wn * 64 + j * 16 + li;
-        b_off[j] = A_BYTES + r * 64 + ((lg ^ swz((r >> 2) & 3)) << 4);
-    }
-    auto frag_read = [&](FragSet& f, int kt) {
-        const char* sb = smem + (kt % STAGES) * STAGE_BYTES;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) f.b[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) f.a[i] = *reinterpret_cast<const bf16x8*>(sb + a_off[i]);
-    };
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nk = K / BK;                                // >= 4 (checked by the launcher)
-    // one pipeline step: `cur` holds tile kt (already in registers); land tile kt+1, start reading it into
-    // `nxt`, and multiply tile kt in four groups of 8 MFMAs with ONE LDS-DMA piece of tile kt+3 issued
-    // behind each group: the DMA issue cost (~60-180 cycles per piece) hides under the matrix pipe instead
-    // of sitting between the barrier and the first MFMA.
-    auto step = [&](FragSet& cur, FragSet& nxt, int kt) __attribute__((always_inline)) {
-        const bool more = kt + 1 < nk, refill = kt + AHEAD < nk;
-        if (more) {
-            // DMA groups outstanding here: tiles kt+1 .. kt+AHEAD-1 (NP pieces each); kt+1 must be complete
-            if (AHEAD == 3 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                 // tile kt+1 landed for every wave; tile kt-1 no longer read by anyone
-            frag_read(nxt, kt + 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // 32 MFMAs in NP groups with ONE LDS-DMA piece of tile kt+AHEAD issued behind each group
-        // group g multiplies a-fragments [lo(g), lo(g+1)): 2,2,2,2 (NP = 4) or 2,2,1,1,1,1 (NP = 6)
-        auto lo = [](int g) { return NP == 4 ? 2 * g : (g < 2 ? 2 * g : g + 2); };
-#pragma unroll
-        for (int g = 0; g < NP; ++g) {
-#pragma unroll
-            for (int i = lo(g); i < lo(g + 1); ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.b[j], cur.a[i], acc[i][j], 0, 0, 0);   // swapped: D[n][m]
-            __builtin_amdgcn_sched_barrier(0);
-            if (refill) dma_piece(kt + AHEAD, g);         // overwrites the stage of tile kt-1
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // the LDS reads of tile kt+1 are waited for HERE, behind the MFMAs of tile kt (the empty asm consumes the
-        // registers, so hipcc places its lgkmcnt wait at this point and treats them as ready afterwards; without
-        // it the loop-carried reads make it wait lgkmcnt(0) in front of the MFMAs, serialising read and multiply)
-        asm volatile("" : "+v"(nxt.a[0]), "+v"(nxt.a[1]), "+v"(nxt.a[2]), "+v"(nxt.a[3]), "+v"(nxt.a[4]), "+v"(nxt.a[5]),
-                          "+v"(nxt.a[6]), "+v"(nxt.a[7]), "+v"(nxt.b[0]), "+v"(nxt.b[1]), "+v"(nxt.b[2]), "+v"(nxt.b[3]));
-    };
-
-#pragma unroll
-    for (int st = 0; st < AHEAD; ++st) stage_issue(st);
-    if (AHEAD == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // tile 0 landed (this wave's share)
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    static_assert((AHEAD == 3 && NP == 4) || (AHEAD == 2 && NP == 6), "the counted waits above are written for these two shapes");
-    __builtin_amdgcn_s_barrier();
-    FragSet f0, f1;
-    frag_read(f0, 0);
-    asm volatile("" : "+v"(f0.a[0]), "+v"(f0.a[1]), "+v"(f0.a[2]), "+v"(f0.a[3]), "+v"(f0.a[4]), "+v"(f0.a[5]),
-                      "+v"(f0.a[6]), "+v"(f0.a[7]), "+v"(f0.b[0]), "+v"(f0.b[1]), "+v"(f0.b[2]), "+v"(f0.b[3]));
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        step(f0, f1, kt);
-        step(f1, f0, kt + 1);
-    }
-    if (kt < nk) step(f0, f1, kt);
-
+    const int M = (int)p.M, N = p.N;
     // ---- epilogue through LDS: per-wave region of 128 rows x 128 B, 16-B chunk c of row r at chunk c ^ (r & 7) ----
     __syncthreads();                                      // every wave is done reading the operand ring
     char* ew = smem + wid * EPI_BYTES;
@@ -318,6 +178,336 @@ __global__ __launch_bounds__(Shape<NW>::NT, Shape<NW>::MINB) void gemm_fast_kern
     }
 }
 
+// block id -> (row tile, column tile): bijective XCD remap (consecutive ids share an XCD and its L2), then column tiles in
+// `ngroups` groups, all row tiles of a group before the next group, the group's column tiles fastest.  With the contiguous
+// XCD ranges an XCD works on ONE group for (nearly) its whole share: the group's weight rows (<= ~2.4 MB) stay in its 4 MB
+// L2 while the activation panels stream through, instead of all of W (3.5 - 4.7 MB for the QKV / MLP GEMMs) being evicted
+// and re-fetched for every batch of row tiles.
+DEV void fast_tile(const dist_gemm_args& p, const int ngroups, const int BN, int& tm, int& tn) {
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (int)((p.M + BM - 1) / BM);
+    const int nblk = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8, x = bid % 8, y = bid / 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    if (ngroups <= 1) { tm = bid / tiles_n; tn = bid % tiles_n; }
+    else {
+        const int gq = tiles_n / ngroups, gr = tiles_n % ngroups;      // the first gr groups hold gq + 1 column tiles
+        const int big = tiles_m * (gq + 1);
+        int g, idg, gsz, g0;
+        if (bid < gr * big) { g = bid / big; idg = bid - g * big; gsz = gq + 1; g0 = g * (gq + 1); }
+        else { const int b2 = bid - gr * big; g = b2 / (tiles_m * gq); idg = b2 - g * (tiles_m * gq); gsz = gq; g0 = gr * (gq + 1) + g * gq; }
+        tm = idg / gsz; tn = g0 + idg % gsz;
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(Shape<NW>::NT, Shape<NW>::MINB) void gemm_fast_kernel(const dist_gemm_args p, const int ngroups) {
+    using S = Shape<NW>;
+    constexpr int BN = S::BN, STAGES = S::STAGES, AHEAD = S::AHEAD, STAGE_BYTES = S::STAGE_BYTES, PA = S::PA, PB = S::PB, NP = S::NP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / S::WN, wn = wid % S::WN;         // 2 x WN waves
+    const int li = lane & 15, lg = lane >> 4;
+
+    int tm, tn;
+    fast_tile(p, ngroups, BN, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int M = (int)p.M, N = p.N, K = p.K;
+    const bf16_t* __restrict__ A = static_cast<const bf16_t*>(p.A);
+    const bf16_t* __restrict__ B = static_cast<const bf16_t*>(p.B);
+
+    // ---- LDS-DMA source addresses: each wave moves PA x 1 KB of A and PB x 1 KB of B per stage.
+    // 1 KB = 16 rows x 64 B; lane l lands at row (l>>2), physical chunk (l&3) and therefore fetches
+    // logical chunk (l&3) ^ f((l>>4)&3) of that row.
+    const int lrow = lane >> 2;
+    const int lchunk = (lane & 3) ^ swz((lane >> 4) & 3);
+    // 32-bit byte offsets from the (wave-uniform) matrix bases: half the address registers of 64-bit pointers, and the
+    // loads take the scalar-base + vector-offset form (the launcher checks that both matrices are < 2 GB)
+    const char* Ab = reinterpret_cast<const char*>(A);
+    const char* Bb = reinterpret_cast<const char*>(B);
+    unsigned ga[PA], gb[PB];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const int r = (wid * PA + j) * 16 + lrow;
+        ga[j] = ((unsigned)rowmap_src(p.amap, min(m0 + r, M - 1), 0, 1) * (unsigned)p.lda + lchunk * 8) * 2u;   // plain / strided / skip-cls rows
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        const int r = (wid * PB + j) * 16 + lrow;
+        gb[j] = ((unsigned)min(n0 + r, N - 1) * (unsigned)p.ldb + lchunk * 8) * 2u;
+    }
+    // piece q of tile kt: q < PA -> this wave's A row groups, then its B row groups
+    auto dma_piece = [&](int kt, int q) __attribute__((always_inline)) {
+        char* sb = smem + (kt % STAGES) * STAGE_BYTES;
+        const int k0 = kt * BK;
+        if (q < PA) __builtin_amdgcn_global_load_lds((gbl_ptr)(Ab + (ga[q] + (unsigned)k0 * 2u)), (lds_ptr)(sb + (wid * PA + q) * 1024), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((gbl_ptr)(Bb + (gb[q - PA] + (unsigned)k0 * 2u)), (lds_ptr)(sb + A_BYTES + (wid * PB + (q - PA)) * 1024), 16, 0, 0);
+    };
+    auto stage_issue = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) dma_piece(kt, q);
+    };
+
+    // fragment read offsets (bytes within a stage): row r, logical chunk lg
+    int a_off[8], b_off[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = wm * 128 + i * 16 + li;
+        a_off[i] = r * 64 + ((lg ^ swz((r >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = wn * 64 + j * 16 + li;
+        b_off[j] = A_BYTES + r * 64 + ((lg ^ swz((r >> 2) & 3)) << 4);
+    }
+    auto frag_read = [&](FragSet& f, int kt) {
+        const char* sb = smem + (kt % STAGES) * STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f.b[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f.a[i] = *reinterpret_cast<const bf16x8*>(sb + a_off[i]);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = K / BK;                                // >= 4 (checked by the launcher)
+    // one pipeline step: `cur` holds tile kt (already in registers); land tile kt+1, start reading it into
+    // `nxt`, and multiply tile kt in four groups of 8 MFMAs with ONE LDS-DMA piece of tile kt+3 issued
+    // behind each group: the DMA issue cost (~60-180 cycles per piece) hides under the matrix pipe instead
+    // of sitting between the barrier and the first MFMA.
+    auto step = [&](FragSet& cur, FragSet& nxt, int kt) __attribute__((always_inline)) {
+        const bool more = kt + 1 < nk, refill = kt + AHEAD < nk;
+        if (more) {
+            // DMA groups outstanding here: tiles kt+1 .. kt+AHEAD-1 (NP pieces each); kt+1 must be complete
+            if (AHEAD == 3 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                 // tile kt+1 landed for every wave; tile kt-1 no longer read by anyone
+            frag_read(nxt, kt + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // 32 MFMAs in NP groups with ONE LDS-DMA piece of tile kt+AHEAD issued behind each group
+        // group g multiplies a-fragments [lo(g), lo(g+1)): 2,2,2,2 (NP = 4) or 2,2,1,1,1,1 (NP = 6)
+        auto lo = [](int g) { return NP == 4 ? 2 * g : (g < 2 ? 2 * g : g + 2); };
+#pragma unroll
+        for (int g = 0; g < NP; ++g) {
+#pragma unroll
+            for (int i = lo(g); i < lo(g + 1); ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.b[j], cur.a[i], acc[i][j], 0, 0, 0);   // swapped: D[n][m]
+            __builtin_amdgcn_sched_barrier(0);
+            if (refill) dma_piece(kt + AHEAD, g);         // overwrites the stage of tile kt-1
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the LDS reads of tile kt+1 are waited for HERE, behind the MFMAs of tile kt (the empty asm consumes the
+        // registers, so hipcc places its lgkmcnt wait at this point and treats them as ready afterwards; without
+        // it the loop-carried reads make it wait lgkmcnt(0) in front of the MFMAs, serialising read and multiply)
+        asm volatile("" : "+v"(nxt.a[0]), "+v"(nxt.a[1]), "+v"(nxt.a[2]), "+v"(nxt.a[3]), "+v"(nxt.a[4]), "+v"(nxt.a[5]),
+                          "+v"(nxt.a[6]), "+v"(nxt.a[7]), "+v"(nxt.b[0]), "+v"(nxt.b[1]), "+v"(nxt.b[2]), "+v"(nxt.b[3]));
+    };
+
+#pragma unroll
+    for (int st = 0; st < AHEAD; ++st) stage_issue(st);
+    if (AHEAD == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // tile 0 landed (this wave's share)
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    static_assert((AHEAD == 3 && NP == 4) || (AHEAD == 2 && NP == 6), "the counted waits above are written for these two shapes");
+    __builtin_amdgcn_s_barrier();
+    FragSet f0, f1;
+    frag_read(f0, 0);
+    asm volatile("" : "+v"(f0.a[0]), "+v"(f0.a[1]), "+v"(f0.a[2]), "+v"(f0.a[3]), "+v"(f0.a[4]), "+v"(f0.a[5]),
+                      "+v"(f0.a[6]), "+v"(f0.a[7]), "+v"(f0.b[0]), "+v"(f0.b[1]), "+v"(f0.b[2]), "+v"(f0.b[3]));
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        step(f0, f1, kt);
+        step(f1, f0, kt + 1);
+    }
+    if (kt < nk) step(f0, f1, kt);
+
+    fast_epilogue(p, acc, smem, wid, lane, m0, n0, wm, wn);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 main loop, two wave groups half a phase apart (cdna_hip_programming.md §5 "8-phase" schedule).
+//
+// In the kernel above the two waves of a SIMD run the same instruction stream in step, so both sit in their LDS-DMA issue
+// and fragment reads at the same time and the matrix pipe idles (profiles/r01_gemm_ablation.md: the loop ran at ~57 % MFMA
+// issue).  Here waves 0-3 (group 0) and waves 4-7 (group 1, the SIMD partners of 0-3) are offset by ONE barrier: every
+// barrier interval has one group in a "load" section (fragment ds_reads for its next 16 MFMAs + 2 LDS-DMA pieces) and the
+// other in a "multiply" section (16 MFMAs on one quadrant of its 128 x 64 sub-tile).
+//
+// LDS: two K-tile buffers of 64 KB; a buffer holds four half-tiles of 128 rows x 128 B:
+//   A-h0 / A-h1: for wave row wr, rows wr*128 + q*64 + [0, 64)  (local row wr*64 + rr)  -> quadrant q of every wave
+//   B-h0 / B-h1: for wave col wc, cols wc*64 + q*32 + [0, 32)   (local row wc*32 + rr)
+// so a half-tile is read in exactly ONE phase of a K-tile and is free for re-staging right after it:
+//   phase 0: read A-h0, B-h0 -> MFMA quadrant (0,0)      stage B-h1 of tile t+1
+//   phase 1: read B-h1       -> MFMA (0,1)               stage A-h1 of tile t+1
+//   phase 2: read A-h1       -> MFMA (1,1)               stage A-h0 of tile t+2
+//   phase 3: (no reads)      -> MFMA (1,0)               stage B-h0 of tile t+2
+// 16-byte chunk c of local row r lives at chunk c ^ ((r >> 1) & 7): a 16-lane ds_read_b128 service group then touches 16
+// distinct slots of the 256-B bank row (rows are 128 B); the LDS-DMA image is lane-linear, so the same involution sits
+// on the per-lane SOURCE address.
+//
+// Ordering rules (L(g) = load section of global phase g, run by group 0 in barrier interval 2g and by group 1 in 2g+1):
+//   RAW: a half-tile is read in L(g) only if every wave waited for its own pieces of it (counted vmcnt) at the end of
+//        L(g-1) or earlier - that wait is followed by a barrier both groups pass before any read of L(g);
+//   WAR: a half-tile last read in L(g) is re-staged in L(g+2) or later (group 1's reads of L(g) retire early in interval
+//        2g+2; group 0's L(g+2) starts at interval 2g+4).
+// Per-wave LDS-DMA issue order is A-h0, B-h0, B-h1, A-h1 of a tile, two pieces each; `vmcnt(8)` at the end of every load
+// section leaves the last four half-tiles in flight and retires exactly the one that the NEXT phase reads.
+constexpr int P8_BK = 64;
+constexpr int P8_HALF = 128 * P8_BK * 2;                  // 16 KB
+constexpr int P8_BUF = 4 * P8_HALF;                       // 64 KB per K-tile
+constexpr int P8_A0 = 0, P8_A1 = P8_HALF, P8_B0 = 2 * P8_HALF, P8_B1 = 3 * P8_HALF;
+
+template <int N> DEV void wait_vm() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else static_assert(N < 0, "unsupported count");
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_args p, const int ngroups) {
+    constexpr int BN = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;                // 2 x 4 waves; wr is also the wave group
+    const int li = lane & 15, lg = lane >> 4;
+
+    int tm, tn;
+    fast_tile(p, ngroups, BN, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int M = (int)p.M, N = p.N, K = p.K;
+    const char* Ab = static_cast<const char*>(p.A);
+    const char* Bb = static_cast<const char*>(p.B);
+
+    // ---- LDS-DMA sources: per half-tile this wave moves local rows 16*wid + 8*j + (lane >> 3), j = 0, 1 (1 KB each)
+    unsigned ga[2][2], gb[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int lr = 16 * wid + 8 * j + (lane >> 3);
+            const int lc = (lane & 7) ^ ((lr >> 1) & 7);
+            const int arow = (lr >> 6) * 128 + q * 64 + (lr & 63);
+            const int bcol = (lr >> 5) * 64 + q * 32 + (lr & 31);
+            ga[q][j] = ((unsigned)rowmap_src(p.amap, min(m0 + arow, M - 1), 0, 1) * (unsigned)p.lda + lc * 8) * 2u;
+            gb[q][j] = ((unsigned)min(n0 + bcol, N - 1) * (unsigned)p.ldb + lc * 8) * 2u;
+        }
+    // stage half-tile `slot` (P8_A0 ...) of K-tile kt into buffer kt & 1
+    auto stage = [&](const int slot, const int kt) __attribute__((always_inline)) {
+        char* sb = smem + (kt & 1) * P8_BUF + slot + wid * 2048;
+        const unsigned k2 = (unsigned)kt * (P8_BK * 2);
+        const bool isA = slot == P8_A0 || slot == P8_A1;
+        const int q = (slot == P8_A1 || slot == P8_B1) ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (isA) __builtin_amdgcn_global_load_lds((gbl_ptr)(Ab + (ga[q][j] + k2)), (lds_ptr)(sb + j * 1024), 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds((gbl_ptr)(Bb + (gb[q][j] + k2)), (lds_ptr)(sb + j * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets inside a half-tile: local row (wr*64 | wc*32) + f*16 + li, logical chunk kk*4 + lg
+    int a_rd[2], b_rd[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int pc = ((kk * 4 + lg) ^ ((li >> 1) & 7)) << 4;
+        a_rd[kk] = (wr * 64 + li) * 128 + pc;
+        b_rd[kk] = (wc * 32 + li) * 128 + pc;
+    }
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    auto read_a = [&](const int buf, const int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fa[i][kk] = *reinterpret_cast<const bf16x8*>(smem + buf * P8_BUF + slot + a_rd[kk] + i * 2048);
+    };
+    auto read_b = [&](bf16x8 (&f)[2][2], const int buf, const int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) f[j][kk] = *reinterpret_cast<const bf16x8*>(smem + buf * P8_BUF + slot + b_rd[kk] + j * 2048);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // multiply section: barrier (the reads and this wave's counted DMA wait are behind it), 16 MFMAs, barrier
+    auto multiply = [&](const int qa, const int qb, const bf16x8 (&f)[2][2]) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[qa * 4 + i][qb * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[j][kk], fa[i][kk], acc[qa * 4 + i][qb * 2 + j], 0, 0, 0);   // swapped: D[n][m]
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // one K-tile = four phases.  The tail is selected by wave-uniform scalars instead of peeled copies of the body (seven
+    // instantiations with different wait counts made hipcc rename accumulators across their joins and spill INSIDE the
+    // loop - and a scratch reload is a vmcnt(0)): s1 = tile kt+1 exists, s2 = tile kt+2 exists.
+    const int nk = K / P8_BK;                             // >= 2 (checked by the launcher)
+    auto ktile = [&](auto buf_c, const int kt) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(buf_c)::value;
+        const bool s1 = kt + 1 < nk, s2 = kt + 2 < nk;
+        // phase 0
+        read_b(fb0, BUF, P8_B0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(BUF, P8_A0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s1) { stage(P8_B1, kt + 1); wait_vm<8>(); } else wait_vm<2>();
+        multiply(0, 0, fb0);
+        // phase 1
+        read_b(fb1, BUF, P8_B1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s1) { stage(P8_A1, kt + 1); wait_vm<8>(); } else wait_vm<0>();
+        multiply(0, 1, fb1);
+        // phase 2
+        read_a(BUF, P8_A1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s2) { stage(P8_A0, kt + 2); wait_vm<8>(); }
+        multiply(1, 1, fb1);
+        // phase 3
+        if (s2) { stage(P8_B0, kt + 2); wait_vm<8>(); } else if (s1) wait_vm<4>();
+        multiply(1, 0, fb0);
+    };
+
+    // prologue: all of tile 0 and the two phase-0 half-tiles of tile 1, in the steady-state issue order
+    stage(P8_A0, 0); stage(P8_B0, 0); stage(P8_B1, 0); stage(P8_A1, 0); stage(P8_A0, 1); stage(P8_B0, 1);
+    wait_vm<8>();                                         // A-h0, B-h0 of tile 0 (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one barrier interval behind group 0
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        ktile(I0{}, kt);
+        ktile(I1{}, kt + 1);
+    }
+    if (kt < nk) ktile(I0{}, kt);
+    if (wr == 0) __builtin_amdgcn_s_barrier();            // pairs with group 1's extra barrier
+    fast_epilogue(p, acc, smem, wid, lane, m0, n0, wr, wc);
+}
+
 }  // namespace
 
 static bool fast_common_ok(const dist_gemm_args* a) {
@@ -379,6 +569,21 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
     }
     if (ng > tiles_n) ng = tiles_n;
     if (ng < 1) ng = 1;
+    // two-group 256x256x64 main loop (gemm_fast8p_kernel) when K is a multiple of 64; DIST_AMD_FAST_8P=0 keeps the
+    // lock-step 256x256x32 loop (measurement knob, and the A/B reference of tools/bench_fast8p.py)
+    static const bool use_8p = !(getenv("DIST_AMD_FAST_8P") && atoi(getenv("DIST_AMD_FAST_8P")) == 0);
+    if (NW == 8 && use_8p && a->K % P8_BK == 0 && a->K >= 2 * P8_BK) {
+        constexpr size_t smem8 = 2 * (size_t)P8_BUF;
+        static_assert(8 * EPI_BYTES <= 2 * P8_BUF, "epilogue staging fits in the operand buffers");
+        static bool attr8_done = false;
+        if (!attr8_done) {
+            HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast8p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8));
+            attr8_done = true;
+        }
+        hipLaunchKernelGGL(gemm_fast8p_kernel, dim3((unsigned)tiles), dim3(512), smem8, s, *a, ng);
+        HIP_CHECK_RET(hipGetLastError());
+        return 1;
+    }
     hipLaunchKernelGGL(gemm_fast_kernel<NW>, dim3((unsigned)tiles), dim3(S::NT), smem, s, *a, ng);
     HIP_CHECK_RET(hipGetLastError());
     return 1;

@@ -149,6 +149,41 @@ def test_conv3x3_frame_epilogues(gpu_lib, dtype, grid, frames, sign):
     torch.testing.assert_close(C4.double(), conv * qgelu_grad(aux.double()), **tol(dtype))
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 256, 192), (1536, 512, 320), (1300, 384, 448), (4096, 768, 1536), (2304, 1536, 384)])
+def test_gemm_fast_two_group_loop_tile_counts(gpu_lib, M, N, K):
+    """256x256x64 two-group main loop (gemm_fast8p_kernel): odd and even K-tile counts (3, 5, 7, 24, 6) walk the
+    scalar-predicated tail (counted vmcnt 8 / 4 / 2 / 0), a half-empty column tile (N = 384) and ragged M."""
+    from dist_amd import ops
+    dtype = torch.bfloat16
+    A, B = rnd((M, K), dtype, 11), rnd((N, K), dtype, 12, K ** -0.5)
+    bias, res = rnd((N,), torch.float32, 13), rnd((M, N), dtype, 14)
+    C = torch.empty(M, N, dtype=dtype, device="cuda")
+    ops.gemm_nt(A, B, M, N, K, bias=bias, res=res, C_out=C)
+    torch.testing.assert_close(C.double(), A.double() @ B.double().t() + bias.double() + res.double(), **tol(dtype))
+
+
+@pytest.mark.parametrize("N,K", [(2304, 768), (768, 3072)])
+def test_gemm_fast_two_group_loop_is_race_free_at_full_size(gpu_lib, N, K):
+    """LDS-DMA data is ordered for a ds_read only by the issuing wave's counted vmcnt plus a barrier: a misplaced wait shows as
+    RARE wrong tiles under memory load.  Full BASELINE row count (50 432 token rows), every block of the chip busy, 12 launches:
+    all bit-identical to each other and equal to the fp32 reference."""
+    from dist_amd import ops
+    dtype = torch.bfloat16
+    M = 50432
+    A, B = rnd((M, K), dtype, 21), rnd((N, K), dtype, 22, K ** -0.5)
+    bias = rnd((N,), torch.float32, 23)
+    ref = (A.float() @ B.float().t() + bias).to(dtype)
+    outs = []
+    for _ in range(12):
+        C = torch.empty(M, N, dtype=dtype, device="cuda")
+        ops.gemm_nt(A, B, M, N, K, bias=bias, C_out=C)
+        outs.append(C)
+    torch.cuda.synchronize()
+    for C in outs[1:]:
+        assert torch.equal(C, outs[0])
+    torch.testing.assert_close(outs[0].float(), ref.float(), **tol(dtype))
+
+
 def test_gemm_fast_patch_embed_maps(gpu_lib):
     """the ViT patch embedding as the 256x256 LDS-DMA kernel sees it: strided source rows (every alpha-th
     frame), rows inserted behind each frame's cls row, residual read at the destination."""
