@@ -334,37 +334,49 @@ __global__ __launch_bounds__(Shape<NW>::NT, Shape<NW>::MINB) void gemm_fast_kern
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 256 x 256 x 64 main loop, two wave groups half a phase apart (cdna_hip_programming.md §5 "8-phase" schedule).
+// 256 x 256 x 64 main loop, two wave groups half a phase apart (cdna_hip_programming.md §5 "8-phase" schedule), fragments
+// read ONE PHASE AHEAD of the MFMAs that consume them.
 //
 // In the kernel above the two waves of a SIMD run the same instruction stream in step, so both sit in their LDS-DMA issue
 // and fragment reads at the same time and the matrix pipe idles (profiles/r01_gemm_ablation.md: the loop ran at ~57 % MFMA
 // issue).  Here waves 0-3 (group 0) and waves 4-7 (group 1, the SIMD partners of 0-3) are offset by ONE barrier: every
-// barrier interval has one group in a "load" section (fragment ds_reads for its next 16 MFMAs + 2 LDS-DMA pieces) and the
-// other in a "multiply" section (16 MFMAs on one quadrant of its 128 x 64 sub-tile).
+// barrier interval has one group in a "load" section (fragment ds_reads + 2 LDS-DMA pieces + a counted DMA wait) and the
+// other in a "multiply" section (16 MFMAs on one quadrant of its 128 x 64 sub-tile).  The fragments a multiply section
+// uses were read in the load section BEFORE the previous multiply section, so their LDS latency lies under 16 MFMAs
+// instead of between the barrier and the first MFMA (first version of this loop: reads in the same phase, 380 cycles per
+// interval for 256 cycles of MFMA; profiles/r02_fast_gemm_two_group.md).
 //
-// LDS: two K-tile buffers of 64 KB; a buffer holds four half-tiles of 128 rows x 128 B:
+// LDS: two K-tile buffers of 64 KB, i.e. four half-tiles of 128 rows x 128 B each (the two buffers of one half-tile are
+// neighbours: A-h0[0], A-h0[1], A-h1[0], A-h1[1] in the first 64 KB, the B half-tiles in the second 64 KB, so ONE base
+// register per k-step reaches both buffers of an operand through the 16-bit ds_read immediate):
 //   A-h0 / A-h1: for wave row wr, rows wr*128 + q*64 + [0, 64)  (local row wr*64 + rr)  -> quadrant q of every wave
 //   B-h0 / B-h1: for wave col wc, cols wc*64 + q*32 + [0, 32)   (local row wc*32 + rr)
-// so a half-tile is read in exactly ONE phase of a K-tile and is free for re-staging right after it:
-//   phase 0: read A-h0, B-h0 -> MFMA quadrant (0,0)      stage B-h1 of tile t+1
-//   phase 1: read B-h1       -> MFMA (0,1)               stage A-h1 of tile t+1
-//   phase 2: read A-h1       -> MFMA (1,1)               stage A-h0 of tile t+2
-//   phase 3: (no reads)      -> MFMA (1,0)               stage B-h0 of tile t+2
-// 16-byte chunk c of local row r lives at chunk c ^ ((r >> 1) & 7): a 16-lane ds_read_b128 service group then touches 16
-// distinct slots of the 256-B bank row (rows are 128 B); the LDS-DMA image is lane-linear, so the same involution sits
-// on the per-lane SOURCE address.
+// so a half-tile is read in exactly ONE phase of a K-tile and is free for re-staging right after it.  K-tile t, buffer t & 1:
+//   phase 0: MFMA A0.B0   load section: read B-h1(t)   -> SB[~t&1]   stage A-h0(t+2)
+//   phase 1: MFMA A0.B1                 read A-h1(t)   -> FA[1]      stage B-h0(t+2)
+//   phase 2: MFMA A1.B1                 read A-h0(t+1) -> FA[0]      stage B-h1(t+2)
+//   phase 3: MFMA A1.B0                 read B-h0(t+1) -> SB[~t&1]   stage A-h1(t+2)
+// (B0 of tile t lives in register set SB[t & 1], B1 in the other one: the set B1 leaves after phase 2 receives the next
+// tile's B0.)  16-byte chunk c of local row r lives at chunk c ^ ((r >> 1) & 7): a 16-lane ds_read_b128 service group then
+// touches 16 distinct slots of the 256-B bank row (rows are 128 B); the LDS-DMA image is lane-linear, so the same
+// involution sits on the per-lane SOURCE offset.
 //
-// Ordering rules (L(g) = load section of global phase g, run by group 0 in barrier interval 2g and by group 1 in 2g+1):
+// Ordering rules (L(g) / M(g) = load / multiply section of global phase g; group 0 runs L(g) in barrier interval 2g and
+// M(g) in 2g+1, group 1 one interval later):
 //   RAW: a half-tile is read in L(g) only if every wave waited for its own pieces of it (counted vmcnt) at the end of
 //        L(g-1) or earlier - that wait is followed by a barrier both groups pass before any read of L(g);
-//   WAR: a half-tile last read in L(g) is re-staged in L(g+2) or later (group 1's reads of L(g) retire early in interval
-//        2g+2; group 0's L(g+2) starts at interval 2g+4).
-// Per-wave LDS-DMA issue order is A-h0, B-h0, B-h1, A-h1 of a tile, two pieces each; `vmcnt(8)` at the end of every load
-// section leaves the last four half-tiles in flight and retires exactly the one that the NEXT phase reads.
+//   WAR: every wave retires the reads of L(g) (lgkmcnt(0)) at the END of M(g), in front of the barrier that closes it, so
+//        a half-tile last read in L(g) may be re-staged in L(g+2) by either group.
+// Per-wave LDS-DMA issue order is A-h0, B-h0, B-h1, A-h1 of a tile, two pieces each, tile t+2 during tile t: `vmcnt(10)`
+// at the end of every load section leaves five half-tiles in flight and retires exactly the one the NEXT load section reads.
+//
+// The pieces are buffer loads (resource descriptor + per-lane offset VGPR + scalar offset): the K-tile and quadrant offsets
+// are scalar, rows beyond N read as zero by the descriptor's bounds check, and the load sections contain no VALU.
 constexpr int P8_BK = 64;
 constexpr int P8_HALF = 128 * P8_BK * 2;                  // 16 KB
-constexpr int P8_BUF = 4 * P8_HALF;                       // 64 KB per K-tile
-constexpr int P8_A0 = 0, P8_A1 = P8_HALF, P8_B0 = 2 * P8_HALF, P8_B1 = 3 * P8_HALF;
+constexpr int P8_BUF = P8_HALF;                           // second buffer of a half-tile: right behind the first
+constexpr int P8_A0 = 0, P8_A1 = 2 * P8_HALF, P8_B0 = 4 * P8_HALF, P8_B1 = 6 * P8_HALF;
+constexpr int P8_LDS = 8 * P8_HALF;                       // 128 KB
 
 template <int N> DEV void wait_vm() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -372,8 +384,15 @@ template <int N> DEV void wait_vm() {
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else static_assert(N < 0, "unsupported count");
 }
+// the compiler may treat these registers as ready from here on (the hand-placed lgkmcnt(0) in front retired their ds_reads;
+// without this it re-waits lgkmcnt(0) in front of the consuming MFMAs, behind the NEXT load section's reads)
+DEV void regs_ready(bf16x8 (&f)[4][2]) {
+    asm volatile("" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[2][0]), "+v"(f[2][1]), "+v"(f[3][0]), "+v"(f[3][1]));
+}
+DEV void regs_ready(bf16x8 (&f)[2][2]) { asm volatile("" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1])); }
 
 __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_args p, const int ngroups) {
     constexpr int BN = 256;
@@ -387,32 +406,34 @@ __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_arg
     fast_tile(p, ngroups, BN, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int M = (int)p.M, N = p.N, K = p.K;
-    const char* Ab = static_cast<const char*>(p.A);
-    const char* Bb = static_cast<const char*>(p.B);
 
-    // ---- LDS-DMA sources: per half-tile this wave moves local rows 16*wid + 8*j + (lane >> 3), j = 0, 1 (1 KB each)
-    unsigned ga[2][2], gb[2][2];
+    // ---- LDS-DMA sources.  Per half-tile this wave moves local rows 16*wid + 8*j + (lane >> 3), j = 0, 1 (1 KB each).
+    // Per-lane byte offsets for piece j of quadrant 0 (plain row maps only: the launcher checks); quadrant 1 and the K-tile
+    // are scalar offsets; both descriptors end behind the last row, so the rows of a ragged last row tile / a half-empty
+    // column tile read as zero instead of being clamped.
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, M * p.lda * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, N * p.ldb * 2, 0x00020000);
+    unsigned ga[2], gb[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int lr = 16 * wid + 8 * j + (lane >> 3);
-            const int lc = (lane & 7) ^ ((lr >> 1) & 7);
-            const int arow = (lr >> 6) * 128 + q * 64 + (lr & 63);
-            const int bcol = (lr >> 5) * 64 + q * 32 + (lr & 31);
-            ga[q][j] = ((unsigned)rowmap_src(p.amap, min(m0 + arow, M - 1), 0, 1) * (unsigned)p.lda + lc * 8) * 2u;
-            gb[q][j] = ((unsigned)min(n0 + bcol, N - 1) * (unsigned)p.ldb + lc * 8) * 2u;
-        }
+    for (int j = 0; j < 2; ++j) {
+        const int lr = 16 * wid + 8 * j + (lane >> 3);
+        const int lc = (lane & 7) ^ ((lr >> 1) & 7);
+        ga[j] = ((unsigned)(m0 + (lr >> 6) * 128 + (lr & 63)) * (unsigned)p.lda + lc * 8) * 2u;
+        gb[j] = ((unsigned)(n0 + (lr >> 5) * 64 + (lr & 31)) * (unsigned)p.ldb + lc * 8) * 2u;
+    }
+    const int aq1 = 64 * p.lda * 2, bq1 = 32 * p.ldb * 2;  // quadrant 1: 64 rows of A / 32 rows of B further
     // stage half-tile `slot` (P8_A0 ...) of K-tile kt into buffer kt & 1
     auto stage = [&](const int slot, const int kt) __attribute__((always_inline)) {
         char* sb = smem + (kt & 1) * P8_BUF + slot + wid * 2048;
-        const unsigned k2 = (unsigned)kt * (P8_BK * 2);
-        const bool isA = slot == P8_A0 || slot == P8_A1;
-        const int q = (slot == P8_A1 || slot == P8_B1) ? 1 : 0;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (isA) __builtin_amdgcn_global_load_lds((gbl_ptr)(Ab + (ga[q][j] + k2)), (lds_ptr)(sb + j * 1024), 16, 0, 0);
-            else __builtin_amdgcn_global_load_lds((gbl_ptr)(Bb + (gb[q][j] + k2)), (lds_ptr)(sb + j * 1024), 16, 0, 0);
+        const int k2 = kt * (P8_BK * 2);
+        if (slot == P8_A0 || slot == P8_A1) {
+            const int so = k2 + (slot == P8_A1 ? aq1 : 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)sb, 16, ga[0], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sb + 1024), 16, ga[1], so, 0, 0);
+        } else {
+            const int so = k2 + (slot == P8_B1 ? bq1 : 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)sb, 16, gb[0], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + 1024), 16, gb[1], so, 0, 0);
         }
     };
 
@@ -422,20 +443,20 @@ __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_arg
     for (int kk = 0; kk < 2; ++kk) {
         const int pc = ((kk * 4 + lg) ^ ((li >> 1) & 7)) << 4;
         a_rd[kk] = (wr * 64 + li) * 128 + pc;
-        b_rd[kk] = (wc * 32 + li) * 128 + pc;
+        b_rd[kk] = P8_B0 + (wc * 32 + li) * 128 + pc;
     }
-    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
-    auto read_a = [&](const int buf, const int slot) __attribute__((always_inline)) {
+    bf16x8 fa[2][4][2], sb_[2][2][2];
+    auto read_a = [&](bf16x8 (&f)[4][2], const int buf, const int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fa[i][kk] = *reinterpret_cast<const bf16x8*>(smem + buf * P8_BUF + slot + a_rd[kk] + i * 2048);
+            for (int kk = 0; kk < 2; ++kk) f[i][kk] = *reinterpret_cast<const bf16x8*>(smem + a_rd[kk] + (slot + buf * P8_BUF + i * 2048));
     };
     auto read_b = [&](bf16x8 (&f)[2][2], const int buf, const int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) f[j][kk] = *reinterpret_cast<const bf16x8*>(smem + buf * P8_BUF + slot + b_rd[kk] + j * 2048);
+            for (int kk = 0; kk < 2; ++kk) f[j][kk] = *reinterpret_cast<const bf16x8*>(smem + b_rd[kk] + (slot - P8_B0 + buf * P8_BUF + j * 2048));
     };
 
     f32x4 acc[8][4];
@@ -444,58 +465,75 @@ __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_arg
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // multiply section: barrier (the reads and this wave's counted DMA wait are behind it), 16 MFMAs, barrier
-    auto multiply = [&](const int qa, const int qb, const bf16x8 (&f)[2][2]) __attribute__((always_inline)) {
+    // multiply section: barrier (this wave's counted DMA wait is behind it), 16 MFMAs on fragments read a phase ago,
+    // retire the reads of the load section in front (they have had the 16 MFMAs to complete), barrier
+    auto mma16q = [&](const int qa, const int qb, const bf16x8 (&a)[4][2], const bf16x8 (&b)[2][2]) __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[qa * 4 + i][qb * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[j][kk], fa[i][kk], acc[qa * 4 + i][qb * 2 + j], 0, 0, 0);   // swapped: D[n][m]
-        __builtin_amdgcn_s_setprio(0);
+                    acc[qa * 4 + i][qb * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][kk], a[i][kk], acc[qa * 4 + i][qb * 2 + j], 0, 0, 0);   // swapped: D[n][m]
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto close_phase = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-    // one K-tile = four phases.  The tail is selected by wave-uniform scalars instead of peeled copies of the body (seven
-    // instantiations with different wait counts made hipcc rename accumulators across their joins and spill INSIDE the
-    // loop - and a scratch reload is a vmcnt(0)): s1 = tile kt+1 exists, s2 = tile kt+2 exists.
+
+    // one K-tile = four phases; the tail is selected by wave-uniform scalars (s1 = tile kt+1 exists, s2 = tile kt+2 exists)
+    // instead of peeled copies of the body: peeled copies made hipcc rename accumulators across their joins and spill
+    // INSIDE the loop - and a scratch reload is a vmcnt(0).
     const int nk = K / P8_BK;                             // >= 2 (checked by the launcher)
     auto ktile = [&](auto buf_c, const int kt) __attribute__((always_inline)) {
-        constexpr int BUF = decltype(buf_c)::value;
+        constexpr int BUF = decltype(buf_c)::value, NB = BUF ^ 1;
         const bool s1 = kt + 1 < nk, s2 = kt + 2 < nk;
         // phase 0
-        read_b(fb0, BUF, P8_B0);
+        read_b(sb_[NB], BUF, P8_B1);
         __builtin_amdgcn_sched_barrier(0);
-        read_a(BUF, P8_A0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s1) { stage(P8_B1, kt + 1); wait_vm<8>(); } else wait_vm<2>();
-        multiply(0, 0, fb0);
+        if (s2) { stage(P8_A0, kt + 2); wait_vm<10>(); } else if (s1) wait_vm<8>(); else wait_vm<0>();
+        mma16q(0, 0, fa[0], sb_[BUF]);
+        regs_ready(sb_[NB]);
+        close_phase();
         // phase 1
-        read_b(fb1, BUF, P8_B1);
+        read_a(fa[1], BUF, P8_A1);
         __builtin_amdgcn_sched_barrier(0);
-        if (s1) { stage(P8_A1, kt + 1); wait_vm<8>(); } else wait_vm<0>();
-        multiply(0, 1, fb1);
+        if (s2) { stage(P8_B0, kt + 2); wait_vm<10>(); } else if (s1) wait_vm<6>();
+        mma16q(0, 1, fa[0], sb_[NB]);
+        regs_ready(fa[1]);
+        close_phase();
         // phase 2
-        read_a(BUF, P8_A1);
+        if (s1) read_a(fa[0], NB, P8_A0);
         __builtin_amdgcn_sched_barrier(0);
-        if (s2) { stage(P8_A0, kt + 2); wait_vm<8>(); }
-        multiply(1, 1, fb1);
+        if (s2) { stage(P8_B1, kt + 2); wait_vm<10>(); } else if (s1) wait_vm<4>();
+        mma16q(1, 1, fa[1], sb_[NB]);
+        regs_ready(fa[0]);
+        close_phase();
         // phase 3
-        if (s2) { stage(P8_B0, kt + 2); wait_vm<8>(); } else if (s1) wait_vm<4>();
-        multiply(1, 0, fb0);
+        if (s1) read_b(sb_[NB], NB, P8_B0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s2) { stage(P8_A1, kt + 2); wait_vm<10>(); } else if (s1) wait_vm<2>();
+        mma16q(1, 0, fa[1], sb_[BUF]);
+        regs_ready(sb_[NB]);
+        close_phase();
     };
 
-    // prologue: all of tile 0 and the two phase-0 half-tiles of tile 1, in the steady-state issue order
-    stage(P8_A0, 0); stage(P8_B0, 0); stage(P8_B1, 0); stage(P8_A1, 0); stage(P8_A0, 1); stage(P8_B0, 1);
-    wait_vm<8>();                                         // A-h0, B-h0 of tile 0 (this wave's pieces)
+    // prologue: tiles 0 and 1 in the steady-state issue order; A-h0, B-h0, B-h1 of tile 0 must have landed (five half-tiles behind)
+    stage(P8_A0, 0); stage(P8_B0, 0); stage(P8_B1, 0); stage(P8_A1, 0);
+    stage(P8_A0, 1); stage(P8_B0, 1); stage(P8_B1, 1); stage(P8_A1, 1);
+    wait_vm<10>();
     __builtin_amdgcn_s_barrier();
+    read_a(fa[0], 0, P8_A0);
+    read_b(sb_[0], 0, P8_B0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    regs_ready(fa[0]); regs_ready(sb_[0]);
+    __builtin_amdgcn_sched_barrier(0);
     if (wr == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one barrier interval behind group 0
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     int kt = 0;
@@ -572,9 +610,9 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
     // two-group 256x256x64 main loop (gemm_fast8p_kernel) when K is a multiple of 64; DIST_AMD_FAST_8P=0 keeps the
     // lock-step 256x256x32 loop (measurement knob, and the A/B reference of tools/bench_fast8p.py)
     static const bool use_8p = !(getenv("DIST_AMD_FAST_8P") && atoi(getenv("DIST_AMD_FAST_8P")) == 0);
-    if (NW == 8 && use_8p && a->K % P8_BK == 0 && a->K >= 2 * P8_BK) {
-        constexpr size_t smem8 = 2 * (size_t)P8_BUF;
-        static_assert(8 * EPI_BYTES <= 2 * P8_BUF, "epilogue staging fits in the operand buffers");
+    if (NW == 8 && use_8p && a->K % P8_BK == 0 && a->K >= 2 * P8_BK && a->amap.mode == DIST_RM_PLAIN) {
+        constexpr size_t smem8 = (size_t)P8_LDS;
+        static_assert(8 * EPI_BYTES <= P8_LDS, "epilogue staging fits in the operand buffers");
         static bool attr8_done = false;
         if (!attr8_done) {
             HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast8p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8));

@@ -17,7 +17,7 @@ def timeit_rot(fns, reps=4):
         best = min(best, s.elapsed_time(e) / (reps * len(fns)) * 1e-3)
     return best
 dt = torch.bfloat16; M = 50432
-tag8 = "lockstep-32" if os.environ.get("DIST_AMD_FAST_8P") == "0" else "two-group-64"
+tag8 = "lockstep-32" if os.environ.get("DIST_AMD_FAST_8P") == "0" else "two-group-64 var=%s stagger=%s" % (os.environ.get("DIST_AMD_FAST_VAR", "0"), os.environ.get("DIST_AMD_FAST_STAGGER", "0"))
 tot = 0.0
 for (N, K, tag, act, cnt) in [(3072, 768, "fc", True, 12), (2304, 768, "qkv", False, 12), (768, 3072, "proj", False, 12), (768, 768, "out", False, 12),
                               (384, 768, "in_lin", False, 12), (8192, 8192, "8192^3", False, 0)]:
