@@ -145,6 +145,11 @@ struct dist_handle {
     // gradient-ready hook + the slices it reports
     dist_grad_ready_fn grad_hook = nullptr; void* grad_hook_user = nullptr;
     std::vector<int64_t> layer_begin, layer_end; int64_t tail_begin = 0;
+    // phase marks (dist_marks_enable / dist_marks_read): device-side timestamps of the last step on the streams the work runs
+    // on, taken WITHOUT a profiler (rocprofv3 makes the ~700 launches of a step host-bound and shows a schedule that the
+    // un-profiled run does not have)
+    bool marks_on = false;
+    hipEvent_t mark_ev[DIST_NMARKS] = {};
     // measurement hook (dist_profile_begin/end)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;           // pairs (start, stop)
@@ -161,6 +166,10 @@ int fail(dist_handle* h, int rc, const char* fmt, ...) {
     vsnprintf(h->err, sizeof(h->err), fmt, ap);
     va_end(ap);
     return rc;
+}
+
+inline void mark(dist_handle* h, int which, hipStream_t st) {
+    if (h->marks_on && h->mark_ev[which]) hipEventRecord(h->mark_ev[which], st);
 }
 #define RUN(call)                                                        \
     do {                                                                 \
@@ -655,6 +664,7 @@ static int ensure_streams(dist_handle* h) {
 extern "C" void dist_destroy(dist_handle* h) {
     if (!h) return;
     for (hipEvent_t e : h->prof_ev) hipEventDestroy(e);
+    for (hipEvent_t& e : h->mark_ev) if (e) { hipEventDestroy(e); e = nullptr; }
     for (hipEvent_t e : h->ev_a) if (e) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_b_dr) if (e) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_b_done) if (e) hipEventDestroy(e);
@@ -735,6 +745,7 @@ extern "C" int dist_pack_weights(dist_handle* h, int what, void* stream) {
         }
         h->vit_fold = true;
     }
+    if (what == 2) mark(h, DIST_MARK_STEP_END, s);
     return DIST_OK;
 }
 
@@ -757,6 +768,7 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
         // the ViT-internal scratch (x0, xa, hbuf, qkv, att, mlp) exists once: consecutive ViT passes are ordered, whatever their streams
         if (h->vit_ran) HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_vit_done, 0));
         HIP_CHECK_RET(hipEventRecord(S.ev_pre, x.s));                   // everything queued before this pass (re-pack, previous step)
+        mark(h, DIST_MARK_VIT_BEGIN, x.s);
         RUN(dist_op_patchify(video, S.patches, b, c.frames, c.resolution, c.resolution, c.patch, c.dtype, stream));
         HIP_CHECK_RET(hipEventRecord(S.ev_feat[c.layers], x.s));       // patch rows ready (temporal stem input)
         // patch embedding of the frames k = alpha*j only (the reference embeds all T frames and drops the
@@ -805,6 +817,7 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
     S.pending_b = b;
     if (l1 == c.layers) {
         HIP_CHECK_RET(hipEventRecord(h->ev_vit_done, x.s));
+        mark(h, DIST_MARK_VIT_END, x.s);
         h->vit_ran = true;
         S.b = b;
     }
@@ -919,6 +932,7 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
     auto ev_m = [&](int i) { return h->ev_a[nl + i]; };
 
     // temporal stem: Conv3d k=(tp,P,P) as a 5-tap row-shifted GEMM over the shared patch rows (dist.py:178-181,225)
+    mark(h, DIST_MARK_FWD_BEGIN, xt.s);
     RUN(gemm(xt, h->patches, h->Kp, x.pk(h->stem.pk.f), rowsX, Ct, h->Kp, h->stem.taps, h->lw[0].X, Ct, x.th(h->stem.bias), nullptr, nullptr, nullptr,
              RM(DIST_RM_SHIFT, T * N, N, 1)));
     for (int i = 0; i < nl; ++i) {
@@ -956,6 +970,7 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
         // R = ffn.c_proj(hf) + temporal_ffn.c_proj(g2): one GEMM over [hf | g2] (K = Ci + C4) with the two weights side by side
         RUN(gemm(x, w.hf, Ci + C4, x.pk(l.pk_proj_f), rowsS, Ci, Ci + C4, 1, w.R, Ci, x.th(l.ffn_proj.bias), nullptr, nullptr, nullptr,
                  RM(), OM(), 0, x.th(l.tf_proj.bias)));
+        if (i == nl / 2 - 1) mark(h, DIST_MARK_FWD_MID, x.s);
     }
     // current_layer_feat = res_feat + updated_mid_feat (dist.py:239)
     RUN(dist_op_add(h->lw[nl - 1].R, h->lw[nl - 1].Mp, h->Fz, rowsS * Ci, c.dtype, stream));
@@ -993,6 +1008,7 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
     RUN(gemm(x, h->zpost, Ci, x.pk(h->proj.pk.f), b, c.embed_dim, Ci, 1, h->v, c.embed_dim, nullptr, nullptr, nullptr, nullptr));
     // join: the caller's stream continues after the branch; the logits kernel runs there (it reads caller-produced text features)
     HIP_CHECK_RET(hipEventRecord(h->ev_join, x.s));
+    mark(h, DIST_MARK_FWD_END, x.s);
     HIP_CHECK_RET(hipStreamWaitEvent(A, h->ev_join, 0));
     // cosine logits (clip.py:509-518)
     RUN(dist_k_logits_loss(h->v, text_features, h->logit_scale, nullptr, h->logits, vid_logits, nullptr, nullptr, nullptr, nullptr, nullptr,
@@ -1075,6 +1091,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
     const int nl = c.layers, na = c.ada_layers;
     const size_t es = h->es;
 
+    mark(h, DIST_MARK_BWD_BEGIN, x.s);
     if (zero_grads) {
         HIP_CHECK_RET(hipMemsetAsync(h->grads, 0, (size_t)h->total[0] * sizeof(float), x.s));
         HIP_CHECK_RET(hipMemsetAsync(h->dlogit_scale, 0, sizeof(float), x.s));
@@ -1212,6 +1229,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
     // join: the caller's stream continues only after every weight gradient is complete
     HIP_CHECK_RET(hipEventRecord(h->ev_join, B));
     HIP_CHECK_RET(hipStreamWaitEvent(A, h->ev_join, 0));
+    mark(h, DIST_MARK_BWD_END, A);
     if (h->grad_hook) {
         for (; hook_next >= 0; --hook_next) h->grad_hook(h->grad_hook_user, h->layer_begin[hook_next], h->layer_end[hook_next]);
         h->grad_hook(h->grad_hook_user, 0, h->layer_begin[0]);
@@ -1222,6 +1240,26 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
 extern "C" int dist_set_grad_ready_hook(dist_handle* h, dist_grad_ready_fn fn, void* user) {
     if (!h) return DIST_ERR_ARG;
     h->grad_hook = fn; h->grad_hook_user = user;
+    return DIST_OK;
+}
+
+extern "C" int dist_marks_enable(dist_handle* h, int on) {
+    if (!h) return DIST_ERR_ARG;
+    if (on) for (hipEvent_t& e : h->mark_ev) if (!e) HIP_CHECK_RET(hipEventCreate(&e));
+    h->marks_on = on != 0;
+    return DIST_OK;
+}
+// ms[i] = time of mark i of the LAST step relative to DIST_MARK_BWD_END of the step before it is not available from events of one
+// step alone, so the reference point is this step's own DIST_MARK_VIT_BEGIN (the first thing a pipelined step queues);
+// a mark that was never recorded reads as NaN.  Synchronises with the device.
+extern "C" int dist_marks_read(dist_handle* h, float* ms, int n) {
+    if (!h || !ms || n < DIST_NMARKS) return DIST_ERR_ARG;
+    if (!h->mark_ev[DIST_MARK_VIT_BEGIN]) return fail(h, DIST_ERR_STATE, "dist_marks_read before dist_marks_enable");
+    HIP_CHECK_RET(hipDeviceSynchronize());
+    for (int i = 0; i < DIST_NMARKS; ++i) {
+        float t = 0.f;
+        ms[i] = hipEventElapsedTime(&t, h->mark_ev[DIST_MARK_VIT_BEGIN], h->mark_ev[i]) == hipSuccess ? t : __builtin_nanf("");
+    }
     return DIST_OK;
 }
 

@@ -12,6 +12,8 @@
 // The MFMA is issued "swapped" (B fragment as the A operand), so each lane ends up with
 // 4 CONSECUTIVE output columns of one output row: bias / residual / activation epilogues
 // and the stores are 4-wide vectors.
+#include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -19,8 +21,8 @@ namespace {
 
 constexpr int PAD = 8;
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, bool GENERIC>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const dist_gemm_args p) {
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool GENERIC, int MINW = 1>
+__global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(const dist_gemm_args p) {
     constexpr int NT = WM * WN * 64;                    // 4 or 8 waves
     constexpr int LD = BK + PAD;
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -296,11 +298,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const dist_gemm_a
     }
 }
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, bool GENERIC>
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool GENERIC, int MINW = 1>
 int launch(const dist_gemm_args& a, hipStream_t s) {
     constexpr size_t smem = (size_t)2 * (BM + BN) * (BK + PAD) * sizeof(T);
     static bool attr_done = false;
-    auto kern = gemm_nt_kernel<T, BM, BN, BK, WM, WN, GENERIC>;
+    auto kern = gemm_nt_kernel<T, BM, BN, BK, WM, WN, GENERIC, MINW>;
     if (!attr_done) {
         HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_done = true;
@@ -320,6 +322,15 @@ int dispatch(const dist_gemm_args& a, hipStream_t s) {
     // 48.6 -> 44.8 us, 384->96 Linear 18.3 -> 16.7 us alone; profiles/r01_nt_8wave.md).  DIST_AMD_NT_W8=0 restores the 4-wave shapes
     // (measurement knob: bit 0 = N % 96 shapes, bit 1 = plain K % 64, bit 2 = generic).
     static const int w8 = getenv("DIST_AMD_NT_W8") ? atoi(getenv("DIST_AMD_NT_W8")) : 7;
+    // DIST_AMD_NT_OCC (measurement knob): bit 0 / 2 = run the N % 96 / generic 8-wave shape compiled for 6 waves per SIMD
+    // (<= 80 registers per lane: three 8-wave blocks per CU instead of two)
+    // Measured (profiles/r02_nt_occupancy.md): N % 96 shape 82 -> 80 registers, conv3x3 59.6 -> 55.8 us, step -0.15 ms: default on;
+    // the generic shape needs 5 spilled registers for it and gains nothing: default off.
+    static const int occ = getenv("DIST_AMD_NT_OCC") ? atoi(getenv("DIST_AMD_NT_OCC")) : 1;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        if (n96 && (occ & 1)) return launch<T, 128, 96, 32, 4, 2, true, 6>(a, s);
+        if (!n96 && !(plain && a.K % 64 == 0) && (occ & 4)) return launch<T, 128, 128, 32, 2, 4, true, 6>(a, s);
+    }
     if (n96) return (w8 & 1) ? launch<T, 128, 96, 32, 4, 2, true>(a, s) : launch<T, 128, 96, 32, 4, 1, true>(a, s);
     if (plain && a.K % 64 == 0) return (w8 & 2) ? launch<T, 128, 128, 64, 2, 4, false>(a, s) : launch<T, 128, 128, 64, 2, 2, false>(a, s);
     return (w8 & 4) ? launch<T, 128, 128, 32, 2, 4, true>(a, s) : launch<T, 128, 128, 32, 2, 2, true>(a, s);

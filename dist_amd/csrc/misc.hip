@@ -486,6 +486,89 @@ extern "C" int dist_op_adamw(float* param, const float* grad, float* m, float* v
     return DIST_OK;
 }
 
+// ---- batch-mode Mixup / CutMix and the soft target (reference dataset/utils/mixup.py:18-23,212-223) ------------------
+// The reference mixes the rank's batch in place on the GPU, clip i with clip b-1-i:
+//   mixup  (:221-222): x_flipped = x.flip(0).mul_(1 - lam); x.mul_(lam).add_(x_flipped)   -> three fp32 roundings per element
+//   cutmix (:219):     x[..., yl:yh, xl:xh] = x.flip(0)[..., yl:yh, xl:xh]                 -> the box is SWAPPED between i and b-1-i
+// One thread owns element e of BOTH clips of a pair, so the in-place update needs no copy of the batch (the reference's
+// flip(0) materialises 308 MB at b = 32).  Contraction is switched off in these kernels, so every product and the sum round
+// to fp32 separately as in torch: the result is bit-identical to the reference.
+namespace {
+constexpr int MIX_NT = 256;
+// a*s + c*t with the three fp32 roundings of torch's mul_, mul_, add_ (hipcc contracts a*b + c into one fma by default, and the
+// __fmul_rn / __fadd_rn header inlines carry their own `contract` flag, so plain operators under contract(off) it is)
+__device__ __forceinline__ float mix_rn(float a, float s, float c, float t) {
+#pragma clang fp contract(off)
+    const float p = a * s;
+    const float q = c * t;
+    return p + q;
+}
+__global__ __launch_bounds__(MIX_NT) void mixup_kernel(float* __restrict__ x, const int b, const long per_clip4, const float lam, const float oml) {
+    const int i = blockIdx.y, j = b - 1 - i;
+    float4* xi = reinterpret_cast<float4*>(x) + (long)i * per_clip4;
+    float4* xj = reinterpret_cast<float4*>(x) + (long)j * per_clip4;
+    for (long e = (long)blockIdx.x * MIX_NT + threadIdx.x; e < per_clip4; e += (long)gridDim.x * MIX_NT) {
+        const float4 a = xi[e], c = xj[e];
+        float4 oi, oj;
+        oi.x = mix_rn(a.x, lam, c.x, oml); oj.x = mix_rn(c.x, lam, a.x, oml);
+        oi.y = mix_rn(a.y, lam, c.y, oml); oj.y = mix_rn(c.y, lam, a.y, oml);
+        oi.z = mix_rn(a.z, lam, c.z, oml); oj.z = mix_rn(c.z, lam, a.z, oml);
+        oi.w = mix_rn(a.w, lam, c.w, oml); oj.w = mix_rn(c.w, lam, a.w, oml);
+        xi[e] = oi;
+        if (i != j) xj[e] = oj;                       // odd batch: the middle clip is mixed with itself
+    }
+}
+// one block per (pair, plane, box row): threads run along the box row
+__global__ __launch_bounds__(MIX_NT) void cutmix_kernel(float* __restrict__ x, const int b, const int planes, const int H, const int W,
+                                                        const int yl, const int yh, const int xl, const int xh) {
+    const int i = blockIdx.z, j = b - 1 - i;
+    if (i == j) return;
+    const int pl = blockIdx.y, y = yl + blockIdx.x;
+    float* ri = x + (((long)i * planes + pl) * H + y) * W;
+    float* rj = x + (((long)j * planes + pl) * H + y) * W;
+    for (int xx = xl + threadIdx.x; xx < xh; xx += MIX_NT) {
+        const float a = ri[xx], c = rj[xx];
+        ri[xx] = c; rj[xx] = a;
+    }
+}
+// mixup_target (:18-23): y1 * lam + y2 * (1 - lam), y1 / y2 = smoothed one-hot rows of target / target.flip(0)
+__global__ __launch_bounds__(MIX_NT) void mixup_target_kernel(const long* __restrict__ labels, const int b, const int K, const float lam, const float oml,
+                                                              const float on, const float off, float* __restrict__ soft) {
+    const long n = (long)b * K;
+    for (long e = (long)blockIdx.x * MIX_NT + threadIdx.x; e < n; e += (long)gridDim.x * MIX_NT) {
+        const int i = (int)(e / K), k = (int)(e - (long)i * K);
+        const float y1 = labels[i] == k ? on : off, y2 = labels[b - 1 - i] == k ? on : off;
+        soft[e] = mix_rn(y1, lam, y2, oml);
+    }
+}
+}  // namespace
+
+extern "C" int dist_op_mixup(float* video, int b, int64_t per_clip, float lam, float one_minus_lam, void* stream) {
+    if (!video || b <= 0 || per_clip <= 0 || per_clip % 4 || (reinterpret_cast<uintptr_t>(video) & 15)) return DIST_ERR_ARG;
+    const long n4 = per_clip / 4;
+    const unsigned gx = (unsigned)min((n4 + MIX_NT - 1) / MIX_NT, (long)4096);
+    hipLaunchKernelGGL(mixup_kernel, dim3(gx, (unsigned)((b + 1) / 2)), dim3(MIX_NT), 0, static_cast<hipStream_t>(stream), video, b, n4, lam, one_minus_lam);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+extern "C" int dist_op_cutmix(float* video, int b, int planes, int H, int W, int yl, int yh, int xl, int xh, void* stream) {
+    if (!video || b <= 0 || planes <= 0 || H <= 0 || W <= 0 || yl < 0 || yh > H || xl < 0 || xh > W || yl > yh || xl > xh) return DIST_ERR_ARG;
+    if (yl == yh || xl == xh || b < 2) return DIST_OK;          // empty box: nothing moves (the reference's slice assignment is a no-op)
+    hipLaunchKernelGGL(cutmix_kernel, dim3((unsigned)(yh - yl), (unsigned)planes, (unsigned)(b / 2)), dim3(MIX_NT), 0, static_cast<hipStream_t>(stream),
+                       video, b, planes, H, W, yl, yh, xl, xh);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+extern "C" int dist_op_mixup_target(const int64_t* labels, int b, int K, float lam, float one_minus_lam, float on_value, float off_value, float* soft, void* stream) {
+    if (!labels || !soft || b <= 0 || K <= 0) return DIST_ERR_ARG;
+    static_assert(sizeof(long) == sizeof(int64_t), "LP64");
+    const long n = (long)b * K;
+    hipLaunchKernelGGL(mixup_target_kernel, dim3((unsigned)min((n + MIX_NT - 1) / MIX_NT, (long)1024)), dim3(MIX_NT), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const long*>(labels), b, K, lam, one_minus_lam, on_value, off_value, soft);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+
 // ---- engine-internal launchers (kernels.h) ------------------------------------------------------------
 namespace {
 template <typename F> int with_type(int dtype, F&& f) { return dtype == DIST_BF16 ? f(bf16_t{}) : f(float{}); }

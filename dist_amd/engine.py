@@ -228,6 +228,17 @@ class Engine:
             self._hook = L.GRAD_HOOK(lambda _user, b, e: fn(int(b), int(e)))
         L.check(self.lib.dist_set_grad_ready_hook(self.h, self._hook, None), self.h)
 
+    MARKS = ("vit_begin", "vit_end", "fwd_begin", "fwd_mid", "fwd_end", "bwd_begin", "bwd_end", "step_end")
+
+    def marks_enable(self, on=True):
+        L.check(self.lib.dist_marks_enable(self.h, int(on)), self.h)
+
+    def marks_read(self):
+        """{mark: ms since this step's vit_begin} of the LAST step (device-side HIP events; synchronises)."""
+        ms = (C.c_float * len(self.MARKS))()
+        L.check(self.lib.dist_marks_read(self.h, ms, len(self.MARKS)), self.h)
+        return dict(zip(self.MARKS, [float(v) for v in ms]))
+
     def profile_begin(self):
         L.check(self.lib.dist_profile_begin(self.h), self.h)
 

@@ -130,6 +130,8 @@ def load():
     _sig(lib, "dist_branch_backward", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p])
     _sig(lib, "dist_loss", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_set_grad_ready_hook", argtypes=[C.c_void_p, GRAD_HOOK, C.c_void_p])
+    _sig(lib, "dist_marks_enable", argtypes=[C.c_void_p, C.c_int])
+    _sig(lib, "dist_marks_read", argtypes=[C.c_void_p, C.POINTER(C.c_float), C.c_int])
     _sig(lib, "dist_profile_begin", argtypes=[C.c_void_p])
     _sig(lib, "dist_profile_end", argtypes=[C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)])
     _sig(lib, "dist_debug_tensor", argtypes=[C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)])
@@ -146,6 +148,9 @@ def load():
     _sig(lib, "dist_op_gelu_bwd", argtypes=[C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p])
     _sig(lib, "dist_op_colsum", argtypes=[C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, RowMap, C.c_int, C.c_void_p])
     _sig(lib, "dist_op_logits_loss", argtypes=[C.c_void_p] * 10 + [C.c_int] * 4 + [C.c_void_p])
+    _sig(lib, "dist_op_mixup", argtypes=[C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_void_p])
+    _sig(lib, "dist_op_cutmix", argtypes=[C.c_void_p] + [C.c_int] * 8 + [C.c_void_p])
+    _sig(lib, "dist_op_mixup_target", argtypes=[C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_op_adamw", argtypes=[C.c_void_p] * 5 + [C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_void_p])
     _lib = lib
     return lib

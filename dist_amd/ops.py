@@ -6,6 +6,7 @@ missing library or a non-zero return code raises DistError.
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import lib as L
@@ -200,3 +201,36 @@ def make_segs(entries, device):
     arr = (L.AdamwSeg * len(entries))(*[L.AdamwSeg(int(b), int(e), float(lr), float(wd)) for b, e, lr, wd in entries])
     buf = bytes(arr)
     return torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(device)
+
+
+# ---- batch-mode Mixup / CutMix (reference dataset/utils/mixup.py:18-23,212-223) --------------------------------------
+def _f32(v):
+    """the fp32 value torch uses for a Python-float scalar operand of an fp32 tensor op"""
+    return float(np.float32(v))
+
+
+def mixup_(video, lam):
+    """in place: x[i] = x[i]*lam + x[b-1-i]*(1-lam) over fp32 clips [b, ...] (Mixup._mix_batch, mixup branch)."""
+    assert video.is_cuda and video.dtype == torch.float32 and video.is_contiguous()
+    b = video.shape[0]
+    L.check(L.load().dist_op_mixup(_p(video), b, video.numel() // b, _f32(lam), _f32(1.0 - lam), _stream()))
+    return video
+
+
+def cutmix_(video, yl, yh, xl, xh):
+    """in place: the box [yl,yh) x [xl,xh) of every plane is swapped between clip i and clip b-1-i (cutmix branch)."""
+    assert video.is_cuda and video.dtype == torch.float32 and video.is_contiguous() and video.dim() >= 3
+    b, H, W = video.shape[0], video.shape[-2], video.shape[-1]
+    L.check(L.load().dist_op_cutmix(_p(video), b, video.numel() // (b * H * W), H, W, int(yl), int(yh), int(xl), int(xh), _stream()))
+    return video
+
+
+def mixup_target(labels, num_classes, lam=1.0, smoothing=0.0):
+    """soft target [b, K] fp32 = y1*lam + y2*(1-lam) with smoothed one-hot rows (reference mixup_target)."""
+    assert labels.is_cuda
+    labels = labels.long().contiguous().view(-1)
+    off = smoothing / num_classes
+    on = 1.0 - smoothing + off
+    soft = torch.empty(labels.numel(), num_classes, dtype=torch.float32, device=labels.device)
+    L.check(L.load().dist_op_mixup_target(_p(labels), labels.numel(), num_classes, _f32(lam), _f32(1.0 - lam), _f32(on), _f32(off), _p(soft), _stream()))
+    return soft

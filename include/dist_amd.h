@@ -166,6 +166,19 @@ typedef struct dist_adamw_seg { int64_t begin, end; float lr, weight_decay; } di
 int dist_op_adamw(float* param, const float* grad, float* m, float* v, const dist_adamw_seg* segs_dev, int nseg,
                   int64_t n, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
 
+/* Batch-mode Mixup / CutMix of one rank's clips, in place on fp32 frames [b][3][T][H][W] (= [b][per_clip]), and the soft
+ * target; replaces Mixup._mix_batch and mixup_target of the reference (dataset/utils/mixup.py:212-223, :18-23; call site
+ * runs/train.py:92-93).  Clip i is paired with clip b-1-i (x.flip(0)), so ranks exchange nothing.  The host draws lam / the
+ * box exactly as the reference does (np.random, dataset/utils/mixup.py:43-64,89-100,160-176) and passes the fp32 values
+ * torch would use: lam = float(lam), one_minus_lam = float(1. - lam) (double subtraction first), on / off as mixup_target
+ * computes them.  Results are bit-identical to the reference's torch ops.
+ *   dist_op_mixup:        x[i] = x[i]*lam + x[b-1-i]*(1-lam) for every i (three roundings per element, as torch)
+ *   dist_op_cutmix:       swaps the box [yl,yh) x [xl,xh) of every (channel, frame) plane between clip i and clip b-1-i
+ *   dist_op_mixup_target: soft[i][k] = y1*lam + y2*(1-lam), y1 / y2 = smoothed one-hot of labels[i] / labels[b-1-i] */
+int dist_op_mixup(float* video, int b, int64_t per_clip, float lam, float one_minus_lam, void* stream);
+int dist_op_cutmix(float* video, int b, int planes, int H, int W, int yl, int yh, int xl, int xh, void* stream);
+int dist_op_mixup_target(const int64_t* labels, int b, int K, float lam, float one_minus_lam, float on_value, float off_value, float* soft, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Engine level: the whole hot path behind one handle.
  * ------------------------------------------------------------------------------------- */
@@ -255,6 +268,13 @@ int dist_loss(dist_handle* h, const float* soft_target, int b, float* loss, floa
 /* measurement hook for bench.py: between begin and end every launch of the dominant kernel (the plain
  * 128x128x64 MFMA GEMM of the frozen ViT) is bracketed by HIP events on its own stream; end() synchronises
  * those events and returns the summed duration, the summed algorithmic FLOPs (2*M*N*K) and the launch count. */
+/* Phase marks: device-side timestamps of the last step (HIP events on the streams the work runs on), for reading the real
+ * schedule of the pipelined step without a profiler.  dist_marks_read synchronises the device and returns, per mark, the
+ * milliseconds since DIST_MARK_VIT_BEGIN of the same step (NaN for a mark that was not recorded). */
+enum { DIST_MARK_VIT_BEGIN = 0, DIST_MARK_VIT_END = 1, DIST_MARK_FWD_BEGIN = 2, DIST_MARK_FWD_MID = 3, DIST_MARK_FWD_END = 4,
+       DIST_MARK_BWD_BEGIN = 5, DIST_MARK_BWD_END = 6, DIST_MARK_STEP_END = 7, DIST_NMARKS = 8 };
+int dist_marks_enable(dist_handle* h, int on);
+int dist_marks_read(dist_handle* h, float* ms, int n);
 int dist_profile_begin(dist_handle* h);
 int dist_profile_end(dist_handle* h, double* ms_total, double* flops_total, int* launches);
 /* read back an intermediate for tests: name in {"feat.<i>","stem","tn_out.<i>","int_out.<i>","x_temporal.<i>","mid.<i>"} */

@@ -5,6 +5,7 @@ summation over NUM_ENSEMBLE_VIEWS x NUM_SPATIAL_CROPS views, top-1 / top-5."""
 import os
 import sys
 
+import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -61,6 +62,7 @@ def perform_test(test_loader, model, test_meter, cfg, texts):
 
 
 def test(cfg):
+    np.random.seed(cfg.RANDOM_SEED)                             # reference runs/test.py:190-191
     torch.manual_seed(cfg.RANDOM_SEED)
     model, _ = build_model(cfg)
     if getattr(cfg.TEST, "CHECKPOINT_FILE_PATH", ""):

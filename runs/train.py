@@ -6,6 +6,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,8 +33,10 @@ def train_epoch(train_loader, model, model_ema, optimizer, cur_epoch, mixup_fn, 
 
     def fetch():
         item = next(it, None)
-        if item is not None and mixup_fn is not None:
-            item[0]["video"], item[1]["supervised"] = mixup_fn(item[0]["video"], item[1]["supervised"])
+        if item is not None and mixup_fn is not None:             # reference runs/train.py:92-93
+            if not item[0]["video"].is_cuda:
+                item[0]["video"] = item[0]["video"].cuda(non_blocking=True)
+            _, item[1]["supervised"] = mixup_fn(item[0], item[1]["supervised"].to(item[0]["video"].device))   # the clips are mixed in place
         return item
 
     nxt = fetch()
@@ -90,6 +93,7 @@ def eval_epoch(val_loader, model, cur_epoch, cfg, texts):
 
 
 def train(cfg):
+    np.random.seed(cfg.RANDOM_SEED)                             # reference runs/train.py:340-342 (Mixup draws from np.random)
     torch.manual_seed(cfg.RANDOM_SEED)
     model, model_ema = build_model(cfg)
     optimizer = optim.construct_optimizer(model, cfg)
@@ -103,11 +107,7 @@ def train(cfg):
     texts = label_texts(cfg, vocab=model.backbone.base_encoder.vocab_size)
     mixup_fn = None
     if cfg.AUGMENTATION.MIXUP.ENABLE or cfg.AUGMENTATION.CUTMIX.ENABLE:
-        mixup_fn = Mixup(mixup_alpha=cfg.AUGMENTATION.MIXUP.ALPHA if cfg.AUGMENTATION.MIXUP.ENABLE else 0.0,
-                         cutmix_alpha=cfg.AUGMENTATION.CUTMIX.ALPHA if cfg.AUGMENTATION.CUTMIX.ENABLE else 0.0,
-                         prob=cfg.AUGMENTATION.MIXUP.PROB, switch_prob=cfg.AUGMENTATION.MIXUP.SWITCH_PROB,
-                         mode=cfg.AUGMENTATION.MIXUP.MODE, label_smoothing=cfg.AUGMENTATION.LABEL_SMOOTHING,
-                         num_classes=cfg.VIDEO.HEAD.NUM_CLASSES, seed=cfg.RANDOM_SEED + du.get_rank())
+        mixup_fn = Mixup(cfg)                                  # reference runs/train.py:388; draws from np.random like the reference
     assert (cfg.OPTIMIZER.MAX_EPOCH - start_epoch) % cfg.TRAIN.NUM_FOLDS == 0, "Total training epochs should be divisible by cfg.TRAIN.NUM_FOLDS."
     stats = {}
     for cur_epoch in range(start_epoch, cfg.OPTIMIZER.MAX_EPOCH, cfg.TRAIN.NUM_FOLDS):

@@ -1,0 +1,145 @@
+"""Batch-mode Mixup / CutMix (reference dataset/utils/mixup.py:18-23,212-223).
+
+Not GPU: the numpy oracle reproduces the golden vectors the REFERENCE's own class produced (oracle/make_golden_mixup.py),
+bit for bit, and the evaluation-order trap of the in-place formula is pinned.
+GPU: the HIP-backed drop-in class (dist_op_mixup / dist_op_cutmix / dist_op_mixup_target behind the C ABI) reproduces the same
+vectors bit for bit from the same np.random seed, plus size-independent properties at the BASELINE batch.
+"""
+import os
+import sys
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import mixup_oracle as mo  # noqa: E402
+
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "mixup.npz"))
+NCASES = int(GOLD["n_cases"])
+
+
+def clips(seed, b, T, H, W):          # the recipe of oracle/make_golden_mixup.py (inputs are procedural, only outputs are stored)
+    return np.random.Generator(np.random.PCG64(1000 + seed)).standard_normal((b, 3, T, H, W)).astype(np.float32)
+
+
+def labels_of(seed, b, K):
+    return np.random.Generator(np.random.PCG64(2000 + seed)).integers(0, K, size=b).astype(np.int64)
+
+
+def case(ci):
+    seed, b, T, H, W, K = (int(v) for v in GOLD[f"c{ci}_meta"])
+    ma, ca, prob, sw, sm = (float(v) for v in GOLD[f"c{ci}_hyper"])
+    return seed, b, T, H, W, K, ma, ca, prob, sw, sm
+
+
+def cfg_of(K, ma, ca, prob, sw, sm):
+    return NS(AUGMENTATION=NS(MIXUP=NS(ALPHA=ma, PROB=prob, SWITCH_PROB=sw, MODE="batch"), CUTMIX=NS(ENABLE=ca > 0.0, ALPHA=ca, MINMAX=None),
+                              LABEL_SMOOTHING=sm), VIDEO=NS(HEAD=NS(NUM_CLASSES=K)))
+
+
+@pytest.mark.parametrize("ci", range(NCASES))
+def test_oracle_reproduces_the_reference_vectors(ci):
+    seed, b, T, H, W, K, ma, ca, prob, sw, sm = case(ci)
+    x, lab = clips(seed, b, T, H, W), labels_of(seed, b, K)
+    np.random.seed(seed)
+    lam, soft, _ = mo.mixup_call(x, lab, K, ma, ca, prob, sw, sm)
+    assert lam == float(GOLD[f"c{ci}_lam"])
+    assert np.array_equal(x, GOLD[f"c{ci}_x"])
+    assert np.array_equal(soft, GOLD[f"c{ci}_soft"])
+
+
+def test_golden_set_covers_mixup_cutmix_identity_and_odd_batches():
+    kinds = set()
+    for ci in range(NCASES):
+        seed, b, T, H, W, K, ma, ca, prob, sw, sm = case(ci)
+        np.random.seed(seed)
+        lam, uc = mo.params_per_batch(ma, ca, prob, sw)
+        kinds.add(("identity" if lam == 1.0 else "cutmix" if uc else "mixup", b % 2))
+    assert {("mixup", 0), ("mixup", 1), ("cutmix", 0), ("cutmix", 1), ("identity", 0)} <= kinds
+
+
+def test_in_place_formula_needs_the_flipped_copy_first():
+    """reference :221-222 takes x.flip(0) BEFORE scaling x; `x.mul_(lam).add_(x.flip(0).mul_(1-lam))` scales first and mixes
+    lam*x with lam*(1-lam)*flip(x) - the defect the round-1 class had."""
+    x0 = torch.from_numpy(clips(0, 4, 1, 4, 4)); lam = 0.3
+    good = x0.clone(); xf = good.flip(0).mul_(1.0 - lam); good.mul_(lam).add_(xf)
+    bad = x0.clone(); bad.mul_(lam).add_(bad.flip(0).mul_(1.0 - lam))
+    ora = x0.numpy().copy(); ora[...] = (ora * np.float32(lam)).astype(np.float32) + (ora[::-1] * np.float32(1.0 - lam)).astype(np.float32)
+    assert np.array_equal(good.numpy(), ora)
+    assert float((good - bad).abs().max()) > 0.1
+
+
+def test_product_class_refuses_cpu_tensors():
+    from dist_amd.dataset.utils.mixup import Mixup
+    fn = Mixup(cfg_of(10, 0.8, 1.0, 1.0, 0.5, 0.1))
+    np.random.seed(0)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        fn({"video": torch.zeros(2, 3, 1, 4, 4)}, torch.zeros(2, dtype=torch.long))
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("ci", range(NCASES))
+def test_hip_mixup_is_bit_identical_to_the_reference(gpu_lib, ci):
+    from dist_amd.dataset.utils.mixup import Mixup
+    seed, b, T, H, W, K, ma, ca, prob, sw, sm = case(ci)
+    x = torch.from_numpy(clips(seed, b, T, H, W)).cuda()
+    lab = torch.from_numpy(labels_of(seed, b, K)).cuda()
+    fn = Mixup(cfg_of(K, ma, ca, prob, sw, sm))
+    np.random.seed(seed)
+    inputs, soft = fn({"video": x}, lab)
+    assert inputs["video"] is x                                   # in place, like the reference
+    assert np.array_equal(x.cpu().numpy(), GOLD[f"c{ci}_x"])
+    assert np.array_equal(soft.cpu().numpy(), GOLD[f"c{ci}_soft"])
+
+
+@pytest.mark.gpu
+def test_hip_mixup_properties_at_the_baseline_batch(gpu_lib):
+    """b = 32 clips of 3 x 16 x 224 x 224 (BASELINE config 2, 308 MB): oracle-sized checks do not reach this size, properties do."""
+    from dist_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x0 = torch.randn(32, 3, 16, 224, 224, generator=g, device="cuda")
+    # cutmix is an involution, leaves everything outside the box untouched and swaps the box between clip i and clip 31-i
+    x = x0.clone()
+    ops.cutmix_(x, 30, 140, 17, 201)
+    assert torch.equal(x[:, :, :, :30], x0[:, :, :, :30]) and torch.equal(x[:, :, :, 140:], x0[:, :, :, 140:])
+    assert torch.equal(x[..., :17], x0[..., :17]) and torch.equal(x[..., 201:], x0[..., 201:])
+    assert torch.equal(x[:, :, :, 30:140, 17:201], x0.flip(0)[:, :, :, 30:140, 17:201])
+    ops.cutmix_(x, 30, 140, 17, 201)
+    assert torch.equal(x, x0)
+    # mixup equals the reference's three torch ops bit for bit, on every element
+    lam = 0.37251
+    x = x0.clone(); ops.mixup_(x, lam)
+    ref = x0.clone(); xf = ref.flip(0).mul_(1.0 - lam); ref.mul_(lam).add_(xf)
+    assert torch.equal(x, ref)
+    del ref, xf
+    # lam = 1 (the class never launches then) is the identity up to -0 / rounding of x*1 + y*0
+    x = x0.clone(); ops.mixup_(x, 1.0)
+    assert torch.equal(x, x0)
+    # soft target: rows sum to 1, and equal the reference's tensor expression bit for bit
+    lab = torch.randint(0, 174, (32,), generator=g, device="cuda")
+    soft = ops.mixup_target(lab, 174, lam, 0.1)
+    off = 0.1 / 174; on = 1.0 - 0.1 + off
+    y1 = torch.full((32, 174), off, device="cuda").scatter_(1, lab.view(-1, 1), on)
+    y2 = torch.full((32, 174), off, device="cuda").scatter_(1, lab.flip(0).view(-1, 1), on)
+    assert torch.equal(soft, y1 * lam + y2 * (1.0 - lam))
+    torch.testing.assert_close(soft.sum(1), torch.ones(32, device="cuda"), rtol=0, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_mixup_edge_cases(gpu_lib):
+    from dist_amd import ops
+    x0 = torch.randn(3, 3, 2, 8, 8, device="cuda")                # odd batch: the middle clip is mixed with itself / keeps its box
+    x = x0.clone(); ops.cutmix_(x, 2, 6, 1, 5)
+    assert torch.equal(x[1], x0[1]) and torch.equal(x[0, ..., 2:6, 1:5], x0[2, ..., 2:6, 1:5])
+    x = x0.clone(); ops.cutmix_(x, 3, 3, 0, 8)                    # empty box: nothing moves
+    assert torch.equal(x, x0)
+    x = x0.clone(); ops.cutmix_(x, 0, 8, 0, 8)                    # whole frame: the batch is flipped
+    assert torch.equal(x, x0.flip(0))
+    x1 = torch.randn(1, 3, 2, 8, 8, device="cuda")                # a single clip pairs with itself
+    y = x1.clone(); ops.mixup_(y, 0.25)
+    r = x1.clone(); rf = r.flip(0).mul_(0.75); r.mul_(0.25).add_(rf)
+    assert torch.equal(y, r)
