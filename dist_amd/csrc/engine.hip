@@ -108,6 +108,7 @@ struct dist_handle {
     void *patches, *x0, *xa, *hbuf, *qkv, *att, *mlp;
     float *lnstats2 = nullptr, *lnstats3 = nullptr; int dummy = 0, dummy_reps = 1;   // perturbation experiment (DIST_AMD_DUMMY)
     float* lnstats = nullptr;                    // [2][rowsS] mean / rstd of the LayerNorm folded into the next ViT GEMM
+    float* lnpart = nullptr;                     // [width / 64][rowsS][2] partial (sum, sum of squares) of the residual stream, left by the GEMM that wrote it
     bool vit_fold = false;                       // ln_1 -> in_proj and ln_2 -> c_fc folded (bf16, shapes the LDS-DMA GEMM takes)
     std::vector<void*> feat;
     // Two feature slots (patch rows + the 12 mid_feat tensors + their events): the frozen ViT of the NEXT batch can fill the
@@ -401,6 +402,7 @@ size_t layout_ws(dist_handle* h, char* base) {
     h->x0 = T_(rowsS, d); h->xa = T_(rowsS, d); h->hbuf = T_(rowsS, d);
     h->qkv = T_(rowsS, 3 * d); h->att = T_(rowsS, d); h->mlp = T_(rowsS, 4 * d);
     h->lnstats = F_(2 * rowsS); h->lnstats2 = F_(2 * rowsS); h->lnstats3 = F_(2 * rowsS);
+    h->lnpart = F_(2 * rowsS * ((c.width + 63) / 64));
     for (int i = 0; i < c.layers; ++i) {
         VitLayer& v = h->vit[i];
         v.cs_qkv = F_(3 * d); v.b_qkv = F_(3 * d); v.cs_fc = F_(4 * d); v.b_fc = F_(4 * d);
@@ -471,10 +473,12 @@ dist_outmap OM(int mode = DIST_OM_PLAIN, int p0 = 0, int p1 = 0, int p2 = 0) { r
 
 // C (and/or C2) = epi(A[amap] . W^T): thin positional wrapper over dist_op_gemm_nt
 int gemm(const Ctx& c, const void* A, int lda, const void* W, long M, int N, int K, int taps, void* C, int ldc,
-         const float* bias, const void* res, const void* aux, void* C2, dist_rowmap am = RM(), dist_outmap om = OM(), int extra_flags = 0, const float* bias2 = nullptr) {
+         const float* bias, const void* res, const void* aux, void* C2, dist_rowmap am = RM(), dist_outmap om = OM(), int extra_flags = 0, const float* bias2 = nullptr,
+         float* rowstats = nullptr) {
     dist_gemm_args g;
     memset(&g, 0, sizeof(g));
     g.A = A; g.B = W; g.C = C; g.C2 = C2; g.bias = bias; g.bias2 = bias2; g.res = res; g.aux = aux;
+    if (rowstats) { g.rowstats = rowstats; extra_flags |= DIST_EPI_ROWSTATS; }
     g.M = M; g.N = N; g.K = K; g.taps = taps;
     g.lda = lda; g.ldb = taps * K; g.ldc = ldc; g.ldc2 = ldc; g.ldres = ldc; g.ldaux = ldc;
     g.amap = am; g.omap = om;
@@ -523,6 +527,16 @@ int gemm_lnfold(const Ctx& c, const void* A, int lda, const void* Wf, long M, in
         h->prof_flops += 2.0 * (double)M * N * K;
     }
     return rc < 0 ? rc : 1;
+}
+// can C = A W^T + bias + res (plain maps) leave DIST_EPI_ROWSTATS partials, i.e. does the LDS-DMA kernel take this shape?
+bool rowstats_ok(const Ctx& c, long M, int N, int K) {
+    dist_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    void* nz = reinterpret_cast<void*>(16);
+    g.A = nz; g.B = nz; g.C = nz; g.res = nz; g.bias = static_cast<const float*>(nz); g.rowstats = static_cast<float*>(nz);
+    g.M = M; g.N = N; g.K = K; g.taps = 1; g.lda = K; g.ldb = K; g.ldc = g.ldc2 = g.ldres = g.ldaux = N;
+    g.amap = RM(); g.omap = OM(); g.flags = DIST_EPI_BIAS | DIST_EPI_RES | DIST_EPI_ROWSTATS; g.dtype = c.dtype;
+    return N % 64 == 0 && dist_k_gemm_fast_eligible(&g);
 }
 int wgrad(const Ctx& c, const Lin& l, const void* dY, int ld_dy, const void* X, int ldx, long M,
           dist_rowmap am = RM(), dist_rowmap bm = RM(), int style = 0, bool with_bias = false) {
@@ -780,6 +794,13 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
     } else {
         xin = S.feat[l0 - 1];
     }
+    // Row statistics of the residual stream from the GEMM that writes it (DIST_EPI_ROWSTATS): `out` leaves the partials ln_2 / c_fc
+    // need, `proj` those of the next block's ln_1 / in_proj; dist_op_ln_stats_from_partials (5 MB in, 0.4 MB out) replaces the
+    // statistics pass over the 77 MB tensor (23 of 24 per ViT pass).  The first block of a call still runs the statistics pass (its input comes from ln_pre, or from an
+    // earlier partial pass).  DIST_AMD_ROWSTATS=0: off (measurement knob).
+    static const bool rs_env = !(getenv("DIST_AMD_ROWSTATS") && atoi(getenv("DIST_AMD_ROWSTATS")) == 0);
+    const bool rs = rs_env && h->vit_fold && rowstats_ok(x, rowsS, d, d) && rowstats_ok(x, rowsS, d, 4 * d);
+    bool part_of_xin = false;                          // lnpart holds the partials of `xin`
     for (int i = l0; i < l1; ++i) {
         const VitLayer& v = h->vit[i];
         // the QKV GEMM writes [frame][head][q|k|v][L][64] (DIST_OM_HEADS, leading dimension 64): every (frame, head) operand of
@@ -788,7 +809,8 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
         // W diag(gamma) and normalises in its epilogue - the normalised tensor is never written or read back.
         int folded = 0;
         if (h->vit_fold) {
-            RUN(ln_fwd(x, h->visual, v.ln1, xin, nullptr, rowsS, h->lnstats, h->lnstats + rowsS));
+            if (part_of_xin) RUN(dist_op_ln_stats_from_partials(h->lnpart, d / 64, rowsS, d, 1e-5f, h->lnstats, h->lnstats + rowsS, stream));
+            else RUN(ln_fwd(x, h->visual, v.ln1, xin, nullptr, rowsS, h->lnstats, h->lnstats + rowsS));
             folded = gemm_lnfold(x, xin, d, x.pk(v.pk_fold_qkv), rowsS, 3 * d, d, h->qkv, 64, v.b_qkv, h->lnstats, v.cs_qkv, nullptr, OM(DIST_OM_HEADS, L, h->heads));
             if (folded < 0) return fail(h, folded, "folded QKV GEMM failed");
         }
@@ -797,10 +819,11 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
             RUN(gemm(x, h->hbuf, d, x.pk(v.qkv.pk.f), rowsS, 3 * d, d, 1, h->qkv, 64, x.vs(v.qkv.bias), nullptr, nullptr, nullptr, RM(), OM(DIST_OM_HEADS, L, h->heads)));
         }
         RUN(dist_op_attention(h->qkv, h->att, b * h->t, L, h->heads, DIST_QKV_HEADS, c.dtype, stream));
-        RUN(gemm(x, h->att, d, x.pk(v.out.pk.f), rowsS, d, d, 1, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr));
+        RUN(gemm(x, h->att, d, x.pk(v.out.pk.f), rowsS, d, d, 1, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr, RM(), OM(), 0, nullptr, rs ? h->lnpart : nullptr));
         folded = 0;
         if (h->vit_fold) {
-            RUN(ln_fwd(x, h->visual, v.ln2, h->xa, nullptr, rowsS, h->lnstats, h->lnstats + rowsS));
+            if (rs) RUN(dist_op_ln_stats_from_partials(h->lnpart, d / 64, rowsS, d, 1e-5f, h->lnstats, h->lnstats + rowsS, stream));
+            else RUN(ln_fwd(x, h->visual, v.ln2, h->xa, nullptr, rowsS, h->lnstats, h->lnstats + rowsS));
             folded = gemm_lnfold(x, h->xa, d, x.pk(v.pk_fold_fc), rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, h->lnstats, v.cs_fc, h->mlp);
             if (folded < 0) return fail(h, folded, "folded MLP GEMM failed");
         }
@@ -808,7 +831,8 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
             RUN(ln_fwd(x, h->visual, v.ln2, h->xa, h->hbuf, rowsS, nullptr, nullptr));
             RUN(gemm(x, h->hbuf, d, x.pk(v.fc.pk.f), rowsS, 4 * d, d, 1, nullptr, 4 * d, x.vs(v.fc.bias), nullptr, nullptr, h->mlp));
         }
-        RUN(gemm(x, h->mlp, 4 * d, x.pk(v.proj.pk.f), rowsS, d, 4 * d, 1, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr));
+        RUN(gemm(x, h->mlp, 4 * d, x.pk(v.proj.pk.f), rowsS, d, 4 * d, 1, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr, RM(), OM(), 0, nullptr, rs ? h->lnpart : nullptr));
+        part_of_xin = rs;
         HIP_CHECK_RET(hipEventRecord(S.ev_feat[i], x.s));               // mid_feat[i] complete: the branch may consume it
         if (h->dummy & 1) for (int r = 0; r < h->dummy_reps; ++r) RUN(ln_fwd(x, h->visual, v.ln1, S.feat[i], nullptr, rowsS, h->lnstats2, h->lnstats2 + rowsS));
         xin = S.feat[i];

@@ -159,6 +159,24 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
         flush(C2, p.ldc2);
     } else {
         flush(C, p.ldc);
+        if ((flags & DIST_EPI_ROWSTATS) && nw < N) {
+            // DIST_EPI_ROWSTATS: sum and sum of squares of the wave's 64 stored columns (one slice; N % 64 == 0), read back from the
+            // staged bf16 tile while its stores drain - the accumulators are dead here (inside the conversion loop above the same
+            // sums cost 60-70 spilled registers).  Lane l owns rows l and l + 64; chunks and elements in a fixed order.
+#pragma unroll 1
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int r = h2 * 64 + lane;
+                float rs = 0.f, rq = 0.f;
+                bf16x8 v[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = *reinterpret_cast<const bf16x8*>(ew + r * 128 + ((c ^ (r & 7)) << 4));
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float x = (float)v[c][e]; rs += x; rq += x * x; }
+                if (mw + r < M) *reinterpret_cast<float2*>(p.rowstats + ((long)(nw >> 6) * M + mw + r) * 2) = make_float2(rs, rq);
+            }
+        }
         if (flags & DIST_EPI_ACT2) {                      // second output = quickgelu(stored value)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -553,8 +571,12 @@ static bool fast_common_ok(const dist_gemm_args* a) {
     if (a->amap.mode != DIST_RM_PLAIN && a->amap.mode != DIST_RM_STRIDED && a->amap.mode != DIST_RM_SKIPCLS) return false;
     if (a->omap.mode != DIST_OM_PLAIN && a->omap.mode != DIST_OM_INSERTCLS && a->omap.mode != DIST_OM_HEADS) return false;
     if (a->flags & DIST_EPI_MULG) return false;
-    if (a->flags & DIST_EPI_LNFOLD) { if (!a->aux || !a->bias2 || a->amap.mode != DIST_RM_PLAIN) return false; }
-    else if (a->bias2) return false;
+    if (a->flags & DIST_EPI_LNFOLD) {
+        if (!a->aux || !a->bias2 || a->amap.mode != DIST_RM_PLAIN) return false;
+    } else if (a->bias2) return false;
+    if (a->flags & DIST_EPI_ROWSTATS) {
+        if (!a->rowstats || !a->C || a->omap.mode != DIST_OM_PLAIN || (a->flags & DIST_EPI_ACT2)) return false;
+    }
     if (a->K % BK || a->K < 4 * BK || a->N % 64 || a->M < 1024) return false;
     if (a->lda % 8 || a->ldb % 8 || a->ldc % 8 || a->ldc2 % 8 || a->ldres % 8) return false;
     if (a->omap.mode == DIST_OM_HEADS && (a->flags & (DIST_EPI_RES | DIST_EPI_ACT2))) return false;

@@ -278,6 +278,36 @@ extern "C" int dist_op_layernorm(const dist_ln_args* a, void* stream) {
     return DIST_OK;
 }
 
+namespace {
+// one thread per row; consecutive threads read consecutive (S, Q) pairs of a slice (coalesced), slices in index order
+__global__ __launch_bounds__(256) void ln_stats_from_partials_kernel(const float2* __restrict__ part, const int slices, const long rows, const float invC,
+                                                                      const float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+    const long m = (long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= rows) return;
+    float s = 0.f, q = 0.f;
+    int sl = 0;
+    for (; sl + 4 <= slices; sl += 4) {                  // four loads in flight before the first addition
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = part[(long)(sl + u) * rows + m];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s += v[u].x; q += v[u].y; }
+    }
+    for (; sl < slices; ++sl) { const float2 v = part[(long)sl * rows + m]; s += v.x; q += v.y; }
+    const float mu = s * invC;
+    mean[m] = mu;
+    rstd[m] = rsqrtf(fmaxf(q * invC - mu * mu, 0.f) + eps);
+}
+}  // namespace
+
+extern "C" int dist_op_ln_stats_from_partials(const float* part, int slices, int64_t rows, int C, float eps, float* mean, float* rstd, void* stream) {
+    if (!part || !mean || !rstd || slices <= 0 || rows <= 0 || C != 64 * slices) return DIST_ERR_ARG;
+    hipLaunchKernelGGL(ln_stats_from_partials_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float2*>(part), slices, (long)rows, 1.f / (float)C, eps, mean, rstd);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+
 extern "C" int dist_op_layernorm_bwd(const dist_ln_bwd_args* a, void* stream) {
     if (!a || !a->x || !a->mean || !a->rstd || !a->dy || !a->w || a->rows <= 0) return DIST_ERR_ARG;
     if (a->C % 8 || a->C > 1024 || a->C < 8) return DIST_ERR_ARG;

@@ -37,7 +37,7 @@ def outmap(mode=L.OM_PLAIN, p0=0, p1=0, p2=0):
 
 
 def gemm_nt(A, B, M, N, K, *, taps=1, bias=None, res=None, aux=None, amap=None, omap=None,
-            C_out=None, C2_out=None, lda=None, ldc=None, mulg_post=False, lnfold=None):
+            C_out=None, C2_out=None, lda=None, ldc=None, mulg_post=False, lnfold=None, rowstats=None):
     """C[omap(m)][n] = epi(sum_tap sum_k A[amap(m,tap)][k] B[n][tap*K+k]); returns None (writes C_out / C2_out)."""
     lib = L.load()
     a = L.GemmArgs()
@@ -60,6 +60,9 @@ def gemm_nt(A, B, M, N, K, *, taps=1, bias=None, res=None, aux=None, amap=None, 
         stats, colsum = lnfold
         a.aux, a.bias2 = _p(stats), _p(colsum)
         a.flags |= L.EPI_LNFOLD
+    if rowstats is not None:        # fp32 [N/64][M][2]: (sum, sum of squares) of the stored values per 64-column slice (EPI_ROWSTATS)
+        a.rowstats = _p(rowstats)
+        a.flags |= L.EPI_ROWSTATS
     a.dtype = _dt(A)
     L.check(lib.dist_op_gemm_nt(C.byref(a), _stream()))
 
@@ -106,6 +109,14 @@ def layernorm(x, w, b, *, y=None, y2=None, w2=None, b2=None, addend=None, period
     a.rows, a.C, a.dtype, a.eps = rows, Cc, _dt(x), eps
     L.check(lib.dist_op_layernorm(C.byref(a), _stream()))
     return y
+
+
+def ln_stats_from_partials(part, C_, eps=1e-5):
+    """fp32 [2*M] = mean then rstd from the [C/64][M][2] partials an EPI_ROWSTATS GEMM left (dist_op_ln_stats_from_partials)."""
+    slices, M = part.shape[0], part.shape[1]
+    stats = torch.empty(2 * M, dtype=torch.float32, device=part.device)
+    L.check(L.load().dist_op_ln_stats_from_partials(_p(part), slices, M, C_, eps, _p(stats[:M]), _p(stats[M:]), _stream()))
+    return stats
 
 
 def layernorm_bwd(x, mean, rstd, dy, w, *, dy2=None, w2=None, dx=None, accumulate=False, dw=None, db=None, dw2=None, db2=None,

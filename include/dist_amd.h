@@ -60,13 +60,20 @@ enum {
     DIST_EPI_RES = 4,    /* v += res[dest][n] */
     DIST_EPI_ACT2 = 8,   /* C2[dest][n] = quickgelu(v)  (C, if non-null, keeps the pre-activation) */
     DIST_EPI_MULG_POST = 16, /* with MULG: the derivative factor is applied AFTER bias and residual: v = (acc + bias + res) * quickgelu'(aux) */
-    DIST_EPI_LNFOLD = 32     /* the GEMM consumes the RAW rows x of a LayerNorm-then-Linear pair (clip.py:160-176: ln_1 -> attn
+    DIST_EPI_LNFOLD = 32,    /* the GEMM consumes the RAW rows x of a LayerNorm-then-Linear pair (clip.py:160-176: ln_1 -> attn
                               * in_proj, ln_2 -> mlp.c_fc) and normalises in the epilogue:
                               *   v = rstd[m] * (acc - mean[m] * colsum[n]) + bias[n]
                               * with B = W * diag(gamma) (bf16), colsum[n] = sum_k B[n][k], bias[n] = b[n] + sum_k W[n][k] beta[k]
                               * (dist_op_ln_fold prepares all three).  `aux` carries the row statistics as fp32 [2][M] (mean, then
                               * rstd: dist_op_layernorm with y = NULL), `bias2` carries colsum.  Large plain bf16 GEMMs only
                               * (the 256x256 LDS-DMA kernel); not combinable with MULG. */
+    DIST_EPI_ROWSTATS = 64   /* producer side of the same fold: besides C, the GEMM stores the row sums of its STORED (rounded)
+                              * values and of their squares over every 64-column slice, rowstats[slice][m] = (S, Q) fp32, slice =
+                              * column / 64 - plain stores in a fixed order (no atomics: results do not depend on the batch a row
+                              * sits in).  dist_op_ln_stats_from_partials turns them into the [2][M] mean / rstd a DIST_EPI_LNFOLD
+                              * GEMM consumes, so the residual stream is never re-read for its LayerNorm statistics
+                              * (clip.py:160-176: x -> ln_2 -> c_fc, x -> ln_1 -> in_proj of the next block).  Large plain bf16
+                              * GEMMs with a plain output map, C != NULL. */
 };
 
 /* C[omap(m)][n] = epi( sum_tap sum_k A[amap(m,tap)][k] * B[n][tap*K + k] )
@@ -80,6 +87,7 @@ typedef struct dist_gemm_args {
     dist_rowmap amap; dist_outmap omap;
     int flags; int dtype;
     const float* bias2;   /* optional second bias, added with `bias` (two Linears evaluated as one GEMM over side-by-side inputs) */
+    float* rowstats;      /* DIST_EPI_ROWSTATS: fp32 [N / 64][M][2] */
 } dist_gemm_args;
 int dist_op_gemm_nt(const dist_gemm_args* a, void* stream);
 /* prepares a LayerNorm-then-Linear pair for DIST_EPI_LNFOLD: Wp[n][k] = bf16(W[n][k] * gamma[k]) (overwrites the packed
@@ -118,6 +126,10 @@ typedef struct dist_ln_args {
     int64_t rows; int C; int dtype; float eps;
 } dist_ln_args;
 int dist_op_layernorm(const dist_ln_args* a, void* stream);
+/* mean[m] = S / C, rstd[m] = rsqrt(Q / C - mean^2 + eps) with (S, Q) = sum over `slices` of part[slice][m] (fp32 [slices][rows][2],
+ * left by a DIST_EPI_ROWSTATS GEMM over a C = 64 * slices wide tensor): the statistics-only form of dist_op_layernorm (y = NULL)
+ * without reading the tensor.  Slices are added in index order. */
+int dist_op_ln_stats_from_partials(const float* part, int slices, int64_t rows, int C, float eps, float* mean, float* rstd, void* stream);
 
 /* dx (+)= LN'(dy [, dy2]); dw/db (+= atomics), all optional except x/mean/rstd */
 typedef struct dist_ln_bwd_args {

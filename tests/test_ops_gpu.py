@@ -510,3 +510,50 @@ def test_layernorm_folded_into_gemm(gpu_lib, M, N, K, act):
     # not combinable with the activation-derivative epilogue, and only for shapes the LDS-DMA kernel takes
     with pytest.raises(L.DistError):
         ops.gemm_nt(x[:512], Wp, 512, N, K, bias=bf, lnfold=(stats, cs), C_out=out[:512])
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 768, 768), (3152, 768, 3072), (1500, 1024, 1024)])
+def test_row_statistics_from_the_producer_gemm(gpu_lib, M, N, K):
+    """DIST_EPI_ROWSTATS / ln_part: the GEMM that writes the residual stream (reference clip.py:160-176, x = x + attn(..),
+    x = x + mlp(..)) leaves, per row and 64-column slice, the sum and the sum of squares of the values it STORED;
+    dist_op_ln_stats_from_partials turns them into the mean / rstd the next LayerNorm-folded GEMM consumes, so the rows are not re-read."""
+    from dist_amd import ops, lib as L
+    torch.manual_seed(1)
+    dev, dt = "cuda", torch.bfloat16
+    A = torch.randn(M, K, device=dev).to(dt)
+    W = (torch.randn(N, K, device=dev) * K ** -0.5).to(dt)
+    bias = torch.randn(N, device=dev)
+    res = (torch.randn(M, N, device=dev) * 1.5 + 0.7).to(dt)
+    X = torch.empty(M, N, dtype=dt, device=dev)
+    part = torch.full((N // 64, M, 2), float("nan"), device=dev)
+    ops.gemm_nt(A, W, M, N, K, bias=bias, res=res, C_out=X, rowstats=part)
+    X0 = torch.empty_like(X)
+    ops.gemm_nt(A, W, M, N, K, bias=bias, res=res, C_out=X0)
+    assert torch.equal(X, X0)                                     # the output itself is untouched by the extra epilogue
+    xs = X.float().reshape(M, N // 64, 64)
+    torch.testing.assert_close(part[:, :, 0].t(), xs.sum(2), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(part[:, :, 1].t(), (xs * xs).sum(2), rtol=1e-5, atol=1e-4)
+    part2 = torch.empty_like(part)                                # fixed summation order: a second launch gives the same bits
+    ops.gemm_nt(A, W, M, N, K, bias=bias, res=res, C_out=X0, rowstats=part2)
+    assert torch.equal(part, part2)
+    # dist_op_ln_stats_from_partials: the statistics dist_op_layernorm(y = NULL) computes from the rows, without the rows
+    st = ops.ln_stats_from_partials(part, N)
+    xf = X.float()
+    torch.testing.assert_close(st[:M], xf.mean(1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(st[M:], torch.rsqrt(xf.var(1, unbiased=False) + 1e-5), rtol=1e-4, atol=1e-5)
+    assert torch.equal(st, ops.ln_stats_from_partials(part, N))
+    # consumer: LayerNorm(X) -> Linear through the fold with those statistics
+    N2 = 1024
+    W2 = torch.randn(N2, N, device=dev) * N ** -0.5
+    b2 = torch.randn(N2, device=dev)
+    gamma = 1.0 + 0.3 * torch.randn(N, device=dev)
+    beta = 0.2 * torch.randn(N, device=dev)
+    Wp, cs, bf = ops.ln_fold(W2, b2, gamma, beta)
+    out = torch.empty(M, N2, dtype=dt, device=dev)
+    ops.gemm_nt(X, Wp, M, N2, N, bias=bf, lnfold=(st, cs), C_out=out)
+    ref = torch.nn.functional.layer_norm(xf, (N,), gamma, beta, 1e-5) @ W2.t() + b2
+    scale = float(ref.abs().max())
+    assert float((out.float() - ref).abs().max()) < 1.5e-2 * scale
+    # only the LDS-DMA kernel leaves partials: other shapes refuse instead of silently skipping them
+    with pytest.raises(L.DistError):
+        ops.gemm_nt(A[:512], W, 512, N, K, bias=bias, res=res[:512], C_out=X[:512], rowstats=part)
