@@ -747,7 +747,9 @@ extern "C" int dist_pack_weights(dist_handle* h, int what, void* stream) {
     RUN(dist_k_pack(descs, blk_desc, blk_first, first, count, h->theta, h->visual, dst, h->cfg.dtype, s));
     // frozen ViT: ln_1 -> attn.in_proj and ln_2 -> mlp.c_fc folded (W diag(gamma), column sums, folded biases); DIST_AMD_LNFOLD=0: off
     static const bool fold_on = !(getenv("DIST_AMD_LNFOLD") && atoi(getenv("DIST_AMD_LNFOLD")) == 0);
-    h->vit_fold = false;
+    // (only a pack of the frozen weights touches the fold: the per-step re-pack of the trainable weights, what = 2, used to reset
+    // vit_fold and every ViT pass after the first optimizer step ran the unfolded LayerNorm + GEMM)
+    if (what & 1) h->vit_fold = false;
     if ((what & 1) && h->cfg.dtype == DIST_BF16 && fold_on && h->vit.size() && h->vit[0].cs_qkv) {
         const int d = h->cfg.width;
         for (VitLayer& v : h->vit) {
@@ -1324,5 +1326,6 @@ extern "C" int dist_debug_tensor(dist_handle* h, const char* name, const void** 
     if (key == "x_temporal" && layer_ok()) { *ptr = (i + 1 < c.layers) ? h->lw[i + 1].X : h->Xlast; *rows = rowsX; *cols = c.temporal_dim; return DIST_OK; }
     if (key == "mid" && layer_ok()) { *ptr = h->lw[i].Mp; *rows = rowsS; *cols = c.integration_dim; return DIST_OK; }
     if (key == "patches") { *ptr = h->patches; *rows = rowsX; *cols = h->Kp; return DIST_OK; }
+    if (key == "vit_ln_out") { *ptr = h->hbuf; *rows = rowsS; *cols = c.width; return DIST_OK; }   // LayerNorm output scratch of the ViT (unused when folded)
     return fail(h, DIST_ERR_ARG, "unknown debug tensor %s", name);
 }

@@ -306,3 +306,19 @@ def test_vit_prefetch_pipeline_equals_the_serial_order(gpu_lib, dtype):
     e2.vit_prefetch(vids[steps % 2]); e2.vit_adopt()
     torch.cuda.synchronize()
     torch.testing.assert_close(ref, e2.debug("feat.0"), rtol=0, atol=0)
+
+
+def test_vit_layernorm_fold_survives_the_optimizer_step(gpu_lib):
+    """The frozen ViT's LayerNorms are folded into the consuming GEMMs (DIST_EPI_LNFOLD, statistics from DIST_EPI_ROWSTATS partials):
+    the normalised tensor is never written.  The per-step re-pack of the TRAINABLE weights must leave that alone - it used to reset
+    the fold, so every ViT pass after the first optimizer step ran LayerNorm + GEMM again (and bench.py measured that)."""
+    g, eng, sd, video, text, tgt = build("b16_8+16f", 2, torch.bfloat16)
+    eng.vit_forward(video); eng.branch_forward(text)
+    scratch = eng.debug("vit_ln_out")
+    for after_step in (False, True):
+        if after_step:
+            _, dl = eng.loss(tgt); eng.backward(dl); eng.adamw_step(3.2e-5, 1e-4, lr_mult=10.0)
+        scratch.fill_(float("nan"))
+        eng.vit_forward(video); eng.branch_forward(text)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(scratch.float()).all()), f"the ViT wrote its LayerNorm output (after_step={after_step}): the fold is off"
