@@ -163,4 +163,35 @@ DEV int rowmap_src(const dist_rowmap& rm, int m, int tap, int taps) {
     }
 }
 
+// Two-stage form for loops that walk the taps of one row: the divisions happen once per row (rowmap_prep), the per-tap step is a few
+// adds and compares (rowmap_src2 == rowmap_src for every (m, tap)).
+struct RowPrep { int a, b; };
+DEV RowPrep rowmap_prep(const dist_rowmap& rm, int m) {
+    switch (rm.mode) {
+        case DIST_RM_SHIFT: return RowPrep{m % rm.p0, 0};
+        case DIST_RM_SPATIAL: { const int n = m % (rm.p0 * rm.p0); return RowPrep{n / rm.p0, n % rm.p0}; }
+        case DIST_RM_STRIDED: return RowPrep{m / rm.p1, m % rm.p1};
+        case DIST_RM_SKIPCLS: return RowPrep{m / rm.p0, m % rm.p0};
+        default: return RowPrep{0, 0};
+    }
+}
+DEV int rowmap_src2(const dist_rowmap& rm, int m, const RowPrep q, int tap, int taps) {
+    switch (rm.mode) {
+        case DIST_RM_SHIFT: {
+            const int off = rm.sign * (tap - taps / 2) * rm.p1;
+            const int r = q.a + off;
+            return (r >= 0 && r < rm.p0) ? m + off : -1;
+        }
+        case DIST_RM_SPATIAL: {
+            const int gsz = rm.p0;
+            const int dy = (tap / 3 - 1) * rm.sign, dx = (tap % 3 - 1) * rm.sign;
+            const int y = q.a + dy, x = q.b + dx;
+            return (y >= 0 && y < gsz && x >= 0 && x < gsz) ? m + dy * gsz + dx : -1;
+        }
+        case DIST_RM_STRIDED: return (q.a * rm.p0 + tap) * rm.p1 + q.b;
+        case DIST_RM_SKIPCLS: return q.a * (rm.p0 + 1) + 1 + q.b;
+        default: return m;
+    }
+}
+
 #define HIP_CHECK_RET(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return -(int)e_ - 1000; } while (0)
