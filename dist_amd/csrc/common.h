@@ -194,4 +194,30 @@ DEV int rowmap_src2(const dist_rowmap& rm, int m, const RowPrep q, int tap, int 
     }
 }
 
+// Stepping a row decomposition by `delta` rows without dividing (loops whose rows advance by a constant: the weight-gradient
+// GEMM walks 64 rows per step).  rowmap_inc_ok: one conditional subtraction per component is enough for this map and delta.
+DEV bool rowmap_inc_ok(const dist_rowmap& rm, int delta) {
+    switch (rm.mode) {
+        case DIST_RM_SHIFT: return delta <= rm.p0;
+        case DIST_RM_SPATIAL: return delta / rm.p0 + 1 <= rm.p0;
+        case DIST_RM_STRIDED: return delta <= rm.p1;
+        case DIST_RM_SKIPCLS: return delta <= rm.p0;
+        default: return true;
+    }
+}
+DEV RowPrep rowmap_step(const dist_rowmap& rm, RowPrep q, int delta) {      // == rowmap_prep(rm, m + delta) given q == rowmap_prep(rm, m)
+    switch (rm.mode) {
+        case DIST_RM_SHIFT: { int a = q.a + delta; a -= (a >= rm.p0) ? rm.p0 : 0; return RowPrep{a, 0}; }
+        case DIST_RM_SPATIAL: {
+            const int g = rm.p0, dq = delta / g, dr = delta - dq * g;          // wave-uniform
+            int x = q.b + dr; const int c = x >= g ? 1 : 0; x -= c ? g : 0;
+            int y = q.a + dq + c; y -= (y >= g) ? g : 0;
+            return RowPrep{y, x};
+        }
+        case DIST_RM_STRIDED: { int n = q.b + delta; const int c = n >= rm.p1 ? 1 : 0; return RowPrep{q.a + c, n - (c ? rm.p1 : 0)}; }
+        case DIST_RM_SKIPCLS: { int n = q.b + delta; const int c = n >= rm.p0 ? 1 : 0; return RowPrep{q.a + c, n - (c ? rm.p0 : 0)}; }
+        default: return q;
+    }
+}
+
 #define HIP_CHECK_RET(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return -(int)e_ - 1000; } while (0)

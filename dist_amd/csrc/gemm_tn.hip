@@ -12,6 +12,8 @@
 // range is split across blocks and partial tiles are combined with fp32 atomics
 // (hardware global_atomic_add_f32, compiled with -munsafe-fp-atomics) straight into the
 // flat gradient buffer, in the reference's parameter layout (so_* strides).
+#include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -64,8 +66,15 @@ DEV void gather_frag<bf16_t, true>(Frag<bf16_t>& f, const bf16_t* tile, int ld, 
     f.v = u.v;
 }
 
-template <typename T, int BI, int BJ, int WI, int WJ, bool TR, bool PLAIN>
+// MODES: the row maps of A and B as compile-time constants, amap.mode * 8 + bmap.mode (0 = both plain), or -1 = read them from the
+// arguments.  With runtime modes hipcc turns the small per-mode switches of rowmap_src2 / rowmap_step into select chains - every
+// mode evaluated for every cell in every step: the incremental loader was 20-25 % SLOWER than re-dividing per load until the
+// combinations the engine uses were instantiated with constant modes (profiles/r02_tn_incremental_rowmaps.md).
+template <typename T, int BI, int BJ, int WI, int WJ, bool TR, int MODES>
 __global__ __launch_bounds__(WI * WJ * 64) void gemm_tn_kernel(const dist_gemm_tn_args p, int chunk, int tiles_i, int tiles_c) {
+    constexpr bool PLAIN = MODES == 0;
+    dist_rowmap amap = p.amap, bmap = p.bmap;
+    if constexpr (MODES >= 0) { amap.mode = MODES / 8; bmap.mode = MODES % 8; }
     constexpr int NT = WI * WJ * 64;             // 4, 6 or 8 waves (shadows the namespace constant used by tn_reduce_kernel)
     constexpr int LDI = BI + PADT, LDJ = BJ + PADT;
     constexpr int WTI = BI / WI, WTJ = BJ / WJ;
@@ -119,27 +128,58 @@ __global__ __launch_bounds__(WI * WJ * 64) void gemm_tn_kernel(const dist_gemm_t
     // is written to LDS): with a branch around each load hipcc loses its load counting and waits vmcnt(0) before the LDS
     // writes, which drains the set that was just requested and defeats the 2-deep prefetch.
     // (thread, i) cells past the tile (BR * VI not a multiple of the block size) load a clamped address and are never stored
+    // The row maps (conv taps, cls-row skips) are NOT re-evaluated per load: every (thread, cell) walks rows that advance by exactly
+    // BR per step, so its row decomposition is computed once (rowmap_prep: the modulo / divides) and stepped without dividing
+    // (rowmap_step); the source row of the block's tap is a few adds and compares (rowmap_src2).  With rowmap_src per load the
+    // row-mapped instantiations ran ~1 370 instructions per two steps against ~270 for the plain ones (24 MFMAs either way), and
+    // with one 6-8 wave block per CU that serial instruction stream was the kernel's time (profiles/r02_tn_incremental_rowmaps.md).
+    // A cell stops advancing when its next row would leave the chunk: its address stays valid, `ld_m` flags it as padding.
     struct Regs { Frag<T> a[I_IT], b[J_IT]; unsigned oka, okb; };
-    auto gload = [&](Regs& R, int mb) __attribute__((always_inline)) {
+    int a_mm[I_IT], b_mm[J_IT];                    // clamped row (address side) of each cell
+    RowPrep a_q[I_IT], b_q[J_IT];
+    const bool a_inc = PLAIN || rowmap_inc_ok(amap, BR), b_inc = PLAIN || rowmap_inc_ok(bmap, BR);
+#pragma unroll
+    for (int i = 0; i < I_IT; ++i) {
+        const int v = min(tid + i * NT, BR * VI - 1);
+        a_mm[i] = min(mbeg + v / VI, mend - 1);
+        a_q[i] = PLAIN ? RowPrep{0, 0} : rowmap_prep(amap, a_mm[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < J_IT; ++i) {
+        const int v = min(tid + i * NT, BR * VJ - 1);
+        b_mm[i] = min(mbeg + v / VJ, mend - 1);
+        b_q[i] = PLAIN ? RowPrep{0, 0} : rowmap_prep(bmap, b_mm[i]);
+    }
+    int ld_m = mbeg;                               // first row of the tile the next gload fetches (wave-uniform)
+    auto gload = [&](Regs& R) __attribute__((always_inline)) {
         R.oka = 0; R.okb = 0;
 #pragma unroll
         for (int i = 0; i < I_IT; ++i) {
             const int v = min(tid + i * NT, BR * VI - 1);
-            const int m = mb + v / VI, col = i0 + (v % VI) * 8;
-            const int mm = min(m, mend - 1), cc = min(col, p.NI - 8);
-            const int src = PLAIN ? mm : rowmap_src(p.amap, mm, 0, 1);
+            const int m = ld_m + v / VI, col = i0 + (v % VI) * 8;
+            const int cc = min(col, p.NI - 8);
+            const int src = PLAIN ? a_mm[i] : rowmap_src2(amap, a_mm[i], a_q[i], 0, 1);
             if (m < mend && col < p.NI && src >= 0) R.oka |= 1u << i;
             frag_load(R.a[i], A + (long)max(src, 0) * p.lda + cc);
+            if (m + BR < mend) {                                             // the cell's next row is still inside the chunk
+                a_mm[i] = m + BR;
+                if (!PLAIN) a_q[i] = a_inc ? rowmap_step(amap, a_q[i], BR) : rowmap_prep(amap, a_mm[i]);
+            }
         }
 #pragma unroll
         for (int i = 0; i < J_IT; ++i) {
             const int v = min(tid + i * NT, BR * VJ - 1);
-            const int m = mb + v / VJ, col = c0 + (v % VJ) * 8;
-            const int mm = min(m, mend - 1), cc = min(col, kvec_last);
-            const int src = PLAIN ? mm : rowmap_src(p.bmap, mm, tap, p.taps);
+            const int m = ld_m + v / VJ, col = c0 + (v % VJ) * 8;
+            const int cc = min(col, kvec_last);
+            const int src = PLAIN ? b_mm[i] : rowmap_src2(bmap, b_mm[i], b_q[i], tap, p.taps);
             if (m < mend && col < p.K && src >= 0) R.okb |= 1u << i;
             frag_load(R.b[i], B + (long)max(src, 0) * p.ldb + cc);
+            if (m + BR < mend) {
+                b_mm[i] = m + BR;
+                if (!PLAIN) b_q[i] = b_inc ? rowmap_step(bmap, b_q[i], BR) : rowmap_prep(bmap, b_mm[i]);
+            }
         }
+        ld_m += BR;
     };
     auto sstore = [&](Regs& R, int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -177,7 +217,7 @@ __global__ __launch_bounds__(WI * WJ * 64) void gemm_tn_kernel(const dist_gemm_t
         // `if (st + 2 < nsteps)` around it the waitcnt pass merges the two paths conservatively and the sstore above
         // waits vmcnt(7..0) instead of vmcnt(15..8), i.e. for BOTH sets - the measured step time was then
         // load time + compute time instead of their maximum
-        gload(R, mbeg + (st + 2) * BR);
+        gload(R);
         const T* ys = Ys + buf * BR * LDI;
         const T* xs = Xs + buf * BR * LDJ;
 #pragma unroll
@@ -194,8 +234,8 @@ __global__ __launch_bounds__(WI * WJ * 64) void gemm_tn_kernel(const dist_gemm_t
         }
     };
     Regs r0, r1;
-    gload(r0, mbeg);
-    gload(r1, mbeg + BR);
+    gload(r0);
+    gload(r1);
     for (int st = 0; st < nsteps; st += 2) {              // an odd count runs one all-zero step at the end
         body(r0, st);
         body(r1, st + 1);
@@ -295,11 +335,11 @@ __global__ __launch_bounds__(NT) void tn_reduce_kernel(const dist_gemm_tn_args p
     atomicAdd(tn_dst(p, ii, c, tap), (a0 + a1) + (a2 + a3));
 }
 
-template <typename T, int BI, int BJ, int WI, int WJ, bool TR, bool PLAIN>
+template <typename T, int BI, int BJ, int WI, int WJ, bool TR, int MODES>
 int launch(const dist_gemm_tn_args& a, hipStream_t s) {
     constexpr size_t smem = (size_t)2 * BR * (BI + BJ + 2 * PADT) * sizeof(T);
     static bool attr_done = false;
-    auto kern = gemm_tn_kernel<T, BI, BJ, WI, WJ, TR, PLAIN>;
+    auto kern = gemm_tn_kernel<T, BI, BJ, WI, WJ, TR, MODES>;
     if (!attr_done) {
         HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_done = true;
@@ -338,31 +378,47 @@ int launch(const dist_gemm_tn_args& a, hipStream_t s) {
     return DIST_OK;
 }
 
-template <typename T, bool TR, bool PLAIN>
+template <typename T, bool TR, int MODES>
 int dispatch2(const dist_gemm_tn_args& a, hipStream_t s) {
     const bool i96 = (a.NI % 96 == 0) && (a.NI % 128 != 0);
     const bool j96 = (a.K % 96 == 0) && (a.K % 128 != 0);
     // 8 (6 for 96 x 96) waves per tile: half the accumulators / fragments / staging registers per lane of the 4-wave shapes
     // (216-280 registers: 1-2 blocks of 4 waves per CU; now 119-152: 8 waves per CU in one block).  10-20 % faster per launch
     // alone (conv3x3 dW 95.5 -> 77.4 us, 384x768 dW 71.9 -> 62.0 us); capping the registers at 128 for two 8-wave blocks spills
-    // and loses (92 us).  DIST_AMD_TN_W8=0: the 4-wave shapes (measurement knob).
+    // and loses (92 us).  DIST_AMD_TN_W8=0: the 4-wave shapes (measurement knob; they exist for plain and runtime modes only).
     static const int w8 = getenv("DIST_AMD_TN_W8") ? atoi(getenv("DIST_AMD_TN_W8")) : 1;
-    if (w8) {
-        if (i96 && j96) return launch<T, 96, 96, 3, 2, TR, PLAIN>(a, s);
-        if (i96) return launch<T, 96, 128, 2, 4, TR, PLAIN>(a, s);
-        if (j96) return launch<T, 128, 96, 4, 2, TR, PLAIN>(a, s);
-        return launch<T, 128, 128, 2, 4, TR, PLAIN>(a, s);
+    if (w8 || MODES > 0) {
+        if (i96 && j96) return launch<T, 96, 96, 3, 2, TR, MODES>(a, s);
+        if (i96) return launch<T, 96, 128, 2, 4, TR, MODES>(a, s);
+        if (j96) return launch<T, 128, 96, 4, 2, TR, MODES>(a, s);
+        return launch<T, 128, 128, 2, 4, TR, MODES>(a, s);
     }
-    if (i96 && j96) return launch<T, 96, 96, 2, 2, TR, PLAIN>(a, s);
-    if (i96) return launch<T, 96, 128, 2, 2, TR, PLAIN>(a, s);
-    if (j96) return launch<T, 128, 96, 2, 2, TR, PLAIN>(a, s);
-    return launch<T, 128, 128, 2, 2, TR, PLAIN>(a, s);
+    if constexpr (MODES <= 0) {
+        if (i96 && j96) return launch<T, 96, 96, 2, 2, TR, MODES>(a, s);
+        if (i96) return launch<T, 96, 128, 2, 2, TR, MODES>(a, s);
+        if (j96) return launch<T, 128, 96, 2, 2, TR, MODES>(a, s);
+        return launch<T, 128, 128, 2, 2, TR, MODES>(a, s);
+    }
+    return DIST_ERR_ARG;
 }
 template <typename T, bool TR>
 int dispatch(const dist_gemm_tn_args& a, hipStream_t s) {
     // plain row maps on both operands (every Linear's dW): no per-row index arithmetic in the loader
-    const bool plain = a.amap.mode == DIST_RM_PLAIN && a.bmap.mode == DIST_RM_PLAIN && a.taps == 1;
-    return plain ? dispatch2<T, TR, true>(a, s) : dispatch2<T, TR, false>(a, s);
+    if (a.amap.mode == DIST_RM_PLAIN && a.bmap.mode == DIST_RM_PLAIN && a.taps == 1) return dispatch2<T, TR, 0>(a, s);
+    // the combinations the engine uses (conv_t / temporal-ffn / stem, conv3x3, I2T, T2I weight gradients) with constant modes
+    if constexpr (std::is_same<T, bf16_t>::value && TR) {
+        static const int w8 = getenv("DIST_AMD_TN_W8") ? atoi(getenv("DIST_AMD_TN_W8")) : 1;
+        static const int spec = getenv("DIST_AMD_TN_MODES") ? atoi(getenv("DIST_AMD_TN_MODES")) : 1;   // 0: runtime modes (measurement knob)
+        const int modes = a.amap.mode * 8 + a.bmap.mode;
+        if (w8 && spec) switch (modes) {
+            case DIST_RM_SHIFT: return dispatch2<T, TR, DIST_RM_SHIFT>(a, s);
+            case DIST_RM_SPATIAL: return dispatch2<T, TR, DIST_RM_SPATIAL>(a, s);
+            case DIST_RM_SKIPCLS: return dispatch2<T, TR, DIST_RM_SKIPCLS>(a, s);
+            case DIST_RM_SKIPCLS * 8 + DIST_RM_STRIDED: return dispatch2<T, TR, DIST_RM_SKIPCLS * 8 + DIST_RM_STRIDED>(a, s);
+            default: break;
+        }
+    }
+    return dispatch2<T, TR, -1>(a, s);
 }
 
 }  // namespace
