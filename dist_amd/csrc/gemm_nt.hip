@@ -26,6 +26,153 @@ namespace {
 
 constexpr int PAD = 8;
 
+// Epilogue shared by the two loaders: bias / activation-derivative / residual / QuickGELU on the accumulators, then out through
+// LDS so that residual / derivative tiles are fetched and result tiles stored as full 16-byte-per-lane rows.
+template <typename T, int BM, int BN, int WM, int WN, bool GENERIC>
+DEV void nt_epilogue(const dist_gemm_args& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, const int m0, const int n0) {
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int FM = WTM / 16, FN = WTN / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int li = lane & 15, lg = lane >> 4;
+    const int M = (int)p.M, N = p.N;
+    // ---- epilogue through LDS.  A lane holds, per fragment, row ..+li and 4 columns ..+4*lg+{0..3}; writing
+    // those 8-byte pieces straight to HBM at a row stride (and fetching the residual the same way) ran at a
+    // fraction of the write bandwidth.  Each wave stages its WTM x WTN sub-tile in LDS instead, so the residual /
+    // activation-derivative tiles are fetched and the result tiles are stored as full 16-byte-per-lane rows.
+    __syncthreads();                                        // operand tiles are dead
+    constexpr int ES = (int)sizeof(T);
+    constexpr int ROWB = WTN * ES + 16;                     // padded staging row (bank spread)
+    constexpr int VPR = WTN * ES / 16, EPV = 16 / ES;       // 16-byte vectors per row, elements per vector
+    char* ew = smem + wid * (WTM * ROWB);
+    T* __restrict__ C = static_cast<T*>(p.C);
+    T* __restrict__ C2 = static_cast<T*>(p.C2);
+    const T* __restrict__ R = static_cast<const T*>(p.res);
+    const T* __restrict__ X = static_cast<const T*>(p.aux);
+    const int flags = p.flags;
+    const int om = GENERIC ? p.omap.mode : (int)DIST_OM_PLAIN;
+    const int op0 = p.omap.p0, op1 = p.omap.p1, op2 = p.omap.p2;
+    const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
+    const int reps = om == DIST_OM_DUP ? op0 : 1;
+
+    // destination (row, column) of logical element (m, n) for repetition `a`
+    auto dest_of = [&](int m, int n, int a, int& ncol) -> long {
+        ncol = n;
+        if (om == DIST_OM_PLAIN) return m;
+        if (om == DIST_OM_INSERTCLS) return (long)(m / op0) * (op0 + 1) + 1 + m % op0;
+        if (om == DIST_OM_HEADS) {                           // [frame][head][q|k|v][token][64]; the leading dimension is 64
+            const int hd = n >> 6, part = hd / op1, hh = hd - part * op1;
+            ncol = n & 63;
+            return ((long)((m / op0) * op1 + hh) * 3 + part) * op0 + m % op0;
+        }
+        const int bj = m / op1, nn = m % op1;
+        if (om == DIST_OM_SPLITCOLS) { a = n / op2; ncol = n - a * op2; }
+        return ((long)bj * op0 + a) * op1 + nn;
+    };
+    auto stage_in = [&](const T* __restrict__ src, int ld, int a) {
+        for (int v = lane; v < WTM * VPR; v += 64) {
+            const int row = v / VPR, vec = v - row * VPR;
+            const int m = mw + row, n = nw + vec * EPV;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (m < M && n < N) { int nc; const long d = dest_of(m, n, a, nc); val = *reinterpret_cast<const uint4*>(src + d * ld + nc); }
+            *reinterpret_cast<uint4*>(ew + row * ROWB + vec * 16) = val;
+        }
+    };
+    auto flush = [&](T* __restrict__ dst, int ld, int a) {
+        for (int v = lane; v < WTM * VPR; v += 64) {
+            const int row = v / VPR, vec = v - row * VPR;
+            const int m = mw + row, n = nw + vec * EPV;
+            if (m < M && n < N) {
+                int nc; const long d = dest_of(m, n, a, nc);
+                store16_nt(dst + d * ld + nc, *reinterpret_cast<const uint4*>(ew + row * ROWB + vec * 16));
+            }
+        }
+    };
+    auto slot = [&](int i, int j) -> T* { return reinterpret_cast<T*>(ew + (i * 16 + li) * ROWB + (j * 16 + lg * 4) * ES); };
+
+    if (flags & DIST_EPI_BIAS) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = nw + j * 16 + lg * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float bv = (n + r < N) ? p.bias[n + r] + (p.bias2 ? p.bias2[n + r] : 0.f) : 0.f;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) acc[i][j][r] += bv;
+            }
+        }
+    }
+    if ((flags & DIST_EPI_MULG) && !(flags & DIST_EPI_MULG_POST)) {   // v *= quickgelu'(aux[dest])   (never combined with DUP)
+        stage_in(X, p.ldaux, 0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                float x[4];
+                load4(slot(i, j), x);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] *= qgelu_grad_t<T>(x[r]);
+            }
+    }
+    const bool act_only = (flags & DIST_EPI_ACT2) && !C;
+    for (int a = 0; a < reps; ++a) {
+        if (flags & DIST_EPI_RES) stage_in(R, p.ldres, a);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (flags & DIST_EPI_RES) {
+                    float x[4];
+                    load4(slot(i, j), x);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += x[r];
+                }
+                if (flags & DIST_EPI_MULG_POST) {            // keep the sum in the accumulators: the factor tile is staged next
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = v[r];
+                    continue;
+                }
+                if (act_only) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = qgelu_t<T>(v[r]);
+                }
+                store4(slot(i, j), v);
+            }
+        if (flags & DIST_EPI_MULG_POST) {                   // v = (acc + bias + res) * quickgelu'(aux[dest])
+            stage_in(X, p.ldaux, a);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    float x[4], v[4];
+                    load4(slot(i, j), x);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * qgelu_grad_t<T>(x[r]);
+                    store4(slot(i, j), v);
+                }
+        }
+        if (act_only) {
+            flush(C2, p.ldc2, a);
+        } else {
+            flush(C, p.ldc, a);
+            if (flags & DIST_EPI_ACT2) {                    // second output = quickgelu(stored value)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        float x[4];
+                        load4(slot(i, j), x);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) x[r] = qgelu_t<T>(x[r]);
+                        store4(slot(i, j), x);
+                    }
+                flush(C2, p.ldc2, a);
+            }
+        }
+    }
+}
+
 template <typename T, int BM, int BN, int BK, int WM, int WN, bool GENERIC, int MINW = 1>
 __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(const dist_gemm_args p) {
     constexpr int NT = WM * WN * 64;                    // 4 or 8 waves
@@ -197,141 +344,141 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(const dist_
     }
     if (tt < total) body(r0, tt);
 
-    // ---- epilogue through LDS.  A lane holds, per fragment, row ..+li and 4 columns ..+4*lg+{0..3}; writing
-    // those 8-byte pieces straight to HBM at a row stride (and fetching the residual the same way) ran at a
-    // fraction of the write bandwidth.  Each wave stages its WTM x WTN sub-tile in LDS instead, so the residual /
-    // activation-derivative tiles are fetched and the result tiles are stored as full 16-byte-per-lane rows.
-    __syncthreads();                                        // operand tiles are dead
-    constexpr int ES = (int)sizeof(T);
-    constexpr int ROWB = WTN * ES + 16;                     // padded staging row (bank spread)
-    constexpr int VPR = WTN * ES / 16, EPV = 16 / ES;       // 16-byte vectors per row, elements per vector
-    char* ew = smem + wid * (WTM * ROWB);
-    T* __restrict__ C = static_cast<T*>(p.C);
-    T* __restrict__ C2 = static_cast<T*>(p.C2);
-    const T* __restrict__ R = static_cast<const T*>(p.res);
-    const T* __restrict__ X = static_cast<const T*>(p.aux);
-    const int flags = p.flags;
-    const int om = GENERIC ? p.omap.mode : (int)DIST_OM_PLAIN;
-    const int op0 = p.omap.p0, op1 = p.omap.p1, op2 = p.omap.p2;
-    const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
-    const int reps = om == DIST_OM_DUP ? op0 : 1;
+    nt_epilogue<T, BM, BN, WM, WN, GENERIC>(p, acc, smem, m0, n0);
+}
 
-    // destination (row, column) of logical element (m, n) for repetition `a`
-    auto dest_of = [&](int m, int n, int a, int& ncol) -> long {
-        ncol = n;
-        if (om == DIST_OM_PLAIN) return m;
-        if (om == DIST_OM_INSERTCLS) return (long)(m / op0) * (op0 + 1) + 1 + m % op0;
-        if (om == DIST_OM_HEADS) {                           // [frame][head][q|k|v][token][64]; the leading dimension is 64
-            const int hd = n >> 6, part = hd / op1, hh = hd - part * op1;
-            ncol = n & 63;
-            return ((long)((m / op0) * op1 + hh) * 3 + part) * op0 + m % op0;
-        }
-        const int bj = m / op1, nn = m % op1;
-        if (om == DIST_OM_SPLITCOLS) { a = n / op2; ncol = n - a * op2; }
-        return ((long)bj * op0 + a) * op1 + nn;
-    };
-    auto stage_in = [&](const T* __restrict__ src, int ld, int a) {
-        for (int v = lane; v < WTM * VPR; v += 64) {
-            const int row = v / VPR, vec = v - row * VPR;
-            const int m = mw + row, n = nw + vec * EPV;
-            uint4 val = make_uint4(0, 0, 0, 0);
-            if (m < M && n < N) { int nc; const long d = dest_of(m, n, a, nc); val = *reinterpret_cast<const uint4*>(src + d * ld + nc); }
-            *reinterpret_cast<uint4*>(ew + row * ROWB + vec * 16) = val;
-        }
-    };
-    auto flush = [&](T* __restrict__ dst, int ld, int a) {
-        for (int v = lane; v < WTM * VPR; v += 64) {
-            const int row = v / VPR, vec = v - row * VPR;
-            const int m = mw + row, n = nw + vec * EPV;
-            if (m < M && n < N) {
-                int nc; const long d = dest_of(m, n, a, nc);
-                store16_nt(dst + d * ld + nc, *reinterpret_cast<const uint4*>(ew + row * ROWB + vec * 16));
-            }
-        }
-    };
-    auto slot = [&](int i, int j) -> T* { return reinterpret_cast<T*>(ew + (i * 16 + li) * ROWB + (j * 16 + lg * 4) * ES); };
+// ---------------------------------------------------------------------------------------------------------------------
+// The same GEMM with an LDS-DMA loader (bf16, K % 32 == 0): operand tiles go L2 / HBM -> LDS by `buffer_load ... lds` into a ring
+// of three 32-deep stages, two K-tiles ahead of the MFMAs, with no staging registers and no ds_write pass.  The register-staged
+// loader above keeps two K-tiles in flight per block and its time follows the bytes a CU ingests (conv3x3: 303 MB of mostly
+// L2-resident re-reads per launch = 1.2 MB per CU, 51 us); here a stage in flight costs LDS only.
+//  * per-lane SOURCE offsets carry everything the row map does: the source row of the current tap (rowmap_prep once, rowmap_src2
+//    per tap), the chunk swizzle of the LDS image (the DMA writes lane-linear 1 KB pieces = 16 rows x 64 B; chunk c of row r
+//    lives at c ^ f((r >> 2) & 3)), and the zero padding: a padded row's offset lies beyond the descriptor, so the piece reads
+//    zeros; K offset and tap * K are scalar offsets;
+//  * every wave moves BM / 128 pieces of A and one piece of B per stage (B is staged as 128 rows: rows >= N read as zero);
+//  * one raw s_barrier per K-tile behind a counted vmcnt: stage t has landed for every wave, stage t - 1 is no longer read.
+typedef __attribute__((address_space(3))) void* nt_lds_ptr;
+template <int N> DEV void nt_wait_vm() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else static_assert(N < 0, "unsupported count");
+}
+template <int BM, int BN, int WM, int WN, bool GENERIC, int MINW>
+__global__ __launch_bounds__(512, MINW) void gemm_nt_dma_kernel(const dist_gemm_args p, const int rotate) {
+    using T = bf16_t;
+    constexpr int BK = 32, STAGES = 3, BNP = 128;
+    constexpr int PA = BM / 128, NP = PA + 1;             // 1 KB pieces per wave per stage
+    constexpr int A_BYTES = BM * 64, STAGE_BYTES = (BM + BNP) * 64;
+    constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 16, FN = WTN / 16;
+    static_assert(WM * WN == 8 && (BM == 128 || BM == 256) && BN <= BNP, "8 waves, one B piece per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WN, wn = wid % WN;
+    const int li = lane & 15, lg = lane >> 4;
 
-    if (flags & DIST_EPI_BIAS) {
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = nw + j * 16 + lg * 4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float bv = (n + r < N) ? p.bias[n + r] + (p.bias2 ? p.bias2[n + r] : 0.f) : 0.f;
-#pragma unroll
-                for (int i = 0; i < FM; ++i) acc[i][j][r] += bv;
-            }
-        }
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (int)((p.M + BM - 1) / BM);
+    const int nblk = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8, x = bid % 8, y = bid / 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
     }
-    if ((flags & DIST_EPI_MULG) && !(flags & DIST_EPI_MULG_POST)) {   // v *= quickgelu'(aux[dest])   (never combined with DUP)
-        stage_in(X, p.ldaux, 0);
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int M = (int)p.M, N = p.N, K = p.K, taps = p.taps;
+    const int total = (K / BK) * taps;
+
+    constexpr unsigned OOB = 0x80000000u;                 // beyond either descriptor: the lane's 16 bytes read as zero
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, N * p.ldb * 2, 0x00020000);
+    const int lrow = lane >> 2;
+    const int lch = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
+    // (scalars, not arrays: with `ga[]` captured by reference, written in retap and read in stage, hipcc silently emits no host
+    // stub for the kernel - the library then fails to load with an undefined symbol)
+    int am[PA]; RowPrep aq[PA];
+    unsigned ga0 = 0, ga1 = 0;
+    bool arow_ok[PA];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const int row = (wid * PA + j) * 16 + lrow;
+        am[j] = min(m0 + row, M - 1);
+        arow_ok[j] = m0 + row < M;
+        if (GENERIC) aq[j] = rowmap_prep(p.amap, am[j]);
+    }
+    const unsigned gb = ((unsigned)(n0 + wid * 16 + lrow) * (unsigned)p.ldb + lch * 8) * 2u;   // rows >= N: beyond rb
+    auto retap = [&](const int tap) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const int src = GENERIC ? rowmap_src2(p.amap, am[j], aq[j], tap, taps) : am[j];
+            const unsigned g = (arow_ok[j] && src >= 0) ? ((unsigned)src * (unsigned)p.lda + lch * 8) * 2u : OOB;
+            if (j == 0) ga0 = g; else ga1 = g;
+        }
+    };
+    // `rotate`: block b starts at K-tile (b mod total) and wraps around - all blocks walk the SAME small weight matrix, and in step
+    // they would all read the same 8 KB of it at the same moment (a handful of L2 channels for the whole chip)
+    const int ktp = K / BK;
+    const int t0 = rotate ? (int)(blockIdx.x % (unsigned)total) : 0;
+    int ld_tap = t0 / ktp, ld_k0 = (t0 - ld_tap * ktp) * BK;
+    retap(ld_tap);
+    auto stage = [&](const int t) __attribute__((always_inline)) {        // K-tile t (tap-major) into ring slot t % 3
+        char* sb = smem + (t % STAGES) * STAGE_BYTES;
+        // (written out: with the builtin inside a loop over the template-dependent PA, hipcc silently emits no host stub for the kernel)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (nt_lds_ptr)(sb + (wid * PA) * 1024), 16, ga0, ld_k0 * 2, 0, 0);
+        if constexpr (PA == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (nt_lds_ptr)(sb + (wid * PA + 1) * 1024), 16, ga1, ld_k0 * 2, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (nt_lds_ptr)(sb + A_BYTES + wid * 1024), 16, gb, (ld_tap * K + ld_k0) * 2, 0, 0);
+        ld_k0 += BK;
+        if (ld_k0 >= K) { ld_k0 = 0; ++ld_tap; if (ld_tap >= taps) ld_tap = 0; retap(ld_tap); }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int co = (lg ^ ((4 - ((li >> 2) & 3)) & 3)) * 16;               // fragment chunk of this lane, bytes (depends on li only)
+    stage(0);
+    if (total > 1) stage(1);
+    for (int t = 0; t < total; ++t) {
+        if (t + 1 < total) nt_wait_vm<NP>(); else nt_wait_vm<0>();       // stage t landed (this wave's pieces); t + 1 may be in flight
+        __builtin_amdgcn_s_barrier();                                     // ... for every wave; nobody reads stage t - 1 any more
+        if (t + 2 < total) stage(t + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        const char* as = smem + (t % STAGES) * STAGE_BYTES + (wm * WTM + li) * 64 + co;
+        const char* bs = smem + (t % STAGES) * STAGE_BYTES + A_BYTES + (wn * WTN + li) * 64 + co;
+        Frag<T> fa[FM], fb[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) fa[i].v = *reinterpret_cast<const bf16x8*>(as + i * 16 * 64);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) fb[j].v = *reinterpret_cast<const bf16x8*>(bs + j * 16 * 64);
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                float x[4];
-                load4(slot(i, j), x);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] *= qgelu_grad_t<T>(x[r]);
-            }
+            for (int j = 0; j < FN; ++j) mma16(fb[j], fa[i], acc[i][j]);   // swapped: D[n][m]
     }
-    const bool act_only = (flags & DIST_EPI_ACT2) && !C;
-    for (int a = 0; a < reps; ++a) {
-        if (flags & DIST_EPI_RES) stage_in(R, p.ldres, a);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (flags & DIST_EPI_RES) {
-                    float x[4];
-                    load4(slot(i, j), x);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += x[r];
-                }
-                if (flags & DIST_EPI_MULG_POST) {            // keep the sum in the accumulators: the factor tile is staged next
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][j][r] = v[r];
-                    continue;
-                }
-                if (act_only) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = qgelu_t<T>(v[r]);
-                }
-                store4(slot(i, j), v);
-            }
-        if (flags & DIST_EPI_MULG_POST) {                   // v = (acc + bias + res) * quickgelu'(aux[dest])
-            stage_in(X, p.ldaux, a);
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    float x[4], v[4];
-                    load4(slot(i, j), x);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * qgelu_grad_t<T>(x[r]);
-                    store4(slot(i, j), v);
-                }
-        }
-        if (act_only) {
-            flush(C2, p.ldc2, a);
-        } else {
-            flush(C, p.ldc, a);
-            if (flags & DIST_EPI_ACT2) {                    // second output = quickgelu(stored value)
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        float x[4];
-                        load4(slot(i, j), x);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) x[r] = qgelu_t<T>(x[r]);
-                        store4(slot(i, j), x);
-                    }
-                flush(C2, p.ldc2, a);
-            }
-        }
+    nt_epilogue<T, BM, BN, WM, WN, GENERIC>(p, acc, smem, m0, n0);
+}
+
+template <int BM, int BN, int WM, int WN, bool GENERIC, int MINW>
+int launch_dma(const dist_gemm_args& a, hipStream_t s) {
+    constexpr size_t ring = (size_t)3 * (BM + 128) * 64;
+    constexpr size_t stag = (size_t)WM * WN * (BM / WM) * ((BN / WN) * 2 + 16);
+    constexpr size_t smem = ring > stag ? ring : stag;
+    static bool attr_done = false;
+    auto kern = gemm_nt_dma_kernel<BM, BN, WM, WN, GENERIC, MINW>;
+    if (!attr_done) {
+        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_done = true;
     }
+    const long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    static const int rotate = getenv("DIST_AMD_NT_ROTATE") ? atoi(getenv("DIST_AMD_NT_ROTATE")) : 1;   // measurement knob
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), smem, s, a, rotate);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
 }
 
 template <typename T, int BM, int BN, int BK, int WM, int WN, bool GENERIC, int MINW = 1>
@@ -367,6 +514,13 @@ int dispatch(const dist_gemm_args& a, hipStream_t s) {
     // generic 128x128x32 shape needs spills at 80 registers and gains nothing, so only N % 96 has the variant.
     static const int occ = getenv("DIST_AMD_NT_OCC") ? atoi(getenv("DIST_AMD_NT_OCC")) : 1;
     if constexpr (std::is_same<T, bf16_t>::value) {
+        // LDS-DMA loader (three stages in flight, no staging registers).  DIST_AMD_NT_DMA=0: the register-staged loader.
+        static const int dma = getenv("DIST_AMD_NT_DMA") ? atoi(getenv("DIST_AMD_NT_DMA")) : 1;
+        if (dma && a.K % 32 == 0) {
+            if (n96 && a.N == 96 && a.M > 768l * 128) return launch_dma<256, 96, 8, 1, true, 4>(a, s);     // 392 blocks: one round of 2 per CU
+            if (n96) return launch_dma<128, 96, 4, 2, true, 6>(a, s);
+            return launch_dma<128, 128, 2, 4, true, 6>(a, s);
+        }
         // A block is a serial chain of latency-bound K-tile steps, so a launch takes (rounds of resident blocks) x (one block's
         // time): 100 352 rows as 128-row tiles are 784 blocks on 768 resident slots (256 CUs x 3) - TWO rounds for 16 blocks.
         // 256-row tiles (8 x 1 waves, 32 x 96 per wave) make the same work 392 blocks = one round.  DIST_AMD_NT_BM256=0: off.
