@@ -28,8 +28,13 @@ constexpr int PAD = 8;
 
 // Epilogue shared by the two loaders: bias / activation-derivative / residual / QuickGELU on the accumulators, then out through
 // LDS so that residual / derivative tiles are fetched and result tiles stored as full 16-byte-per-lane rows.
-template <typename T, int BM, int BN, int WM, int WN, bool GENERIC>
-DEV void nt_epilogue(const dist_gemm_args& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, const int m0, const int n0) {
+//
+// FREESLOT (the LDS-DMA loader): each wave's staging area is `region`, unpadded rows in ring slots that the last K-tile does not
+// read, so no block barrier precedes the epilogue; with `pre` the first tile the epilogue would fetch (the activation-derivative
+// tile, else the residual tile) is already on its way there by LDS-DMA (requested in one go by nt_prefetch_tile).
+template <typename T, int BM, int BN, int WM, int WN, bool GENERIC, bool FREESLOT = false>
+DEV void nt_epilogue(const dist_gemm_args& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, const int m0, const int n0,
+                     char* region = nullptr, bool pre = false) {
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int FM = WTM / 16, FN = WTN / 16;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -40,11 +45,11 @@ DEV void nt_epilogue(const dist_gemm_args& p, f32x4 (&acc)[BM / WM / 16][BN / WN
     // those 8-byte pieces straight to HBM at a row stride (and fetching the residual the same way) ran at a
     // fraction of the write bandwidth.  Each wave stages its WTM x WTN sub-tile in LDS instead, so the residual /
     // activation-derivative tiles are fetched and the result tiles are stored as full 16-byte-per-lane rows.
-    __syncthreads();                                        // operand tiles are dead
+    if (!FREESLOT) __syncthreads();                         // operand tiles are dead
     constexpr int ES = (int)sizeof(T);
-    constexpr int ROWB = WTN * ES + 16;                     // padded staging row (bank spread)
+    constexpr int ROWB = WTN * ES + (FREESLOT ? 0 : 16);    // staging row (padded for bank spread where LDS allows)
     constexpr int VPR = WTN * ES / 16, EPV = 16 / ES;       // 16-byte vectors per row, elements per vector
-    char* ew = smem + wid * (WTM * ROWB);
+    char* ew = FREESLOT ? region : smem + wid * (WTM * ROWB);
     T* __restrict__ C = static_cast<T*>(p.C);
     T* __restrict__ C2 = static_cast<T*>(p.C2);
     const T* __restrict__ R = static_cast<const T*>(p.res);
@@ -70,6 +75,11 @@ DEV void nt_epilogue(const dist_gemm_args& p, f32x4 (&acc)[BM / WM / 16][BN / WN
         return ((long)bj * op0 + a) * op1 + nn;
     };
     auto stage_in = [&](const T* __restrict__ src, int ld, int a) {
+        if (FREESLOT && pre) {                              // already requested: wait for this wave's LDS-DMA pieces
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pre = false;
+            return;
+        }
         for (int v = lane; v < WTM * VPR; v += 64) {
             const int row = v / VPR, vec = v - row * VPR;
             const int m = mw + row, n = nw + vec * EPV;
@@ -365,6 +375,12 @@ template <int N> DEV void nt_wait_vm() {
     else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else static_assert(N < 0, "unsupported count");
 }
+// byte offset of 16-byte vector v (row-major over a wave's sub-tile, VPR vectors per row) of a plain bf16 matrix; beyond it: reads zero
+template <int VPR> DEV unsigned nt_pre_off(const int v, const int mw, const int nw, const int M, const int N, const int ld) {
+    const int row = v / VPR, vec = v - row * VPR;
+    const int m = mw + row, n = nw + vec * 8;
+    return (m < M && n < N) ? ((unsigned)m * (unsigned)ld + (unsigned)n) * 2u : 0x80000000u;
+}
 template <int BM, int BN, int WM, int WN, bool GENERIC, int MINW>
 __global__ __launch_bounds__(512, MINW) void gemm_nt_dma_kernel(const dist_gemm_args p, const int rotate) {
     using T = bf16_t;
@@ -418,10 +434,12 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_dma_kernel(const dist_gemm_
             if (j == 0) ga0 = g; else ga1 = g;
         }
     };
-    // `rotate`: block b starts at K-tile (b mod total) and wraps around - all blocks walk the SAME small weight matrix, and in step
-    // they would all read the same 8 KB of it at the same moment (a handful of L2 channels for the whole chip)
+    // `rotate` bit 0 (measurement knob, off): block b starts at K-tile (b mod total) and wraps around - all blocks walk the SAME small
+    // weight matrix, and in step they all read the same 8 KB of it at the same moment.  Measured: not a limiter (conv3x3 47.5 vs
+    // 47.8 us), and the summation order of a row would depend on the block that holds it, i.e. on the batch it is part of - the
+    // engine's results are bit-identical for a clip whatever it is batched with, and stay so.
     const int ktp = K / BK;
-    const int t0 = rotate ? (int)(blockIdx.x % (unsigned)total) : 0;
+    const int t0 = (rotate & 1) ? (int)(blockIdx.x % (unsigned)total) : 0;
     int ld_tap = t0 / ktp, ld_k0 = (t0 - ld_tap * ktp) * BK;
     retap(ld_tap);
     auto stage = [&](const int t) __attribute__((always_inline)) {        // K-tile t (tap-major) into ring slot t % 3
@@ -460,7 +478,39 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_dma_kernel(const dist_gemm_
 #pragma unroll
             for (int j = 0; j < FN; ++j) mma16(fb[j], fa[i], acc[i][j]);   // swapped: D[n][m]
     }
-    nt_epilogue<T, BM, BN, WM, WN, GENERIC>(p, acc, smem, m0, n0);
+    // ---- epilogue.  The last K-tile reads ring slot (total - 1) % 3 only: the other two slots are free for every wave that is past
+    // that tile's barrier, and hold exactly one BM x BN bf16 tile - waves 0-3 stage in one, waves 4-7 in the other, without a block
+    // barrier.  The tile the epilogue fetches first (activation derivative, else residual) is requested here in ONE go by LDS-DMA
+    // (no registers, no dependent round trips; rows / columns beyond the matrix read as zero through the descriptor's bound): fetched
+    // piece by piece inside the epilogue it was half of conv3x3's time (profiles/r02_nt_instruction_mix.md).
+    constexpr int WTILE = WTM * WTN * 2, NPRE = WTILE / 1024, VPR = WTN / 8;
+    static_assert(WTILE % 1024 == 0 && NPRE <= 6 && 4 * WTILE <= STAGE_BYTES, "per-wave staging tile: whole 1 KB pieces, four per ring slot");
+    char* region = smem + ((total + (wid >> 2)) % STAGES) * STAGE_BYTES + (wid & 3) * WTILE;
+    bool pre = false;
+    {
+        const int flags = p.flags;
+        const bool first_aux = (flags & DIST_EPI_MULG) && !(flags & DIST_EPI_MULG_POST);
+        const void* src = first_aux ? p.aux : ((flags & DIST_EPI_RES) ? p.res : nullptr);
+        const int ld = first_aux ? p.ldaux : p.ldres;
+        const int om = GENERIC ? p.omap.mode : (int)DIST_OM_PLAIN;
+        if (src && om == DIST_OM_PLAIN && (long)M * ld < (1l << 30) && !(rotate & 2)) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src), 0, (int)((long)M * ld * 2), 0x00020000);
+            const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
+            const unsigned o0 = nt_pre_off<VPR>(lane, mw, nw, M, N, ld), o1 = nt_pre_off<VPR>(lane + 64, mw, nw, M, N, ld);
+            const unsigned o2 = nt_pre_off<VPR>(lane + 128, mw, nw, M, N, ld), o3 = nt_pre_off<VPR>(lane + 192, mw, nw, M, N, ld);
+            const unsigned o4 = nt_pre_off<VPR>(lane + 256, mw, nw, M, N, ld), o5 = nt_pre_off<VPR>(lane + 320, mw, nw, M, N, ld);
+            // (written out, as in stage(): the builtin inside a loop over a template-dependent count, or with a dependent call among
+            // its arguments, loses the kernel's host stub)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (nt_lds_ptr)(region), 16, o0, 0, 0, 0);
+            if constexpr (NPRE > 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (nt_lds_ptr)(region + 1024), 16, o1, 0, 0, 0);
+            if constexpr (NPRE > 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (nt_lds_ptr)(region + 2048), 16, o2, 0, 0, 0);
+            if constexpr (NPRE > 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (nt_lds_ptr)(region + 3072), 16, o3, 0, 0, 0);
+            if constexpr (NPRE > 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (nt_lds_ptr)(region + 4096), 16, o4, 0, 0, 0);
+            if constexpr (NPRE > 5) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (nt_lds_ptr)(region + 5120), 16, o5, 0, 0, 0);
+            pre = true;
+        }
+    }
+    nt_epilogue<T, BM, BN, WM, WN, GENERIC, true>(p, acc, smem, m0, n0, region, pre);
 }
 
 template <int BM, int BN, int WM, int WN, bool GENERIC, int MINW>
@@ -475,7 +525,7 @@ int launch_dma(const dist_gemm_args& a, hipStream_t s) {
         attr_done = true;
     }
     const long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    static const int rotate = getenv("DIST_AMD_NT_ROTATE") ? atoi(getenv("DIST_AMD_NT_ROTATE")) : 1;   // measurement knob
+    static const int rotate = getenv("DIST_AMD_NT_ROTATE") ? atoi(getenv("DIST_AMD_NT_ROTATE")) : 0;   // measurement knob: 1 = rotated K order, 2 = no tile prefetch
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), smem, s, a, rotate);
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
