@@ -152,6 +152,9 @@ def load():
     _sig(lib, "dist_op_mixup", argtypes=[C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_void_p])
     _sig(lib, "dist_op_cutmix", argtypes=[C.c_void_p] + [C.c_int] * 8 + [C.c_void_p])
     _sig(lib, "dist_op_mixup_target", argtypes=[C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p])
+    _sig(lib, "dist_op_softmax_rows", argtypes=[C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p])
+    _sig(lib, "dist_op_topk_correct", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p])
+    _sig(lib, "dist_op_ensemble_update", argtypes=[C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_op_adamw", argtypes=[C.c_void_p] * 5 + [C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_void_p])
     _lib = lib
     return lib

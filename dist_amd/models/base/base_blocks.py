@@ -1,7 +1,8 @@
 """Head registry + `ClipVideoTextIdentity` (reference models/base/base_blocks.py:541-585): parameter-free,
-mean over dim 1, softmax only at eval."""
+mean over dim 1, softmax only at eval (dist_op_softmax_rows on device logits)."""
 import torch.nn as nn
 
+from ... import ops
 from ...utils.registry import Registry
 
 HEAD_REGISTRY = Registry("Head")
@@ -26,5 +27,8 @@ class ClipVideoTextIdentity(nn.Module):
     def forward(self, x):
         out = x["logits_per_image"].mean(dim=1) if isinstance(x, dict) else x.mean(dim=1)
         if not self.training:
-            out = self.activation(out)
+            if isinstance(self.activation, nn.Softmax) and out.is_cuda and out.dim() == 2:
+                out = ops.softmax_rows(out)                      # fp32, same formula as nn.Softmax(dim=-1)
+            else:
+                out = self.activation(out)
         return out, x

@@ -245,3 +245,40 @@ def mixup_target(labels, num_classes, lam=1.0, smoothing=0.0):
     soft = torch.empty(labels.numel(), num_classes, dtype=torch.float32, device=labels.device)
     L.check(L.load().dist_op_mixup_target(_p(labels), labels.numel(), num_classes, _f32(lam), _f32(1.0 - lam), _f32(on), _f32(off), _p(soft), _stream()))
     return soft
+
+
+# ---- evaluation side (reference base_blocks.py:573-585, utils/metrics.py:100-129, utils/meters.py:82-112) ------------------
+ENSEMBLE_SUM, ENSEMBLE_MAX = 0, 1
+
+
+def softmax_rows(x, out=None):
+    """fp32 softmax over the last axis of logits [rows, K] (the head's eval activation)."""
+    assert x.is_cuda and x.dim() == 2
+    x = x.float().contiguous()
+    y = torch.empty_like(x) if out is None else out
+    L.check(L.load().dist_op_softmax_rows(_p(x), x.shape[0], x.shape[1], _p(y), _stream()))
+    return y
+
+
+def topk_correct(preds, labels, ks):
+    """fp32 tensor [len(ks)]: number of rows whose label is within the ks[i] best scores (reference topks_correct)."""
+    assert preds.is_cuda and labels.is_cuda and preds.dim() == 2 and 0 < len(ks) <= 4
+    assert preds.size(0) == labels.size(0), "Batch dim of predictions and labels must match"
+    preds = preds.float().contiguous()
+    labels = labels.long().contiguous().view(-1)
+    out = torch.empty(len(ks), dtype=torch.float32, device=preds.device)
+    kk = (C.c_int * len(ks))(*[int(k) for k in ks])
+    L.check(L.load().dist_op_topk_correct(_p(preds), _p(labels), preds.shape[0], preds.shape[1], kk, len(ks), _p(out), _stream()))
+    return out
+
+
+def ensemble_update(video_preds, video_labels, clip_count, preds, labels, clip_ids, num_clips, method, err):
+    """TestMeter.update_stats on device state (fp32 [V,K], int64 [V], int64 [V]); err: int32 [1] flag word."""
+    assert all(t.is_cuda for t in (video_preds, video_labels, clip_count, preds, labels, clip_ids, err))
+    assert video_preds.dtype == torch.float32 and video_labels.dtype == torch.int64 and clip_count.dtype == torch.int64 and err.dtype == torch.int32
+    preds = preds.float().contiguous()
+    labels = labels.long().contiguous().view(-1)
+    clip_ids = clip_ids.long().contiguous().view(-1)
+    assert preds.shape[0] == labels.numel() == clip_ids.numel() and preds.shape[1] == video_preds.shape[1]
+    L.check(L.load().dist_op_ensemble_update(_p(video_preds), _p(video_labels), _p(clip_count), _p(preds), _p(labels), _p(clip_ids),
+                                             preds.shape[0], preds.shape[1], video_preds.shape[0], int(num_clips), int(method), _p(err), _stream()))

@@ -1,13 +1,16 @@
-"""top-k helpers (reference utils/metrics.py:100-133)."""
-import torch
+"""top-k helpers with the reference's names and return types (utils/metrics.py:100-159), computed by dist_op_topk_correct on the
+predictions where they are (device tensors): no topk / sort / host copy per iteration.  CPU tensors are refused - there is no
+CPU path in the product (the numpy restatement used by the tests lives in oracle/meters_oracle.py)."""
+from .. import ops
 
 
 def topks_correct(preds, labels, ks):
-    assert preds.size(0) == labels.size(0)
-    _, top = torch.topk(preds, max(ks), dim=1, largest=True, sorted=True)
-    rep = labels.view(1, -1).expand_as(top.t())
-    correct = top.t().eq(rep)
-    return [correct[:k].reshape(-1).float().sum() for k in ks]
+    """list of 0-dim fp32 tensors: number of rows whose label is among the top-k scores, one per k in `ks`."""
+    if not (preds.is_cuda and labels.is_cuda):
+        raise RuntimeError("dist_amd.utils.metrics needs device tensors (the HIP library computes the ranks)")
+    assert preds.size(0) == labels.size(0), "Batch dim of predictions and labels must match"
+    out = ops.topk_correct(preds, labels, tuple(ks))
+    return [out[i] for i in range(len(ks))]
 
 
 def topk_errors(preds, labels, ks):

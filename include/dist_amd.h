@@ -191,6 +191,25 @@ int dist_op_mixup(float* video, int b, int64_t per_clip, float lam, float one_mi
 int dist_op_cutmix(float* video, int b, int planes, int H, int W, int yl, int yh, int xl, int xh, void* stream);
 int dist_op_mixup_target(const int64_t* labels, int b, int K, float lam, float one_minus_lam, float on_value, float off_value, float* soft, void* stream);
 
+/* Evaluation side: the operators that consume the predictions right behind the forward pass, so that the
+ * multi-view test loop (runs/test.py:24-178) and the per-iteration training metrics (runs/train.py:165-178) need no host round trip.
+ *   dist_op_softmax_rows:    y[r][:] = softmax(x[r][:]) in fp32 - the head's eval activation (models/base/base_blocks.py:573-585,
+ *                            nn.Softmax(dim=-1) on logits_per_image.mean(dim=1)); x, y fp32 [rows][K], may alias.
+ *   dist_op_topk_correct:    correct[i] = number of rows whose label is among the ks[i] highest scores (utils/metrics.py:100-129
+ *                            topks_correct; fp32 counts like the reference's .float().sum()).  nk <= 4.  Exactly equal scores rank
+ *                            by class index (torch.topk leaves that order unspecified); labels outside [0, K) never count.
+ *   dist_op_ensemble_update: TestMeter.update_stats (utils/meters.py:82-112): for every clip i in order, vid = clip_ids[i] / num_clips,
+ *                            video_preds[vid] += preds[i] (DIST_ENSEMBLE_SUM, same fp32 addition order as the reference's loop) or
+ *                            = max(video_preds[vid], preds[i]) (DIST_ENSEMBLE_MAX); video_labels[vid] = labels[i]; clip_count[vid] += 1.
+ *                            *err |= 1 when two views of a video carry different labels (the reference's assert, which like the
+ *                            reference only fires once the stored label is > 0), |= 2 for a clip id outside [0, num_videos * num_clips)
+ *                            (the reference raises IndexError); the caller zeroes *err and reads it when it finalises. */
+enum { DIST_ENSEMBLE_SUM = 0, DIST_ENSEMBLE_MAX = 1 };
+int dist_op_softmax_rows(const float* x, int rows, int K, float* y, void* stream);
+int dist_op_topk_correct(const float* preds, const int64_t* labels, int n, int K, const int* ks, int nk, float* correct, void* stream);
+int dist_op_ensemble_update(float* video_preds, int64_t* video_labels, int64_t* clip_count, const float* preds, const int64_t* labels,
+                            const int64_t* clip_ids, int n, int K, int64_t num_videos, int num_clips, int method, int* err, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Engine level: the whole hot path behind one handle.
  * ------------------------------------------------------------------------------------- */

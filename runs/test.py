@@ -14,36 +14,14 @@ from dist_amd.dataset.synthetic import build_loader, label_texts
 from dist_amd.models.base.builder import build_model
 from dist_amd.utils import checkpoint as cu
 from dist_amd.utils import distributed as du
-from dist_amd.utils import metrics
-
-
-class TestMeter:
-    def __init__(self, num_videos, num_clips, num_cls):
-        self.num_clips = num_clips
-        self.video_preds = torch.zeros(num_videos, num_cls)
-        self.video_labels = torch.zeros(num_videos, dtype=torch.long)
-        self.clip_count = torch.zeros(num_videos, dtype=torch.long)
-
-    def update_stats(self, preds, labels, clip_ids):
-        for p, l, c in zip(preds, labels, clip_ids):
-            vid = int(c) // self.num_clips
-            if self.clip_count[vid] > 0:
-                assert int(self.video_labels[vid]) == int(l), "label mismatch between views of one video"
-            self.video_labels[vid] = l
-            self.video_preds[vid] += p
-            self.clip_count[vid] += 1
-
-    def finalize_metrics(self, ks=(1, 5)):
-        ok = self.clip_count > 0
-        accs = metrics.topk_accuracies(self.video_preds[ok], self.video_labels[ok], ks)
-        return {f"top{k}_acc": float(a) for k, a in zip(ks, accs)}
+from dist_amd.utils.meters import TestMeter
 
 
 @torch.no_grad()
 def perform_test(test_loader, model, test_meter, cfg, texts):
     model.eval()
     # one batch of look-ahead (TRAIN.PIPELINE_VIT): the frozen-ViT pass of the next batch runs beside the branch forward,
-    # the all-gather and the host-side meter update of this one (dist_vit_prefetch / dist_vit_adopt)
+    # the all-gather and the device-side meter update of this one (dist_vit_prefetch / dist_vit_adopt)
     pipe = bool(getattr(cfg.TRAIN, "PIPELINE_VIT", True)) and hasattr(model, "prefetch")
     it = iter(test_loader)
     nxt = next(it, None)
@@ -57,8 +35,10 @@ def perform_test(test_loader, model, test_meter, cfg, texts):
         if pipe and nxt is not None:
             model.adopt()
         preds, lab, idx = du.all_gather([preds, labels["supervised"], video_idx])
-        test_meter.update_stats(preds.cpu(), lab.cpu(), idx.cpu())
-    return test_meter.finalize_metrics()
+        test_meter.update_stats(preds, lab, idx)                # device-side ensemble: no host copy, no synchronisation per iteration
+    out = test_meter.finalize_metrics()
+    test_meter.reset()
+    return {k: (float(v) if k.startswith("top") else v) for k, v in out.items()}
 
 
 def test(cfg):
@@ -70,7 +50,8 @@ def test(cfg):
     loader = build_loader(cfg, "test")
     views = cfg.TEST.NUM_ENSEMBLE_VIEWS * cfg.TEST.NUM_SPATIAL_CROPS
     assert len(loader.dataset) % views == 0
-    meter = TestMeter(len(loader.dataset) // views, views, cfg.VIDEO.HEAD.NUM_CLASSES)
+    meter = TestMeter(cfg, len(loader.dataset) // views, views, cfg.VIDEO.HEAD.NUM_CLASSES, len(loader),
+                      getattr(cfg.DATA, "ENSEMBLE_METHOD", "sum"))                      # reference runs/test.py:240-248
     texts = label_texts(cfg, vocab=model.backbone.base_encoder.vocab_size)
     out = perform_test(loader, model, meter, cfg, texts)
     if du.is_master_proc():
