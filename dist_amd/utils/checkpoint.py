@@ -1,7 +1,7 @@
 """Checkpoints (reference utils/checkpoint.py:102-143,277-347,452-576; process_dist_cpkt.py:10-30).
 
 Loads the reference's published layout ({"model_state": {"backbone.base_encoder.<clip keys>": ...}},
-`ladder_net.*` -> `dist_net.*` rename included) and OpenAI CLIP state-dicts; saves ONLY dist_net (+ the
+the pre-release `ladder_net.*` module names included: process_dist_cpkt.py's table, pinned by tests/golden/ckpt_rename.json) and OpenAI CLIP state-dicts; saves ONLY dist_net (+ the
 optimizer moments) instead of the whole 168 M-parameter model the reference writes every time."""
 import os
 
@@ -31,8 +31,37 @@ def get_last_checkpoint(path_to_job):
     return os.path.join(d, names[-1])
 
 
+# pre-release module names of the branch -> released names (reference process_dist_cpkt.py:10-30); longest prefix first
+_LADDER = (
+    ("ladder_net.input_map_feat_nets", "dist_net.input_linears"),
+    ("ladder_net.final_temporal_nets", "dist_net.adapooling_nets"),
+    ("ladder_net.s2t_fuse_nets", "dist_net.integration2temporal_nets"),
+    ("ladder_net.t2s_fuse_nets", "dist_net.temporal2integration_nets"),
+    ("ladder_net.spatial_nets", "dist_net.integration_nets"),
+    ("ladder_net.", "dist_net."),
+)
+
+
+def rename_key(k):
+    """one checkpoint key in either spelling -> the released spelling (prefixes such as `backbone.base_encoder.` stay)."""
+    i = k.find("ladder_net.")
+    if i < 0:
+        return k
+    head, tail = k[:i], k[i:]
+    for old, new in _LADDER:
+        if tail.startswith(old):
+            return head + new + tail[len(old):]
+    return k
+
+
+def rename_model_state(model_state):
+    """drop-in for the reference's process_dist_cpkt.rename_model_state (same result, order kept)."""
+    return {rename_key(k): v for k, v in model_state.items()}
+
+
 def normalize_state_dict(sd):
-    """reference key spellings -> CLIP keys (visual.*, dist_net.*, logit_scale, text tower)."""
+    """reference key spellings -> CLIP keys (visual.*, dist_net.*, logit_scale, text tower): unwraps {"model_state": ...},
+    strips the DDP `module.` and the `backbone.base_encoder.` prefixes, applies the pre-release -> released rename."""
     if "model_state" in sd:
         sd = sd["model_state"]
     out = {}
@@ -41,9 +70,7 @@ def normalize_state_dict(sd):
             k = k[7:]
         if k.startswith(PREFIX):
             k = k[len(PREFIX):]
-        if k.startswith("ladder_net."):
-            k = "dist_net." + k[len("ladder_net."):]
-        out[k] = v
+        out[rename_key(k)] = v
     return out
 
 
@@ -63,10 +90,17 @@ def save_checkpoint(path_to_job, model, optimizer, epoch, cfg, full=False):
 
 
 def load_checkpoint(path, model, optimizer=None, strict=False):
+    """reference utils/checkpoint.py:277-347: non-strict load, the two mismatch lists are reported (and kept in
+    `load_checkpoint.last_mismatch`); `strict=True` raises when a dist_net / visual tensor of the model is missing or a
+    dist_net / ladder_net key of the file is left over."""
+    assert os.path.exists(path), "Checkpoint '{}' not found".format(path)
     ck = torch.load(path, map_location="cpu")
     sd = normalize_state_dict(ck)
     clip = model.backbone.base_encoder
     missing = clip.load_state_dict(sd, strict=False)
+    load_checkpoint.last_mismatch = (list(missing.missing_keys), list(missing.unexpected_keys))
+    for what, keys in (("model", missing.missing_keys), ("checkpoint", missing.unexpected_keys)):
+        print("Keys in {} not matched: {}{}".format(what, len(keys), " (" + ", ".join(keys[:4]) + (", ..." if len(keys) > 4 else "") + ")" if keys else ""))
     if strict and (missing.missing_keys or missing.unexpected_keys):
         raise KeyError(f"checkpoint mismatch: {missing}")
     eng = clip.engine
@@ -77,3 +111,6 @@ def load_checkpoint(path, model, optimizer=None, strict=False):
             eng.exp_avg = st["exp_avg"].to(eng.device)
             eng.exp_avg_sq = st["exp_avg_sq"].to(eng.device)
     return ck.get("epoch", -1) if isinstance(ck, dict) else -1
+
+
+load_checkpoint.last_mismatch = ([], [])

@@ -1,0 +1,70 @@
+"""Checkpoint key compatibility (reference process_dist_cpkt.py:10-30, utils/checkpoint.py:277-347).
+
+Not GPU: `dist_amd.utils.checkpoint.rename_model_state` / `normalize_state_dict` against tests/golden/ckpt_rename.json, the output of
+the REFERENCE's own `rename_model_state` over every dist_net tensor name in its pre-release spelling (oracle/make_golden_ckpt.py).
+GPU: a checkpoint written in the pre-release spelling (and with the DDP `module.` prefix) loads into the engine with no dist_net
+tensor left unmatched, and round-trips bit for bit."""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "ckpt_rename.json")))
+
+
+def test_rename_table_matches_the_reference_for_every_tensor_name():
+    from dist_amd import synth
+    from dist_amd.utils import checkpoint as cu
+    assert sum("ladder_net" in k for k in GOLD) >= 383 and not any("ladder_net" in v for v in GOLD.values())
+    for old, new in GOLD.items():
+        assert cu.rename_key(old) == new, (old, cu.rename_key(old), new)
+    got = cu.rename_model_state({k: i for i, k in enumerate(GOLD)})
+    assert list(got.keys()) == [GOLD[k] for k in GOLD] and list(got.values()) == list(range(len(GOLD)))      # order and values kept
+    # every tensor the engine owns is reachable from the pre-release spelling
+    g = synth.geometry("b16_8+16f")
+    released = {v[len(cu.PREFIX):] for v in GOLD.values()}
+    assert set(synth.dist_net_shapes(g)) <= released and len(synth.dist_net_shapes(g)) == 383
+
+
+def test_normalize_strips_wrappers_and_prefixes():
+    from dist_amd.utils import checkpoint as cu
+    sd = {"model_state": {"module.backbone.base_encoder.ladder_net.s2t_fuse_nets.3.linear_fuse.weight": 1,
+                          "backbone.base_encoder.ladder_net.proj": 2, "backbone.base_encoder.visual.proj": 3,
+                          "backbone.base_encoder.dist_net.input_linears.0.bias": 4, "logit_scale": 5}}
+    assert cu.normalize_state_dict(sd) == {"dist_net.integration2temporal_nets.3.linear_fuse.weight": 1, "dist_net.proj": 2, "visual.proj": 3,
+                                           "dist_net.input_linears.0.bias": 4, "logit_scale": 5}
+    assert cu.normalize_state_dict({"visual.proj": 7}) == {"visual.proj": 7}                                   # a bare CLIP state-dict passes through
+
+
+@pytest.mark.gpu
+def test_pre_release_checkpoint_loads_completely(gpu_lib, tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_dropin_gpu import tiny_cfg
+    from dist_amd.models.base.builder import build_model
+    from dist_amd.utils import checkpoint as cu
+    cfg = tiny_cfg()
+    model, _ = build_model(cfg)
+    eng = model.backbone.base_encoder.engine
+    path = cu.save_checkpoint(str(tmp_path), model, None, 0, cfg)
+    ck = torch.load(path, map_location="cpu")
+    inverse = {v: k for k, v in GOLD.items() if "ladder_net" in k}
+    old = {"module." + inverse.get(k, k): v for k, v in ck["model_state"].items()}
+    assert sum("ladder_net" in k for k in old) == len(eng.tables[0]) and any("final_temporal_nets" in k for k in old)
+    p2 = str(tmp_path / "pre_release.pyth")
+    torch.save({"model_state": old}, p2)
+    want = {n: eng.view(n).clone() for n in eng.tables[0]}
+    for n in eng.tables[0]:
+        eng.view(n).zero_()
+    epoch = cu.load_checkpoint(p2, model)
+    assert epoch == -1                                                          # no "epoch" entry (reference :341-345)
+    missing, unexpected = cu.load_checkpoint.last_mismatch
+    assert not [k for k in missing if k.startswith("dist_net.")] and not unexpected
+    for n, w in want.items():
+        assert torch.equal(eng.view(n), w), n
+    with pytest.raises(KeyError):
+        cu.load_checkpoint(p2, model, strict=True)                              # the frozen tower is not in a dist_net-only file
+    with pytest.raises(AssertionError):
+        cu.load_checkpoint(str(tmp_path / "nope.pyth"), model)
