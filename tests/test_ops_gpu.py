@@ -124,7 +124,7 @@ def test_gemm_nt_rowmaps(gpu_lib, dtype, mode, kw, taps, N):
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("grid,frames,sign", [(14, 5, 1), (14, 3, -1), (16, 3, 1)])
 def test_conv3x3_frame_epilogues(gpu_lib, dtype, grid, frames, sign):
-    """3x3 frame convolution, 96 channels (bf16: the frame-resident kernel of conv3x3.hip; fp32: the tiled kernel) with
+    """3x3 frame convolution, 96 channels (the spatial row map of dist_op_gemm_nt, 9 taps; bf16: the LDS-DMA kernel) with
     every epilogue the TemporalNet uses: bias + residual + second activated output (forward), activation derivative (backward)."""
     from dist_amd import ops
     K = N = 96
