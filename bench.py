@@ -33,7 +33,7 @@ GF_PER_CLIP = {"b16_8+16f": dict(fwd=325.73, fwd_bwd=398.0)}
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(gname, seconds_budget=25.0):
+def cpu_baseline(gname, seconds_budget=15.0):
     """The oracle (CPU restatement of the reference, kind 'port') timed on this host's cores:
     BASELINE config 1 shape (b=2) forward+backward.  Bounded: threads = the cores this process may
     use (capped at 32: more threads only add contention for a b=2 problem), and the timed
@@ -53,7 +53,7 @@ def cpu_baseline(gname, seconds_budget=25.0):
     video, text, tgt = synth.video(g, b), synth.text_features(g), synth.soft_target(g, b)[0]
     times = []
     t_all = time.time()
-    for it in range(4):
+    for it in range(16):                                     # about 10-15 s of CPU work on the GPU box's host (1.1 s per b=2 iteration)
         t0 = time.time()
         o.forward_backward(video, text, tgt)
         times.append(time.time() - t0)
@@ -218,6 +218,33 @@ def main():
                 "alone": {"achieved": round(ach1, 1), "frac": round(ach1 / PEAK_BF16_TFLOPS, 4), "launches": lps1, "avg_launch_us": round(avg1, 1),
                           "note": "the launches of one frozen-ViT pass with no other stream active"}}
 
+    # forward only (what the multi-view evaluation loop runs; SURVEY §8(d) quotes a forward-only roofline fraction): frozen ViT of
+    # batch n+1 beside the branch forward of batch n, no loss / backward / AdamW
+    fwd_only = None
+    if not args.no_roofline and world == 1:
+        def fwd(n):
+            if pipelined:
+                eng.vit_prefetch(videos[(n + 1) % 2])
+            else:
+                eng.vit_forward(videos[n % 2])
+            eng.branch_forward(text)
+            if pipelined:
+                eng.vit_adopt()
+        for n in range(3):
+            fwd(n)
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        nf = max(1, min(10, args.steps))
+        for n in range(nf):
+            fwd(n)
+        torch.cuda.synchronize()
+        dtf = (time.perf_counter() - tf0) / nf
+        gff = GF_PER_CLIP.get(args.config, {}).get("fwd")
+        fwd_only = {"ms_per_iteration": round(dtf * 1e3, 3), "value": round(b / dtf, 1), "unit": "clips/s", "iterations": nf}
+        if gff:
+            fwd_only["path_tflops_per_gpu"] = round(b / dtf * gff / 1e3, 1)
+            fwd_only["path_mfma_frac"] = round(b / dtf * gff / 1e3 / PEAK_BF16_TFLOPS, 4)
+
     if rank == 0:
         clips = world * b * args.steps
         value = clips / dt
@@ -249,6 +276,8 @@ def main():
             out["serial_order"] = serial
         if roof:
             out["roofline"] = roof
+        if fwd_only:
+            out["forward_only"] = fwd_only
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config)
         # RCCL's version banner sits in the C stdio buffer until exit: flush it first so that the JSON line is the LAST line of stdout
