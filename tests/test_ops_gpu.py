@@ -184,6 +184,36 @@ def test_gemm_fast_two_group_loop_is_race_free_at_full_size(gpu_lib, N, K):
     torch.testing.assert_close(outs[0].float(), ref.float(), **tol(dtype))
 
 
+@pytest.mark.parametrize("M,N,K,taps,mode,kw", [(100352, 96, 96, 9, "spatial", dict(p0=14)), (50432 - 5, 384, 96, 1, "plain", {}), (50432, 96, 384, 1, "plain", {})])
+def test_gemm_nt_epilogue_tile_prefetch_is_race_free_at_full_size(gpu_lib, M, N, K, taps, mode, kw):
+    """The branch GEMM's epilogue stages in ring slots the last K-tile no longer reads, without a block barrier, and requests its first
+    input tile (activation derivative, else residual) by LDS-DMA behind the last MFMA: full BASELINE row counts (three tile shapes),
+    the in-place residual the engine uses, derivative + residual together, and a second activated output; 6 launches per case are
+    bit-identical to each other, and the first / last rows equal the fp64 statement."""
+    from dist_amd import ops
+    dtype = torch.bfloat16
+    A, B = rnd((M, K), dtype, 31), rnd((N, taps * K), dtype, 32, (taps * K) ** -0.5)
+    bias, R, X = rnd((N,), torch.float32, 33), rnd((M, N), dtype, 34), rnd((M, N), dtype, 35)
+    am = ops.rowmap(MODES[mode], kw.get("p0", 0), kw.get("p1", 0))
+    rows = torch.cat([torch.arange(0, 400), torch.arange(M - 400, M)]).cuda()
+    lin = sum(gather(A, mode, M, t, taps, **kw)[rows] @ B.double()[:, t * K:(t + 1) * K].t() for t in range(taps)) + bias.double()
+    want = {"res_inplace": lin + R.double()[rows], "aux+res": lin * qgelu_grad(X.double()[rows]) + R.double()[rows], "res+act": lin + R.double()[rows]}
+    for combo in ("res_inplace", "aux+res", "res+act"):
+        outs = []
+        for _ in range(6):
+            C = R.clone() if combo == "res_inplace" else torch.full((M, N), 7.0, dtype=dtype, device="cuda")
+            C2 = torch.full((M, N), 7.0, dtype=dtype, device="cuda") if combo == "res+act" else None
+            ops.gemm_nt(A, B, M, N, K, taps=taps, bias=bias, res=C if combo == "res_inplace" else R, aux=X if combo == "aux+res" else None,
+                        C_out=C, C2_out=C2, amap=am)
+            outs.append((C, C2))
+        torch.cuda.synchronize()
+        for C, C2 in outs[1:]:
+            assert torch.equal(C, outs[0][0]) and (C2 is None or torch.equal(C2, outs[0][1])), combo
+        torch.testing.assert_close(outs[0][0][rows].double(), want[combo], **tol(dtype))
+        if combo == "res+act":
+            torch.testing.assert_close(outs[0][1][rows].double(), qgelu(outs[0][0][rows].double()), **tol(dtype))
+
+
 def test_gemm_fast_patch_embed_maps(gpu_lib):
     """the ViT patch embedding as the 256x256 LDS-DMA kernel sees it: strided source rows (every alpha-th
     frame), rows inserted behind each frame's cls row, residual read at the destination."""
