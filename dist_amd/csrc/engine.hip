@@ -611,7 +611,7 @@ extern "C" const char* dist_strerror(int code) {
         default: return code <= -1000 ? hipGetErrorString((hipError_t)(-code - 1000)) : "unknown error";
     }
 }
-extern "C" int dist_abi_version(void) { return 5; }   // 5: dist_gemm_args.rowstats, marks, mixup and evaluation-side operators (round 2)
+extern "C" int dist_abi_version(void) { return 6; }   // 5: dist_gemm_args.rowstats, marks, mixup, evaluation side; 6: fp8 operands (a_scale / b_scale, DIST_EPI_FP8)
 extern "C" int dist_abi_sizeof(const char* n) {
     if (!n) return -1;
 #define DIST_SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)

@@ -411,9 +411,23 @@ DEV void regs_ready(bf16x8 (&f)[4][2]) {
     asm volatile("" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[2][0]), "+v"(f[2][1]), "+v"(f[3][0]), "+v"(f[3][1]));
 }
 DEV void regs_ready(bf16x8 (&f)[2][2]) { asm volatile("" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1])); }
+// fp8: a fragment is ONE 32-byte MFMA operand (8 consecutive VGPRs, filled by two 16-byte ds_reads)
+typedef int v8i32_t __attribute__((ext_vector_type(8)));
+typedef int v4i32_t __attribute__((ext_vector_type(4)));
+DEV void regs_ready(v8i32_t (&f)[4][1]) { asm volatile("" : "+v"(f[0][0]), "+v"(f[1][0]), "+v"(f[2][0]), "+v"(f[3][0])); }
+DEV void regs_ready(v8i32_t (&f)[2][1]) { asm volatile("" : "+v"(f[0][0]), "+v"(f[1][0])); }
 
+// FP8 (DIST_EPI_FP8): the same bytes move the same way - a K-tile is still 128 BYTES per row, now 128 e4m3 elements - and a lane's
+// two 16-byte fragment reads of a row (chunks lg and 4 + lg) are the 32 k-values of ONE block-scaled MFMA
+// (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales: twice the bf16 rate): 8 MFMAs per phase instead of 16, each K-tile twice as
+// deep.  Which k a (lane, byte) stands for is free as long as A and B agree, and both come through the same swizzle.  The fp32
+// per-row scales of A and B multiply the accumulators in front of the shared epilogue.
+DEV v8i32_t fp8_operand(const v4i32_t& lo, const v4i32_t& hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+template <bool FP8>
 __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_args p, const int ngroups) {
     constexpr int BN = 256;
+    constexpr unsigned ES = FP8 ? 1u : 2u;                // bytes per operand element
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -429,17 +443,17 @@ __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_arg
     // Per-lane byte offsets for piece j of quadrant 0 (plain row maps only: the launcher checks); quadrant 1 and the K-tile
     // are scalar offsets; both descriptors end behind the last row, so the rows of a ragged last row tile / a half-empty
     // column tile read as zero instead of being clamped.
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, M * p.lda * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, N * p.ldb * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, M * p.lda * (int)ES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, N * p.ldb * (int)ES, 0x00020000);
     unsigned ga[2], gb[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int lr = 16 * wid + 8 * j + (lane >> 3);
         const int lc = (lane & 7) ^ ((lr >> 1) & 7);
-        ga[j] = ((unsigned)(m0 + (lr >> 6) * 128 + (lr & 63)) * (unsigned)p.lda + lc * 8) * 2u;
-        gb[j] = ((unsigned)(n0 + (lr >> 5) * 64 + (lr & 31)) * (unsigned)p.ldb + lc * 8) * 2u;
+        ga[j] = (unsigned)(m0 + (lr >> 6) * 128 + (lr & 63)) * (unsigned)p.lda * ES + lc * 16;
+        gb[j] = (unsigned)(n0 + (lr >> 5) * 64 + (lr & 31)) * (unsigned)p.ldb * ES + lc * 16;
     }
-    const int aq1 = 64 * p.lda * 2, bq1 = 32 * p.ldb * 2;  // quadrant 1: 64 rows of A / 32 rows of B further
+    const int aq1 = 64 * p.lda * (int)ES, bq1 = 32 * p.ldb * (int)ES;  // quadrant 1: 64 rows of A / 32 rows of B further
     // stage half-tile `slot` (P8_A0 ...) of K-tile kt into buffer kt & 1
     auto stage = [&](const int slot, const int kt) __attribute__((always_inline)) {
         char* sb = smem + (kt & 1) * P8_BUF + slot + wid * 2048;
@@ -463,18 +477,30 @@ __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_arg
         a_rd[kk] = (wr * 64 + li) * 128 + pc;
         b_rd[kk] = P8_B0 + (wc * 32 + li) * 128 + pc;
     }
-    bf16x8 fa[2][4][2], sb_[2][2][2];
-    auto read_a = [&](bf16x8 (&f)[4][2], const int buf, const int slot) __attribute__((always_inline)) {
+    using frag_t = std::conditional_t<FP8, v8i32_t, bf16x8>;
+    constexpr int KK = FP8 ? 1 : 2;                       // fragments per row block and K-tile
+    frag_t fa[2][4][KK], sb_[2][2][KK];
+    auto read_a = [&](frag_t (&f)[4][KK], const int buf, const int slot) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            const char* q = smem + (slot + buf * P8_BUF + i * 2048);
+            if constexpr (FP8) f[i][0] = fp8_operand(*reinterpret_cast<const v4i32_t*>(q + a_rd[0]), *reinterpret_cast<const v4i32_t*>(q + a_rd[1]));
+            else {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) f[i][kk] = *reinterpret_cast<const bf16x8*>(smem + a_rd[kk] + (slot + buf * P8_BUF + i * 2048));
+                for (int kk = 0; kk < 2; ++kk) f[i][kk] = *reinterpret_cast<const bf16x8*>(q + a_rd[kk]);
+            }
+        }
     };
-    auto read_b = [&](bf16x8 (&f)[2][2], const int buf, const int slot) __attribute__((always_inline)) {
+    auto read_b = [&](frag_t (&f)[2][KK], const int buf, const int slot) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            const char* q = smem + (slot - P8_B0 + buf * P8_BUF + j * 2048);
+            if constexpr (FP8) f[j][0] = fp8_operand(*reinterpret_cast<const v4i32_t*>(q + b_rd[0]), *reinterpret_cast<const v4i32_t*>(q + b_rd[1]));
+            else {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) f[j][kk] = *reinterpret_cast<const bf16x8*>(smem + b_rd[kk] + (slot - P8_B0 + buf * P8_BUF + j * 2048));
+                for (int kk = 0; kk < 2; ++kk) f[j][kk] = *reinterpret_cast<const bf16x8*>(q + b_rd[kk]);
+            }
+        }
     };
 
     f32x4 acc[8][4];
@@ -485,17 +511,30 @@ __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_arg
 
     // multiply section: barrier (this wave's counted DMA wait is behind it), 16 MFMAs on fragments read a phase ago,
     // retire the reads of the load section in front (they have had the 16 MFMAs to complete), barrier
-    auto mma16q = [&](const int qa, const int qb, const bf16x8 (&a)[4][2], const bf16x8 (&b)[2][2]) __attribute__((always_inline)) {
+    auto mma16q = [&](const int qa, const int qb, const frag_t (&a)[4][KK], const frag_t (&b)[2][KK]) __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        if constexpr (FP8) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[qa * 4 + i][qb * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][kk], a[i][kk], acc[qa * 4 + i][qb * 2 + j], 0, 0, 0);   // swapped: D[n][m]
+                for (int j = 0; j < 2; ++j)                  // e4m3 x e4m3, block scales 2^0 (E8M0 127 in every byte); swapped: D[n][m]
+                    acc[qa * 4 + i][qb * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                        b[j][0], a[i][0], acc[qa * 4 + i][qb * 2 + j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            // pin the eight results to this phase: without it hipcc sinks all 64 scaled MFMAs of the loop body behind its last
+            // barrier (they have no side effects and their results are only used a K-tile later) and spills the accumulators
+            asm volatile("" : "+v"(acc[qa * 4][qb * 2]), "+v"(acc[qa * 4][qb * 2 + 1]), "+v"(acc[qa * 4 + 1][qb * 2]), "+v"(acc[qa * 4 + 1][qb * 2 + 1]),
+                              "+v"(acc[qa * 4 + 2][qb * 2]), "+v"(acc[qa * 4 + 2][qb * 2 + 1]), "+v"(acc[qa * 4 + 3][qb * 2]), "+v"(acc[qa * 4 + 3][qb * 2 + 1]));
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[qa * 4 + i][qb * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][kk], a[i][kk], acc[qa * 4 + i][qb * 2 + j], 0, 0, 0);   // swapped: D[n][m]
+        }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
@@ -508,7 +547,7 @@ __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_arg
     // one K-tile = four phases; the tail is selected by wave-uniform scalars (s1 = tile kt+1 exists, s2 = tile kt+2 exists)
     // instead of peeled copies of the body: peeled copies made hipcc rename accumulators across their joins and spill
     // INSIDE the loop - and a scratch reload is a vmcnt(0).
-    const int nk = K / P8_BK;                             // >= 2 (checked by the launcher)
+    const int nk = K / (FP8 ? 2 * P8_BK : P8_BK);         // >= 2 (checked by the launcher); a K-tile is 128 bytes per row
     auto ktile = [&](auto buf_c, const int kt) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_c)::value, NB = BUF ^ 1;
         const bool s1 = kt + 1 < nk, s2 = kt + 2 < nk;
@@ -527,14 +566,15 @@ __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_arg
         regs_ready(fa[1]);
         close_phase();
         // phase 2
-        if (s1) read_a(fa[0], NB, P8_A0);
+        if (s1 || FP8) read_a(fa[0], NB, P8_A0);          // (fp8: unconditional - a stale tile is read behind the last one and never used;
+                                                          //  conditional definitions of 8-register fragments made hipcc spill inside the loop)
         __builtin_amdgcn_sched_barrier(0);
         if (s2) { stage(P8_B1, kt + 2); wait_vm<10>(); } else if (s1) wait_vm<4>();
         mma16q(1, 1, fa[1], sb_[NB]);
         regs_ready(fa[0]);
         close_phase();
         // phase 3
-        if (s1) read_b(sb_[NB], NB, P8_B0);
+        if (s1 || FP8) read_b(sb_[NB], NB, P8_B0);
         __builtin_amdgcn_sched_barrier(0);
         if (s2) { stage(P8_A1, kt + 2); wait_vm<10>(); } else if (s1) wait_vm<2>();
         mma16q(1, 0, fa[1], sb_[BUF]);
@@ -555,12 +595,32 @@ __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_arg
     if (wr == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one barrier interval behind group 0
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     int kt = 0;
+#pragma unroll 1
     for (; kt + 1 < nk; kt += 2) {
         ktile(I0{}, kt);
         ktile(I1{}, kt + 1);
     }
     if (kt < nk) ktile(I0{}, kt);
     if (wr == 0) __builtin_amdgcn_s_barrier();            // pairs with group 1's extra barrier
+    if constexpr (FP8) {                                  // acc[i][j][r]: row mw + i*16 + li, column nw + j*16 + lg*4 + r
+        const int mw = m0 + wr * 128, nw = n0 + wc * 64;
+        float sb4[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = nw + j * 16 + lg * 4 + r;
+                sb4[j][r] = n < N ? p.b_scale[n] : 0.f;
+            }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float sa = p.a_scale[min(mw + i * 16 + li, M - 1)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] *= sa * sb4[j][r];
+        }
+    }
     fast_epilogue(p, acc, smem, wid, lane, m0, n0, wr, wc);
 }
 
@@ -579,6 +639,10 @@ static bool fast_common_ok(const dist_gemm_args* a) {
     }
     if (a->K % BK || a->K < 4 * BK || a->N % 64 || a->M < 1024) return false;
     if (a->lda % 8 || a->ldb % 8 || a->ldc % 8 || a->ldc2 % 8 || a->ldres % 8) return false;
+    if (a->flags & DIST_EPI_FP8) {                        // e4m3 operands: 16-byte row alignment, whole 128-deep K-tiles, plain row map
+        if (!a->a_scale || !a->b_scale || a->amap.mode != DIST_RM_PLAIN || a->K % 128 || a->K < 256 || a->lda % 16 || a->ldb % 16) return false;
+        if (a->N < 256 || (a->N % 256 > 0 && a->N % 256 < 128)) return false;
+    }
     if (a->omap.mode == DIST_OM_HEADS && (a->flags & (DIST_EPI_RES | DIST_EPI_ACT2))) return false;
     const long a_rows = a->amap.mode == DIST_RM_PLAIN ? a->M : 2 * a->M + a->M / 64 + 64;   // generous bound for the strided / skip-cls images
     if (a_rows * a->lda >= (1l << 30) || (long)a->N * a->ldb >= (1l << 30)) return false;     // 32-bit byte offsets
@@ -589,7 +653,8 @@ static bool fast_common_ok(const dist_gemm_args* a) {
 static int fast_variant(const dist_gemm_args* a) {
     if (!fast_common_ok(a)) return 0;
     static const int forced = [] { const char* e = getenv("DIST_AMD_FAST_NW"); return e ? atoi(e) : 0; }();   // measurement knob
-    const bool ok8 = a->N >= 256 && !(a->N % 256 > 0 && (a->N % 256 < 128 || a->K < 768));
+    // (a half-empty last column tile only pays with a deep K loop - bf16 has the branch-GEMM kernels for the rest; fp8 has no other kernel)
+    const bool ok8 = a->N >= 256 && !(a->N % 256 > 0 && (a->N % 256 < 128 || (a->K < 768 && !(a->flags & DIST_EPI_FP8))));
     const bool ok4 = a->N >= 128 && a->N % 128 == 0;
     // measured (tools/bench_fastk.py, profiles/r01_fast_gemm_shapes.md): the two-block shape hides ~40 % of the fixed
     // per-block cost but its K loop is ~30 % slower (prefetch depth 2, 1.5x the LDS-DMA pieces per FLOP) - it loses on
@@ -618,10 +683,11 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
     if (forced_ng == 0) {
         // fabric bytes of the launch ~ ng x (activation bytes) + 8 XCDs x (weight bytes) when a group's weight rows stay in L2,
         // and ~7 re-fetches of W per XCD when they do not (QKV measured: 276 MB = 77 + 8 x 7 x 3.5, profiles/r01_pmc_fast_gemm.md)
-        const double A = (double)a->M * a->K * 2.0, W = (double)a->N * a->K * 2.0;
+        const double es = (a->flags & DIST_EPI_FP8) ? 1.0 : 2.0;
+        const double A = (double)a->M * a->K * es, W = (double)a->N * a->K * es;
         double best = A + 8.0 * W * (W <= 2.5e6 ? 1.0 : 7.0);
         for (int g = 2; g <= 4 && g <= tiles_n; ++g) {
-            const double wg = (double)((tiles_n + g - 1) / g) * S::BN * a->K * 2.0;
+            const double wg = (double)((tiles_n + g - 1) / g) * S::BN * a->K * es;
             if (wg > 2.5e6) continue;
             const double cost = g * A + 8.0 * W;
             if (cost < 0.85 * best) { best = cost; ng = g; }
@@ -632,15 +698,26 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
     // two-group 256x256x64 main loop (gemm_fast8p_kernel) when K is a multiple of 64; DIST_AMD_FAST_8P=0 keeps the
     // lock-step 256x256x32 loop (measurement knob, and the A/B reference of tools/bench_fast8p.py)
     static const bool use_8p = !(getenv("DIST_AMD_FAST_8P") && atoi(getenv("DIST_AMD_FAST_8P")) == 0);
+    constexpr size_t smem8 = (size_t)P8_LDS;
+    static_assert(8 * EPI_BYTES <= P8_LDS, "epilogue staging fits in the operand buffers");
+    if (a->flags & DIST_EPI_FP8) {                        // fast_common_ok checked the shape; only the two-group loop has the fp8 MFMAs
+        if (NW != 8) return DIST_ERR_ARG;
+        static bool attr8f_done = false;
+        if (!attr8f_done) {
+            HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast8p_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8));
+            attr8f_done = true;
+        }
+        hipLaunchKernelGGL(gemm_fast8p_kernel<true>, dim3((unsigned)tiles), dim3(512), smem8, s, *a, ng);
+        HIP_CHECK_RET(hipGetLastError());
+        return 1;
+    }
     if (NW == 8 && use_8p && a->K % P8_BK == 0 && a->K >= 2 * P8_BK && a->amap.mode == DIST_RM_PLAIN) {
-        constexpr size_t smem8 = (size_t)P8_LDS;
-        static_assert(8 * EPI_BYTES <= P8_LDS, "epilogue staging fits in the operand buffers");
         static bool attr8_done = false;
         if (!attr8_done) {
-            HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast8p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8));
+            HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast8p_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8));
             attr8_done = true;
         }
-        hipLaunchKernelGGL(gemm_fast8p_kernel, dim3((unsigned)tiles), dim3(512), smem8, s, *a, ng);
+        hipLaunchKernelGGL(gemm_fast8p_kernel<false>, dim3((unsigned)tiles), dim3(512), smem8, s, *a, ng);
         HIP_CHECK_RET(hipGetLastError());
         return 1;
     }

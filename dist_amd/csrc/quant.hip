@@ -1,0 +1,63 @@
+// Per-row symmetric quantisation to OCP e4m3 (dist_op_quant_rows_fp8): the operands of the DIST_EPI_FP8 GEMM (BASELINE config 5:
+// fp8 frozen spatial branch).  One wave per row: the row is read once (16-byte vectors, kept in registers), amax by a wave
+// reduction, then 8 e4m3 bytes per vector.  HBM-bound: 2 (bf16) or 4 (fp32) bytes in, 1 byte out per element.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int QV = 16;                                     // vectors of 8 elements per lane: rows up to 8192 elements
+
+template <typename T>
+__global__ __launch_bounds__(NT) void quant_rows_fp8_kernel(const T* __restrict__ x, const long rows, const int K, const int ld,
+                                                            unsigned char* __restrict__ q, const int ldq, float* __restrict__ scale) {
+    const long row = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const T* xr = x + row * ld;
+    const int nv = K / 8;
+    Frag<T> f[QV];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < QV; ++i) {
+        const int v = lane + i * 64;
+        if (v < nv) {
+            frag_load(f[i], xr + v * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(frag_get(f[i], e)));
+        }
+    }
+    amax = wave_max(amax, 64);
+    const float inv = amax > 0.f ? 448.f / amax : 1.f;     // IEEE division: the same factor a host restatement computes
+    if (lane == 0) scale[row] = amax > 0.f ? amax / 448.f : 1.f;
+    unsigned char* qr = q + row * ldq;
+#pragma unroll
+    for (int i = 0; i < QV; ++i) {
+        const int v = lane + i * 64;
+        if (v < nv) {
+            int lo = 0, hi = 0;                             // v_cvt_pk_fp8_f32: two fp32 -> two e4m3 (round to nearest even) into one half of a dword
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(frag_get(f[i], 0) * inv, frag_get(f[i], 1) * inv, lo, false);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(frag_get(f[i], 2) * inv, frag_get(f[i], 3) * inv, lo, true);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(frag_get(f[i], 4) * inv, frag_get(f[i], 5) * inv, hi, false);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(frag_get(f[i], 6) * inv, frag_get(f[i], 7) * inv, hi, true);
+            *reinterpret_cast<int2*>(qr + v * 8) = make_int2(lo, hi);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dist_op_quant_rows_fp8(const void* x, int dtype, int64_t rows, int K, int ld, void* q, int ldq, float* scale, void* stream) {
+    if (!x || !q || !scale || rows <= 0 || K <= 0 || K % 8 || ld % 8 || ldq % 8 || K > QV * 64 * 8 || ld < K || ldq < K) return DIST_ERR_ARG;
+    if (dtype != DIST_BF16 && dtype != DIST_F32) return DIST_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned blocks = (unsigned)((rows + NT / 64 - 1) / (NT / 64));
+    if (dtype == DIST_BF16)
+        hipLaunchKernelGGL(quant_rows_fp8_kernel<bf16_t>, dim3(blocks), dim3(NT), 0, s, static_cast<const bf16_t*>(x), (long)rows, K, ld,
+                           static_cast<unsigned char*>(q), ldq, scale);
+    else
+        hipLaunchKernelGGL(quant_rows_fp8_kernel<float>, dim3(blocks), dim3(NT), 0, s, static_cast<const float*>(x), (long)rows, K, ld,
+                           static_cast<unsigned char*>(q), ldq, scale);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}

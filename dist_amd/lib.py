@@ -10,7 +10,7 @@ F32, BF16 = 0, 1
 RM_PLAIN, RM_SHIFT, RM_SPATIAL, RM_STRIDED, RM_SKIPCLS = range(5)
 OM_PLAIN, OM_DUP, OM_INSERTCLS, OM_SPLITCOLS, OM_HEADS = range(5)
 QKV_ROWS, QKV_HEADS = 0, 1
-EPI_BIAS, EPI_MULG, EPI_RES, EPI_ACT2, EPI_MULG_POST, EPI_LNFOLD, EPI_ROWSTATS = 1, 2, 4, 8, 16, 32, 64
+EPI_BIAS, EPI_MULG, EPI_RES, EPI_ACT2, EPI_MULG_POST, EPI_LNFOLD, EPI_ROWSTATS, EPI_FP8 = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 class RowMap(C.Structure):
@@ -26,7 +26,8 @@ class GemmArgs(C.Structure):
                 ("bias", C.c_void_p), ("res", C.c_void_p), ("aux", C.c_void_p),
                 ("M", C.c_int64), ("N", C.c_int), ("K", C.c_int), ("taps", C.c_int),
                 ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int), ("ldc2", C.c_int), ("ldres", C.c_int), ("ldaux", C.c_int),
-                ("amap", RowMap), ("omap", OutMap), ("flags", C.c_int), ("dtype", C.c_int), ("bias2", C.c_void_p), ("rowstats", C.c_void_p)]
+                ("amap", RowMap), ("omap", OutMap), ("flags", C.c_int), ("dtype", C.c_int), ("bias2", C.c_void_p), ("rowstats", C.c_void_p),
+                ("a_scale", C.c_void_p), ("b_scale", C.c_void_p)]
 
 
 class GemmTnArgs(C.Structure):
@@ -152,6 +153,7 @@ def load():
     _sig(lib, "dist_op_mixup", argtypes=[C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_void_p])
     _sig(lib, "dist_op_cutmix", argtypes=[C.c_void_p] + [C.c_int] * 8 + [C.c_void_p])
     _sig(lib, "dist_op_mixup_target", argtypes=[C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p])
+    _sig(lib, "dist_op_quant_rows_fp8", argtypes=[C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_op_softmax_rows", argtypes=[C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_op_topk_correct", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_op_ensemble_update", argtypes=[C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p])

@@ -37,7 +37,7 @@ def outmap(mode=L.OM_PLAIN, p0=0, p1=0, p2=0):
 
 
 def gemm_nt(A, B, M, N, K, *, taps=1, bias=None, res=None, aux=None, amap=None, omap=None,
-            C_out=None, C2_out=None, lda=None, ldc=None, mulg_post=False, lnfold=None, rowstats=None):
+            C_out=None, C2_out=None, lda=None, ldc=None, mulg_post=False, lnfold=None, rowstats=None, fp8=None):
     """C[omap(m)][n] = epi(sum_tap sum_k A[amap(m,tap)][k] B[n][tap*K+k]); returns None (writes C_out / C2_out)."""
     lib = L.load()
     a = L.GemmArgs()
@@ -63,7 +63,13 @@ def gemm_nt(A, B, M, N, K, *, taps=1, bias=None, res=None, aux=None, amap=None, 
     if rowstats is not None:        # fp32 [N/64][M][2]: (sum, sum of squares) of the stored values per 64-column slice (EPI_ROWSTATS)
         a.rowstats = _p(rowstats)
         a.flags |= L.EPI_ROWSTATS
-    a.dtype = _dt(A)
+    if fp8 is not None:             # (a_scale fp32 [M], b_scale fp32 [N]): A / B hold e4m3 bytes (quant_rows_fp8), outputs are bf16 (EPI_FP8)
+        assert A.dtype == torch.uint8 and B.dtype == torch.uint8
+        a.a_scale, a.b_scale = _p(fp8[0]), _p(fp8[1])
+        a.flags |= L.EPI_FP8
+        a.dtype = L.BF16
+    else:
+        a.dtype = _dt(A)
     L.check(lib.dist_op_gemm_nt(C.byref(a), _stream()))
 
 
@@ -282,3 +288,14 @@ def ensemble_update(video_preds, video_labels, clip_count, preds, labels, clip_i
     assert preds.shape[0] == labels.numel() == clip_ids.numel() and preds.shape[1] == video_preds.shape[1]
     L.check(L.load().dist_op_ensemble_update(_p(video_preds), _p(video_labels), _p(clip_count), _p(preds), _p(labels), _p(clip_ids),
                                              preds.shape[0], preds.shape[1], video_preds.shape[0], int(num_clips), int(method), _p(err), _stream()))
+
+
+# ---- fp8 operands of the frozen spatial branch (BASELINE config 5) -----------------------------------------------------------
+def quant_rows_fp8(x, q=None, scale=None):
+    """per-row e4m3 quantisation of x [rows, K] (bf16 / fp32): returns (q uint8 [rows, K] holding OCP e4m3 bytes, scale fp32 [rows])."""
+    assert x.is_cuda and x.dim() == 2 and x.is_contiguous()
+    rows, K = x.shape
+    q = torch.empty(rows, K, dtype=torch.uint8, device=x.device) if q is None else q
+    scale = torch.empty(rows, dtype=torch.float32, device=x.device) if scale is None else scale
+    L.check(L.load().dist_op_quant_rows_fp8(_p(x), _dt(x), rows, K, x.stride(0), _p(q), q.stride(0), _p(scale), _stream()))
+    return q, scale

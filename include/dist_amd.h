@@ -67,13 +67,21 @@ enum {
                               * (dist_op_ln_fold prepares all three).  `aux` carries the row statistics as fp32 [2][M] (mean, then
                               * rstd: dist_op_layernorm with y = NULL), `bias2` carries colsum.  Large plain bf16 GEMMs only
                               * (the 256x256 LDS-DMA kernel); not combinable with MULG. */
-    DIST_EPI_ROWSTATS = 64   /* producer side of the same fold: besides C, the GEMM stores the row sums of its STORED (rounded)
+    DIST_EPI_ROWSTATS = 64,  /* producer side of the same fold: besides C, the GEMM stores the row sums of its STORED (rounded)
                               * values and of their squares over every 64-column slice, rowstats[slice][m] = (S, Q) fp32, slice =
                               * column / 64 - plain stores in a fixed order (no atomics: results do not depend on the batch a row
                               * sits in).  dist_op_ln_stats_from_partials turns them into the [2][M] mean / rstd a DIST_EPI_LNFOLD
                               * GEMM consumes, so the residual stream is never re-read for its LayerNorm statistics
                               * (clip.py:160-176: x -> ln_2 -> c_fc, x -> ln_1 -> in_proj of the next block).  Large plain bf16
                               * GEMMs with a plain output map, C != NULL. */
+    DIST_EPI_FP8 = 128       /* BASELINE config 5 (fp8 frozen spatial branch): A [M][K] and B [N][K] hold OCP e4m3 bytes (lda / ldb in
+                              * elements = bytes, multiples of 16; K a multiple of 128, >= 256), a_scale[m] / b_scale[n] are their fp32
+                              * per-row scales (dist_op_quant_rows_fp8), the product runs on the block-scaled fp8 MFMA of CDNA4
+                              * (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales) at twice the bf16 rate, and
+                              *   acc[m][n] = a_scale[m] * b_scale[n] * sum_k A[m][k] * B[n][k]   (fp32)
+                              * enters the same epilogue as the bf16 kernel (bias, LayerNorm fold, residual, QuickGELU, head-major /
+                              * insert-cls outputs, row statistics); C / C2 / res are bf16 (dtype = DIST_BF16).  Large plain GEMMs
+                              * only (the 256x256 LDS-DMA kernel; M >= 1024, N % 64 == 0). */
 };
 
 /* C[omap(m)][n] = epi( sum_tap sum_k A[amap(m,tap)][k] * B[n][tap*K + k] )
@@ -88,8 +96,15 @@ typedef struct dist_gemm_args {
     int flags; int dtype;
     const float* bias2;   /* optional second bias, added with `bias` (two Linears evaluated as one GEMM over side-by-side inputs) */
     float* rowstats;      /* DIST_EPI_ROWSTATS: fp32 [N / 64][M][2] */
+    const float* a_scale; /* DIST_EPI_FP8: fp32 [M] */
+    const float* b_scale; /* DIST_EPI_FP8: fp32 [N] */
 } dist_gemm_args;
 int dist_op_gemm_nt(const dist_gemm_args* a, void* stream);
+/* per-row symmetric quantisation to OCP e4m3 (the operands of a DIST_EPI_FP8 GEMM; torch: (x.float() * (448 / amax)).to(float8_e4m3fn)):
+ *   amax = max_k |x[r][k]| (fp32), scale[r] = amax / 448 (1 when the row is all zero), q[r][k] = e4m3_rne(float(x[r][k]) * (448 / amax)).
+ * x [rows][ld] of `dtype` (bf16 / fp32), K % 8 == 0, K <= 8192, ld % 8 == 0; q [rows][ldq] bytes, ldq % 8 == 0 (% 16 for a GEMM operand).  Used once per frozen weight at
+ * pack time (per output channel) and per GEMM input row at run time (per token). */
+int dist_op_quant_rows_fp8(const void* x, int dtype, int64_t rows, int K, int ld, void* q, int ldq, float* scale, void* stream);
 /* prepares a LayerNorm-then-Linear pair for DIST_EPI_LNFOLD: Wp[n][k] = bf16(W[n][k] * gamma[k]) (overwrites the packed
  * forward-layout copy of W), colsum[n] = sum_k float(Wp[n][k]), bias_out[n] = bias[n] + sum_k W[n][k] * beta[k] */
 int dist_op_ln_fold(const float* W, const float* bias, const float* gamma, const float* beta, void* Wp, float* colsum, float* bias_out,

@@ -22,7 +22,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert len(syms) >= 30
     for s in syms:
         assert hasattr(l, s), s
-    assert l.dist_abi_version() == 5
+    assert l.dist_abi_version() == 6
     # the ctypes mirrors of the argument structs have the library's layout size (checked without a GPU)
     for cname, mirror in (("dist_gemm_args", lib.GemmArgs), ("dist_gemm_tn_args", lib.GemmTnArgs), ("dist_ln_args", lib.LnArgs),
                           ("dist_ln_bwd_args", lib.LnBwdArgs), ("dist_adamw_seg", lib.AdamwSeg), ("dist_config", lib.Config),

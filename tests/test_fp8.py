@@ -1,0 +1,128 @@
+"""fp8 operands of the frozen spatial branch (BASELINE config 5): dist_op_quant_rows_fp8 + the DIST_EPI_FP8 mode of
+dist_op_gemm_nt (block-scaled e4m3 MFMA, 256x256 LDS-DMA kernel).  The reference has no fp8 path (oracle/fp8_oracle.py: parity
+unpinned); the oracle is pinned to torch's float8_e4m3fn cast.
+
+Not GPU: the oracle's quantisation round-trips and bounds.  GPU: the quantiser is bit-identical to the oracle; the GEMM equals the fp64
+product of the dequantised operands within fp32-accumulation tolerance for every epilogue the ViT uses; the end-to-end quantisation
+error against the unquantised product is within the e4m3 bound."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import fp8_oracle as fo  # noqa: E402
+
+
+def rnd(shape, seed, scale=1.0, dtype=torch.bfloat16, device="cuda"):
+    g = torch.Generator(device=device).manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device=device) * scale).to(dtype)
+
+
+def test_oracle_quantisation_bounds_and_edge_rows():
+    x = rnd((64, 256), 1, 3.0, torch.float32, "cpu")
+    x[3] = 0                                                        # all-zero row keeps scale 1 and zero bytes
+    x[5, 7] = 1000.0                                                # an outlier sets the row's scale
+    q, s = fo.quant_rows(x)
+    assert q.dtype == torch.uint8 and s.dtype == torch.float32 and float(s[3]) == 1.0 and int(q[3].sum()) == 0
+    d = fo.dequant(q, s)
+    assert float(d[5, 7]) == pytest.approx(1000.0, rel=1e-6)        # amax maps to 448 exactly
+    rel = (d - x.double()).abs() / x.double().abs().clamp_min(1e-30)
+    big = x.abs() > (x.abs().amax(dim=1, keepdim=True) * 2.0 ** -6) # normal range of e4m3 below the row maximum: 3 mantissa bits
+    assert float(rel[big].max()) <= 2.0 ** -4 + 1e-6
+    assert not torch.isnan(d).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,K", [(1000, 768), (513, 1024), (64, 4096), (300, 3072), (7, 8)])
+def test_hip_quantiser_is_bit_identical_to_the_oracle(gpu_lib, dtype, rows, K):
+    from dist_amd import ops
+    x = rnd((rows, K), 11, 2.5, dtype)
+    x[1] = 0
+    x[2, K // 2] = 3.0e4 if dtype == torch.float32 else 3.0e4
+    q, s = ops.quant_rows_fp8(x)
+    qo, so = fo.quant_rows(x.cpu())
+    assert torch.equal(s.cpu(), so)
+    assert torch.equal(q.cpu(), qo)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(2048, 768, 768), (1300, 2304, 768), (4096, 1024, 4096), (1024, 384, 256), (3000, 3072, 1024)])
+def test_fp8_gemm_matches_the_dequantised_product(gpu_lib, M, N, K):
+    from dist_amd import ops
+    A, W = rnd((M, K), 21), rnd((N, K), 22, K ** -0.5)
+    qa, sa = ops.quant_rows_fp8(A)
+    qw, sw = ops.quant_rows_fp8(W)
+    bias = rnd((N,), 23, 1.0, torch.float32)
+    C = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(qa, qw, M, N, K, bias=bias, C_out=C, fp8=(sa, sw))
+    ref = fo.gemm(qa.cpu(), sa.cpu(), qw.cpu(), sw.cpu()) + bias.cpu().double()
+    torch.testing.assert_close(C.cpu().double(), ref, rtol=1.2e-2, atol=1.2e-2)           # bf16 output rounding
+    # the quantisation error itself, against the unquantised operands: ~2^-4 per element, averaged down by the K-sum
+    exact = A.cpu().double() @ W.cpu().double().t() + bias.cpu().double()
+    err = (ref - exact).abs().max() / exact.abs().max()
+    assert float(err) < 0.05, float(err)
+
+
+@pytest.mark.gpu
+def test_fp8_gemm_epilogues_of_the_vit(gpu_lib):
+    """residual + row statistics (out / proj), LayerNorm fold + head-major output (qkv), LayerNorm fold + QuickGELU-only output (fc)."""
+    from dist_amd import ops, lib as L
+    M, N, K = 197 * 12, 768, 768
+    A, W = rnd((M, K), 31, 2.0), rnd((N, K), 32, K ** -0.5)
+    qa, sa = ops.quant_rows_fp8(A)
+    qw, sw = ops.quant_rows_fp8(W)
+    lin = fo.gemm(qa.cpu(), sa.cpu(), qw.cpu(), sw.cpu())
+    bias, R = rnd((N,), 33, 1.0, torch.float32), rnd((M, N), 34)
+    # residual + ROWSTATS
+    C = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    part = torch.zeros(N // 64, M, 2, device="cuda")
+    ops.gemm_nt(qa, qw, M, N, K, bias=bias, res=R, C_out=C, rowstats=part, fp8=(sa, sw))
+    torch.testing.assert_close(C.cpu().double(), lin + bias.cpu().double() + R.cpu().double(), rtol=1.2e-2, atol=1.2e-2)
+    Cs = C.float().view(M, N // 64, 64)
+    torch.testing.assert_close(part[..., 0].t(), Cs.sum(-1), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(part[..., 1].t(), (Cs * Cs).sum(-1), rtol=1e-4, atol=1e-3)
+    # LayerNorm fold: v = rstd * (acc - mean * colsum) + bias, QuickGELU-only output
+    stats = torch.stack([A.float().mean(1), (A.float().var(1, unbiased=False) + 1e-5).rsqrt()]).contiguous()
+    colsum = fo.dequant(qw.cpu(), sw.cpu()).sum(1).float().cuda()
+    C2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(qa, qw, M, N, K, bias=bias, C2_out=C2, lnfold=(stats, colsum), fp8=(sa, sw))
+    v = stats[1].cpu().double()[:, None] * (lin - stats[0].cpu().double()[:, None] * colsum.cpu().double()[None, :]) + bias.cpu().double()
+    torch.testing.assert_close(C2.cpu().double(), v * torch.sigmoid(1.702 * v), rtol=2e-2, atol=2e-2)
+    # head-major q | k | v output
+    heads, L_ = 4, 197
+    N3 = 3 * 64 * heads
+    W3 = rnd((N3, K), 35, K ** -0.5)
+    qw3, sw3 = ops.quant_rows_fp8(W3)
+    out = torch.full((12 * heads * 3 * L_, 64), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(qa, qw3, M, N3, K, C_out=out, ldc=64, omap=ops.outmap(L.OM_HEADS, L_, heads), fp8=(sa, sw3))
+    ref = fo.gemm(qa.cpu(), sa.cpu(), qw3.cpu(), sw3.cpu()).view(12, L_, 3, heads, 64).permute(0, 3, 2, 1, 4).reshape(-1, 64)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1.2e-2, atol=1.2e-2)
+
+
+@pytest.mark.gpu
+def test_fp8_gemm_is_race_free_at_full_size_and_refuses_bad_shapes(gpu_lib):
+    from dist_amd import ops, lib as L
+    M, N, K = 50432, 2304, 768
+    A, W = rnd((M, K), 41), rnd((N, K), 42, K ** -0.5)
+    qa, sa = ops.quant_rows_fp8(A)
+    qw, sw = ops.quant_rows_fp8(W)
+    outs = []
+    for _ in range(8):
+        C = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        ops.gemm_nt(qa, qw, M, N, K, C_out=C, fp8=(sa, sw))
+        outs.append(C)
+    torch.cuda.synchronize()
+    assert all(torch.equal(C, outs[0]) for C in outs[1:])
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M)])
+    ref = fo.gemm(qa.cpu()[rows], sa.cpu()[rows], qw.cpu(), sw.cpu())
+    torch.testing.assert_close(outs[0].cpu()[rows].double(), ref, rtol=1.2e-2, atol=1.2e-2)
+    C = torch.empty(2048, 256, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(L.DistError):                                 # K not a multiple of 128
+        ops.gemm_nt(qa[:2048, :192].contiguous(), qw[:256, :192].contiguous(), 2048, 256, 192, C_out=C, fp8=(sa, sw))
+    with pytest.raises(L.DistError):                                 # fewer than 1024 rows: no fp8 kernel for small GEMMs
+        ops.gemm_nt(qa[:512], qw[:256], 512, 256, K, C_out=C, fp8=(sa, sw))
