@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="serial order: ViT forward of a batch inside its own step")
     ap.add_argument("--no-serial-ref", action="store_true", help="skip the short serial-order reference run after the timed loop")
+    ap.add_argument("--vit-fp8", type=int, default=0, help="BASELINE config 5: bit mask of the frozen-ViT GEMMs on e4m3 operands "
+                    "(1 in_proj, 2 out_proj, 4 c_fc, 8 c_proj).  Not the headline configuration: the line's dtype says so")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,7 +99,7 @@ def main():
 
     g = synth.geometry(args.config)
     b = args.batch
-    eng = Engine(config_from_geometry(g, b, torch.bfloat16))
+    eng = Engine(config_from_geometry(g, b, torch.bfloat16, True, args.vit_fp8))
     eng.load_state_dict(synth.state_dict(g))
     # clips are sharded per rank (independent units); every rank gets its own synthetic shard
     # two resident batches alternate (batch n+1 is a different tensor from batch n)
@@ -254,7 +256,8 @@ def main():
                       else f"video clips/sec/node (train fwd+bwd), {args.config} B={b}/GPU",
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if not args.vit_fp8 else f"bf16, frozen-ViT GEMMs mask {args.vit_fp8} on fp8 e4m3 operands (fp32 accumulate)",
+            "data": "synthetic",
             "pipeline": ("frozen-ViT forward of batch n+1 on a low-priority stream beside branch fwd/bwd/AdamW of batch n "
                          "(2 feature slots; one ViT forward per timed step)") if pipelined else "serial (--no-pipeline)",
             "config": {"workload": f"ViT-{args.config} bf16, synthetic 224^2 frames, batch={b}/GPU, fwd+bwd+AdamW, DP{world}",

@@ -47,6 +47,11 @@ struct VitLayer {
     // LayerNorm fold (DIST_EPI_LNFOLD): W diag(gamma) in bf16 (packed-buffer element offsets), column sums and folded biases
     long pk_fold_qkv = -1, pk_fold_fc = -1;
     float *cs_qkv = nullptr, *b_qkv = nullptr, *cs_fc = nullptr, *b_fc = nullptr;
+    // fp8 frozen spatial branch (dist_config.vit_fp8, BASELINE config 5): e4m3 copies [N][K] of the four GEMM weights (the folded ones for
+    // qkv / fc) with per-output-channel scales, and the column sums of the DEQUANTISED folded weights (what the fold's mean term must use)
+    struct Fp8W { unsigned char* q = nullptr; float* s = nullptr; };
+    Fp8W q_qkv, q_out, q_fc, q_proj;
+    float *cs8_qkv = nullptr, *cs8_fc = nullptr;
 };
 struct DistLayer {
     LNp tn_ln; Lin tn_fc1, tn_fc2;           // TemporalNet
@@ -109,6 +114,7 @@ struct dist_handle {
     float *lnstats2 = nullptr, *lnstats3 = nullptr; int dummy = 0, dummy_reps = 1;   // perturbation experiment (DIST_AMD_DUMMY)
     float* lnstats = nullptr;                    // [2][rowsS] mean / rstd of the LayerNorm folded into the next ViT GEMM
     float* lnpart = nullptr;                     // [width / 64][rowsS][2] partial (sum, sum of squares) of the residual stream, left by the GEMM that wrote it
+    unsigned char* aq = nullptr; float* sa = nullptr;   // vit_fp8: e4m3 image [rowsS][<= 4 width] + per-row scales of the GEMM input being consumed
     bool vit_fold = false;                       // ln_1 -> in_proj and ln_2 -> c_fc folded (bf16, shapes the LDS-DMA GEMM takes)
     std::vector<void*> feat;
     // Two feature slots (patch rows + the 12 mid_feat tensors + their events): the frozen ViT of the NEXT batch can fill the
@@ -407,6 +413,17 @@ size_t layout_ws(dist_handle* h, char* base) {
         VitLayer& v = h->vit[i];
         v.cs_qkv = F_(3 * d); v.b_qkv = F_(3 * d); v.cs_fc = F_(4 * d); v.b_fc = F_(4 * d);
     }
+    if (c.vit_fp8 && c.dtype == DIST_BF16) {
+        auto B_ = [&](long n) { return static_cast<unsigned char*>(a.take((size_t)n)); };
+        h->aq = B_(rowsS * 4 * d); h->sa = F_(rowsS);
+        for (int i = 0; i < c.layers; ++i) {
+            VitLayer& v = h->vit[i];
+            v.q_qkv.q = B_((long)3 * d * d); v.q_qkv.s = F_(3 * d); v.cs8_qkv = F_(3 * d);
+            v.q_out.q = B_((long)d * d); v.q_out.s = F_(d);
+            v.q_fc.q = B_((long)4 * d * d); v.q_fc.s = F_(4 * d); v.cs8_fc = F_(4 * d);
+            v.q_proj.q = B_((long)4 * d * d); v.q_proj.s = F_(d);
+        }
+    }
     for (int k = 0; k < 2; ++k) {
         h->slot[k].feat.resize(c.layers);
         for (int i = 0; i < c.layers; ++i) h->slot[k].feat[i] = T_(rowsS, d);
@@ -526,6 +543,25 @@ int gemm_lnfold(const Ctx& c, const void* A, int lda, const void* Wf, long M, in
         h->prof_n += 2;
         h->prof_flops += 2.0 * (double)M * N * K;
     }
+    return rc < 0 ? rc : 1;
+}
+// C (or C2 = quickgelu) = epi(Aq . Wq^T) on e4m3 operands (DIST_EPI_FP8): Aq / sa from dist_op_quant_rows_fp8 over the bf16 input, Wq / its
+// scales from the pack.  `stats` != nullptr: LayerNorm fold (bias = folded bias, colsum of the dequantised weights).  Returns 1 when
+// launched, 0 when the shape is not eligible (the caller runs the bf16 GEMM), < 0 on error.
+int gemm_fp8(const Ctx& c, const unsigned char* Aq, const float* sa, const VitLayer::Fp8W& W, long M, int N, int K, void* C, int ldc,
+             const float* bias, const void* res, void* C2, const float* stats, const float* colsum, float* rowstats, dist_outmap om = OM()) {
+    dist_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = Aq; g.B = W.q; g.C = C; g.C2 = C2; g.bias = bias; g.bias2 = colsum; g.aux = stats; g.res = res;
+    g.a_scale = sa; g.b_scale = W.s; g.rowstats = rowstats;
+    g.M = M; g.N = N; g.K = K; g.taps = 1;
+    g.lda = K; g.ldb = K; g.ldc = ldc; g.ldc2 = ldc; g.ldres = ldc; g.ldaux = ldc;
+    g.amap = RM(); g.omap = om;
+    g.flags = DIST_EPI_FP8 | (bias ? DIST_EPI_BIAS : 0) | (res ? DIST_EPI_RES : 0) | (stats ? DIST_EPI_LNFOLD : 0) | (C2 ? DIST_EPI_ACT2 : 0) |
+              (rowstats ? DIST_EPI_ROWSTATS : 0);
+    g.dtype = DIST_BF16;
+    if (!dist_k_gemm_fast_eligible(&g)) return 0;
+    const int rc = dist_op_gemm_nt(&g, c.s);
     return rc < 0 ? rc : 1;
 }
 // can C = A W^T + bias + res (plain maps) leave DIST_EPI_ROWSTATS partials, i.e. does the LDS-DMA kernel take this shape?
@@ -760,6 +796,19 @@ extern "C" int dist_pack_weights(dist_handle* h, int what, void* stream) {
                                 base + (size_t)v.pk_fold_fc * h->es, v.cs_fc, v.b_fc, 4 * d, d, s));
         }
         h->vit_fold = true;
+        if (h->cfg.vit_fp8 && h->aq) {
+            // fp8 frozen spatial branch: per-output-channel e4m3 copies of the (folded) GEMM weights; the fold's mean term uses the column
+            // sums of the weights the MFMA really multiplies by
+            for (VitLayer& v : h->vit) {
+                char* base = h->packed + h->packed_hdr;
+                RUN(dist_op_quant_rows_fp8(base + (size_t)v.pk_fold_qkv * h->es, DIST_BF16, 3 * d, d, d, v.q_qkv.q, d, v.q_qkv.s, s));
+                RUN(dist_op_fp8_rowsum(v.q_qkv.q, v.q_qkv.s, 3 * d, d, d, v.cs8_qkv, s));
+                RUN(dist_op_quant_rows_fp8(base + (size_t)v.out.pk.f * h->es, DIST_BF16, d, d, d, v.q_out.q, d, v.q_out.s, s));
+                RUN(dist_op_quant_rows_fp8(base + (size_t)v.pk_fold_fc * h->es, DIST_BF16, 4 * d, d, d, v.q_fc.q, d, v.q_fc.s, s));
+                RUN(dist_op_fp8_rowsum(v.q_fc.q, v.q_fc.s, 4 * d, d, d, v.cs8_fc, s));
+                RUN(dist_op_quant_rows_fp8(base + (size_t)v.proj.pk.f * h->es, DIST_BF16, d, 4 * d, 4 * d, v.q_proj.q, 4 * d, v.q_proj.s, s));
+            }
+        }
     }
     if (what == 2) mark(h, DIST_MARK_STEP_END, s);
     return DIST_OK;
@@ -803,6 +852,9 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
     static const bool rs_env = !(getenv("DIST_AMD_ROWSTATS") && atoi(getenv("DIST_AMD_ROWSTATS")) == 0);
     const bool rs = rs_env && h->vit_fold && rowstats_ok(x, rowsS, d, d) && rowstats_ok(x, rowsS, d, 4 * d);
     bool part_of_xin = false;                          // lnpart holds the partials of `xin`
+    // dist_config.vit_fp8 (BASELINE config 5): which of the four GEMMs of a block run on e4m3 operands - bit 0 in_proj, 1 out_proj, 2 c_fc,
+    // 3 c_proj.  Needs the LayerNorm fold (bf16 engine); a GEMM whose shape the fp8 kernel does not take runs in bf16.
+    const int f8 = (h->aq && h->vit_fold) ? c.vit_fp8 : 0;
     for (int i = l0; i < l1; ++i) {
         const VitLayer& v = h->vit[i];
         // the QKV GEMM writes [frame][head][q|k|v][L][64] (DIST_OM_HEADS, leading dimension 64): every (frame, head) operand of
@@ -813,7 +865,12 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
         if (h->vit_fold) {
             if (part_of_xin) RUN(dist_op_ln_stats_from_partials(h->lnpart, d / 64, rowsS, d, 1e-5f, h->lnstats, h->lnstats + rowsS, stream));
             else RUN(ln_fwd(x, h->visual, v.ln1, xin, nullptr, rowsS, h->lnstats, h->lnstats + rowsS));
-            folded = gemm_lnfold(x, xin, d, x.pk(v.pk_fold_qkv), rowsS, 3 * d, d, h->qkv, 64, v.b_qkv, h->lnstats, v.cs_qkv, nullptr, OM(DIST_OM_HEADS, L, h->heads));
+            if (f8 & 1) {                                  // e4m3 image of the raw rows, then the folded GEMM on the block-scaled fp8 MFMA
+                RUN(dist_op_quant_rows_fp8(xin, DIST_BF16, rowsS, d, d, h->aq, d, h->sa, stream));
+                folded = gemm_fp8(x, h->aq, h->sa, v.q_qkv, rowsS, 3 * d, d, h->qkv, 64, v.b_qkv, nullptr, nullptr, h->lnstats, v.cs8_qkv, nullptr, OM(DIST_OM_HEADS, L, h->heads));
+                if (folded < 0) return fail(h, folded, "fp8 QKV GEMM failed");
+            }
+            if (!folded) folded = gemm_lnfold(x, xin, d, x.pk(v.pk_fold_qkv), rowsS, 3 * d, d, h->qkv, 64, v.b_qkv, h->lnstats, v.cs_qkv, nullptr, OM(DIST_OM_HEADS, L, h->heads));
             if (folded < 0) return fail(h, folded, "folded QKV GEMM failed");
         }
         if (!folded) {
@@ -821,19 +878,36 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
             RUN(gemm(x, h->hbuf, d, x.pk(v.qkv.pk.f), rowsS, 3 * d, d, 1, h->qkv, 64, x.vs(v.qkv.bias), nullptr, nullptr, nullptr, RM(), OM(DIST_OM_HEADS, L, h->heads)));
         }
         RUN(dist_op_attention(h->qkv, h->att, b * h->t, L, h->heads, DIST_QKV_HEADS, c.dtype, stream));
-        RUN(gemm(x, h->att, d, x.pk(v.out.pk.f), rowsS, d, d, 1, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr, RM(), OM(), 0, nullptr, rs ? h->lnpart : nullptr));
+        int done8 = 0;
+        if (f8 & 2) {
+            RUN(dist_op_quant_rows_fp8(h->att, DIST_BF16, rowsS, d, d, h->aq, d, h->sa, stream));
+            done8 = gemm_fp8(x, h->aq, h->sa, v.q_out, rowsS, d, d, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr, nullptr, rs ? h->lnpart : nullptr);
+            if (done8 < 0) return fail(h, done8, "fp8 out-projection GEMM failed");
+        }
+        if (!done8) RUN(gemm(x, h->att, d, x.pk(v.out.pk.f), rowsS, d, d, 1, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr, RM(), OM(), 0, nullptr, rs ? h->lnpart : nullptr));
         folded = 0;
         if (h->vit_fold) {
             if (rs) RUN(dist_op_ln_stats_from_partials(h->lnpart, d / 64, rowsS, d, 1e-5f, h->lnstats, h->lnstats + rowsS, stream));
             else RUN(ln_fwd(x, h->visual, v.ln2, h->xa, nullptr, rowsS, h->lnstats, h->lnstats + rowsS));
-            folded = gemm_lnfold(x, h->xa, d, x.pk(v.pk_fold_fc), rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, h->lnstats, v.cs_fc, h->mlp);
+            if (f8 & 4) {
+                RUN(dist_op_quant_rows_fp8(h->xa, DIST_BF16, rowsS, d, d, h->aq, d, h->sa, stream));
+                folded = gemm_fp8(x, h->aq, h->sa, v.q_fc, rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, nullptr, h->mlp, h->lnstats, v.cs8_fc, nullptr);
+                if (folded < 0) return fail(h, folded, "fp8 MLP GEMM failed");
+            }
+            if (!folded) folded = gemm_lnfold(x, h->xa, d, x.pk(v.pk_fold_fc), rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, h->lnstats, v.cs_fc, h->mlp);
             if (folded < 0) return fail(h, folded, "folded MLP GEMM failed");
         }
         if (!folded) {
             RUN(ln_fwd(x, h->visual, v.ln2, h->xa, h->hbuf, rowsS, nullptr, nullptr));
             RUN(gemm(x, h->hbuf, d, x.pk(v.fc.pk.f), rowsS, 4 * d, d, 1, nullptr, 4 * d, x.vs(v.fc.bias), nullptr, nullptr, h->mlp));
         }
-        RUN(gemm(x, h->mlp, 4 * d, x.pk(v.proj.pk.f), rowsS, d, 4 * d, 1, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr, RM(), OM(), 0, nullptr, rs ? h->lnpart : nullptr));
+        done8 = 0;
+        if (f8 & 8) {
+            RUN(dist_op_quant_rows_fp8(h->mlp, DIST_BF16, rowsS, 4 * d, 4 * d, h->aq, 4 * d, h->sa, stream));
+            done8 = gemm_fp8(x, h->aq, h->sa, v.q_proj, rowsS, d, 4 * d, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr, nullptr, rs ? h->lnpart : nullptr);
+            if (done8 < 0) return fail(h, done8, "fp8 MLP projection GEMM failed");
+        }
+        if (!done8) RUN(gemm(x, h->mlp, 4 * d, x.pk(v.proj.pk.f), rowsS, d, 4 * d, 1, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr, RM(), OM(), 0, nullptr, rs ? h->lnpart : nullptr));
         part_of_xin = rs;
         HIP_CHECK_RET(hipEventRecord(S.ev_feat[i], x.s));               // mid_feat[i] complete: the branch may consume it
         if (h->dummy & 1) for (int r = 0; r < h->dummy_reps; ++r) RUN(ln_fwd(x, h->visual, v.ln1, S.feat[i], nullptr, rowsS, h->lnstats2, h->lnstats2 + rowsS));

@@ -45,7 +45,34 @@ __global__ __launch_bounds__(NT) void quant_rows_fp8_kernel(const T* __restrict_
     }
 }
 
+// out[r] = scale[r] * sum_k e4m3(q[r][k]): one wave per row, 8 bytes per lane per step, fixed order
+__global__ __launch_bounds__(NT) void fp8_rowsum_kernel(const unsigned char* __restrict__ q, const float* __restrict__ scale, const long rows, const int K,
+                                                        const int ldq, float* __restrict__ out) {
+    const long row = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const unsigned char* qr = q + row * ldq;
+    float acc = 0.f;
+    for (int v = lane; v < K / 8; v += 64) {
+        const int2 w = *reinterpret_cast<const int2*>(qr + v * 8);
+        typedef float f2_t __attribute__((ext_vector_type(2)));
+        const f2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(w.x, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(w.x, true);
+        const f2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(w.y, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(w.y, true);
+        acc += ((a[0] + a[1]) + (b[0] + b[1])) + ((c[0] + c[1]) + (d[0] + d[1]));
+    }
+    acc = wave_sum(acc, 64);
+    if (lane == 0) out[row] = acc * scale[row];
+}
+
 }  // namespace
+
+extern "C" int dist_op_fp8_rowsum(const void* q, const float* scale, int64_t rows, int K, int ldq, float* out, void* stream) {
+    if (!q || !scale || !out || rows <= 0 || K <= 0 || K % 8 || ldq % 8 || ldq < K) return DIST_ERR_ARG;
+    hipLaunchKernelGGL(fp8_rowsum_kernel, dim3((unsigned)((rows + NT / 64 - 1) / (NT / 64))), dim3(NT), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const unsigned char*>(q), scale, (long)rows, K, ldq, out);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
 
 extern "C" int dist_op_quant_rows_fp8(const void* x, int dtype, int64_t rows, int K, int ld, void* q, int ldq, float* scale, void* stream) {
     if (!x || !q || !scale || rows <= 0 || K <= 0 || K % 8 || ld % 8 || ldq % 8 || K > QV * 64 * 8 || ld < K || ldq < K) return DIST_ERR_ARG;

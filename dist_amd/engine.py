@@ -15,8 +15,9 @@ from . import lib as L
 from . import ops
 
 
-def config_from_geometry(g, batch, dtype, use_tr=True):
-    """g: dist_amd.synth.Geometry (or any object with the same attributes)."""
+def config_from_geometry(g, batch, dtype, use_tr=True, vit_fp8=0):
+    """g: dist_amd.synth.Geometry (or any object with the same attributes).  vit_fp8: bit mask of the frozen-ViT GEMMs on e4m3 operands
+    (1 in_proj, 2 out_proj, 4 c_fc, 8 c_proj; BASELINE config 5), bf16 engines only."""
     c = L.Config()
     c.dtype = L.BF16 if dtype == torch.bfloat16 else L.F32
     c.batch, c.frames, c.alpha = batch, g.T, g.alpha
@@ -26,6 +27,7 @@ def config_from_geometry(g, batch, dtype, use_tr=True):
     c.int_temporal_div = int(round(1.0 / g.int_t_ratio))
     c.ada_layers, c.num_classes, c.embed_dim = g.ada, g.K, g.E
     c.use_tr = int(use_tr)
+    c.vit_fp8 = int(vit_fp8)
     return c
 
 

@@ -63,7 +63,7 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "dtype", "batch", "frames", "alpha", "resolution", "patch", "width", "layers",
         "integration_dim", "temporal_dim", "temporal_kernel", "temporal_patch", "int_temporal_div",
-        "ada_layers", "num_classes", "embed_dim", "use_tr")]
+        "ada_layers", "num_classes", "embed_dim", "use_tr", "vit_fp8")]
 
 
 GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
@@ -154,6 +154,7 @@ def load():
     _sig(lib, "dist_op_cutmix", argtypes=[C.c_void_p] + [C.c_int] * 8 + [C.c_void_p])
     _sig(lib, "dist_op_mixup_target", argtypes=[C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_op_quant_rows_fp8", argtypes=[C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p])
+    _sig(lib, "dist_op_fp8_rowsum", argtypes=[C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_op_softmax_rows", argtypes=[C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_op_topk_correct", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_op_ensemble_update", argtypes=[C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p])

@@ -105,6 +105,8 @@ int dist_op_gemm_nt(const dist_gemm_args* a, void* stream);
  * x [rows][ld] of `dtype` (bf16 / fp32), K % 8 == 0, K <= 8192, ld % 8 == 0; q [rows][ldq] bytes, ldq % 8 == 0 (% 16 for a GEMM operand).  Used once per frozen weight at
  * pack time (per output channel) and per GEMM input row at run time (per token). */
 int dist_op_quant_rows_fp8(const void* x, int dtype, int64_t rows, int K, int ld, void* q, int ldq, float* scale, void* stream);
+/* out[r] = scale[r] * sum_k e4m3(q[r][k]) in fp32 (fixed order): the column sums a DIST_EPI_LNFOLD GEMM on e4m3 weights needs */
+int dist_op_fp8_rowsum(const void* q, const float* scale, int64_t rows, int K, int ldq, float* out, void* stream);
 /* prepares a LayerNorm-then-Linear pair for DIST_EPI_LNFOLD: Wp[n][k] = bf16(W[n][k] * gamma[k]) (overwrites the packed
  * forward-layout copy of W), colsum[n] = sum_k float(Wp[n][k]), bias_out[n] = bias[n] + sum_k W[n][k] * beta[k] */
 int dist_op_ln_fold(const float* W, const float* bias, const float* gamma, const float* beta, void* Wp, float* colsum, float* bias_out,
@@ -246,6 +248,9 @@ typedef struct dist_config {
     int num_classes;      /* VIDEO.HEAD.NUM_CLASSES */
     int embed_dim;        /* CLIP embed dim E */
     int use_tr;           /* bf16 dW GEMMs use LDS transpose reads */
+    int vit_fp8;          /* BASELINE config 5 (fp8 frozen spatial branch; bf16 engines only): bit mask of the frozen-ViT GEMMs that run on
+                           * e4m3 operands (DIST_EPI_FP8; weights quantised per output channel at pack time, inputs per token in front of
+                           * the GEMM): 1 = attn.in_proj, 2 = attn.out_proj, 4 = mlp.c_fc, 8 = mlp.c_proj; 0 = bf16 everywhere */
 } dist_config;
 
 typedef struct dist_handle dist_handle;

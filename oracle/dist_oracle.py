@@ -41,11 +41,14 @@ def layer_norm(x, w, b, eps=1e-5):
 
 
 class Oracle:
-    def __init__(self, g, params, dtype=torch.float32, bf16=False):
-        """g: dist_amd.synth.Geometry; params: name -> tensor (reference state-dict names)."""
+    def __init__(self, g, params, dtype=torch.float32, bf16=False, vit_fp8=0):
+        """g: dist_amd.synth.Geometry; params: name -> tensor (reference state-dict names).
+        vit_fp8 (with bf16=True): bit mask of the frozen-ViT GEMMs evaluated on per-row e4m3 operands the way dist_config.vit_fp8 does
+        (1 in_proj, 2 out_proj, 4 c_fc, 8 c_proj; oracle/fp8_oracle.py - no counterpart in the reference, parity unpinned)."""
         self.g = g
         self.dtype = dtype
         self.bf16 = bf16
+        self.vit_fp8 = vit_fp8 if bf16 else 0
         self.p = {k: torch.as_tensor(v).to(dtype) for k, v in params.items()}
         self.selected = list(range(g.layers))
 
@@ -87,19 +90,54 @@ class Oracle:
                 feats.append(x)
         return feats
 
+    # ---- e4m3 operands (dist_config.vit_fp8) ---------------------------------------------
+    def _fp8_lin(self, a, W, bias):
+        """a [..., K] (bf16-valued) x W [N, K] (bf16 working copy) on per-row e4m3 operands: dequantised product + bias"""
+        import fp8_oracle as fo
+        qa, sa = fo.quant_rows(a.reshape(-1, a.shape[-1]))
+        qw, sw = fo.quant_rows(W)
+        return (fo.gemm(qa, sa, qw, sw).to(self.dtype) + bias).reshape(*a.shape[:-1], W.shape[0])
+
+    def _fp8_ln_lin(self, x, W, bias, gamma, beta):
+        """LayerNorm folded into the GEMM as the engine does it: raw rows and W diag(gamma) (bf16) in e4m3, the statistics applied behind:
+        rstd * (deq(xq) deq(Wq)^T - mean * colsum(deq(Wq))) + (bias + W beta)"""
+        import fp8_oracle as fo
+        xr = x.reshape(-1, x.shape[-1])
+        mean = xr.mean(dim=1, keepdim=True)
+        rstd = (xr.var(dim=1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+        Wf = self.rnd(W * gamma[None, :])
+        qa, sa = fo.quant_rows(xr)
+        qw, sw = fo.quant_rows(Wf)
+        colsum = fo.dequant(qw, sw).sum(dim=1).to(self.dtype)
+        y = rstd * (fo.gemm(qa, sa, qw, sw).to(self.dtype) - mean * colsum[None, :]) + (bias + W @ beta)
+        return y.reshape(*x.shape[:-1], W.shape[0])
+
     def vit_block(self, x, i):
         g, p = self.g, self.p
         pre = f"visual.transformer.resblocks.{i}."
         b, t, L, d = x.shape
-        h = self.rnd(layer_norm(x, p[pre + "ln_1.weight"], p[pre + "ln_1.bias"]))
-        qkv = self.rnd(h @ self.w(pre + "attn.in_proj_weight").t() + p[pre + "attn.in_proj_bias"])
+        f8 = self.vit_fp8
+        if f8 & 1:
+            qkv = self.rnd(self._fp8_ln_lin(x, p[pre + "attn.in_proj_weight"], p[pre + "attn.in_proj_bias"], p[pre + "ln_1.weight"], p[pre + "ln_1.bias"]))
+        else:
+            h = self.rnd(layer_norm(x, p[pre + "ln_1.weight"], p[pre + "ln_1.bias"]))
+            qkv = self.rnd(h @ self.w(pre + "attn.in_proj_weight").t() + p[pre + "attn.in_proj_bias"])
         q, k, v = qkv.reshape(b * t, L, 3, g.heads, 64).permute(2, 0, 3, 1, 4)   # [bt,h,L,64]
         att = torch.softmax((q @ k.transpose(-1, -2)) / 8.0, dim=-1)
         o = self.rnd((att @ v).permute(0, 2, 1, 3).reshape(b, t, L, d))
-        x = self.rnd(x + o @ self.w(pre + "attn.out_proj.weight").t() + p[pre + "attn.out_proj.bias"])
-        h = self.rnd(layer_norm(x, p[pre + "ln_2.weight"], p[pre + "ln_2.bias"]))
-        h = self.rnd(qgelu(h @ self.w(pre + "mlp.c_fc.weight").t() + p[pre + "mlp.c_fc.bias"]))
-        x = self.rnd(x + h @ self.w(pre + "mlp.c_proj.weight").t() + p[pre + "mlp.c_proj.bias"])
+        if f8 & 2:
+            x = self.rnd(x + self._fp8_lin(o, self.w(pre + "attn.out_proj.weight"), p[pre + "attn.out_proj.bias"]))
+        else:
+            x = self.rnd(x + o @ self.w(pre + "attn.out_proj.weight").t() + p[pre + "attn.out_proj.bias"])
+        if f8 & 4:
+            h = self.rnd(qgelu(self._fp8_ln_lin(x, p[pre + "mlp.c_fc.weight"], p[pre + "mlp.c_fc.bias"], p[pre + "ln_2.weight"], p[pre + "ln_2.bias"])))
+        else:
+            h = self.rnd(layer_norm(x, p[pre + "ln_2.weight"], p[pre + "ln_2.bias"]))
+            h = self.rnd(qgelu(h @ self.w(pre + "mlp.c_fc.weight").t() + p[pre + "mlp.c_fc.bias"]))
+        if f8 & 8:
+            x = self.rnd(x + self._fp8_lin(h, self.w(pre + "mlp.c_proj.weight"), p[pre + "mlp.c_proj.bias"]))
+        else:
+            x = self.rnd(x + h @ self.w(pre + "mlp.c_proj.weight").t() + p[pre + "mlp.c_proj.bias"])
         return x
 
     # ---- DiST branch (reference dist.py:222-247) ---------------------------------------

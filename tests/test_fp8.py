@@ -14,6 +14,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
 import fp8_oracle as fo  # noqa: E402
 
 
@@ -126,3 +127,64 @@ def test_fp8_gemm_is_race_free_at_full_size_and_refuses_bad_shapes(gpu_lib):
         ops.gemm_nt(qa[:2048, :192].contiguous(), qw[:256, :192].contiguous(), 2048, 256, 192, C_out=C, fp8=(sa, sw))
     with pytest.raises(L.DistError):                                 # fewer than 1024 rows: no fp8 kernel for small GEMMs
         ops.gemm_nt(qa[:512], qw[:256], 512, 256, K, C_out=C, fp8=(sa, sw))
+
+
+# ---- the engine's fp8 frozen spatial branch (dist_config.vit_fp8) ---------------------------------------------------------------
+def _engine(gname, b, vit_fp8):
+    from dist_amd import synth
+    from dist_amd.engine import Engine, config_from_geometry
+    g = synth.geometry(gname)
+    eng = Engine(config_from_geometry(g, b, torch.bfloat16, True, vit_fp8))
+    sd = synth.state_dict(g)
+    eng.load_state_dict(sd)
+    video = torch.from_numpy(synth.video(g, b)).cuda()
+    text = torch.from_numpy(synth.text_features(g)).cuda()
+    tgt = torch.from_numpy(synth.soft_target(g, b)[0]).cuda()
+    return g, eng, sd, video, text, tgt
+
+
+def _rel(a, b):
+    a, b = a.double().cpu().reshape(-1), torch.as_tensor(b).double().cpu().reshape(-1)
+    return float((a - b).norm() / b.norm())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mask", [15, 5])
+def test_engine_fp8_vit_matches_the_oracle_with_the_same_quantisation_points(gpu_lib, mask):
+    """BASELINE config 1 geometry (ViT-B/16 8+16f, b = 2; 3152 token rows: the fp8 kernel takes every GEMM of the frozen tower): the
+    saved features of every block against the CPU oracle that quantises the same operands at the same points (per-row e4m3, folded
+    LayerNorm), and the logits against the bf16 engine and the reference's fp32 golden."""
+    from dist_oracle import Oracle
+    g, eng, sd, video, text, tgt = _engine("b16_8+16f", 2, mask)
+    loss, logits = eng.forward_backward(video, text, tgt)
+    feats = [eng.debug(f"feat.{i}").clone().cpu().float() for i in range(g.layers)]
+    o8, o16 = Oracle(g, sd, dtype=torch.float32, bf16=True, vit_fp8=mask), Oracle(g, sd, dtype=torch.float32, bf16=True)
+    # block by block on the ENGINE's own input of the block: e4m3 has a 6 % rounding step, so bf16-level differences of an input flip
+    # a few per cent of the roundings and decorrelate most of the quantisation noise - errors must not be allowed to accumulate
+    for i in (1, 6, 11):
+        x_in = feats[i - 1].reshape(2, g.t, g.L, g.d)
+        with torch.no_grad():
+            r8, r16 = o8.vit_block(x_in, i), o16.vit_block(x_in, i)
+        e8, e16, q = _rel(feats[i], r8), _rel(feats[i], r16), _rel(r8, r16)
+        print(f"fp8 mask {mask} block {i}: engine vs fp8 oracle {e8:.4f}, engine vs bf16 oracle {e16:.4f}, fp8 oracle vs bf16 oracle {q:.4f}")
+        assert e8 < 0.012 and e8 < 0.6 * q and e16 > 0.8 * q, (i, e8, e16, q)      # the engine follows the fp8 oracle, not the bf16 one
+        assert 0.003 < q < 0.05, q                                                   # the quantisation is visible and bounded
+    g0, eng0, _, _, _, _ = _engine("b16_8+16f", 2, 0)
+    loss0, logits0 = eng0.forward_backward(video, text, tgt)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "b16_b2.npz"))
+    gap16 = float((logits.float() - logits0.float()).abs().max())
+    gap32 = float((logits.cpu().double() - torch.from_numpy(gold["logits"]).double()).abs().max())
+    print(f"fp8 mask {mask}: logits vs bf16 engine {gap16:.4f}, vs fp32 reference golden {gap32:.4f}")
+    assert 0 < gap16 < 0.25 and gap32 < 0.35
+    assert (logits.cpu().argmax(1) == torch.from_numpy(gold["logits"]).argmax(1)).all()
+    assert torch.isfinite(eng.grads).all() and abs(float(loss) - float(gold["loss"])) < 0.05
+
+
+@pytest.mark.gpu
+def test_engine_fp8_mode_falls_back_to_bf16_for_shapes_the_kernel_does_not_take(gpu_lib):
+    """tiny geometry (width 128: K below the fp8 kernel's 256): the mode is accepted and every GEMM runs in bf16 - bit-identical results"""
+    g, eng, sd, video, text, tgt = _engine("tiny", 2, 15)
+    _, logits = eng.forward_backward(video, text, tgt)
+    g0, eng0, _, _, _, _ = _engine("tiny", 2, 0)
+    _, logits0 = eng0.forward_backward(video, text, tgt)
+    assert torch.equal(logits, logits0)
