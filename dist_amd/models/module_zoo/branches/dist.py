@@ -31,6 +31,9 @@ def engine_config(cfg, width, layers, patch, resolution, embed_dim, batch, dtype
     c.int_temporal_div = int(round(1.0 / float(d.INTEGRATION_TEMPORAL_MLP_RATIO)))
     c.ada_layers, c.num_classes, c.embed_dim = int(d.ADA_POOLING_LAYERS), int(cfg.VIDEO.HEAD.NUM_CLASSES), embed_dim
     c.use_tr = 1
+    # BASELINE config 5 (fp8 frozen spatial branch): VIDEO.BACKBONE.FP8_SPATIAL = bit mask of the frozen-ViT GEMMs on e4m3 operands
+    # (15 = all four; absent / 0 = bf16).  Not a key of the reference's yamls: pass it as a trailing KEY VAL override.
+    c.vit_fp8 = int(getattr(cfg.VIDEO.BACKBONE, "FP8_SPATIAL", 0) or 0) if dtype == torch.bfloat16 else 0
     return c
 
 
