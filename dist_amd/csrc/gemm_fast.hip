@@ -155,8 +155,50 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
             }
         }
     };
+    // DIST_EPI_OUT8: the staged bf16 tile (what C, or C2 with the activation, holds) leaves a second time as e4m3 with the caller's per-tensor
+    // scale.  Row block i: all four slots of a lane are read, then its four packed dwords land in the first 64 bytes of the same lines
+    // (a wave runs in lock-step: every read of a row block is issued before any of its writes), then 64-byte rows go out 16 bytes per lane.
+    auto out8_pass = [&]() {
+        unsigned char* __restrict__ C8 = static_cast<unsigned char*>(p.C8);
+        const float inv = 1.0f / p.out8_scale[0];
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = i * 16 + li;
+            float x[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                load4(reinterpret_cast<const bf16_t*>(ew + r * 128 + ((((j << 1) | (lg >> 1)) ^ (r & 7)) << 4) + ((lg & 1) << 3)), x[j]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float y[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    amax = fmaxf(amax, fabsf(x[j][q]));
+                    y[q] = fminf(fmaxf(x[j][q] * inv, -448.f), 448.f);
+                }
+                int w = 0;
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], w, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], w, true);
+                *reinterpret_cast<int*>(ew + r * 128 + j * 16 + lg * 4) = w;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = it * 16 + (lane >> 2), pc = lane & 3;
+            const int m = mw + r, n = nw + pc * 16;
+            const uint4 v = *reinterpret_cast<const uint4*>(ew + r * 128 + pc * 16);
+            if (m < M && n < N) store16_nt(C8 + (long)m * p.ldc8 + n, v);
+        }
+        if (p.out8_amax) {
+            amax = wave_max(amax, 64);
+            if (lane == 0 && mw < M && nw < N) atomicMax(reinterpret_cast<unsigned*>(p.out8_amax), __float_as_uint(amax));   // >= 0: bit order = value order
+        }
+    };
     if (act_only) {
-        flush(C2, p.ldc2);
+        if (C2) flush(C2, p.ldc2);
+        if (flags & DIST_EPI_OUT8) out8_pass();
     } else {
         flush(C, p.ldc);
         if ((flags & DIST_EPI_ROWSTATS) && nw < N) {
@@ -177,6 +219,7 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
                 if (mw + r < M) *reinterpret_cast<float2*>(p.rowstats + ((long)(nw >> 6) * M + mw + r) * 2) = make_float2(rs, rq);
             }
         }
+        if (flags & DIST_EPI_OUT8) out8_pass();           // (never together with a second activated output: the launcher checks)
         if (flags & DIST_EPI_ACT2) {                      // second output = quickgelu(stored value)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -614,7 +657,7 @@ __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_arg
             }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float sa = p.a_scale[min(mw + i * 16 + li, M - 1)];
+            const float sa = p.a_scale[(p.flags & DIST_EPI_FP8_ASCALAR) ? 0 : min(mw + i * 16 + li, M - 1)];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -639,6 +682,9 @@ static bool fast_common_ok(const dist_gemm_args* a) {
     }
     if (a->K % BK || a->K < 4 * BK || a->N % 64 || a->M < 1024) return false;
     if (a->lda % 8 || a->ldb % 8 || a->ldc % 8 || a->ldc2 % 8 || a->ldres % 8) return false;
+    if (a->flags & DIST_EPI_OUT8) {                       // e4m3 image of the output: plain map, 16-byte rows, not beside a second activated output
+        if (!a->C8 || !a->out8_scale || a->ldc8 % 16 || a->omap.mode != DIST_OM_PLAIN || ((a->flags & DIST_EPI_ACT2) && a->C)) return false;
+    }
     if (a->flags & DIST_EPI_FP8) {                        // e4m3 operands: 16-byte row alignment, whole 128-deep K-tiles, plain row map
         if (!a->a_scale || !a->b_scale || a->amap.mode != DIST_RM_PLAIN || a->K % 128 || a->K < 256 || a->lda % 16 || a->ldb % 16) return false;
         if (a->N < 256 || (a->N % 256 > 0 && a->N % 256 < 128)) return false;

@@ -604,7 +604,7 @@ extern "C" int dist_op_gemm_nt(const dist_gemm_args* a, void* stream) {
         if (a_rows * a->lda * es >= (1ll << 31) || (int64_t)a->N * a->ldb * es >= (1ll << 31)) return DIST_ERR_ARG;
     }
     if (!a->C && !(a->flags & DIST_EPI_ACT2)) return DIST_ERR_ARG;
-    if ((a->flags & DIST_EPI_ACT2) && !a->C2) return DIST_ERR_ARG;
+    if ((a->flags & DIST_EPI_ACT2) && !a->C2 && !(a->flags & DIST_EPI_OUT8)) return DIST_ERR_ARG;   // (e4m3-only activated output: C8)
     if ((a->flags & DIST_EPI_BIAS) && !a->bias) return DIST_ERR_ARG;
     if ((a->flags & DIST_EPI_RES) && !a->res) return DIST_ERR_ARG;
     if ((a->flags & DIST_EPI_MULG) && !a->aux) return DIST_ERR_ARG;
@@ -612,6 +612,11 @@ extern "C" int dist_op_gemm_nt(const dist_gemm_args* a, void* stream) {
     if (a->omap.mode == DIST_OM_HEADS && (a->omap.p0 <= 0 || a->omap.p1 <= 0 || a->N != 3 * 64 * a->omap.p1 || a->ldc != 64 ||
                                           (a->flags & (DIST_EPI_RES | DIST_EPI_MULG | DIST_EPI_ACT2)) || !a->C)) return DIST_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((a->flags & DIST_EPI_OUT8) && !(a->flags & DIST_EPI_FP8)) {   // e4m3 image of the output: only the 256x256 LDS-DMA kernels write it
+        if (a->dtype != DIST_BF16 || (a->flags & DIST_EPI_MULG)) return DIST_ERR_ARG;
+        const int fast = dist_k_gemm_fast(a, s);
+        return fast > 0 ? DIST_OK : (fast < 0 ? fast : DIST_ERR_ARG);
+    }
     if (a->flags & DIST_EPI_FP8) {                             // e4m3 operands: only the two-group 256x256 LDS-DMA kernel has the fp8 MFMAs
         if (a->dtype != DIST_BF16 || !a->a_scale || !a->b_scale || (a->flags & DIST_EPI_MULG)) return DIST_ERR_ARG;
         if ((a->flags & DIST_EPI_LNFOLD) && (!a->aux || !a->bias2)) return DIST_ERR_ARG;

@@ -64,7 +64,47 @@ __global__ __launch_bounds__(NT) void fp8_rowsum_kernel(const unsigned char* __r
     if (lane == 0) out[row] = acc * scale[row];
 }
 
+// scale[i] = 2^ceil(log2(max(amax[i], tiny) * margin / 448)); amax[i] = 0
+__global__ void fp8_scale_update_kernel(float* __restrict__ amax, float* __restrict__ scale, const int n, const float margin) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float t = fmaxf(amax[i], 1e-30f) * margin * (1.0f / 448.f);
+    int e;
+    const float f = frexpf(t, &e);                         // t = f * 2^e, f in [0.5, 1)
+    scale[i] = ldexpf(1.0f, f == 0.5f ? e - 1 : e);        // smallest power of two >= t
+    amax[i] = 0.f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void amax_kernel(const T* __restrict__ x, const long n, float* __restrict__ amax) {
+    float a = 0.f;
+    for (long v = (long)blockIdx.x * NT + threadIdx.x; v < n / 8; v += (long)gridDim.x * NT) {
+        Frag<T> f;
+        frag_load(f, x + v * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a = fmaxf(a, fabsf(frag_get(f, e)));
+    }
+    a = wave_max(a, 64);
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(a));
+}
+
 }  // namespace
+
+extern "C" int dist_op_fp8_scale_update(float* amax, float* scale, int n, float margin, void* stream) {
+    if (!amax || !scale || n <= 0 || !(margin >= 1.f)) return DIST_ERR_ARG;
+    hipLaunchKernelGGL(fp8_scale_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), amax, scale, n, margin);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+
+extern "C" int dist_op_amax(const void* x, int dtype, int64_t n, float* amax, void* stream) {
+    if (!x || !amax || n <= 0 || n % 8 || (dtype != DIST_BF16 && dtype != DIST_F32)) return DIST_ERR_ARG;
+    const unsigned blocks = (unsigned)min((long)((n / 8 + NT - 1) / NT), 2048l);
+    if (dtype == DIST_BF16) hipLaunchKernelGGL(amax_kernel<bf16_t>, dim3(blocks), dim3(NT), 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(x), (long)n, amax);
+    else hipLaunchKernelGGL(amax_kernel<float>, dim3(blocks), dim3(NT), 0, static_cast<hipStream_t>(stream), static_cast<const float*>(x), (long)n, amax);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
 
 extern "C" int dist_op_fp8_rowsum(const void* q, const float* scale, int64_t rows, int K, int ldq, float* out, void* stream) {
     if (!q || !scale || !out || rows <= 0 || K <= 0 || K % 8 || ldq % 8 || ldq < K) return DIST_ERR_ARG;

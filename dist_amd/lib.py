@@ -11,6 +11,7 @@ RM_PLAIN, RM_SHIFT, RM_SPATIAL, RM_STRIDED, RM_SKIPCLS = range(5)
 OM_PLAIN, OM_DUP, OM_INSERTCLS, OM_SPLITCOLS, OM_HEADS = range(5)
 QKV_ROWS, QKV_HEADS = 0, 1
 EPI_BIAS, EPI_MULG, EPI_RES, EPI_ACT2, EPI_MULG_POST, EPI_LNFOLD, EPI_ROWSTATS, EPI_FP8 = 1, 2, 4, 8, 16, 32, 64, 128
+EPI_FP8_ASCALAR, EPI_OUT8 = 256, 512
 
 
 class RowMap(C.Structure):
@@ -27,7 +28,8 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int64), ("N", C.c_int), ("K", C.c_int), ("taps", C.c_int),
                 ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int), ("ldc2", C.c_int), ("ldres", C.c_int), ("ldaux", C.c_int),
                 ("amap", RowMap), ("omap", OutMap), ("flags", C.c_int), ("dtype", C.c_int), ("bias2", C.c_void_p), ("rowstats", C.c_void_p),
-                ("a_scale", C.c_void_p), ("b_scale", C.c_void_p)]
+                ("a_scale", C.c_void_p), ("b_scale", C.c_void_p),
+                ("C8", C.c_void_p), ("ldc8", C.c_int), ("out8_scale", C.c_void_p), ("out8_amax", C.c_void_p)]
 
 
 class GemmTnArgs(C.Structure):
@@ -154,6 +156,8 @@ def load():
     _sig(lib, "dist_op_cutmix", argtypes=[C.c_void_p] + [C.c_int] * 8 + [C.c_void_p])
     _sig(lib, "dist_op_mixup_target", argtypes=[C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_op_quant_rows_fp8", argtypes=[C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p])
+    _sig(lib, "dist_op_fp8_scale_update", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p])
+    _sig(lib, "dist_op_amax", argtypes=[C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_op_fp8_rowsum", argtypes=[C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_op_softmax_rows", argtypes=[C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_op_topk_correct", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p])

@@ -37,7 +37,7 @@ def outmap(mode=L.OM_PLAIN, p0=0, p1=0, p2=0):
 
 
 def gemm_nt(A, B, M, N, K, *, taps=1, bias=None, res=None, aux=None, amap=None, omap=None,
-            C_out=None, C2_out=None, lda=None, ldc=None, mulg_post=False, lnfold=None, rowstats=None, fp8=None):
+            C_out=None, C2_out=None, lda=None, ldc=None, mulg_post=False, lnfold=None, rowstats=None, fp8=None, out8=None, act_only8=False):
     """C[omap(m)][n] = epi(sum_tap sum_k A[amap(m,tap)][k] B[n][tap*K+k]); returns None (writes C_out / C2_out)."""
     lib = L.load()
     a = L.GemmArgs()
@@ -46,7 +46,7 @@ def gemm_nt(A, B, M, N, K, *, taps=1, bias=None, res=None, aux=None, amap=None, 
     a.M, a.N, a.K, a.taps = M, N, K, taps
     a.lda = lda if lda is not None else A.shape[-1]
     a.ldb = B.shape[-1]
-    ldo = ldc if ldc is not None else (C_out.shape[-1] if C_out is not None else C2_out.shape[-1])
+    ldo = ldc if ldc is not None else (C_out.shape[-1] if C_out is not None else (C2_out.shape[-1] if C2_out is not None else N))
     a.ldc = ldo
     a.ldc2 = C2_out.shape[-1] if C2_out is not None else ldo
     a.ldres = res.shape[-1] if res is not None else ldo
@@ -63,10 +63,14 @@ def gemm_nt(A, B, M, N, K, *, taps=1, bias=None, res=None, aux=None, amap=None, 
     if rowstats is not None:        # fp32 [N/64][M][2]: (sum, sum of squares) of the stored values per 64-column slice (EPI_ROWSTATS)
         a.rowstats = _p(rowstats)
         a.flags |= L.EPI_ROWSTATS
-    if fp8 is not None:             # (a_scale fp32 [M], b_scale fp32 [N]): A / B hold e4m3 bytes (quant_rows_fp8), outputs are bf16 (EPI_FP8)
+    if out8 is not None:            # (C8 uint8 [M, N], scale fp32 [1], amax fp32 [1] or None): e4m3 image of the output (EPI_OUT8)
+        c8, sc, am = out8
+        a.C8, a.ldc8, a.out8_scale, a.out8_amax = _p(c8), c8.shape[-1], _p(sc), _p(am)
+        a.flags |= L.EPI_OUT8 | (L.EPI_ACT2 if act_only8 else 0)      # act_only8: C8 = e4m3(quickgelu(v)) with no bf16 output at all
+    if fp8 is not None:             # (a_scale fp32 [M] or [1], b_scale fp32 [N]): A / B hold e4m3 bytes (quant_rows_fp8), outputs are bf16 (EPI_FP8)
         assert A.dtype == torch.uint8 and B.dtype == torch.uint8
         a.a_scale, a.b_scale = _p(fp8[0]), _p(fp8[1])
-        a.flags |= L.EPI_FP8
+        a.flags |= L.EPI_FP8 | (L.EPI_FP8_ASCALAR if fp8[0].numel() == 1 else 0)
         a.dtype = L.BF16
     else:
         a.dtype = _dt(A)
@@ -299,3 +303,15 @@ def quant_rows_fp8(x, q=None, scale=None):
     scale = torch.empty(rows, dtype=torch.float32, device=x.device) if scale is None else scale
     L.check(L.load().dist_op_quant_rows_fp8(_p(x), _dt(x), rows, K, x.stride(0), _p(q), q.stride(0), _p(scale), _stream()))
     return q, scale
+
+
+def fp8_scale_update(amax, scale, margin=4.0):
+    """scale[i] = smallest power of two >= amax[i] * margin / 448; amax[i] = 0 (per-tensor scales for EPI_OUT8 producers)."""
+    assert amax.is_cuda and scale.is_cuda and amax.dtype == scale.dtype == torch.float32 and amax.numel() == scale.numel()
+    L.check(L.load().dist_op_fp8_scale_update(_p(amax), _p(scale), amax.numel(), float(margin), _stream()))
+
+
+def amax_(x, amax):
+    """amax[0] = max(amax[0], max |x|) (calibration of a tensor no EPI_OUT8 producer has written yet)."""
+    assert x.is_cuda and x.is_contiguous() and amax.dtype == torch.float32
+    L.check(L.load().dist_op_amax(_p(x), _dt(x), x.numel(), _p(amax), _stream()))

@@ -74,7 +74,7 @@ enum {
                               * GEMM consumes, so the residual stream is never re-read for its LayerNorm statistics
                               * (clip.py:160-176: x -> ln_2 -> c_fc, x -> ln_1 -> in_proj of the next block).  Large plain bf16
                               * GEMMs with a plain output map, C != NULL. */
-    DIST_EPI_FP8 = 128       /* BASELINE config 5 (fp8 frozen spatial branch): A [M][K] and B [N][K] hold OCP e4m3 bytes (lda / ldb in
+    DIST_EPI_FP8 = 128,      /* BASELINE config 5 (fp8 frozen spatial branch): A [M][K] and B [N][K] hold OCP e4m3 bytes (lda / ldb in
                               * elements = bytes, multiples of 16; K a multiple of 128, >= 256), a_scale[m] / b_scale[n] are their fp32
                               * per-row scales (dist_op_quant_rows_fp8), the product runs on the block-scaled fp8 MFMA of CDNA4
                               * (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales) at twice the bf16 rate, and
@@ -82,6 +82,14 @@ enum {
                               * enters the same epilogue as the bf16 kernel (bias, LayerNorm fold, residual, QuickGELU, head-major /
                               * insert-cls outputs, row statistics); C / C2 / res are bf16 (dtype = DIST_BF16).  Large plain GEMMs
                               * only (the 256x256 LDS-DMA kernel; M >= 1024, N % 64 == 0). */
+    DIST_EPI_FP8_ASCALAR = 256, /* with DIST_EPI_FP8: A carries ONE scale for all rows, a_scale[0] (an operand a producer wrote with DIST_EPI_OUT8) */
+    DIST_EPI_OUT8 = 512      /* the producer side of the fp8 operands: besides C / C2 (either may then be NULL), the stored value v (after bias,
+                              * residual and - when C is NULL with DIST_EPI_ACT2 - the QuickGELU) also leaves as OCP e4m3,
+                              *   C8[m][n] = e4m3_rne(clamp(float(bf16(v)) / out8_scale[0], -448, 448)),   C8 bytes [M][ldc8], ldc8 % 16 == 0,
+                              * with a per-TENSOR scale the caller read from an earlier pass (e4m3 is a floating format: 14 binades of normal
+                              * range make a per-tensor scale with a margin as precise as a per-row one), and *out8_amax (optional, fp32 >= 0 as
+                              * its bit pattern) = max(*out8_amax, max |float(bf16(v))|) for the next pass's scale (dist_op_fp8_scale_update).
+                              * Plain output map, 256x256 LDS-DMA kernel only. */
 };
 
 /* C[omap(m)][n] = epi( sum_tap sum_k A[amap(m,tap)][k] * B[n][tap*K + k] )
@@ -96,8 +104,10 @@ typedef struct dist_gemm_args {
     int flags; int dtype;
     const float* bias2;   /* optional second bias, added with `bias` (two Linears evaluated as one GEMM over side-by-side inputs) */
     float* rowstats;      /* DIST_EPI_ROWSTATS: fp32 [N / 64][M][2] */
-    const float* a_scale; /* DIST_EPI_FP8: fp32 [M] */
+    const float* a_scale; /* DIST_EPI_FP8: fp32 [M] ([1] with DIST_EPI_FP8_ASCALAR) */
     const float* b_scale; /* DIST_EPI_FP8: fp32 [N] */
+    void* C8; int ldc8;   /* DIST_EPI_OUT8: e4m3 image of the output */
+    const float* out8_scale; float* out8_amax;
 } dist_gemm_args;
 int dist_op_gemm_nt(const dist_gemm_args* a, void* stream);
 /* per-row symmetric quantisation to OCP e4m3 (the operands of a DIST_EPI_FP8 GEMM; torch: (x.float() * (448 / amax)).to(float8_e4m3fn)):
@@ -105,6 +115,11 @@ int dist_op_gemm_nt(const dist_gemm_args* a, void* stream);
  * x [rows][ld] of `dtype` (bf16 / fp32), K % 8 == 0, K <= 8192, ld % 8 == 0; q [rows][ldq] bytes, ldq % 8 == 0 (% 16 for a GEMM operand).  Used once per frozen weight at
  * pack time (per output channel) and per GEMM input row at run time (per token). */
 int dist_op_quant_rows_fp8(const void* x, int dtype, int64_t rows, int K, int ld, void* q, int ldq, float* scale, void* stream);
+/* per-tensor scales for DIST_EPI_OUT8 from collected maxima: for i < n: scale[i] = 2^ceil(log2(max(amax[i], 1e-30) * margin / 448)),
+ * then amax[i] = 0 (ready to collect the next pass).  dist_op_amax: *amax = max(*amax, max |x|) over a bf16 / fp32 tensor (the
+ * calibration pass of a tensor no DIST_EPI_OUT8 producer has written yet). */
+int dist_op_fp8_scale_update(float* amax, float* scale, int n, float margin, void* stream);
+int dist_op_amax(const void* x, int dtype, int64_t n, float* amax, void* stream);
 /* out[r] = scale[r] * sum_k e4m3(q[r][k]) in fp32 (fixed order): the column sums a DIST_EPI_LNFOLD GEMM on e4m3 weights needs */
 int dist_op_fp8_rowsum(const void* q, const float* scale, int64_t rows, int K, int ldq, float* out, void* stream);
 /* prepares a LayerNorm-then-Linear pair for DIST_EPI_LNFOLD: Wp[n][k] = bf16(W[n][k] * gamma[k]) (overwrites the packed

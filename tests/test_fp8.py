@@ -188,3 +188,70 @@ def test_engine_fp8_mode_falls_back_to_bf16_for_shapes_the_kernel_does_not_take(
     g0, eng0, _, _, _, _ = _engine("tiny", 2, 0)
     _, logits0 = eng0.forward_backward(video, text, tgt)
     assert torch.equal(logits, logits0)
+
+
+# ---- producer side: DIST_EPI_OUT8 (e4m3 image of a GEMM's output with a per-tensor scale) ------------------------------------------
+def _e4m3_image(v_bf16, scale):
+    """the header's statement: e4m3_rne(clamp(float(bf16(v)) / scale, -448, 448)) as bytes"""
+    return (v_bf16.float().cpu() / float(scale)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+@pytest.mark.gpu
+def test_scale_update_and_amax_ops(gpu_lib):
+    from dist_amd import ops
+    amax = torch.tensor([0.0, 448.0, 449.0, 1.0, 3.3e4, 112.0], device="cuda")
+    scale = torch.zeros(6, device="cuda")
+    ops.fp8_scale_update(amax, scale, 4.0)
+    want = [2.0 ** -96, 4.0, 8.0, 2.0 ** -6, 512.0, 1.0]                       # smallest power of two >= amax * 4 / 448
+    got = scale.cpu().tolist()
+    assert got[1:] == want[1:] and got[0] <= 2.0 ** -90 and float(amax.abs().sum()) == 0
+    x = rnd((1000, 768), 5, 3.0)
+    a = torch.zeros(1, device="cuda")
+    ops.amax_(x, a)
+    assert float(a) == float(x.float().abs().max())
+    ops.amax_(x * 0.5, a)
+    assert float(a) == float(x.float().abs().max())                            # a running maximum
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fp8_in", [False, True])
+def test_out8_image_of_the_output(gpu_lib, fp8_in):
+    """C8 beside C (residual stream: bias + residual + row statistics) and C8 instead of everything (QuickGELU'd hidden tensor), from a bf16
+    and from an e4m3 GEMM; the collected maximum; then the image consumed by the next GEMM with its one scalar scale."""
+    from dist_amd import ops
+    M, N, K = 197 * 16, 1024, 768
+    A, W = rnd((M, K), 51, 2.0), rnd((N, K), 52, K ** -0.5)
+    bias, R = rnd((N,), 53, 1.0, torch.float32), rnd((M, N), 54)
+    kw = {}
+    Ain, Win = A, W
+    if fp8_in:
+        (Ain, sa), (Win, sw) = ops.quant_rows_fp8(A), ops.quant_rows_fp8(W)
+        kw = dict(fp8=(sa, sw))
+    scale, amax = torch.tensor([0.25], device="cuda"), torch.zeros(1, device="cuda")
+    C = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    C8 = torch.zeros(M, N, dtype=torch.uint8, device="cuda")
+    part = torch.zeros(N // 64, M, 2, device="cuda")
+    ops.gemm_nt(Ain, Win, M, N, K, bias=bias, res=R, C_out=C, rowstats=part, out8=(C8, scale, amax), **kw)
+    assert torch.equal(C8.cpu(), _e4m3_image(C, 0.25))                        # the image of exactly the stored bf16 values
+    assert float(amax) == float(C.float().abs().max())
+    Cs = C.float().view(M, N // 64, 64)
+    torch.testing.assert_close(part[..., 0].t(), Cs.sum(-1), rtol=1e-4, atol=1e-3)   # the row statistics saw the bf16 tile, not the image
+    # activation-only, e4m3 only
+    H8 = torch.zeros(M, N, dtype=torch.uint8, device="cuda")
+    amax.zero_()
+    ops.gemm_nt(Ain, Win, M, N, K, bias=bias, out8=(H8, scale, amax), act_only8=True, **kw)
+    H = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(Ain, Win, M, N, K, bias=bias, C2_out=H, **kw)                # the bf16 activated output of the same GEMM
+    assert torch.equal(H8.cpu(), _e4m3_image(H, 0.25)) and float(amax) == float(H.float().abs().max())
+    # consumer: the image as the A operand of an e4m3 GEMM, one scalar scale for all rows
+    W2 = rnd((256, N), 55, N ** -0.5)
+    qw2, sw2 = ops.quant_rows_fp8(W2)
+    Y = torch.empty(M, 256, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(H8, qw2, M, 256, N, C_out=Y, fp8=(scale, sw2))
+    ref = (H8.cpu().view(torch.float8_e4m3fn).double() * 0.25) @ fo.dequant(qw2.cpu(), sw2.cpu()).t()
+    torch.testing.assert_close(Y.cpu().double(), ref, rtol=1.2e-2, atol=1.2e-2)
+    # a saturating scale: values beyond 448 * scale clamp instead of becoming NaN
+    tiny = torch.tensor([2.0 ** -12], device="cuda")
+    ops.gemm_nt(Ain, Win, M, N, K, bias=bias, out8=(H8, tiny, None), act_only8=True, **kw)
+    img = H8.cpu().view(torch.float8_e4m3fn).float()
+    assert not torch.isnan(img).any() and float(img.max()) == 448.0
