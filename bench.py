@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="serial order: ViT forward of a batch inside its own step")
     ap.add_argument("--no-serial-ref", action="store_true", help="skip the short serial-order reference run after the timed loop")
     ap.add_argument("--vit-fp8", type=int, default=0, help="BASELINE config 5: bit mask of the frozen-ViT GEMMs on e4m3 operands "
-                    "(1 in_proj, 2 out_proj, 4 c_fc, 8 c_proj).  Not the headline configuration: the line's dtype says so")
+                    "(1 in_proj, 2 out_proj, 4 c_fc, 8 c_proj, 16 producers write the images: 31 = everything).  Not the headline configuration: the line's dtype says so")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

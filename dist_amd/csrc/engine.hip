@@ -115,6 +115,10 @@ struct dist_handle {
     float* lnstats = nullptr;                    // [2][rowsS] mean / rstd of the LayerNorm folded into the next ViT GEMM
     float* lnpart = nullptr;                     // [width / 64][rowsS][2] partial (sum, sum of squares) of the residual stream, left by the GEMM that wrote it
     unsigned char* aq = nullptr; float* sa = nullptr;   // vit_fp8: e4m3 image [rowsS][<= 4 width] + per-row scales of the GEMM input being consumed
+    // vit_fp8 & 16: the producing epilogues write the e4m3 images themselves (DIST_EPI_OUT8) with per-tensor scales of the PREVIOUS pass:
+    // per block three tensors - 0 = attention-block output (c_fc input), 1 = hidden (c_proj input), 2 = block output (next in_proj input)
+    unsigned char *x8 = nullptr, *xa8 = nullptr; float *f8_amax = nullptr, *f8_scale = nullptr;
+    long f8_passes = 0; int x8_layer = -1;
     bool vit_fold = false;                       // ln_1 -> in_proj and ln_2 -> c_fc folded (bf16, shapes the LDS-DMA GEMM takes)
     std::vector<void*> feat;
     // Two feature slots (patch rows + the 12 mid_feat tensors + their events): the frozen ViT of the NEXT batch can fill the
@@ -416,6 +420,7 @@ size_t layout_ws(dist_handle* h, char* base) {
     if (c.vit_fp8 && c.dtype == DIST_BF16) {
         auto B_ = [&](long n) { return static_cast<unsigned char*>(a.take((size_t)n)); };
         h->aq = B_(rowsS * 4 * d); h->sa = F_(rowsS);
+        if (c.vit_fp8 & 16) { h->x8 = B_(rowsS * d); h->xa8 = B_(rowsS * d); h->f8_amax = F_(3 * c.layers); h->f8_scale = F_(3 * c.layers); }
         for (int i = 0; i < c.layers; ++i) {
             VitLayer& v = h->vit[i];
             v.q_qkv.q = B_((long)3 * d * d); v.q_qkv.s = F_(3 * d); v.cs8_qkv = F_(3 * d);
@@ -548,8 +553,9 @@ int gemm_lnfold(const Ctx& c, const void* A, int lda, const void* Wf, long M, in
 // C (or C2 = quickgelu) = epi(Aq . Wq^T) on e4m3 operands (DIST_EPI_FP8): Aq / sa from dist_op_quant_rows_fp8 over the bf16 input, Wq / its
 // scales from the pack.  `stats` != nullptr: LayerNorm fold (bias = folded bias, colsum of the dequantised weights).  Returns 1 when
 // launched, 0 when the shape is not eligible (the caller runs the bf16 GEMM), < 0 on error.
-int gemm_fp8(const Ctx& c, const unsigned char* Aq, const float* sa, const VitLayer::Fp8W& W, long M, int N, int K, void* C, int ldc,
-             const float* bias, const void* res, void* C2, const float* stats, const float* colsum, float* rowstats, dist_outmap om = OM()) {
+struct Out8 { unsigned char* img = nullptr; const float* scale = nullptr; float* amax = nullptr; bool act = false; };   // DIST_EPI_OUT8 (act: QuickGELU'd, e4m3 only)
+int gemm_fp8(const Ctx& c, const unsigned char* Aq, const float* sa, bool sa_scalar, const VitLayer::Fp8W& W, long M, int N, int K, void* C, int ldc,
+             const float* bias, const void* res, void* C2, const float* stats, const float* colsum, float* rowstats, dist_outmap om = OM(), Out8 o8 = Out8()) {
     dist_gemm_args g;
     memset(&g, 0, sizeof(g));
     g.A = Aq; g.B = W.q; g.C = C; g.C2 = C2; g.bias = bias; g.bias2 = colsum; g.aux = stats; g.res = res;
@@ -557,12 +563,23 @@ int gemm_fp8(const Ctx& c, const unsigned char* Aq, const float* sa, const VitLa
     g.M = M; g.N = N; g.K = K; g.taps = 1;
     g.lda = K; g.ldb = K; g.ldc = ldc; g.ldc2 = ldc; g.ldres = ldc; g.ldaux = ldc;
     g.amap = RM(); g.omap = om;
-    g.flags = DIST_EPI_FP8 | (bias ? DIST_EPI_BIAS : 0) | (res ? DIST_EPI_RES : 0) | (stats ? DIST_EPI_LNFOLD : 0) | (C2 ? DIST_EPI_ACT2 : 0) |
-              (rowstats ? DIST_EPI_ROWSTATS : 0);
+    g.flags = DIST_EPI_FP8 | (sa_scalar ? DIST_EPI_FP8_ASCALAR : 0) | (bias ? DIST_EPI_BIAS : 0) | (res ? DIST_EPI_RES : 0) | (stats ? DIST_EPI_LNFOLD : 0) |
+              ((C2 || o8.act) ? DIST_EPI_ACT2 : 0) | (rowstats ? DIST_EPI_ROWSTATS : 0);
+    if (o8.img) { g.C8 = o8.img; g.ldc8 = N; g.out8_scale = o8.scale; g.out8_amax = o8.amax; g.flags |= DIST_EPI_OUT8; }
     g.dtype = DIST_BF16;
     if (!dist_k_gemm_fast_eligible(&g)) return 0;
     const int rc = dist_op_gemm_nt(&g, c.s);
     return rc < 0 ? rc : 1;
+}
+// does the e4m3 mode of the LDS-DMA kernel take C [M][N] = A [M][K] W^T ?
+bool fp8_shape_ok(const Ctx& c, long M, int N, int K) {
+    dist_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    void* nz = reinterpret_cast<void*>(16);
+    g.A = nz; g.B = nz; g.C = nz; g.a_scale = static_cast<const float*>(nz); g.b_scale = static_cast<const float*>(nz);
+    g.M = M; g.N = N; g.K = K; g.taps = 1; g.lda = K; g.ldb = K; g.ldc = g.ldc2 = g.ldres = g.ldaux = N;
+    g.amap = RM(); g.omap = OM(); g.flags = DIST_EPI_FP8; g.dtype = DIST_BF16;
+    return dist_k_gemm_fast_eligible(&g);
 }
 // can C = A W^T + bias + res (plain maps) leave DIST_EPI_ROWSTATS partials, i.e. does the LDS-DMA kernel take this shape?
 bool rowstats_ok(const Ctx& c, long M, int N, int K) {
@@ -797,6 +814,8 @@ extern "C" int dist_pack_weights(dist_handle* h, int what, void* stream) {
         }
         h->vit_fold = true;
         if (h->cfg.vit_fp8 && h->aq) {
+            h->f8_passes = 0;                              // new weights: the next pass calibrates the per-tensor scales again
+            if (h->f8_amax) HIP_CHECK_RET(hipMemsetAsync(h->f8_amax, 0, sizeof(float) * 3 * h->cfg.layers, s));
             // fp8 frozen spatial branch: per-output-channel e4m3 copies of the (folded) GEMM weights; the fold's mean term uses the column
             // sums of the weights the MFMA really multiplies by
             for (VitLayer& v : h->vit) {
@@ -855,6 +874,14 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
     // dist_config.vit_fp8 (BASELINE config 5): which of the four GEMMs of a block run on e4m3 operands - bit 0 in_proj, 1 out_proj, 2 c_fc,
     // 3 c_proj.  Needs the LayerNorm fold (bf16 engine); a GEMM whose shape the fp8 kernel does not take runs in bf16.
     const int f8 = (h->aq && h->vit_fold) ? c.vit_fp8 : 0;
+    // producers write the e4m3 images (bit 16): needs all four GEMMs on e4m3, scales from an earlier pass, shapes the fp8 kernel takes
+    const bool img_mode = (f8 & 31) == 31 && h->x8 && fp8_shape_ok(x, rowsS, 3 * d, d) && fp8_shape_ok(x, rowsS, d, d) && fp8_shape_ok(x, rowsS, 4 * d, d) &&
+                          fp8_shape_ok(x, rowsS, d, 4 * d);
+    if (img_mode && l0 == 0) {
+        if (h->f8_passes > 0) RUN(dist_op_fp8_scale_update(h->f8_amax, h->f8_scale, 3 * c.layers, 4.0f, stream));   // last pass's maxima -> this pass's scales
+        h->x8_layer = -1;
+    }
+    const bool fused = img_mode && h->f8_passes > 0;      // the first pass after a pack calibrates: per-token quantisers + dist_op_amax
     for (int i = l0; i < l1; ++i) {
         const VitLayer& v = h->vit[i];
         // the QKV GEMM writes [frame][head][q|k|v][L][64] (DIST_OM_HEADS, leading dimension 64): every (frame, head) operand of
@@ -866,8 +893,13 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
             if (part_of_xin) RUN(dist_op_ln_stats_from_partials(h->lnpart, d / 64, rowsS, d, 1e-5f, h->lnstats, h->lnstats + rowsS, stream));
             else RUN(ln_fwd(x, h->visual, v.ln1, xin, nullptr, rowsS, h->lnstats, h->lnstats + rowsS));
             if (f8 & 1) {                                  // e4m3 image of the raw rows, then the folded GEMM on the block-scaled fp8 MFMA
-                RUN(dist_op_quant_rows_fp8(xin, DIST_BF16, rowsS, d, d, h->aq, d, h->sa, stream));
-                folded = gemm_fp8(x, h->aq, h->sa, v.q_qkv, rowsS, 3 * d, d, h->qkv, 64, v.b_qkv, nullptr, nullptr, h->lnstats, v.cs8_qkv, nullptr, OM(DIST_OM_HEADS, L, h->heads));
+                if (fused && i > 0 && h->x8_layer == i - 1) {     // the previous block's c_proj left the image
+                    folded = gemm_fp8(x, h->x8, h->f8_scale + 3 * (i - 1) + 2, true, v.q_qkv, rowsS, 3 * d, d, h->qkv, 64, v.b_qkv, nullptr, nullptr, h->lnstats, v.cs8_qkv, nullptr,
+                                      OM(DIST_OM_HEADS, L, h->heads));
+                } else {
+                    RUN(dist_op_quant_rows_fp8(xin, DIST_BF16, rowsS, d, d, h->aq, d, h->sa, stream));
+                    folded = gemm_fp8(x, h->aq, h->sa, false, v.q_qkv, rowsS, 3 * d, d, h->qkv, 64, v.b_qkv, nullptr, nullptr, h->lnstats, v.cs8_qkv, nullptr, OM(DIST_OM_HEADS, L, h->heads));
+                }
                 if (folded < 0) return fail(h, folded, "fp8 QKV GEMM failed");
             }
             if (!folded) folded = gemm_lnfold(x, xin, d, x.pk(v.pk_fold_qkv), rowsS, 3 * d, d, h->qkv, 64, v.b_qkv, h->lnstats, v.cs_qkv, nullptr, OM(DIST_OM_HEADS, L, h->heads));
@@ -881,8 +913,11 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
         int done8 = 0;
         if (f8 & 2) {
             RUN(dist_op_quant_rows_fp8(h->att, DIST_BF16, rowsS, d, d, h->aq, d, h->sa, stream));
-            done8 = gemm_fp8(x, h->aq, h->sa, v.q_out, rowsS, d, d, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr, nullptr, rs ? h->lnpart : nullptr);
+            Out8 o8;
+            if (fused) { o8.img = h->xa8; o8.scale = h->f8_scale + 3 * i; o8.amax = h->f8_amax + 3 * i; }
+            done8 = gemm_fp8(x, h->aq, h->sa, false, v.q_out, rowsS, d, d, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr, nullptr, rs ? h->lnpart : nullptr, OM(), o8);
             if (done8 < 0) return fail(h, done8, "fp8 out-projection GEMM failed");
+            if (img_mode && !fused) RUN(dist_op_amax(h->xa, DIST_BF16, rowsS * d, h->f8_amax + 3 * i, stream));
         }
         if (!done8) RUN(gemm(x, h->att, d, x.pk(v.out.pk.f), rowsS, d, d, 1, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr, RM(), OM(), 0, nullptr, rs ? h->lnpart : nullptr));
         folded = 0;
@@ -890,8 +925,15 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
             if (rs) RUN(dist_op_ln_stats_from_partials(h->lnpart, d / 64, rowsS, d, 1e-5f, h->lnstats, h->lnstats + rowsS, stream));
             else RUN(ln_fwd(x, h->visual, v.ln2, h->xa, nullptr, rowsS, h->lnstats, h->lnstats + rowsS));
             if (f8 & 4) {
-                RUN(dist_op_quant_rows_fp8(h->xa, DIST_BF16, rowsS, d, d, h->aq, d, h->sa, stream));
-                folded = gemm_fp8(x, h->aq, h->sa, v.q_fc, rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, nullptr, h->mlp, h->lnstats, v.cs8_fc, nullptr);
+                if (fused) {                               // input: the image out_proj left; output: the QuickGELU'd hidden tensor as e4m3 ONLY (h->aq)
+                    Out8 o8;
+                    o8.img = h->aq; o8.scale = h->f8_scale + 3 * i + 1; o8.amax = h->f8_amax + 3 * i + 1; o8.act = true;
+                    folded = gemm_fp8(x, h->xa8, h->f8_scale + 3 * i, true, v.q_fc, rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, nullptr, nullptr, h->lnstats, v.cs8_fc, nullptr, OM(), o8);
+                } else {
+                    RUN(dist_op_quant_rows_fp8(h->xa, DIST_BF16, rowsS, d, d, h->aq, d, h->sa, stream));
+                    folded = gemm_fp8(x, h->aq, h->sa, false, v.q_fc, rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, nullptr, h->mlp, h->lnstats, v.cs8_fc, nullptr);
+                    if (img_mode && folded > 0) RUN(dist_op_amax(h->mlp, DIST_BF16, rowsS * 4 * d, h->f8_amax + 3 * i + 1, stream));
+                }
                 if (folded < 0) return fail(h, folded, "fp8 MLP GEMM failed");
             }
             if (!folded) folded = gemm_lnfold(x, h->xa, d, x.pk(v.pk_fold_fc), rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, h->lnstats, v.cs_fc, h->mlp);
@@ -903,8 +945,17 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
         }
         done8 = 0;
         if (f8 & 8) {
-            RUN(dist_op_quant_rows_fp8(h->mlp, DIST_BF16, rowsS, 4 * d, 4 * d, h->aq, 4 * d, h->sa, stream));
-            done8 = gemm_fp8(x, h->aq, h->sa, v.q_proj, rowsS, d, 4 * d, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr, nullptr, rs ? h->lnpart : nullptr);
+            if (fused) {
+                Out8 o8;
+                o8.img = h->x8; o8.scale = h->f8_scale + 3 * i + 2; o8.amax = h->f8_amax + 3 * i + 2;
+                done8 = gemm_fp8(x, h->aq, h->f8_scale + 3 * i + 1, true, v.q_proj, rowsS, d, 4 * d, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr, nullptr,
+                                 rs ? h->lnpart : nullptr, OM(), o8);
+                if (done8 > 0) h->x8_layer = i;
+            } else {
+                RUN(dist_op_quant_rows_fp8(h->mlp, DIST_BF16, rowsS, 4 * d, 4 * d, h->aq, 4 * d, h->sa, stream));
+                done8 = gemm_fp8(x, h->aq, h->sa, false, v.q_proj, rowsS, d, 4 * d, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr, nullptr, rs ? h->lnpart : nullptr);
+                if (img_mode && done8 > 0) RUN(dist_op_amax(S.feat[i], DIST_BF16, rowsS * d, h->f8_amax + 3 * i + 2, stream));
+            }
             if (done8 < 0) return fail(h, done8, "fp8 MLP projection GEMM failed");
         }
         if (!done8) RUN(gemm(x, h->mlp, 4 * d, x.pk(v.proj.pk.f), rowsS, d, 4 * d, 1, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr, RM(), OM(), 0, nullptr, rs ? h->lnpart : nullptr));
@@ -915,6 +966,7 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
     }
     S.next_layer = l1;
     S.pending_b = b;
+    if (l1 == c.layers && img_mode) ++h->f8_passes;
     if (l1 == c.layers) {
         HIP_CHECK_RET(hipEventRecord(h->ev_vit_done, x.s));
         mark(h, DIST_MARK_VIT_END, x.s);

@@ -181,19 +181,23 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
                 int w = 0;
                 w = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], w, false);
                 w = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], w, true);
-                *reinterpret_cast<int*>(ew + r * 128 + j * 16 + lg * 4) = w;
+                *reinterpret_cast<int*>(ew + r * 128 + (((j ^ (r & 3)) + ((r >> 2) & 1) * 4) << 4) + lg * 4) = w;   // piece j of row r: spread over the banks
             }
         }
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int r = it * 16 + (lane >> 2), pc = lane & 3;
             const int m = mw + r, n = nw + pc * 16;
-            const uint4 v = *reinterpret_cast<const uint4*>(ew + r * 128 + pc * 16);
+            const uint4 v = *reinterpret_cast<const uint4*>(ew + r * 128 + (((pc ^ (r & 3)) + ((r >> 2) & 1) * 4) << 4));
             if (m < M && n < N) store16_nt(C8 + (long)m * p.ldc8 + n, v);
         }
         if (p.out8_amax) {
             amax = wave_max(amax, 64);
-            if (lane == 0 && mw < M && nw < N) atomicMax(reinterpret_cast<unsigned*>(p.out8_amax), __float_as_uint(amax));   // >= 0: bit order = value order
+            // >= 0: bit order = value order.  Read first: the running maximum only grows, so a (possibly stale) value that already covers this
+            // tile makes the atomic unnecessary - a million same-address atomics per ViT pass cost more than the quantiser passes they replace
+            // (a plain load: served by the CU's own L1 - staleness only costs a redundant atomic)
+            if (lane == 0 && mw < M && nw < N && amax > *static_cast<const volatile float*>(p.out8_amax))
+                atomicMax(reinterpret_cast<unsigned*>(p.out8_amax), __float_as_uint(amax));
         }
     };
     if (act_only) {

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(NT) void amax_kernel(const T* __restrict__ x, const
         for (int e = 0; e < 8; ++e) a = fmaxf(a, fabsf(frag_get(f, e)));
     }
     a = wave_max(a, 64);
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(a));
+    if ((threadIdx.x & 63) == 0 && a > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(a));
 }
 
 }  // namespace

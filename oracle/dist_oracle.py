@@ -91,14 +91,26 @@ class Oracle:
         return feats
 
     # ---- e4m3 operands (dist_config.vit_fp8) ---------------------------------------------
-    def _fp8_lin(self, a, W, bias):
-        """a [..., K] (bf16-valued) x W [N, K] (bf16 working copy) on per-row e4m3 operands: dequantised product + bias"""
+    @staticmethod
+    def _fp8_rows(a2, per_tensor):
+        """e4m3 image of a [rows, K]: per-row amax / 448 scales, or (the producers' DIST_EPI_OUT8 images, vit_fp8 bit 16) ONE power-of-two
+        scale for the tensor, the smallest >= amax * 4 / 448 (dist_op_fp8_scale_update), values clamped to +-448"""
         import fp8_oracle as fo
-        qa, sa = fo.quant_rows(a.reshape(-1, a.shape[-1]))
+        if not per_tensor:
+            return fo.quant_rows(a2)
+        t = max(float(a2.abs().max()), 1e-30) * 4.0 / 448.0
+        sc = 2.0 ** int(math.ceil(math.log2(t)))
+        q = (a2.float() / sc).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+        return q, torch.full((a2.shape[0],), sc, dtype=torch.float32)
+
+    def _fp8_lin(self, a, W, bias, per_tensor=False):
+        """a [..., K] (bf16-valued) x W [N, K] (bf16 working copy) on e4m3 operands: dequantised product + bias"""
+        import fp8_oracle as fo
+        qa, sa = self._fp8_rows(a.reshape(-1, a.shape[-1]), per_tensor)
         qw, sw = fo.quant_rows(W)
         return (fo.gemm(qa, sa, qw, sw).to(self.dtype) + bias).reshape(*a.shape[:-1], W.shape[0])
 
-    def _fp8_ln_lin(self, x, W, bias, gamma, beta):
+    def _fp8_ln_lin(self, x, W, bias, gamma, beta, per_tensor=False):
         """LayerNorm folded into the GEMM as the engine does it: raw rows and W diag(gamma) (bf16) in e4m3, the statistics applied behind:
         rstd * (deq(xq) deq(Wq)^T - mean * colsum(deq(Wq))) + (bias + W beta)"""
         import fp8_oracle as fo
@@ -106,7 +118,7 @@ class Oracle:
         mean = xr.mean(dim=1, keepdim=True)
         rstd = (xr.var(dim=1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
         Wf = self.rnd(W * gamma[None, :])
-        qa, sa = fo.quant_rows(xr)
+        qa, sa = self._fp8_rows(xr, per_tensor)
         qw, sw = fo.quant_rows(Wf)
         colsum = fo.dequant(qw, sw).sum(dim=1).to(self.dtype)
         y = rstd * (fo.gemm(qa, sa, qw, sw).to(self.dtype) - mean * colsum[None, :]) + (bias + W @ beta)
@@ -117,8 +129,10 @@ class Oracle:
         pre = f"visual.transformer.resblocks.{i}."
         b, t, L, d = x.shape
         f8 = self.vit_fp8
+        img = bool(f8 & 16)                                  # producers' per-tensor images (every block input but the attention output)
         if f8 & 1:
-            qkv = self.rnd(self._fp8_ln_lin(x, p[pre + "attn.in_proj_weight"], p[pre + "attn.in_proj_bias"], p[pre + "ln_1.weight"], p[pre + "ln_1.bias"]))
+            qkv = self.rnd(self._fp8_ln_lin(x, p[pre + "attn.in_proj_weight"], p[pre + "attn.in_proj_bias"], p[pre + "ln_1.weight"], p[pre + "ln_1.bias"],
+                                            per_tensor=img and i > 0))
         else:
             h = self.rnd(layer_norm(x, p[pre + "ln_1.weight"], p[pre + "ln_1.bias"]))
             qkv = self.rnd(h @ self.w(pre + "attn.in_proj_weight").t() + p[pre + "attn.in_proj_bias"])
@@ -130,12 +144,12 @@ class Oracle:
         else:
             x = self.rnd(x + o @ self.w(pre + "attn.out_proj.weight").t() + p[pre + "attn.out_proj.bias"])
         if f8 & 4:
-            h = self.rnd(qgelu(self._fp8_ln_lin(x, p[pre + "mlp.c_fc.weight"], p[pre + "mlp.c_fc.bias"], p[pre + "ln_2.weight"], p[pre + "ln_2.bias"])))
+            h = self.rnd(qgelu(self._fp8_ln_lin(x, p[pre + "mlp.c_fc.weight"], p[pre + "mlp.c_fc.bias"], p[pre + "ln_2.weight"], p[pre + "ln_2.bias"], per_tensor=img)))
         else:
             h = self.rnd(layer_norm(x, p[pre + "ln_2.weight"], p[pre + "ln_2.bias"]))
             h = self.rnd(qgelu(h @ self.w(pre + "mlp.c_fc.weight").t() + p[pre + "mlp.c_fc.bias"]))
         if f8 & 8:
-            x = self.rnd(x + self._fp8_lin(h, self.w(pre + "mlp.c_proj.weight"), p[pre + "mlp.c_proj.bias"]))
+            x = self.rnd(x + self._fp8_lin(h, self.w(pre + "mlp.c_proj.weight"), p[pre + "mlp.c_proj.bias"], per_tensor=img))
         else:
             x = self.rnd(x + h @ self.w(pre + "mlp.c_proj.weight").t() + p[pre + "mlp.c_proj.bias"])
         return x

@@ -181,9 +181,38 @@ def test_engine_fp8_vit_matches_the_oracle_with_the_same_quantisation_points(gpu
 
 
 @pytest.mark.gpu
+def test_engine_fp8_producer_images_follow_the_oracle_after_the_calibration_pass(gpu_lib):
+    """vit_fp8 = 31: the first pass after a pack runs the per-token quantisers and collects the tensor maxima; from the second pass on the
+    out_proj / c_fc / c_proj epilogues write the e4m3 images themselves (per-tensor power-of-two scales of the previous pass) and the hidden
+    tensor exists in e4m3 only.  Block by block on the engine's own block input against the oracle with the same quantisation points."""
+    from dist_oracle import Oracle
+    g, eng, sd, video, text, tgt = _engine("b16_8+16f", 2, 31)
+    eng.forward_backward(video, text, tgt)                          # calibration pass (per-token quantisers)
+    cal = [eng.debug(f"feat.{i}").clone().cpu().float() for i in range(g.layers)]
+    loss, logits = eng.forward_backward(video, text, tgt)           # producers' images
+    feats = [eng.debug(f"feat.{i}").clone().cpu().float() for i in range(g.layers)]
+    assert not torch.equal(cal[5], feats[5])                        # the second pass really took the other path
+    o8, o16 = Oracle(g, sd, dtype=torch.float32, bf16=True, vit_fp8=31), Oracle(g, sd, dtype=torch.float32, bf16=True)
+    for i in (1, 6, 11):
+        x_in = feats[i - 1].reshape(2, g.t, g.L, g.d)
+        with torch.no_grad():
+            r8, r16 = o8.vit_block(x_in, i), o16.vit_block(x_in, i)
+        e8, e16, q = _rel(feats[i], r8), _rel(feats[i], r16), _rel(r8, r16)
+        print(f"fp8 images block {i}: engine vs fp8 oracle {e8:.4f}, engine vs bf16 oracle {e16:.4f}, fp8 oracle vs bf16 oracle {q:.4f}")
+        assert e8 < 0.012 and e8 < 0.6 * q and e16 > 0.8 * q, (i, e8, e16, q)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "b16_b2.npz"))
+    gap32 = float((logits.cpu().double() - torch.from_numpy(gold["logits"]).double()).abs().max())
+    print(f"fp8 images: logits vs fp32 reference golden {gap32:.4f}")
+    assert gap32 < 0.35 and (logits.cpu().argmax(1) == torch.from_numpy(gold["logits"]).argmax(1)).all()
+    loss3, logits3 = eng.forward_backward(video, text, tgt)         # third pass: scales from the second - same batch, same powers of two
+    assert torch.equal(logits3, logits)
+
+
+@pytest.mark.gpu
 def test_engine_fp8_mode_falls_back_to_bf16_for_shapes_the_kernel_does_not_take(gpu_lib):
     """tiny geometry (width 128: K below the fp8 kernel's 256): the mode is accepted and every GEMM runs in bf16 - bit-identical results"""
-    g, eng, sd, video, text, tgt = _engine("tiny", 2, 15)
+    g, eng, sd, video, text, tgt = _engine("tiny", 2, 31)
+    _, logits = eng.forward_backward(video, text, tgt)
     _, logits = eng.forward_backward(video, text, tgt)
     g0, eng0, _, _, _, _ = _engine("tiny", 2, 0)
     _, logits0 = eng0.forward_backward(video, text, tgt)
