@@ -31,7 +31,8 @@ DEV void v_frag_tr(Frag<bf16_t>& f, const bf16_t* p0, int stride16) {
 DEV void v_frag_tr(Frag<float>&, const float*, int) {}
 
 template <typename T>
-__global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int heads, int Lp, int hm) {
+__global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int heads, int Lp, int hm,
+                                                  unsigned char* __restrict__ out8, const float* __restrict__ out8_scale, float* __restrict__ out8_amax) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KLD = HD + KPAD, VLD = Lp + KPAD;
     constexpr bool TRV = sizeof(T) == 2;         // bf16: V stays row-major and is gathered with LDS transpose reads
@@ -186,7 +187,37 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
             l += __shfl_xor(l, 16, 64);
             l += __shfl_xor(l, 32, 64);
             const float inv = 1.f / l;
-            if (TRV) {
+            if (TRV && out8) {
+                // e4m3 output (the A operand of a DIST_EPI_FP8 out-projection): e4m3(clamp(bf16(o) / scale)) with the caller's per-tensor
+                // scale, INSTEAD of the bf16 rows; same lane exchange as below on one dword (4 columns) per fragment
+                const float si = 1.0f / out8_scale[0];
+                float am = 0.f;
+                auto pk4 = [&](int j) __attribute__((always_inline)) -> int {
+                    float y[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = (float)(bf16_t)(o[u][j][r] * inv);
+                        am = fmaxf(am, fabsf(v));
+                        y[r] = fminf(fmaxf(v * si, -448.f), 448.f);
+                    }
+                    int w = 0;
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], w, false);
+                    return __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], w, true);
+                };
+                const int a = pk4(0), b = pk4(1), c = pk4(2), d4 = pk4(3);
+                const bool odd = lg & 1;
+                const int r0 = __shfl_xor(odd ? a : c, 16, 64), r1 = __shfl_xor(odd ? b : d4, 16, 64);
+                if (qrow[u] < L) {
+                    unsigned char* orow = out8 + ((long)f * L + qrow[u]) * d + h * HD + (odd ? 32 : 0) + (lg >> 1) * 8;
+                    *reinterpret_cast<int2*>(orow) = odd ? make_int2(r0, c) : make_int2(a, r0);
+                    *reinterpret_cast<int2*>(orow + 16) = odd ? make_int2(r1, d4) : make_int2(b, r1);
+                }
+                if (out8_amax) {
+                    am = qrow[u] < L ? am : 0.f;
+                    am = wave_max(am, 64);
+                    if (lane == 0 && am > *static_cast<const volatile float*>(out8_amax)) atomicMax(reinterpret_cast<unsigned*>(out8_amax), __float_as_uint(am));
+                }
+            } else if (TRV) {
                 // a lane holds 4 consecutive columns per 16-column fragment (8 bytes of bf16): lanes lg and lg ^ 1 swap
                 // two fragments each, so every lane ends up with 8 consecutive columns of two fragments and writes two
                 // 16-byte pieces instead of four 8-byte ones (the epilogue is store-issue-bound)
@@ -345,7 +376,8 @@ __global__ __launch_bounds__(64) void xattn1q_bwd(const T* __restrict__ q, const
 }
 
 template <typename T>
-int launch_attn(const void* qkv, void* out, int frames, int L, int heads, int hm, hipStream_t s) {
+int launch_attn(const void* qkv, void* out, int frames, int L, int heads, int hm, hipStream_t s, unsigned char* out8 = nullptr,
+                const float* out8_scale = nullptr, float* out8_amax = nullptr) {
     const int Lp = (L + 31) / 32 * 32;
     const size_t smem = sizeof(T) == 2 ? (size_t)2 * Lp * (HD + KPAD) * sizeof(T)
                                        : ((size_t)Lp * (HD + KPAD) + (size_t)HD * (Lp + KPAD)) * sizeof(T);
@@ -355,7 +387,8 @@ int launch_attn(const void* qkv, void* out, int frames, int L, int heads, int hm
         HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_smem = smem;
     }
-    hipLaunchKernelGGL(attn_kernel<T>, dim3(frames * heads), dim3(NT), smem, s, static_cast<const T*>(qkv), static_cast<T*>(out), L, heads, Lp, hm);
+    hipLaunchKernelGGL(attn_kernel<T>, dim3(frames * heads), dim3(NT), smem, s, static_cast<const T*>(qkv), static_cast<T*>(out), L, heads, Lp, hm,
+                       out8, out8_scale, out8_amax);
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
 }
@@ -367,6 +400,13 @@ extern "C" int dist_op_attention(const void* qkv, void* out, int frames, int L, 
     if (qkv_layout != DIST_QKV_ROWS && qkv_layout != DIST_QKV_HEADS) return DIST_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return dtype == DIST_BF16 ? launch_attn<bf16_t>(qkv, out, frames, L, heads, qkv_layout, s) : launch_attn<float>(qkv, out, frames, L, heads, qkv_layout, s);
+}
+
+extern "C" int dist_op_attention_out8(const void* qkv, void* out8, const float* out8_scale, float* out8_amax, int frames, int L, int heads, int qkv_layout,
+                                      void* stream) {
+    if (!qkv || !out8 || !out8_scale || frames <= 0 || L <= 0 || heads <= 0) return DIST_ERR_ARG;
+    if (qkv_layout != DIST_QKV_ROWS && qkv_layout != DIST_QKV_HEADS) return DIST_ERR_ARG;
+    return launch_attn<bf16_t>(qkv, nullptr, frames, L, heads, qkv_layout, static_cast<hipStream_t>(stream), static_cast<unsigned char*>(out8), out8_scale, out8_amax);
 }
 
 extern "C" int dist_op_xattn1q(const void* q, const void* kv, void* o, float* probs, int B, int S, int C, int dtype, void* stream) {

@@ -116,7 +116,8 @@ struct dist_handle {
     float* lnpart = nullptr;                     // [width / 64][rowsS][2] partial (sum, sum of squares) of the residual stream, left by the GEMM that wrote it
     unsigned char* aq = nullptr; float* sa = nullptr;   // vit_fp8: e4m3 image [rowsS][<= 4 width] + per-row scales of the GEMM input being consumed
     // vit_fp8 & 16: the producing epilogues write the e4m3 images themselves (DIST_EPI_OUT8) with per-tensor scales of the PREVIOUS pass:
-    // per block three tensors - 0 = attention-block output (c_fc input), 1 = hidden (c_proj input), 2 = block output (next in_proj input)
+    // per block four tensors - 0 = attention-block output (c_fc input), 1 = hidden (c_proj input), 2 = block output (next in_proj input),
+    // 3 = attention output (out_proj input; written as e4m3 by the attention kernel itself)
     unsigned char *x8 = nullptr, *xa8 = nullptr; float *f8_amax = nullptr, *f8_scale = nullptr;
     long f8_passes = 0; int x8_layer = -1;
     bool vit_fold = false;                       // ln_1 -> in_proj and ln_2 -> c_fc folded (bf16, shapes the LDS-DMA GEMM takes)
@@ -420,7 +421,7 @@ size_t layout_ws(dist_handle* h, char* base) {
     if (c.vit_fp8 && c.dtype == DIST_BF16) {
         auto B_ = [&](long n) { return static_cast<unsigned char*>(a.take((size_t)n)); };
         h->aq = B_(rowsS * 4 * d); h->sa = F_(rowsS);
-        if (c.vit_fp8 & 16) { h->x8 = B_(rowsS * d); h->xa8 = B_(rowsS * d); h->f8_amax = F_(3 * c.layers); h->f8_scale = F_(3 * c.layers); }
+        if (c.vit_fp8 & 16) { h->x8 = B_(rowsS * d); h->xa8 = B_(rowsS * d); h->f8_amax = F_(4 * c.layers); h->f8_scale = F_(4 * c.layers); }
         for (int i = 0; i < c.layers; ++i) {
             VitLayer& v = h->vit[i];
             v.q_qkv.q = B_((long)3 * d * d); v.q_qkv.s = F_(3 * d); v.cs8_qkv = F_(3 * d);
@@ -815,7 +816,7 @@ extern "C" int dist_pack_weights(dist_handle* h, int what, void* stream) {
         h->vit_fold = true;
         if (h->cfg.vit_fp8 && h->aq) {
             h->f8_passes = 0;                              // new weights: the next pass calibrates the per-tensor scales again
-            if (h->f8_amax) HIP_CHECK_RET(hipMemsetAsync(h->f8_amax, 0, sizeof(float) * 3 * h->cfg.layers, s));
+            if (h->f8_amax) HIP_CHECK_RET(hipMemsetAsync(h->f8_amax, 0, sizeof(float) * 4 * h->cfg.layers, s));
             // fp8 frozen spatial branch: per-output-channel e4m3 copies of the (folded) GEMM weights; the fold's mean term uses the column
             // sums of the weights the MFMA really multiplies by
             for (VitLayer& v : h->vit) {
@@ -878,7 +879,7 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
     const bool img_mode = (f8 & 31) == 31 && h->x8 && fp8_shape_ok(x, rowsS, 3 * d, d) && fp8_shape_ok(x, rowsS, d, d) && fp8_shape_ok(x, rowsS, 4 * d, d) &&
                           fp8_shape_ok(x, rowsS, d, 4 * d);
     if (img_mode && l0 == 0) {
-        if (h->f8_passes > 0) RUN(dist_op_fp8_scale_update(h->f8_amax, h->f8_scale, 3 * c.layers, 4.0f, stream));   // last pass's maxima -> this pass's scales
+        if (h->f8_passes > 0) RUN(dist_op_fp8_scale_update(h->f8_amax, h->f8_scale, 4 * c.layers, 4.0f, stream));   // last pass's maxima -> this pass's scales
         h->x8_layer = -1;
     }
     const bool fused = img_mode && h->f8_passes > 0;      // the first pass after a pack calibrates: per-token quantisers + dist_op_amax
@@ -894,7 +895,7 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
             else RUN(ln_fwd(x, h->visual, v.ln1, xin, nullptr, rowsS, h->lnstats, h->lnstats + rowsS));
             if (f8 & 1) {                                  // e4m3 image of the raw rows, then the folded GEMM on the block-scaled fp8 MFMA
                 if (fused && i > 0 && h->x8_layer == i - 1) {     // the previous block's c_proj left the image
-                    folded = gemm_fp8(x, h->x8, h->f8_scale + 3 * (i - 1) + 2, true, v.q_qkv, rowsS, 3 * d, d, h->qkv, 64, v.b_qkv, nullptr, nullptr, h->lnstats, v.cs8_qkv, nullptr,
+                    folded = gemm_fp8(x, h->x8, h->f8_scale + 4 * (i - 1) + 2, true, v.q_qkv, rowsS, 3 * d, d, h->qkv, 64, v.b_qkv, nullptr, nullptr, h->lnstats, v.cs8_qkv, nullptr,
                                       OM(DIST_OM_HEADS, L, h->heads));
                 } else {
                     RUN(dist_op_quant_rows_fp8(xin, DIST_BF16, rowsS, d, d, h->aq, d, h->sa, stream));
@@ -909,15 +910,23 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
             RUN(ln_fwd(x, h->visual, v.ln1, xin, h->hbuf, rowsS, nullptr, nullptr));
             RUN(gemm(x, h->hbuf, d, x.pk(v.qkv.pk.f), rowsS, 3 * d, d, 1, h->qkv, 64, x.vs(v.qkv.bias), nullptr, nullptr, nullptr, RM(), OM(DIST_OM_HEADS, L, h->heads)));
         }
-        RUN(dist_op_attention(h->qkv, h->att, b * h->t, L, h->heads, DIST_QKV_HEADS, c.dtype, stream));
+        if (fused) RUN(dist_op_attention_out8(h->qkv, h->aq, h->f8_scale + 4 * i + 3, h->f8_amax + 4 * i + 3, b * h->t, L, h->heads, DIST_QKV_HEADS, stream));
+        else RUN(dist_op_attention(h->qkv, h->att, b * h->t, L, h->heads, DIST_QKV_HEADS, c.dtype, stream));
         int done8 = 0;
         if (f8 & 2) {
-            RUN(dist_op_quant_rows_fp8(h->att, DIST_BF16, rowsS, d, d, h->aq, d, h->sa, stream));
-            Out8 o8;
-            if (fused) { o8.img = h->xa8; o8.scale = h->f8_scale + 3 * i; o8.amax = h->f8_amax + 3 * i; }
-            done8 = gemm_fp8(x, h->aq, h->sa, false, v.q_out, rowsS, d, d, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr, nullptr, rs ? h->lnpart : nullptr, OM(), o8);
+            if (fused) {                                   // the attention kernel left the e4m3 image in h->aq
+                Out8 o8;
+                o8.img = h->xa8; o8.scale = h->f8_scale + 4 * i; o8.amax = h->f8_amax + 4 * i;
+                done8 = gemm_fp8(x, h->aq, h->f8_scale + 4 * i + 3, true, v.q_out, rowsS, d, d, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr, nullptr, rs ? h->lnpart : nullptr, OM(), o8);
+            } else {
+                RUN(dist_op_quant_rows_fp8(h->att, DIST_BF16, rowsS, d, d, h->aq, d, h->sa, stream));
+                done8 = gemm_fp8(x, h->aq, h->sa, false, v.q_out, rowsS, d, d, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr, nullptr, rs ? h->lnpart : nullptr);
+                if (img_mode && done8 > 0) {
+                    RUN(dist_op_amax(h->xa, DIST_BF16, rowsS * d, h->f8_amax + 4 * i, stream));
+                    RUN(dist_op_amax(h->att, DIST_BF16, rowsS * d, h->f8_amax + 4 * i + 3, stream));
+                }
+            }
             if (done8 < 0) return fail(h, done8, "fp8 out-projection GEMM failed");
-            if (img_mode && !fused) RUN(dist_op_amax(h->xa, DIST_BF16, rowsS * d, h->f8_amax + 3 * i, stream));
         }
         if (!done8) RUN(gemm(x, h->att, d, x.pk(v.out.pk.f), rowsS, d, d, 1, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr, RM(), OM(), 0, nullptr, rs ? h->lnpart : nullptr));
         folded = 0;
@@ -927,12 +936,12 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
             if (f8 & 4) {
                 if (fused) {                               // input: the image out_proj left; output: the QuickGELU'd hidden tensor as e4m3 ONLY (h->aq)
                     Out8 o8;
-                    o8.img = h->aq; o8.scale = h->f8_scale + 3 * i + 1; o8.amax = h->f8_amax + 3 * i + 1; o8.act = true;
-                    folded = gemm_fp8(x, h->xa8, h->f8_scale + 3 * i, true, v.q_fc, rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, nullptr, nullptr, h->lnstats, v.cs8_fc, nullptr, OM(), o8);
+                    o8.img = h->aq; o8.scale = h->f8_scale + 4 * i + 1; o8.amax = h->f8_amax + 4 * i + 1; o8.act = true;
+                    folded = gemm_fp8(x, h->xa8, h->f8_scale + 4 * i, true, v.q_fc, rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, nullptr, nullptr, h->lnstats, v.cs8_fc, nullptr, OM(), o8);
                 } else {
                     RUN(dist_op_quant_rows_fp8(h->xa, DIST_BF16, rowsS, d, d, h->aq, d, h->sa, stream));
                     folded = gemm_fp8(x, h->aq, h->sa, false, v.q_fc, rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, nullptr, h->mlp, h->lnstats, v.cs8_fc, nullptr);
-                    if (img_mode && folded > 0) RUN(dist_op_amax(h->mlp, DIST_BF16, rowsS * 4 * d, h->f8_amax + 3 * i + 1, stream));
+                    if (img_mode && folded > 0) RUN(dist_op_amax(h->mlp, DIST_BF16, rowsS * 4 * d, h->f8_amax + 4 * i + 1, stream));
                 }
                 if (folded < 0) return fail(h, folded, "fp8 MLP GEMM failed");
             }
@@ -947,14 +956,14 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
         if (f8 & 8) {
             if (fused) {
                 Out8 o8;
-                o8.img = h->x8; o8.scale = h->f8_scale + 3 * i + 2; o8.amax = h->f8_amax + 3 * i + 2;
-                done8 = gemm_fp8(x, h->aq, h->f8_scale + 3 * i + 1, true, v.q_proj, rowsS, d, 4 * d, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr, nullptr,
+                o8.img = h->x8; o8.scale = h->f8_scale + 4 * i + 2; o8.amax = h->f8_amax + 4 * i + 2;
+                done8 = gemm_fp8(x, h->aq, h->f8_scale + 4 * i + 1, true, v.q_proj, rowsS, d, 4 * d, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr, nullptr,
                                  rs ? h->lnpart : nullptr, OM(), o8);
                 if (done8 > 0) h->x8_layer = i;
             } else {
                 RUN(dist_op_quant_rows_fp8(h->mlp, DIST_BF16, rowsS, 4 * d, 4 * d, h->aq, 4 * d, h->sa, stream));
                 done8 = gemm_fp8(x, h->aq, h->sa, false, v.q_proj, rowsS, d, 4 * d, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr, nullptr, rs ? h->lnpart : nullptr);
-                if (img_mode && done8 > 0) RUN(dist_op_amax(S.feat[i], DIST_BF16, rowsS * d, h->f8_amax + 3 * i + 2, stream));
+                if (img_mode && done8 > 0) RUN(dist_op_amax(S.feat[i], DIST_BF16, rowsS * d, h->f8_amax + 4 * i + 2, stream));
             }
             if (done8 < 0) return fail(h, done8, "fp8 MLP projection GEMM failed");
         }

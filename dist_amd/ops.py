@@ -315,3 +315,11 @@ def amax_(x, amax):
     """amax[0] = max(amax[0], max |x|) (calibration of a tensor no EPI_OUT8 producer has written yet)."""
     assert x.is_cuda and x.is_contiguous() and amax.dtype == torch.float32
     L.check(L.load().dist_op_amax(_p(x), _dt(x), x.numel(), _p(amax), _stream()))
+
+
+def attention_out8(qkv, frames, Ltok, heads, scale, amax=None, layout=L.QKV_HEADS):
+    """ViT attention with the output as e4m3 bytes [frames*Ltok, heads*64] (per-tensor scale fp32 [1]; amax fp32 [1] collects max |o|)."""
+    assert qkv.is_cuda and qkv.dtype == torch.bfloat16 and scale.dtype == torch.float32
+    out8 = torch.empty(frames * Ltok, heads * 64, dtype=torch.uint8, device=qkv.device)
+    L.check(L.load().dist_op_attention_out8(_p(qkv), _p(out8), _p(scale), _p(amax), frames, Ltok, heads, layout, _stream()))
+    return out8

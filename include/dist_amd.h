@@ -182,6 +182,11 @@ int dist_op_layernorm_bwd(const dist_ln_bwd_args* a, void* stream);
  *            (frame, head) operand is one contiguous 25 KB block instead of 128-byte pieces at a 3*d row stride. */
 enum { DIST_QKV_ROWS = 0, DIST_QKV_HEADS = 1 };
 int dist_op_attention(const void* qkv, void* out, int frames, int L, int heads, int qkv_layout, int dtype, void* stream);
+/* the same attention (bf16 qkv) with its output written as OCP e4m3 INSTEAD of bf16 - the A operand of a DIST_EPI_FP8 out-projection with
+ * DIST_EPI_FP8_ASCALAR: out8[row][c] = e4m3_rne(clamp(float(bf16(o)) / out8_scale[0], -448, 448)), out8 bytes [frames*L][heads*64];
+ * *out8_amax (optional) = running maximum of |bf16(o)| for the next pass's scale (see DIST_EPI_OUT8). */
+int dist_op_attention_out8(const void* qkv, void* out8, const float* out8_scale, float* out8_amax, int frames, int L, int heads, int qkv_layout,
+                           void* stream);
 
 /* one-query cross attention (CrossAttentionBlockGenral, clip.py:139-147; dist.py:144,158):
  * q [B, C], kv [B*S, 2C] -> o [B, C], probs [B, H, S] (fp32, saved for backward) */

@@ -129,7 +129,7 @@ class Oracle:
         pre = f"visual.transformer.resblocks.{i}."
         b, t, L, d = x.shape
         f8 = self.vit_fp8
-        img = bool(f8 & 16)                                  # producers' per-tensor images (every block input but the attention output)
+        img = bool(f8 & 16)                                  # producers' per-tensor images of every GEMM input
         if f8 & 1:
             qkv = self.rnd(self._fp8_ln_lin(x, p[pre + "attn.in_proj_weight"], p[pre + "attn.in_proj_bias"], p[pre + "ln_1.weight"], p[pre + "ln_1.bias"],
                                             per_tensor=img and i > 0))
@@ -140,7 +140,7 @@ class Oracle:
         att = torch.softmax((q @ k.transpose(-1, -2)) / 8.0, dim=-1)
         o = self.rnd((att @ v).permute(0, 2, 1, 3).reshape(b, t, L, d))
         if f8 & 2:
-            x = self.rnd(x + self._fp8_lin(o, self.w(pre + "attn.out_proj.weight"), p[pre + "attn.out_proj.bias"]))
+            x = self.rnd(x + self._fp8_lin(o, self.w(pre + "attn.out_proj.weight"), p[pre + "attn.out_proj.bias"], per_tensor=img))
         else:
             x = self.rnd(x + o @ self.w(pre + "attn.out_proj.weight").t() + p[pre + "attn.out_proj.bias"])
         if f8 & 4:

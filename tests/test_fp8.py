@@ -284,3 +284,19 @@ def test_out8_image_of_the_output(gpu_lib, fp8_in):
     ops.gemm_nt(Ain, Win, M, N, K, bias=bias, out8=(H8, tiny, None), act_only8=True, **kw)
     img = H8.cpu().view(torch.float8_e4m3fn).float()
     assert not torch.isnan(img).any() and float(img.max()) == 448.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames,L_,heads", [(16, 197, 12), (6, 257, 16), (3, 50, 4)])
+def test_attention_writes_its_output_as_e4m3(gpu_lib, frames, L_, heads):
+    """dist_op_attention_out8: the image of exactly the bf16 rows dist_op_attention stores, with the caller's per-tensor scale; running maximum"""
+    from dist_amd import ops, lib as L
+    qkv = rnd((frames * heads * 3 * L_, 64), 61, 1.0)
+    o = ops.attention(qkv, frames, L_, heads, layout=L.QKV_HEADS)
+    scale, amax = torch.tensor([2.0 ** -6], device="cuda"), torch.zeros(1, device="cuda")
+    o8 = ops.attention_out8(qkv, frames, L_, heads, scale, amax)
+    assert torch.equal(o8.cpu(), _e4m3_image(o, 2.0 ** -6))
+    assert float(amax) == float(o.float().abs().max())
+    o8b = ops.attention_out8(qkv, frames, L_, heads, torch.tensor([2.0 ** -14], device="cuda"), None)      # saturates, no NaN
+    img = o8b.cpu().view(torch.float8_e4m3fn).float()
+    assert not torch.isnan(img).any() and float(img.abs().max()) == 448.0
