@@ -11,11 +11,14 @@
 // (2) dist_op_xattn1q(+_bwd): the one-query cross attention of the ada-pooling network
 //     (CrossAttentionBlockGenral, clip.py:139-147; dist.py:144,158): latency-bound, one
 //     wave per (batch element, head).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
 
-constexpr int NT = 448;           // 7 waves x two 16-query tiles = 14 tile slots for the 13 tiles of L = 197 (8 waves left 3 of them half idle)
+// waves per workgroup x two 16-query tiles = tile slots of one pass over the keys: 7 waves (14 slots) for the 13 tiles of L = 197 (8 waves left 3 of
+// them half idle); 9 waves (18 slots) for the 17 tiles of L = 257 (ViT-L/14), which 7 waves served in a second pass with four of them idle
+constexpr int NT7 = 448, NT9 = 576;
 constexpr int HD = 64;           // head dim
 constexpr int KPAD = 8;
 
@@ -30,7 +33,7 @@ DEV void v_frag_tr(Frag<bf16_t>& f, const bf16_t* p0, int stride16) {
 }
 DEV void v_frag_tr(Frag<float>&, const float*, int) {}
 
-template <typename T>
+template <typename T, int NT>
 __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int heads, int Lp, int hm,
                                                   unsigned char* __restrict__ out8, const float* __restrict__ out8_scale, float* __restrict__ out8_amax) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -382,13 +385,26 @@ int launch_attn(const void* qkv, void* out, int frames, int L, int heads, int hm
     const size_t smem = sizeof(T) == 2 ? (size_t)2 * Lp * (HD + KPAD) * sizeof(T)
                                        : ((size_t)Lp * (HD + KPAD) + (size_t)HD * (Lp + KPAD)) * sizeof(T);
     if (smem > 160 * 1024) return DIST_ERR_ARG;
-    static size_t attr_smem = 0;
-    if (smem > attr_smem) {
-        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_smem = smem;
+    const int nq = (L + 15) / 16;
+    static const int nt_env = getenv("DIST_AMD_ATTN_NT") ? atoi(getenv("DIST_AMD_ATTN_NT")) : 0;      // measurement knob: 448 / 576
+    const bool nine = nt_env ? nt_env == NT9 : (nq > 14 && nq <= 18);
+    if (nine) {
+        static size_t attr9 = 0;
+        if (smem > attr9) {
+            HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<T, NT9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr9 = smem;
+        }
+        hipLaunchKernelGGL((attn_kernel<T, NT9>), dim3(frames * heads), dim3(NT9), smem, s, static_cast<const T*>(qkv), static_cast<T*>(out), L, heads, Lp, hm,
+                           out8, out8_scale, out8_amax);
+    } else {
+        static size_t attr7 = 0;
+        if (smem > attr7) {
+            HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<T, NT7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr7 = smem;
+        }
+        hipLaunchKernelGGL((attn_kernel<T, NT7>), dim3(frames * heads), dim3(NT7), smem, s, static_cast<const T*>(qkv), static_cast<T*>(out), L, heads, Lp, hm,
+                           out8, out8_scale, out8_amax);
     }
-    hipLaunchKernelGGL(attn_kernel<T>, dim3(frames * heads), dim3(NT), smem, s, static_cast<const T*>(qkv), static_cast<T*>(out), L, heads, Lp, hm,
-                       out8, out8_scale, out8_amax);
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
 }
