@@ -39,8 +39,12 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KLD = HD + KPAD, VLD = Lp + KPAD;
     constexpr bool TRV = sizeof(T) == 2;         // bf16: V stays row-major and is gathered with LDS transpose reads
-    T* Ks = reinterpret_cast<T*>(smem);          // [Lp][KLD]
-    T* Vt = Ks + Lp * KLD;                       // fp32: [HD][VLD] (transposed) | bf16: [Lp][KLD] (row-major)
+    // bf16: K keeps only the rows up to the next multiple of 16: the key slabs read up to Lp rows, but a score of a key >= L is
+    // replaced, never used, so those reads may land in V's first rows (finite data) - V keeps all Lp rows (zeros behind L: 0 x V).
+    // L = 257: (272 + 288) x 144 B = 80 640 B, and TWO 7-wave workgroups share a CU's 160 KB (82 944 B each did not)
+    const int Lk = TRV ? (L + 15) / 16 * 16 : Lp;
+    T* Ks = reinterpret_cast<T*>(smem);          // [Lk][KLD]
+    T* Vt = Ks + Lk * KLD;                       // fp32: [HD][VLD] (transposed) | bf16: [Lp][KLD] (row-major)
 
     const int f = blockIdx.x / heads, h = blockIdx.x % heads;
     const int d = heads * HD;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
             if (it < n_it && v < Lp * (HD / 8)) {
                 const int key = v / (HD / 8), dv = v % (HD / 8);
                 if (key >= L) { frag_zero(rk[it]); if (TRV) frag_zero(rv[it]); }
-                frag_store(rk[it], Ks + key * KLD + dv * 8);
+                if (key < Lk) frag_store(rk[it], Ks + key * KLD + dv * 8);
                 if (TRV) frag_store(rv[it], Vt + key * KLD + dv * 8);
             }
         }
@@ -382,12 +386,15 @@ template <typename T>
 int launch_attn(const void* qkv, void* out, int frames, int L, int heads, int hm, hipStream_t s, unsigned char* out8 = nullptr,
                 const float* out8_scale = nullptr, float* out8_amax = nullptr) {
     const int Lp = (L + 31) / 32 * 32;
-    const size_t smem = sizeof(T) == 2 ? (size_t)2 * Lp * (HD + KPAD) * sizeof(T)
+    const int Lk = (L + 15) / 16 * 16;
+    const size_t smem = sizeof(T) == 2 ? (size_t)(Lk + Lp) * (HD + KPAD) * sizeof(T)
                                        : ((size_t)Lp * (HD + KPAD) + (size_t)HD * (Lp + KPAD)) * sizeof(T);
     if (smem > 160 * 1024) return DIST_ERR_ARG;
     const int nq = (L + 15) / 16;
     static const int nt_env = getenv("DIST_AMD_ATTN_NT") ? atoi(getenv("DIST_AMD_ATTN_NT")) : 0;      // measurement knob: 448 / 576
-    const bool nine = nt_env ? nt_env == NT9 : (nq > 14 && nq <= 18);
+    // nine waves only where two 7-wave workgroups do not fit a CU's LDS anyway (L = 257: 234 us with nine waves and one workgroup per CU,
+    // 190 us with seven waves and two - tools/bench_attn.py)
+    const bool nine = nt_env ? nt_env == NT9 : (nq > 14 && nq <= 18 && smem > 80 * 1024);
     if (nine) {
         static size_t attr9 = 0;
         if (smem > attr9) {
