@@ -71,7 +71,8 @@ class TestMeter(object):
         self.check()
         incomplete = (self.clip_count != self.num_clips).nonzero().view(-1).tolist()
         if incomplete:
-            print("clip count {} ~= num clips {}".format(", ".join("{}: {}".format(i, int(self.clip_count[i])) for i in incomplete[:32]), self.num_clips))
+            seen = ", ".join(f"video {i} has {int(self.clip_count[i])}" for i in incomplete[:32])
+            print(f"TestMeter: {len(incomplete)} videos did not receive all {self.num_clips} views ({seen}{', ...' if len(incomplete) > 32 else ''})")
         num_topks_correct = metrics.topks_correct(self.video_preds, self.video_labels, ks)
         topks = [(x / self.video_preds.size(0)) * 100.0 for x in num_topks_correct]
         stats = {"split": "test_final" if not self.model_ema_enabled else "ema_test_final"}
