@@ -33,9 +33,23 @@ DEV void v_frag_tr(Frag<bf16_t>& f, const bf16_t* p0, int stride16) {
 }
 DEV void v_frag_tr(Frag<float>&, const float*, int) {}
 
+// 8 OCP e4m3 bytes -> a bf16 fragment (exact: every e4m3 value is a bf16 value)
+DEV void frag_load_e4m3(Frag<bf16_t>& f, const unsigned char* p) {
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const int2 w = *reinterpret_cast<const int2*>(p);
+    const f2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(w.x, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(w.x, true);
+    const f2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(w.y, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(w.y, true);
+    f.v = bf16x8{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)c[0], (bf16_t)c[1], (bf16_t)d[0], (bf16_t)d[1]};
+}
+DEV void frag_load_e4m3(Frag<float>&, const unsigned char*) {}
+
+// qkv8 (bf16 instantiation, head-major layout only): q | k | v arrive as e4m3 bytes with ONE scale in_scale[0] (a DIST_EPI_OUT8 image of the
+// in_proj output): they are widened to bf16 on their way into LDS / the query fragments, the products stay bf16 MFMAs, the scale enters the
+// scores as scale^2 and the output as scale.
 template <typename T, int NT>
 __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int heads, int Lp, int hm,
-                                                  unsigned char* __restrict__ out8, const float* __restrict__ out8_scale, float* __restrict__ out8_amax) {
+                                                  unsigned char* __restrict__ out8, const float* __restrict__ out8_scale, float* __restrict__ out8_amax,
+                                                  const unsigned char* __restrict__ qkv8, const float* __restrict__ in_scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KLD = HD + KPAD, VLD = Lp + KPAD;
     constexpr bool TRV = sizeof(T) == 2;         // bf16: V stays row-major and is gathered with LDS transpose reads
@@ -56,6 +70,15 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
     const T* vb = hm ? kb + (long)L * HD : kb + d;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
+    const bool in8 = TRV && qkv8 != nullptr;
+    const unsigned char* q8 = qkv8 + ((long)(f * heads + h) * 3) * L * HD;
+    const unsigned char* k8 = q8 + (long)L * HD;
+    const unsigned char* v8 = k8 + (long)L * HD;
+    const float s_in = in8 ? in_scale[0] : 1.f;
+    const float sc_qk = 0.125f * s_in * s_in;
+    auto ldf = [&](Frag<T>& fr, const T* p, const unsigned char* p8, long off) __attribute__((always_inline)) {
+        if (in8) frag_load_e4m3(fr, p8 + off); else frag_load(fr, p + off);
+    };
 
     const int nq = (L + 15) / 16, nslab = Lp / 32;
     constexpr int NW = NT / 64;
@@ -66,9 +89,9 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
         for (int u = 0; u < 2; ++u) {
             const int qt = qt0 + u * NW;
             qrow[u] = qt < nq ? qt * 16 + li : L;          // L = "no query" (clamped load, nothing stored)
-            const T* qp = qb + (long)min(qrow[u], L - 1) * ld + lg * 8;
-            frag_load(fq[u][0], qp);
-            frag_load(fq[u][1], qp + 32);
+            const long qo = (long)min(qrow[u], L - 1) * ld + lg * 8;
+            ldf(fq[u][0], qb, q8, qo);
+            ldf(fq[u][1], qb, q8, qo + 32);
         }
     };
     int qrow[2];
@@ -86,8 +109,8 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
             if (it < n_it) {
                 const int v = min(tid + it * NT, Lp * (HD / 8) - 1);
                 const int key = min(v / (HD / 8), L - 1), dv = v % (HD / 8);
-                frag_load(rk[it], kb + (long)key * ld + dv * 8);
-                if (TRV) frag_load(rv[it], vb + (long)key * ld + dv * 8);
+                ldf(rk[it], kb, k8, (long)key * ld + dv * 8);
+                if (TRV) ldf(rv[it], vb, v8, (long)key * ld + dv * 8);
             }
         }
 #pragma unroll
@@ -160,7 +183,7 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = s * 32 + t * 16 + lg * 4 + r;
-                        st[t][r] = key < L ? st[t][r] * 0.125f : -1e30f;
+                        st[t][r] = key < L ? st[t][r] * sc_qk : -1e30f;
                         mx = fmaxf(mx, st[t][r]);
                     }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -193,7 +216,7 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
             float l = lrun[u];
             l += __shfl_xor(l, 16, 64);
             l += __shfl_xor(l, 32, 64);
-            const float inv = 1.f / l;
+            const float inv = s_in / l;
             if (TRV && out8) {
                 // e4m3 output (the A operand of a DIST_EPI_FP8 out-projection): e4m3(clamp(bf16(o) / scale)) with the caller's per-tensor
                 // scale, INSTEAD of the bf16 rows; same lane exchange as below on one dword (4 columns) per fragment
@@ -384,7 +407,7 @@ __global__ __launch_bounds__(64) void xattn1q_bwd(const T* __restrict__ q, const
 
 template <typename T>
 int launch_attn(const void* qkv, void* out, int frames, int L, int heads, int hm, hipStream_t s, unsigned char* out8 = nullptr,
-                const float* out8_scale = nullptr, float* out8_amax = nullptr) {
+                const float* out8_scale = nullptr, float* out8_amax = nullptr, const unsigned char* qkv8 = nullptr, const float* in_scale = nullptr) {
     const int Lp = (L + 31) / 32 * 32;
     const int Lk = (L + 15) / 16 * 16;
     const size_t smem = sizeof(T) == 2 ? (size_t)(Lk + Lp) * (HD + KPAD) * sizeof(T)
@@ -402,7 +425,7 @@ int launch_attn(const void* qkv, void* out, int frames, int L, int heads, int hm
             attr9 = smem;
         }
         hipLaunchKernelGGL((attn_kernel<T, NT9>), dim3(frames * heads), dim3(NT9), smem, s, static_cast<const T*>(qkv), static_cast<T*>(out), L, heads, Lp, hm,
-                           out8, out8_scale, out8_amax);
+                           out8, out8_scale, out8_amax, qkv8, in_scale);
     } else {
         static size_t attr7 = 0;
         if (smem > attr7) {
@@ -410,7 +433,7 @@ int launch_attn(const void* qkv, void* out, int frames, int L, int heads, int hm
             attr7 = smem;
         }
         hipLaunchKernelGGL((attn_kernel<T, NT7>), dim3(frames * heads), dim3(NT7), smem, s, static_cast<const T*>(qkv), static_cast<T*>(out), L, heads, Lp, hm,
-                           out8, out8_scale, out8_amax);
+                           out8, out8_scale, out8_amax, qkv8, in_scale);
     }
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
@@ -430,6 +453,13 @@ extern "C" int dist_op_attention_out8(const void* qkv, void* out8, const float* 
     if (!qkv || !out8 || !out8_scale || frames <= 0 || L <= 0 || heads <= 0) return DIST_ERR_ARG;
     if (qkv_layout != DIST_QKV_ROWS && qkv_layout != DIST_QKV_HEADS) return DIST_ERR_ARG;
     return launch_attn<bf16_t>(qkv, nullptr, frames, L, heads, qkv_layout, static_cast<hipStream_t>(stream), static_cast<unsigned char*>(out8), out8_scale, out8_amax);
+}
+
+extern "C" int dist_op_attention_fp8(const void* qkv8, const float* in_scale, void* out, void* out8, const float* out8_scale, float* out8_amax,
+                                     int frames, int L, int heads, void* stream) {
+    if (!qkv8 || !in_scale || (!out && !out8) || (out8 && !out8_scale) || frames <= 0 || L <= 0 || heads <= 0) return DIST_ERR_ARG;
+    return launch_attn<bf16_t>(nullptr, out8 ? nullptr : out, frames, L, heads, DIST_QKV_HEADS, static_cast<hipStream_t>(stream), static_cast<unsigned char*>(out8),
+                               out8_scale, out8_amax, static_cast<const unsigned char*>(qkv8), in_scale);
 }
 
 extern "C" int dist_op_xattn1q(const void* q, const void* kv, void* o, float* probs, int B, int S, int C, int dtype, void* stream) {

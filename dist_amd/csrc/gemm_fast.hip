@@ -189,7 +189,14 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
             const int r = it * 16 + (lane >> 2), pc = lane & 3;
             const int m = mw + r, n = nw + pc * 16;
             const uint4 v = *reinterpret_cast<const uint4*>(ew + r * 128 + (((pc ^ (r & 3)) + ((r >> 2) & 1) * 4) << 4));
-            if (m < M && n < N) store16_nt(C8 + (long)m * p.ldc8 + n, v);
+            if (m < M && n < N) {
+                if (heads_om) {                           // [frame][head][q|k|v][token][64] bytes: this wave's 64 columns are one (part, head) slice
+                    const int fr = m / p.omap.p0, tok = m - fr * p.omap.p0;
+                    store16_nt(C8 + ((((long)fr * p.omap.p1 + hp_head) * 3 + hp_part) * p.omap.p0 + tok) * 64 + pc * 16, v);
+                } else {
+                    store16_nt(C8 + (long)m * p.ldc8 + n, v);
+                }
+            }
         }
         if (p.out8_amax) {
             amax = wave_max(amax, 64);
@@ -204,7 +211,7 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
         if (C2) flush(C2, p.ldc2);
         if (flags & DIST_EPI_OUT8) out8_pass();
     } else {
-        flush(C, p.ldc);
+        if (C) flush(C, p.ldc);                           // (NULL with DIST_EPI_OUT8: the e4m3 image is the only output)
         if ((flags & DIST_EPI_ROWSTATS) && nw < N) {
             // DIST_EPI_ROWSTATS: sum and sum of squares of the wave's 64 stored columns (one slice; N % 64 == 0), read back from the
             // staged bf16 tile while its stores drain - the accumulators are dead here (inside the conversion loop above the same
@@ -687,7 +694,9 @@ static bool fast_common_ok(const dist_gemm_args* a) {
     if (a->K % BK || a->K < 4 * BK || a->N % 64 || a->M < 1024) return false;
     if (a->lda % 8 || a->ldb % 8 || a->ldc % 8 || a->ldc2 % 8 || a->ldres % 8) return false;
     if (a->flags & DIST_EPI_OUT8) {                       // e4m3 image of the output: plain map, 16-byte rows, not beside a second activated output
-        if (!a->C8 || !a->out8_scale || a->ldc8 % 16 || a->omap.mode != DIST_OM_PLAIN || ((a->flags & DIST_EPI_ACT2) && a->C)) return false;
+        if (!a->C8 || !a->out8_scale || a->ldc8 % 16 || (a->omap.mode != DIST_OM_PLAIN && a->omap.mode != DIST_OM_HEADS) || ((a->flags & DIST_EPI_ACT2) && a->C)) return false;
+        if (a->omap.mode == DIST_OM_HEADS && a->ldc8 != 64) return false;
+        if (!a->C && (a->flags & DIST_EPI_ROWSTATS)) return false;
     }
     if (a->flags & DIST_EPI_FP8) {                        // e4m3 operands: 16-byte row alignment, whole 128-deep K-tiles, plain row map
         if (!a->a_scale || !a->b_scale || a->amap.mode != DIST_RM_PLAIN || a->K % 128 || a->K < 256 || a->lda % 16 || a->ldb % 16) return false;

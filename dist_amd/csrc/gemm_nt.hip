@@ -603,14 +603,14 @@ extern "C" int dist_op_gemm_nt(const dist_gemm_args* a, void* stream) {
         const int64_t a_rows = a->amap.mode == DIST_RM_PLAIN ? a->M : 2 * a->M + a->M / 64 + 64;
         if (a_rows * a->lda * es >= (1ll << 31) || (int64_t)a->N * a->ldb * es >= (1ll << 31)) return DIST_ERR_ARG;
     }
-    if (!a->C && !(a->flags & DIST_EPI_ACT2)) return DIST_ERR_ARG;
+    if (!a->C && !(a->flags & (DIST_EPI_ACT2 | DIST_EPI_OUT8))) return DIST_ERR_ARG;   // (an e4m3 image may be the only output)
     if ((a->flags & DIST_EPI_ACT2) && !a->C2 && !(a->flags & DIST_EPI_OUT8)) return DIST_ERR_ARG;   // (e4m3-only activated output: C8)
     if ((a->flags & DIST_EPI_BIAS) && !a->bias) return DIST_ERR_ARG;
     if ((a->flags & DIST_EPI_RES) && !a->res) return DIST_ERR_ARG;
     if ((a->flags & DIST_EPI_MULG) && !a->aux) return DIST_ERR_ARG;
     if (a->omap.mode == DIST_OM_SPLITCOLS && (a->omap.p2 % 4 || a->N != a->omap.p0 * a->omap.p2)) return DIST_ERR_ARG;
-    if (a->omap.mode == DIST_OM_HEADS && (a->omap.p0 <= 0 || a->omap.p1 <= 0 || a->N != 3 * 64 * a->omap.p1 || a->ldc != 64 ||
-                                          (a->flags & (DIST_EPI_RES | DIST_EPI_MULG | DIST_EPI_ACT2)) || !a->C)) return DIST_ERR_ARG;
+    if (a->omap.mode == DIST_OM_HEADS && (a->omap.p0 <= 0 || a->omap.p1 <= 0 || a->N != 3 * 64 * a->omap.p1 || (a->C && a->ldc != 64) ||
+                                          (a->flags & (DIST_EPI_RES | DIST_EPI_MULG | DIST_EPI_ACT2)) || (!a->C && !(a->flags & DIST_EPI_OUT8)))) return DIST_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if ((a->flags & DIST_EPI_OUT8) && !(a->flags & DIST_EPI_FP8)) {   // e4m3 image of the output: only the 256x256 LDS-DMA kernels write it
         if (a->dtype != DIST_BF16 || (a->flags & DIST_EPI_MULG)) return DIST_ERR_ARG;

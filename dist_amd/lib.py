@@ -146,6 +146,7 @@ def load():
     _sig(lib, "dist_op_layernorm_bwd", argtypes=[C.POINTER(LnBwdArgs), C.c_void_p])
     _sig(lib, "dist_op_attention", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p])
     _sig(lib, "dist_op_attention_out8", argtypes=[C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p])
+    _sig(lib, "dist_op_attention_fp8", argtypes=[C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_void_p])
     _sig(lib, "dist_op_xattn1q", argtypes=[C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p])
     _sig(lib, "dist_op_xattn1q_bwd", argtypes=[C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p])
     _sig(lib, "dist_op_patchify", argtypes=[C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p])

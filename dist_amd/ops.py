@@ -323,3 +323,15 @@ def attention_out8(qkv, frames, Ltok, heads, scale, amax=None, layout=L.QKV_HEAD
     out8 = torch.empty(frames * Ltok, heads * 64, dtype=torch.uint8, device=qkv.device)
     L.check(L.load().dist_op_attention_out8(_p(qkv), _p(out8), _p(scale), _p(amax), frames, Ltok, heads, layout, _stream()))
     return out8
+
+
+def attention_fp8(qkv8, in_scale, frames, Ltok, heads, out8_scale=None, amax=None):
+    """ViT attention on the head-major e4m3 q | k | v image (uint8, one scale fp32 [1]); returns bf16 rows, or e4m3 bytes when out8_scale is given."""
+    assert qkv8.is_cuda and qkv8.dtype == torch.uint8 and in_scale.dtype == torch.float32
+    if out8_scale is None:
+        out = torch.empty(frames * Ltok, heads * 64, dtype=torch.bfloat16, device=qkv8.device)
+        L.check(L.load().dist_op_attention_fp8(_p(qkv8), _p(in_scale), _p(out), None, None, None, frames, Ltok, heads, _stream()))
+        return out
+    out8 = torch.empty(frames * Ltok, heads * 64, dtype=torch.uint8, device=qkv8.device)
+    L.check(L.load().dist_op_attention_fp8(_p(qkv8), _p(in_scale), None, _p(out8), _p(out8_scale), _p(amax), frames, Ltok, heads, _stream()))
+    return out8

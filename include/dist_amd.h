@@ -89,7 +89,8 @@ enum {
                               * with a per-TENSOR scale the caller read from an earlier pass (e4m3 is a floating format: 14 binades of normal
                               * range make a per-tensor scale with a margin as precise as a per-row one), and *out8_amax (optional, fp32 >= 0 as
                               * its bit pattern) = max(*out8_amax, max |float(bf16(v))|) for the next pass's scale (dist_op_fp8_scale_update).
-                              * Plain output map, 256x256 LDS-DMA kernel only. */
+                              * Plain output map, or DIST_OM_HEADS (ldc8 = 64: the q | k | v image dist_op_attention_fp8 reads); 256x256 LDS-DMA
+                              * kernel only. */
 };
 
 /* C[omap(m)][n] = epi( sum_tap sum_k A[amap(m,tap)][k] * B[n][tap*K + k] )
@@ -187,6 +188,11 @@ int dist_op_attention(const void* qkv, void* out, int frames, int L, int heads, 
  * *out8_amax (optional) = running maximum of |bf16(o)| for the next pass's scale (see DIST_EPI_OUT8). */
 int dist_op_attention_out8(const void* qkv, void* out8, const float* out8_scale, float* out8_amax, int frames, int L, int heads, int qkv_layout,
                            void* stream);
+/* ... and with q | k | v arriving as e4m3 too: qkv8 = the head-major DIST_EPI_OUT8 image of the in_proj output with ONE scale in_scale[0]
+ * (bytes [frame][head][q|k|v][L][64]).  The bytes are widened to bf16 on their way into LDS (exact), the products stay bf16 MFMAs, the
+ * scale enters the scores as in_scale^2 and the output as in_scale.  Exactly one of out (bf16 [frames*L][heads*64]) / out8 (as above). */
+int dist_op_attention_fp8(const void* qkv8, const float* in_scale, void* out, void* out8, const float* out8_scale, float* out8_amax,
+                          int frames, int L, int heads, void* stream);
 
 /* one-query cross attention (CrossAttentionBlockGenral, clip.py:139-147; dist.py:144,158):
  * q [B, C], kv [B*S, 2C] -> o [B, C], probs [B, H, S] (fp32, saved for backward) */

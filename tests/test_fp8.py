@@ -300,3 +300,30 @@ def test_attention_writes_its_output_as_e4m3(gpu_lib, frames, L_, heads):
     o8b = ops.attention_out8(qkv, frames, L_, heads, torch.tensor([2.0 ** -14], device="cuda"), None)      # saturates, no NaN
     img = o8b.cpu().view(torch.float8_e4m3fn).float()
     assert not torch.isnan(img).any() and float(img.abs().max()) == 448.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames,L_,heads", [(12, 197, 12), (5, 257, 16)])
+def test_qkv_as_e4m3_from_the_gemm_through_the_attention(gpu_lib, frames, L_, heads):
+    """in_proj writes q | k | v head-major as e4m3 ONLY (DIST_EPI_OUT8 with DIST_OM_HEADS), dist_op_attention_fp8 widens the bytes to bf16
+    on their way into LDS: with a power-of-two scale the result is bit-identical to dist_op_attention on the dequantised bf16 tensor."""
+    from dist_amd import ops, lib as L
+    M, d = frames * L_, heads * 64
+    K = 768 if d == 768 else 1024
+    A, W = rnd((M, K), 71, 1.5), rnd((3 * d, K), 72, K ** -0.5)
+    bias = rnd((3 * d,), 73, 1.0, torch.float32)
+    qa, sa = ops.quant_rows_fp8(A)
+    qw, sw = ops.quant_rows_fp8(W)
+    qkv16 = torch.empty(frames * heads * 3 * L_, 64, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(qa, qw, M, 3 * d, K, bias=bias, C_out=qkv16, ldc=64, omap=ops.outmap(L.OM_HEADS, L_, heads), fp8=(sa, sw))
+    scale, amax = torch.tensor([2.0 ** -5], device="cuda"), torch.zeros(1, device="cuda")
+    qkv8 = torch.zeros(frames * heads * 3 * L_, 64, dtype=torch.uint8, device="cuda")
+    ops.gemm_nt(qa, qw, M, 3 * d, K, bias=bias, omap=ops.outmap(L.OM_HEADS, L_, heads), out8=(qkv8, scale, amax), fp8=(sa, sw))
+    assert torch.equal(qkv8.cpu(), _e4m3_image(qkv16, 2.0 ** -5)) and float(amax) == float(qkv16.float().abs().max())
+    deq = (qkv8.cpu().view(torch.float8_e4m3fn).float() * 2.0 ** -5).to(torch.bfloat16).cuda()       # exact in bf16
+    want = ops.attention(deq, frames, L_, heads, layout=L.QKV_HEADS)
+    got = ops.attention_fp8(qkv8, scale, frames, L_, heads)
+    assert torch.equal(got, want)
+    s2 = torch.tensor([2.0 ** -7], device="cuda")
+    got8 = ops.attention_fp8(qkv8, scale, frames, L_, heads, out8_scale=s2, amax=amax.zero_())
+    assert torch.equal(got8.cpu(), _e4m3_image(want, 2.0 ** -7)) and float(amax) == float(want.float().abs().max())
