@@ -34,12 +34,16 @@ DEV void v_frag_tr(Frag<bf16_t>& f, const bf16_t* p0, int stride16) {
 DEV void v_frag_tr(Frag<float>&, const float*, int) {}
 
 // 8 OCP e4m3 bytes -> a bf16 fragment (exact: every e4m3 value is a bf16 value)
-DEV void frag_load_e4m3(Frag<bf16_t>& f, const unsigned char* p) {
+DEV void frag_from_e4m3(Frag<bf16_t>& f, const int lo, const int hi) {
     typedef float f2_t __attribute__((ext_vector_type(2)));
-    const int2 w = *reinterpret_cast<const int2*>(p);
-    const f2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(w.x, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(w.x, true);
-    const f2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(w.y, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(w.y, true);
+    const f2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+    const f2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
     f.v = bf16x8{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)c[0], (bf16_t)c[1], (bf16_t)d[0], (bf16_t)d[1]};
+}
+DEV void frag_from_e4m3(Frag<float>&, int, int) {}
+DEV void frag_load_e4m3(Frag<bf16_t>& f, const unsigned char* p) {
+    const int2 w = *reinterpret_cast<const int2*>(p);
+    frag_from_e4m3(f, w.x, w.y);
 }
 DEV void frag_load_e4m3(Frag<float>&, const unsigned char*) {}
 
@@ -102,7 +106,34 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
     // per loop iteration
     constexpr int KV_IT = 6;                                  // covers Lp * 8 vectors up to Lp = 336 (L = 257 -> Lp = 288)
     const int n_it = (Lp * (HD / 8) + NT - 1) / NT;           // block-uniform
-    {
+    if (in8) {
+        // e4m3 rows are 64 bytes: 16-byte loads carry two 8-element vectors (8-byte loads run at little more than half the rate)
+        constexpr int P_IT = KV_IT / 2;
+        const int np = (Lp * (HD / 16) + NT - 1) / NT;
+        int4 wk[P_IT], wv[P_IT];
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            if (it < np) {
+                const int pv = min(tid + it * NT, Lp * (HD / 16) - 1);
+                const int key = min(pv / (HD / 16), L - 1), dp = pv % (HD / 16);
+                wk[it] = *reinterpret_cast<const int4*>(k8 + (long)key * HD + dp * 16);
+                wv[it] = *reinterpret_cast<const int4*>(v8 + (long)key * HD + dp * 16);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const int pv = tid + it * NT;
+            if (it < np && pv < Lp * (HD / 16)) {
+                const int key = pv / (HD / 16), dp = pv % (HD / 16);
+                if (key >= L) { wk[it] = make_int4(0, 0, 0, 0); wv[it] = make_int4(0, 0, 0, 0); }
+                Frag<T> a, b;
+                frag_from_e4m3(a, wk[it].x, wk[it].y); frag_from_e4m3(b, wk[it].z, wk[it].w);
+                if (key < Lk) { frag_store(a, Ks + key * KLD + dp * 16); frag_store(b, Ks + key * KLD + dp * 16 + 8); }
+                frag_from_e4m3(a, wv[it].x, wv[it].y); frag_from_e4m3(b, wv[it].z, wv[it].w);
+                frag_store(a, Vt + key * KLD + dp * 16); frag_store(b, Vt + key * KLD + dp * 16 + 8);
+            }
+        }
+    } else {
         Frag<T> rk[KV_IT], rv[KV_IT];
 #pragma unroll
         for (int it = 0; it < KV_IT; ++it) {

@@ -117,7 +117,7 @@ struct dist_handle {
     unsigned char* aq = nullptr; float* sa = nullptr;   // vit_fp8: e4m3 image [rowsS][<= 4 width] + per-row scales of the GEMM input being consumed
     // vit_fp8 & 16: the producing epilogues write the e4m3 images themselves (DIST_EPI_OUT8) with per-tensor scales of the PREVIOUS pass:
     // per block four tensors - 0 = attention-block output (c_fc input), 1 = hidden (c_proj input), 2 = block output (next in_proj input),
-    // 3 = attention output (out_proj input; written as e4m3 by the attention kernel itself)
+    // 3 = attention output (out_proj input; written as e4m3 by the attention kernel itself), 4 = q | k | v (in_proj output, head-major e4m3 only)
     unsigned char *x8 = nullptr, *xa8 = nullptr; float *f8_amax = nullptr, *f8_scale = nullptr;
     long f8_passes = 0; int x8_layer = -1;
     bool vit_fold = false;                       // ln_1 -> in_proj and ln_2 -> c_fc folded (bf16, shapes the LDS-DMA GEMM takes)
@@ -421,7 +421,7 @@ size_t layout_ws(dist_handle* h, char* base) {
     if (c.vit_fp8 && c.dtype == DIST_BF16) {
         auto B_ = [&](long n) { return static_cast<unsigned char*>(a.take((size_t)n)); };
         h->aq = B_(rowsS * 4 * d); h->sa = F_(rowsS);
-        if (c.vit_fp8 & 16) { h->x8 = B_(rowsS * d); h->xa8 = B_(rowsS * d); h->f8_amax = F_(4 * c.layers); h->f8_scale = F_(4 * c.layers); }
+        if (c.vit_fp8 & 16) { h->x8 = B_(rowsS * d); h->xa8 = B_(rowsS * d); h->f8_amax = F_(5 * c.layers); h->f8_scale = F_(5 * c.layers); }
         for (int i = 0; i < c.layers; ++i) {
             VitLayer& v = h->vit[i];
             v.q_qkv.q = B_((long)3 * d * d); v.q_qkv.s = F_(3 * d); v.cs8_qkv = F_(3 * d);
@@ -566,7 +566,7 @@ int gemm_fp8(const Ctx& c, const unsigned char* Aq, const float* sa, bool sa_sca
     g.amap = RM(); g.omap = om;
     g.flags = DIST_EPI_FP8 | (sa_scalar ? DIST_EPI_FP8_ASCALAR : 0) | (bias ? DIST_EPI_BIAS : 0) | (res ? DIST_EPI_RES : 0) | (stats ? DIST_EPI_LNFOLD : 0) |
               ((C2 || o8.act) ? DIST_EPI_ACT2 : 0) | (rowstats ? DIST_EPI_ROWSTATS : 0);
-    if (o8.img) { g.C8 = o8.img; g.ldc8 = N; g.out8_scale = o8.scale; g.out8_amax = o8.amax; g.flags |= DIST_EPI_OUT8; }
+    if (o8.img) { g.C8 = o8.img; g.ldc8 = om.mode == DIST_OM_HEADS ? 64 : N; g.out8_scale = o8.scale; g.out8_amax = o8.amax; g.flags |= DIST_EPI_OUT8; }
     g.dtype = DIST_BF16;
     if (!dist_k_gemm_fast_eligible(&g)) return 0;
     const int rc = dist_op_gemm_nt(&g, c.s);
@@ -816,7 +816,7 @@ extern "C" int dist_pack_weights(dist_handle* h, int what, void* stream) {
         h->vit_fold = true;
         if (h->cfg.vit_fp8 && h->aq) {
             h->f8_passes = 0;                              // new weights: the next pass calibrates the per-tensor scales again
-            if (h->f8_amax) HIP_CHECK_RET(hipMemsetAsync(h->f8_amax, 0, sizeof(float) * 4 * h->cfg.layers, s));
+            if (h->f8_amax) HIP_CHECK_RET(hipMemsetAsync(h->f8_amax, 0, sizeof(float) * 5 * h->cfg.layers, s));
             // fp8 frozen spatial branch: per-output-channel e4m3 copies of the (folded) GEMM weights; the fold's mean term uses the column
             // sums of the weights the MFMA really multiplies by
             for (VitLayer& v : h->vit) {
@@ -879,7 +879,7 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
     const bool img_mode = (f8 & 31) == 31 && h->x8 && fp8_shape_ok(x, rowsS, 3 * d, d) && fp8_shape_ok(x, rowsS, d, d) && fp8_shape_ok(x, rowsS, 4 * d, d) &&
                           fp8_shape_ok(x, rowsS, d, 4 * d);
     if (img_mode && l0 == 0) {
-        if (h->f8_passes > 0) RUN(dist_op_fp8_scale_update(h->f8_amax, h->f8_scale, 4 * c.layers, 4.0f, stream));   // last pass's maxima -> this pass's scales
+        if (h->f8_passes > 0) RUN(dist_op_fp8_scale_update(h->f8_amax, h->f8_scale, 5 * c.layers, 4.0f, stream));   // last pass's maxima -> this pass's scales
         h->x8_layer = -1;
     }
     const bool fused = img_mode && h->f8_passes > 0;      // the first pass after a pack calibrates: per-token quantisers + dist_op_amax
@@ -894,13 +894,17 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
             if (part_of_xin) RUN(dist_op_ln_stats_from_partials(h->lnpart, d / 64, rowsS, d, 1e-5f, h->lnstats, h->lnstats + rowsS, stream));
             else RUN(ln_fwd(x, h->visual, v.ln1, xin, nullptr, rowsS, h->lnstats, h->lnstats + rowsS));
             if (f8 & 1) {                                  // e4m3 image of the raw rows, then the folded GEMM on the block-scaled fp8 MFMA
+                Out8 q8o;                                  // image mode: q | k | v leave as e4m3 ONLY (head-major bytes in h->qkv)
+                if (fused) { q8o.img = static_cast<unsigned char*>(h->qkv); q8o.scale = h->f8_scale + 5 * i + 4; q8o.amax = h->f8_amax + 5 * i + 4; }
+                void* qkv16 = fused ? nullptr : h->qkv;
                 if (fused && i > 0 && h->x8_layer == i - 1) {     // the previous block's c_proj left the image
-                    folded = gemm_fp8(x, h->x8, h->f8_scale + 4 * (i - 1) + 2, true, v.q_qkv, rowsS, 3 * d, d, h->qkv, 64, v.b_qkv, nullptr, nullptr, h->lnstats, v.cs8_qkv, nullptr,
-                                      OM(DIST_OM_HEADS, L, h->heads));
+                    folded = gemm_fp8(x, h->x8, h->f8_scale + 5 * (i - 1) + 2, true, v.q_qkv, rowsS, 3 * d, d, qkv16, 64, v.b_qkv, nullptr, nullptr, h->lnstats, v.cs8_qkv, nullptr,
+                                      OM(DIST_OM_HEADS, L, h->heads), q8o);
                 } else {
                     RUN(dist_op_quant_rows_fp8(xin, DIST_BF16, rowsS, d, d, h->aq, d, h->sa, stream));
-                    folded = gemm_fp8(x, h->aq, h->sa, false, v.q_qkv, rowsS, 3 * d, d, h->qkv, 64, v.b_qkv, nullptr, nullptr, h->lnstats, v.cs8_qkv, nullptr, OM(DIST_OM_HEADS, L, h->heads));
+                    folded = gemm_fp8(x, h->aq, h->sa, false, v.q_qkv, rowsS, 3 * d, d, qkv16, 64, v.b_qkv, nullptr, nullptr, h->lnstats, v.cs8_qkv, nullptr, OM(DIST_OM_HEADS, L, h->heads), q8o);
                 }
+                if (img_mode && !fused && folded > 0) RUN(dist_op_amax(h->qkv, DIST_BF16, rowsS * 3 * d, h->f8_amax + 5 * i + 4, stream));
                 if (folded < 0) return fail(h, folded, "fp8 QKV GEMM failed");
             }
             if (!folded) folded = gemm_lnfold(x, xin, d, x.pk(v.pk_fold_qkv), rowsS, 3 * d, d, h->qkv, 64, v.b_qkv, h->lnstats, v.cs_qkv, nullptr, OM(DIST_OM_HEADS, L, h->heads));
@@ -910,20 +914,20 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
             RUN(ln_fwd(x, h->visual, v.ln1, xin, h->hbuf, rowsS, nullptr, nullptr));
             RUN(gemm(x, h->hbuf, d, x.pk(v.qkv.pk.f), rowsS, 3 * d, d, 1, h->qkv, 64, x.vs(v.qkv.bias), nullptr, nullptr, nullptr, RM(), OM(DIST_OM_HEADS, L, h->heads)));
         }
-        if (fused) RUN(dist_op_attention_out8(h->qkv, h->aq, h->f8_scale + 4 * i + 3, h->f8_amax + 4 * i + 3, b * h->t, L, h->heads, DIST_QKV_HEADS, stream));
+        if (fused) RUN(dist_op_attention_fp8(h->qkv, h->f8_scale + 5 * i + 4, nullptr, h->aq, h->f8_scale + 5 * i + 3, h->f8_amax + 5 * i + 3, b * h->t, L, h->heads, stream));
         else RUN(dist_op_attention(h->qkv, h->att, b * h->t, L, h->heads, DIST_QKV_HEADS, c.dtype, stream));
         int done8 = 0;
         if (f8 & 2) {
             if (fused) {                                   // the attention kernel left the e4m3 image in h->aq
                 Out8 o8;
-                o8.img = h->xa8; o8.scale = h->f8_scale + 4 * i; o8.amax = h->f8_amax + 4 * i;
-                done8 = gemm_fp8(x, h->aq, h->f8_scale + 4 * i + 3, true, v.q_out, rowsS, d, d, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr, nullptr, rs ? h->lnpart : nullptr, OM(), o8);
+                o8.img = h->xa8; o8.scale = h->f8_scale + 5 * i; o8.amax = h->f8_amax + 5 * i;
+                done8 = gemm_fp8(x, h->aq, h->f8_scale + 5 * i + 3, true, v.q_out, rowsS, d, d, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr, nullptr, rs ? h->lnpart : nullptr, OM(), o8);
             } else {
                 RUN(dist_op_quant_rows_fp8(h->att, DIST_BF16, rowsS, d, d, h->aq, d, h->sa, stream));
                 done8 = gemm_fp8(x, h->aq, h->sa, false, v.q_out, rowsS, d, d, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr, nullptr, rs ? h->lnpart : nullptr);
                 if (img_mode && done8 > 0) {
-                    RUN(dist_op_amax(h->xa, DIST_BF16, rowsS * d, h->f8_amax + 4 * i, stream));
-                    RUN(dist_op_amax(h->att, DIST_BF16, rowsS * d, h->f8_amax + 4 * i + 3, stream));
+                    RUN(dist_op_amax(h->xa, DIST_BF16, rowsS * d, h->f8_amax + 5 * i, stream));
+                    RUN(dist_op_amax(h->att, DIST_BF16, rowsS * d, h->f8_amax + 5 * i + 3, stream));
                 }
             }
             if (done8 < 0) return fail(h, done8, "fp8 out-projection GEMM failed");
@@ -936,12 +940,12 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
             if (f8 & 4) {
                 if (fused) {                               // input: the image out_proj left; output: the QuickGELU'd hidden tensor as e4m3 ONLY (h->aq)
                     Out8 o8;
-                    o8.img = h->aq; o8.scale = h->f8_scale + 4 * i + 1; o8.amax = h->f8_amax + 4 * i + 1; o8.act = true;
-                    folded = gemm_fp8(x, h->xa8, h->f8_scale + 4 * i, true, v.q_fc, rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, nullptr, nullptr, h->lnstats, v.cs8_fc, nullptr, OM(), o8);
+                    o8.img = h->aq; o8.scale = h->f8_scale + 5 * i + 1; o8.amax = h->f8_amax + 5 * i + 1; o8.act = true;
+                    folded = gemm_fp8(x, h->xa8, h->f8_scale + 5 * i, true, v.q_fc, rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, nullptr, nullptr, h->lnstats, v.cs8_fc, nullptr, OM(), o8);
                 } else {
                     RUN(dist_op_quant_rows_fp8(h->xa, DIST_BF16, rowsS, d, d, h->aq, d, h->sa, stream));
                     folded = gemm_fp8(x, h->aq, h->sa, false, v.q_fc, rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, nullptr, h->mlp, h->lnstats, v.cs8_fc, nullptr);
-                    if (img_mode && folded > 0) RUN(dist_op_amax(h->mlp, DIST_BF16, rowsS * 4 * d, h->f8_amax + 4 * i + 1, stream));
+                    if (img_mode && folded > 0) RUN(dist_op_amax(h->mlp, DIST_BF16, rowsS * 4 * d, h->f8_amax + 5 * i + 1, stream));
                 }
                 if (folded < 0) return fail(h, folded, "fp8 MLP GEMM failed");
             }
@@ -956,14 +960,14 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
         if (f8 & 8) {
             if (fused) {
                 Out8 o8;
-                o8.img = h->x8; o8.scale = h->f8_scale + 4 * i + 2; o8.amax = h->f8_amax + 4 * i + 2;
-                done8 = gemm_fp8(x, h->aq, h->f8_scale + 4 * i + 1, true, v.q_proj, rowsS, d, 4 * d, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr, nullptr,
+                o8.img = h->x8; o8.scale = h->f8_scale + 5 * i + 2; o8.amax = h->f8_amax + 5 * i + 2;
+                done8 = gemm_fp8(x, h->aq, h->f8_scale + 5 * i + 1, true, v.q_proj, rowsS, d, 4 * d, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr, nullptr,
                                  rs ? h->lnpart : nullptr, OM(), o8);
                 if (done8 > 0) h->x8_layer = i;
             } else {
                 RUN(dist_op_quant_rows_fp8(h->mlp, DIST_BF16, rowsS, 4 * d, 4 * d, h->aq, 4 * d, h->sa, stream));
                 done8 = gemm_fp8(x, h->aq, h->sa, false, v.q_proj, rowsS, d, 4 * d, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr, nullptr, rs ? h->lnpart : nullptr);
-                if (img_mode && done8 > 0) RUN(dist_op_amax(S.feat[i], DIST_BF16, rowsS * d, h->f8_amax + 4 * i + 2, stream));
+                if (img_mode && done8 > 0) RUN(dist_op_amax(S.feat[i], DIST_BF16, rowsS * d, h->f8_amax + 5 * i + 2, stream));
             }
             if (done8 < 0) return fail(h, done8, "fp8 MLP projection GEMM failed");
         }

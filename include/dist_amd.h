@@ -279,7 +279,8 @@ typedef struct dist_config {
                            * the GEMM): 1 = attn.in_proj, 2 = attn.out_proj, 4 = mlp.c_fc, 8 = mlp.c_proj; 0 = bf16 everywhere.
                            * 16 (with all of 1 | 2 | 4 | 8): the producing epilogues write the e4m3 images themselves (DIST_EPI_OUT8, per-tensor
                            * power-of-two scales from the previous pass's maxima; the first pass after a pack calibrates with the per-token
-                           * quantisers) - the hidden tensor of the MLP then exists as e4m3 only */
+                           * quantisers) - the hidden tensor of the MLP, the q | k | v tensor and the attention output then exist as e4m3
+                           * only */
 } dist_config;
 
 typedef struct dist_handle dist_handle;

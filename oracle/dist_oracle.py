@@ -136,6 +136,9 @@ class Oracle:
         else:
             h = self.rnd(layer_norm(x, p[pre + "ln_1.weight"], p[pre + "ln_1.bias"]))
             qkv = self.rnd(h @ self.w(pre + "attn.in_proj_weight").t() + p[pre + "attn.in_proj_bias"])
+        if f8 & 1 and img:                                   # image mode: q | k | v exist as e4m3 only (one power-of-two scale for the tensor)
+            q8, s8 = self._fp8_rows(qkv.reshape(-1, qkv.shape[-1]), True)
+            qkv = (q8.view(torch.float8_e4m3fn).to(self.dtype) * s8[:, None].to(self.dtype)).reshape(qkv.shape)
         q, k, v = qkv.reshape(b * t, L, 3, g.heads, 64).permute(2, 0, 3, 1, 4)   # [bt,h,L,64]
         att = torch.softmax((q @ k.transpose(-1, -2)) / 8.0, dim=-1)
         o = self.rnd((att @ v).permute(0, 2, 1, 3).reshape(b, t, L, d))
