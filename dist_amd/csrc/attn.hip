@@ -217,12 +217,12 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = s * 32 + t * 16 + lg * 4 + r;
-                        st[t][r] = key < L ? st[t][r] * sc_qk : -1e30f;
+                        st[t][r] = key < L ? st[t][r] : -1e30f;   // raw products: the scale (> 0) commutes with the maximum ...
                         mx = fmaxf(mx, st[t][r]);
                     }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                const float mnew = fmaxf(mrun[u], mx);
+                const float mnew = fmaxf(mrun[u], mx * sc_qk);
                 const float scale = __builtin_amdgcn_exp2f(mrun[u] - mnew);
                 mrun[u] = mnew;
                 Frag<T> fp;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float pv = __builtin_amdgcn_exp2f(st[t][r] - mnew);   // (a masked key holds -1e30: 2^(-1e30 - max) is exactly 0)
+                        const float pv = __builtin_amdgcn_exp2f(fmaf(st[t][r], sc_qk, -mnew));   // ... and folds into one fma per score; a masked key holds -1e30: exactly 0
                         ps += pv;
                         frag_set(fp, t * 4 + r, pv);
                     }
