@@ -151,6 +151,21 @@ __global__ __launch_bounds__(WI * WJ * 64) void gemm_tn_kernel(const dist_gemm_t
         b_q[i] = PLAIN ? RowPrep{0, 0} : rowmap_prep(bmap, b_mm[i]);
     }
     int ld_m = mbeg;                               // first row of the tile the next gload fetches (wave-uniform)
+    // Plain maps, a tile inside both matrices and a whole number of step PAIRS: every cell of every step is valid (the launcher rounds
+    // the row chunks to 2 * BR for these instantiations, so only the split that holds row M - 1 can differ).  The validity flags and
+    // the zeroing of invalid cells - 56 v_cndmask + the flag arithmetic per two steps, in a loop that issues ~190 VALU for 32 MFMAs -
+    // are skipped on a block-uniform branch.
+    const bool all_ok = PLAIN && (mend - mbeg) % (2 * BR) == 0 && i0 + BI <= p.NI && c0 + BJ <= p.K && (BR * VI) % NT == 0 && (BR * VJ) % NT == 0;
+    f32x4 acc[FI][FJ];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = (mend - mbeg + BR - 1) / BR;
+    // (a generic lambda instantiated for both values: as a runtime flag hipcc folds it into the selects instead of branching around them)
+    auto run = [&](auto okc) __attribute__((always_inline)) {
+    constexpr bool OK = decltype(okc)::value;
     auto gload = [&](Regs& R) __attribute__((always_inline)) {
         R.oka = 0; R.okb = 0;
 #pragma unroll
@@ -159,7 +174,7 @@ __global__ __launch_bounds__(WI * WJ * 64) void gemm_tn_kernel(const dist_gemm_t
             const int m = ld_m + v / VI, col = i0 + (v % VI) * 8;
             const int cc = min(col, p.NI - 8);
             const int src = PLAIN ? a_mm[i] : rowmap_src2(amap, a_mm[i], a_q[i], 0, 1);
-            if (m < mend && col < p.NI && src >= 0) R.oka |= 1u << i;
+            if (!OK && m < mend && col < p.NI && src >= 0) R.oka |= 1u << i;
             frag_load(R.a[i], A + (long)max(src, 0) * p.lda + cc);
             if (m + BR < mend) {                                             // the cell's next row is still inside the chunk
                 a_mm[i] = m + BR;
@@ -172,7 +187,7 @@ __global__ __launch_bounds__(WI * WJ * 64) void gemm_tn_kernel(const dist_gemm_t
             const int m = ld_m + v / VJ, col = c0 + (v % VJ) * 8;
             const int cc = min(col, kvec_last);
             const int src = PLAIN ? b_mm[i] : rowmap_src2(bmap, b_mm[i], b_q[i], tap, p.taps);
-            if (m < mend && col < p.K && src >= 0) R.okb |= 1u << i;
+            if (!OK && m < mend && col < p.K && src >= 0) R.okb |= 1u << i;
             frag_load(R.b[i], B + (long)max(src, 0) * p.ldb + cc);
             if (m + BR < mend) {
                 b_mm[i] = m + BR;
@@ -185,7 +200,7 @@ __global__ __launch_bounds__(WI * WJ * 64) void gemm_tn_kernel(const dist_gemm_t
 #pragma unroll
         for (int i = 0; i < I_IT; ++i) {
             const int v = tid + i * NT;
-            if (!((R.oka >> i) & 1u)) frag_zero(R.a[i]);
+            if (!OK && !((R.oka >> i) & 1u)) frag_zero(R.a[i]);
             if ((BR * VI) % NT != 0 && v >= BR * VI) continue;
             frag_store(R.a[i], Ys + (buf * BR + v / VI) * LDI + (v % VI) * 8);
             if (do_colsum) {
@@ -196,19 +211,12 @@ __global__ __launch_bounds__(WI * WJ * 64) void gemm_tn_kernel(const dist_gemm_t
 #pragma unroll
         for (int i = 0; i < J_IT; ++i) {
             const int v = tid + i * NT;
-            if (!((R.okb >> i) & 1u)) frag_zero(R.b[i]);
+            if (!OK && !((R.okb >> i) & 1u)) frag_zero(R.b[i]);
             if ((BR * VJ) % NT != 0 && v >= BR * VJ) continue;
             frag_store(R.b[i], Xs + (buf * BR + v / VJ) * LDJ + (v % VJ) * 8);
         }
     };
 
-    f32x4 acc[FI][FJ];
-#pragma unroll
-    for (int i = 0; i < FI; ++i)
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nsteps = (mend - mbeg + BR - 1) / BR;
     auto body = [&](Regs& R, int st) __attribute__((always_inline)) {
         const int buf = st & 1;
         sstore(R, buf);                                   // waits for this set's loads only
@@ -240,6 +248,8 @@ __global__ __launch_bounds__(WI * WJ * 64) void gemm_tn_kernel(const dist_gemm_t
         body(r0, st);
         body(r1, st + 1);
     }
+    };
+    if (all_ok) run(std::true_type{}); else run(std::false_type{});
     __syncthreads();                                      // the tiles are dead: LDS is reused by the bias-gradient reduction
 
     if (do_colsum) {
@@ -357,7 +367,9 @@ int launch(const dist_gemm_tn_args& a, hipStream_t s) {
     if (msplit > max_split) msplit = max_split;
     if (msplit < 1) msplit = 1;
     int chunk = (int)((a.M + msplit - 1) / msplit);
-    chunk = (chunk + BR - 1) / BR * BR;
+    static const bool pairs = !(getenv("DIST_AMD_TN_PAIRS") && atoi(getenv("DIST_AMD_TN_PAIRS")) == 0);   // measurement knob: 0 = no fast path
+    const int CH = (MODES == 0 && pairs) ? 2 * BR : BR;   // plain maps: whole step pairs per block (the kernel's all-valid fast path)
+    chunk = (chunk + CH - 1) / CH * CH;
     msplit = (a.M + chunk - 1) / chunk;
     dist_gemm_tn_args b = a;
     const bool two_phase = a.partial != nullptr && msplit > 1 && tiles * msplit * (long)(BI * BJ) + msplit * (long)tiles_i * BI <= a.partial_elems;
