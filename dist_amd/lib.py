@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdist_amd.so")
+LIB_PATH = os.environ.get("DIST_AMD_LIB") or os.path.join(_HERE, "csrc", "libdist_amd.so")   # DIST_AMD_LIB: another build of the same ABI (A/B measurements)
 
 F32, BF16 = 0, 1
 RM_PLAIN, RM_SHIFT, RM_SPATIAL, RM_STRIDED, RM_SKIPCLS = range(5)
