@@ -137,7 +137,9 @@ __global__ __launch_bounds__(WI * WJ * 64) void gemm_tn_kernel(const dist_gemm_t
     struct Regs { Frag<T> a[I_IT], b[J_IT]; unsigned oka, okb; };
     int a_mm[I_IT], b_mm[J_IT];                    // clamped row (address side) of each cell
     RowPrep a_q[I_IT], b_q[J_IT];
-    const bool a_inc = PLAIN || rowmap_inc_ok(amap, BR), b_inc = PLAIN || rowmap_inc_ok(bmap, BR);
+    // (constant-mode instantiations are only launched when the maps can be stepped - the launcher checks: with `inc` a runtime
+    // flag hipcc evaluated BOTH arms of `inc ? rowmap_step : rowmap_prep` every step, i.e. the modulo / divides the stepping replaced)
+    const bool a_inc = PLAIN || MODES > 0 || rowmap_inc_ok(amap, BR), b_inc = PLAIN || MODES > 0 || rowmap_inc_ok(bmap, BR);
 #pragma unroll
     for (int i = 0; i < I_IT; ++i) {
         const int v = min(tid + i * NT, BR * VI - 1);
@@ -422,7 +424,16 @@ int dispatch(const dist_gemm_tn_args& a, hipStream_t s) {
         static const int w8 = getenv("DIST_AMD_TN_W8") ? atoi(getenv("DIST_AMD_TN_W8")) : 1;
         static const int spec = getenv("DIST_AMD_TN_MODES") ? atoi(getenv("DIST_AMD_TN_MODES")) : 1;   // 0: runtime modes (measurement knob)
         const int modes = a.amap.mode * 8 + a.bmap.mode;
-        if (w8 && spec) switch (modes) {
+        auto steppable = [](const dist_rowmap& rm) {       // rowmap_inc_ok for a step of BR rows
+            switch (rm.mode) {
+                case DIST_RM_SHIFT: return BR <= rm.p0;
+                case DIST_RM_SPATIAL: return rm.p0 > 0 && BR / rm.p0 + 1 <= rm.p0;
+                case DIST_RM_STRIDED: return BR <= rm.p1;
+                case DIST_RM_SKIPCLS: return BR <= rm.p0;
+                default: return true;
+            }
+        };
+        if (w8 && spec && steppable(a.amap) && steppable(a.bmap)) switch (modes) {
             case DIST_RM_SHIFT: return dispatch2<T, TR, DIST_RM_SHIFT>(a, s);
             case DIST_RM_SPATIAL: return dispatch2<T, TR, DIST_RM_SPATIAL>(a, s);
             case DIST_RM_SKIPCLS: return dispatch2<T, TR, DIST_RM_SKIPCLS>(a, s);
