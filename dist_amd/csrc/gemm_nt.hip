@@ -381,7 +381,9 @@ template <int VPR> DEV unsigned nt_pre_off(const int v, const int mw, const int 
     const int m = mw + row, n = nw + vec * 8;
     return (m < M && n < N) ? ((unsigned)m * (unsigned)ld + (unsigned)n) * 2u : 0x80000000u;
 }
-template <int BM, int BN, int WM, int WN, bool GENERIC, int MINW>
+// OGEN = false: the output map is known to be plain at compile time (the epilogue's row-piece loops then carry no code for the other maps -
+// their divides - at all; as a runtime mode hipcc keeps them in the loop bodies behind branches or selects)
+template <int BM, int BN, int WM, int WN, bool GENERIC, int MINW, bool OGEN = true>
 __global__ __launch_bounds__(512, MINW) void gemm_nt_dma_kernel(const dist_gemm_args p, const int rotate) {
     using T = bf16_t;
     constexpr int BK = 32, STAGES = 3, BNP = 128;
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_dma_kernel(const dist_gemm_
         const bool first_aux = (flags & DIST_EPI_MULG) && !(flags & DIST_EPI_MULG_POST);
         const void* src = first_aux ? p.aux : ((flags & DIST_EPI_RES) ? p.res : nullptr);
         const int ld = first_aux ? p.ldaux : p.ldres;
-        const int om = GENERIC ? p.omap.mode : (int)DIST_OM_PLAIN;
+        const int om = OGEN ? p.omap.mode : (int)DIST_OM_PLAIN;
         if (src && om == DIST_OM_PLAIN && (long)M * ld < (1l << 30) && !(rotate & 2)) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src), 0, (int)((long)M * ld * 2), 0x00020000);
             const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
@@ -510,16 +512,16 @@ __global__ __launch_bounds__(512, MINW) void gemm_nt_dma_kernel(const dist_gemm_
             pre = true;
         }
     }
-    nt_epilogue<T, BM, BN, WM, WN, GENERIC, true>(p, acc, smem, m0, n0, region, pre);
+    nt_epilogue<T, BM, BN, WM, WN, OGEN, true>(p, acc, smem, m0, n0, region, pre);
 }
 
-template <int BM, int BN, int WM, int WN, bool GENERIC, int MINW>
+template <int BM, int BN, int WM, int WN, bool GENERIC, int MINW, bool OGEN = true>
 int launch_dma(const dist_gemm_args& a, hipStream_t s) {
     constexpr size_t ring = (size_t)3 * (BM + 128) * 64;
     constexpr size_t stag = (size_t)WM * WN * (BM / WM) * ((BN / WN) * 2 + 16);
     constexpr size_t smem = ring > stag ? ring : stag;
     static bool attr_done = false;
-    auto kern = gemm_nt_dma_kernel<BM, BN, WM, WN, GENERIC, MINW>;
+    auto kern = gemm_nt_dma_kernel<BM, BN, WM, WN, GENERIC, MINW, OGEN>;
     if (!attr_done) {
         HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_done = true;
@@ -567,9 +569,12 @@ int dispatch(const dist_gemm_args& a, hipStream_t s) {
         // LDS-DMA loader (three stages in flight, no staging registers).  DIST_AMD_NT_DMA=0: the register-staged loader.
         static const int dma = getenv("DIST_AMD_NT_DMA") ? atoi(getenv("DIST_AMD_NT_DMA")) : 1;
         if (dma && a.K % 32 == 0) {
-            if (n96 && a.N == 96 && a.M > 768l * 128) return launch_dma<256, 96, 8, 1, true, 4>(a, s);     // 392 blocks: one round of 2 per CU
-            if (n96) return launch_dma<128, 96, 4, 2, true, 6>(a, s);
-            return launch_dma<128, 128, 2, 4, true, 6>(a, s);
+            static const bool oplain_on = !(getenv("DIST_AMD_NT_OPLAIN") && atoi(getenv("DIST_AMD_NT_OPLAIN")) == 0);   // measurement knob
+            const bool op = oplain_on && a.omap.mode == DIST_OM_PLAIN;
+            if (n96 && a.N == 96 && a.M > 768l * 128)                                                      // 392 blocks: one round of 2 per CU
+                return op ? launch_dma<256, 96, 8, 1, true, 4, false>(a, s) : launch_dma<256, 96, 8, 1, true, 4>(a, s);
+            if (n96) return op ? launch_dma<128, 96, 4, 2, true, 6, false>(a, s) : launch_dma<128, 96, 4, 2, true, 6>(a, s);
+            return op ? launch_dma<128, 128, 2, 4, true, 6, false>(a, s) : launch_dma<128, 128, 2, 4, true, 6>(a, s);
         }
         // A block is a serial chain of latency-bound K-tile steps, so a launch takes (rounds of resident blocks) x (one block's
         // time): 100 352 rows as 128-row tiles are 784 blocks on 768 resident slots (256 CUs x 3) - TWO rounds for 16 blocks.
