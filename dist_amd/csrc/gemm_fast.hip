@@ -140,19 +140,20 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
     // C tiles are written once and read by a later kernel: streaming stores keep them from evicting the A / B panels that
     // the other column tiles on this XCD are still re-reading from L2 (QKV: 208 -> 189 us, FETCH_SIZE 350 -> 264 MB)
     auto flush = [&](bf16_t* __restrict__ dst, int ld) {
+        // head-major rows: (frame, token) of the lane's first row by ONE division, then stepped by 8 rows per piece (16 divisions per
+        // lane and tile were ~400 VALU of the QKV epilogue)
+        int hfr = 0, htok = 0;
+        if (heads_om) { hfr = (mw + crow) / p.omap.p0; htok = (mw + crow) - hfr * p.omap.p0; }
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int r = it * 8 + crow;
             const int m = mw + r, n = nw + cchunk * 8;
             const uint4 v = *reinterpret_cast<const uint4*>(ew + r * 128 + ((cchunk ^ (r & 7)) << 4));
             if (m < M && n < N) {
-                if (heads_om) {
-                    const int fr = m / p.omap.p0, tok = m - fr * p.omap.p0;
-                    store16_nt(dst + ((((long)fr * p.omap.p1 + hp_head) * 3 + hp_part) * p.omap.p0 + tok) * 64 + cchunk * 8, v);
-                } else {
-                    store16_nt(dst + dest_row(m) * ld + n, v);
-                }
+                if (heads_om) store16_nt(dst + ((((long)hfr * p.omap.p1 + hp_head) * 3 + hp_part) * p.omap.p0 + htok) * 64 + cchunk * 8, v);
+                else store16_nt(dst + dest_row(m) * ld + n, v);
             }
+            if (heads_om) { htok += 8; if (htok >= p.omap.p0) { htok -= p.omap.p0; ++hfr; } }      // (the launcher checks p0 >= 16)
         }
     };
     // DIST_EPI_OUT8: the staged bf16 tile (what C, or C2 with the activation, holds) leaves a second time as e4m3 with the caller's per-tensor
@@ -184,19 +185,19 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
                 *reinterpret_cast<int*>(ew + r * 128 + (((j ^ (r & 3)) + ((r >> 2) & 1) * 4) << 4) + lg * 4) = w;   // piece j of row r: spread over the banks
             }
         }
+        int hfr = 0, htok = 0;
+        if (heads_om) { hfr = (mw + (lane >> 2)) / p.omap.p0; htok = (mw + (lane >> 2)) - hfr * p.omap.p0; }
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int r = it * 16 + (lane >> 2), pc = lane & 3;
             const int m = mw + r, n = nw + pc * 16;
             const uint4 v = *reinterpret_cast<const uint4*>(ew + r * 128 + (((pc ^ (r & 3)) + ((r >> 2) & 1) * 4) << 4));
             if (m < M && n < N) {
-                if (heads_om) {                           // [frame][head][q|k|v][token][64] bytes: this wave's 64 columns are one (part, head) slice
-                    const int fr = m / p.omap.p0, tok = m - fr * p.omap.p0;
-                    store16_nt(C8 + ((((long)fr * p.omap.p1 + hp_head) * 3 + hp_part) * p.omap.p0 + tok) * 64 + pc * 16, v);
-                } else {
-                    store16_nt(C8 + (long)m * p.ldc8 + n, v);
-                }
+                // [frame][head][q|k|v][token][64] bytes: this wave's 64 columns are one (part, head) slice
+                if (heads_om) store16_nt(C8 + ((((long)hfr * p.omap.p1 + hp_head) * 3 + hp_part) * p.omap.p0 + htok) * 64 + pc * 16, v);
+                else store16_nt(C8 + (long)m * p.ldc8 + n, v);
             }
+            if (heads_om) { htok += 16; if (htok >= p.omap.p0) { htok -= p.omap.p0; ++hfr; } }
         }
         if (p.out8_amax) {
             amax = wave_max(amax, 64);
@@ -702,7 +703,7 @@ static bool fast_common_ok(const dist_gemm_args* a) {
         if (!a->a_scale || !a->b_scale || a->amap.mode != DIST_RM_PLAIN || a->K % 128 || a->K < 256 || a->lda % 16 || a->ldb % 16) return false;
         if (a->N < 256 || (a->N % 256 > 0 && a->N % 256 < 128)) return false;
     }
-    if (a->omap.mode == DIST_OM_HEADS && (a->flags & (DIST_EPI_RES | DIST_EPI_ACT2))) return false;
+    if (a->omap.mode == DIST_OM_HEADS && ((a->flags & (DIST_EPI_RES | DIST_EPI_ACT2)) || a->omap.p0 < 16)) return false;   // (rows stepped by 8 / 16 tokens)
     const long a_rows = a->amap.mode == DIST_RM_PLAIN ? a->M : 2 * a->M + a->M / 64 + 64;   // generous bound for the strided / skip-cls images
     if (a_rows * a->lda >= (1l << 30) || (long)a->N * a->ldb >= (1l << 30)) return false;     // 32-bit byte offsets
     return true;
