@@ -364,17 +364,32 @@ __global__ __launch_bounds__(NT) void pack_kernel(const PackDesc* __restrict__ d
         const int pitch = d.cols + (sizeof(T) == 2 ? 2 : 1);
         const bool fits = (long)rpb * pitch <= PACK_B_ELEMS + 2 * rpb;
         if (fits) {
-            for (int e = threadIdx.x; e < nr * d.cols; e += NT) {
-                const int cl = e % nr, c = e / nr;
-                const int ci = r0 + cl, tap = c / d.co, co = c % d.co;
-                float v = 0.f;
-                if (ci < d.kin) v = src[(long)co * d.s_co + (long)tap * d.s_tap + (long)(ci / d.inner) * d.s_outer + (ci % d.inner)];
-                tile[cl * pitch + c] = from_f<T>(v);
+            // (indices stepped by NT elements per iteration, one division per thread and loop: see the element loop below)
+            const bool one_tap = d.cols <= d.co;
+            {
+                const int dq = NT / nr, dm = NT - dq * nr;
+                int c = threadIdx.x / nr, cl = threadIdx.x - c * nr;
+                for (int e = threadIdx.x; e < nr * d.cols; e += NT) {
+                    const int ci = r0 + cl, tap = one_tap ? 0 : c / d.co, co = c - tap * d.co;
+                    float v = 0.f;
+                    if (ci < d.kin) {
+                        const int og = d.inner == 1 ? ci : ci / d.inner;
+                        v = src[(long)co * d.s_co + (long)tap * d.s_tap + (d.inner == 1 ? (long)ci * d.s_outer : (long)og * d.s_outer + (ci - og * d.inner))];
+                    }
+                    tile[cl * pitch + c] = from_f<T>(v);
+                    c += dq; cl += dm;
+                    if (cl >= nr) { cl -= nr; ++c; }
+                }
             }
             __syncthreads();
-            for (int e = threadIdx.x; e < nr * d.cols; e += NT) {
-                const int cl = e / d.cols, c = e % d.cols;
-                dst[(long)(r0 + cl) * d.cols + c] = tile[cl * pitch + c];
+            {
+                const int dq = NT / d.cols, dm = NT - dq * d.cols;
+                int cl = threadIdx.x / d.cols, c = threadIdx.x - cl * d.cols;
+                for (int e = threadIdx.x; e < nr * d.cols; e += NT) {
+                    dst[(long)(r0 + cl) * d.cols + c] = tile[cl * pitch + c];
+                    cl += dq; c += dm;
+                    if (c >= d.cols) { c -= d.cols; ++cl; }
+                }
             }
             return;
         }
@@ -386,16 +401,26 @@ __global__ __launch_bounds__(NT) void pack_kernel(const PackDesc* __restrict__ d
         }
         return;
     }
-    const long beg = (long)(blk - blk_first[di]) * PACK_PER_BLOCK;
-    const long end = min(total, beg + PACK_PER_BLOCK);
-    for (long i = beg + threadIdx.x; i < end; i += NT) {
-        const int r = (int)(i / d.cols), c = (int)(i % d.cols);
+    // (row, column) of a thread's first element by one division, then stepped by NT elements per iteration; taps and `inner` groups
+    // only divide where a weight has them (per element: a 64-bit and up to four 32-bit divisions made this pass VALU-bound, 6x its bytes)
+    const unsigned beg = (unsigned)(blk - blk_first[di]) * PACK_PER_BLOCK;
+    const unsigned end = (unsigned)min(total, (long)beg + PACK_PER_BLOCK);
+    const unsigned cols = (unsigned)d.cols, dr = NT / cols, dc = NT - dr * cols;
+    unsigned i = beg + threadIdx.x;
+    unsigned r = i / cols, c = i - r * cols;
+    const bool one_tap = d.layout == PACK_F ? d.cols <= d.kpad : d.rows <= d.kpad;
+    for (; i < end; i += NT) {
         int co, tap, ci;
-        if (d.layout == PACK_F) { co = r; tap = c / d.kpad; ci = c % d.kpad; }
-        else { tap = r / d.kpad; ci = r % d.kpad; co = c; }      // PACK_FT
+        if (d.layout == PACK_F) { co = (int)r; tap = one_tap ? 0 : (int)(c / (unsigned)d.kpad); ci = (int)c - tap * d.kpad; }
+        else { tap = one_tap ? 0 : (int)(r / (unsigned)d.kpad); ci = (int)r - tap * d.kpad; co = (int)c; }      // PACK_FT
         float v = 0.f;
-        if (ci < d.kin) v = src[(long)co * d.s_co + (long)tap * d.s_tap + (long)(ci / d.inner) * d.s_outer + (ci % d.inner)];
-        dst[d.dpitch ? (long)r * d.dpitch + c : i] = from_f<T>(v);
+        if (ci < d.kin) {
+            const int og = d.inner == 1 ? ci : ci / d.inner;
+            v = src[(long)co * d.s_co + (long)tap * d.s_tap + (d.inner == 1 ? (long)ci * d.s_outer : (long)og * d.s_outer + (ci - og * d.inner))];
+        }
+        dst[d.dpitch ? (long)r * d.dpitch + c : (long)i] = from_f<T>(v);
+        r += dr; c += dc;
+        if (c >= cols) { c -= cols; ++r; }
     }
 }
 
