@@ -209,6 +209,30 @@ def test_engine_fp8_producer_images_follow_the_oracle_after_the_calibration_pass
 
 
 @pytest.mark.gpu
+def test_engine_fp8_images_on_the_vit_l14_geometry(gpu_lib):
+    """BASELINE config 5's tower (ViT-L/14: width 1024, 16 heads, 257 tokens per frame, 24 blocks) at T = 8, b = 1 (1028 token rows - just
+    above the fp8 kernel's minimum): vit_fp8 = 31 after its calibration pass, two blocks against the oracle on the engine's own block inputs."""
+    from dist_oracle import Oracle
+    g, eng, sd, video, text, tgt = _engine("l14_tiny_t", 1, 31)
+    eng.forward_backward(video, text, tgt)
+    loss, logits = eng.forward_backward(video, text, tgt)
+    feats = {i: eng.debug(f"feat.{i}").clone().cpu().float() for i in (2, 3, 22, 23)}
+    o8, o16 = Oracle(g, sd, dtype=torch.float32, bf16=True, vit_fp8=31), Oracle(g, sd, dtype=torch.float32, bf16=True)
+    for i in (3, 23):
+        x_in = feats[i - 1].reshape(1, g.t, g.L, g.d)
+        with torch.no_grad():
+            r8, r16 = o8.vit_block(x_in, i), o16.vit_block(x_in, i)
+        e8, e16, q = _rel(feats[i], r8), _rel(feats[i], r16), _rel(r8, r16)
+        print(f"L/14 fp8 images block {i}: engine vs fp8 oracle {e8:.4f}, engine vs bf16 oracle {e16:.4f}, fp8 oracle vs bf16 oracle {q:.4f}")
+        assert e8 < 0.012 and e8 < 0.6 * q and e16 > 0.8 * q, (i, e8, e16, q)
+    g0, eng0, _, _, _, _ = _engine("l14_tiny_t", 1, 0)
+    loss0, logits0 = eng0.forward_backward(video, text, tgt)
+    gap = float((logits.float() - logits0.float()).abs().max())
+    print(f"L/14 fp8 images: logits vs bf16 engine {gap:.4f}")
+    assert 0 < gap < 0.3 and torch.isfinite(eng.grads).all() and abs(float(loss) - float(loss0)) < 0.05
+
+
+@pytest.mark.gpu
 def test_engine_fp8_mode_falls_back_to_bf16_for_shapes_the_kernel_does_not_take(gpu_lib):
     """tiny geometry (width 128: K below the fp8 kernel's 256): the mode is accepted and every GEMM runs in bf16 - bit-identical results"""
     g, eng, sd, video, text, tgt = _engine("tiny", 2, 31)
