@@ -3,6 +3,7 @@
 // vectors of the row in registers, statistics are fp32 (reference clip.py:181-187).
 // Forward can add a periodic fp32 table first (cls/positional embedding, clip.py:274-276)
 // and can emit a second affine output sharing the statistics (dist.py:43-45).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -320,7 +321,8 @@ extern "C" int dist_op_layernorm_bwd(const dist_ln_bwd_args* a, void* stream) {
     // same-line atomic traffic, not HBM, sets the time, so fewer, longer blocks win (measured, tools/bench_ln2.py:
     // dual-input 62 -> 52 us at 256 blocks, single-input 42 -> 33 us at 384); without them 1024 blocks stream best
     const bool want_w = a->dw || a->db || a->dw2 || a->db2;
-    const long gcap = !want_w ? 1024 : (a->dy2 ? 256 : 384);
+    static const int gcap_env = getenv("DIST_AMD_LN_GCAP") ? atoi(getenv("DIST_AMD_LN_GCAP")) : 0;     // measurement knob
+    const long gcap = gcap_env > 0 ? gcap_env : (!want_w ? 1024 : (a->dy2 ? 256 : 384));
     if (g > gcap) g = gcap;
     const int grid = (int)g;
     const bool dual = a->dy2 != nullptr;
