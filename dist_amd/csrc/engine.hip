@@ -665,7 +665,10 @@ extern "C" const char* dist_strerror(int code) {
         default: return code <= -1000 ? hipGetErrorString((hipError_t)(-code - 1000)) : "unknown error";
     }
 }
-extern "C" int dist_abi_version(void) { return 6; }   // 5: dist_gemm_args.rowstats, marks, mixup, evaluation side; 6: fp8 operands (a_scale / b_scale, DIST_EPI_FP8)
+// 5: dist_gemm_args.rowstats, marks, mixup, evaluation side; 6: fp8 operands (a_scale / b_scale, DIST_EPI_FP8);
+// 7: dist_config.vit_fp8 and dist_gemm_args.C8 / ldc8 / out8_scale / out8_amax (both structs grew after 6 without a bump), vit_fp8 range-checked.
+// Rule: EVERY change of a public struct's layout bumps this number (dist_amd/lib.py and tests/test_abi_and_host.py pin it).
+extern "C" int dist_abi_version(void) { return 7; }
 extern "C" int dist_abi_sizeof(const char* n) {
     if (!n) return -1;
 #define DIST_SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)
@@ -685,6 +688,9 @@ extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
     if (c.int_temporal_div <= 0 || c.integration_dim % c.int_temporal_div || (c.integration_dim / c.int_temporal_div) % 8) return DIST_ERR_ARG;
     if (c.temporal_kernel % 2 == 0 || c.temporal_patch % 2 == 0 || c.num_classes <= 0 || c.embed_dim % 8 || c.embed_dim > 1024) return DIST_ERR_ARG;
     if (c.width > 1024 || c.integration_dim > 1024) return DIST_ERR_ARG;
+    // vit_fp8: bits 1 | 2 | 4 | 8 select GEMMs, 16 needs all four; bf16 engines only (a binding built against the 17-field struct of
+    // ABI <= 6 hands over 4 bytes of garbage here: refuse instead of silently switching the frozen ViT to e4m3)
+    if ((c.vit_fp8 & ~31) || (c.vit_fp8 && c.dtype != DIST_BF16) || ((c.vit_fp8 & 16) && (c.vit_fp8 & 15) != 15)) return DIST_ERR_ARG;
     dist_handle* h = new (std::nothrow) dist_handle();
     if (!h) return DIST_ERR_ARG;
     h->cfg = c;

@@ -719,7 +719,7 @@ static int fast_variant(const dist_gemm_args* a) {
     // measured (tools/bench_fastk.py, profiles/r01_fast_gemm_shapes.md): the two-block shape hides ~40 % of the fixed
     // per-block cost but its K loop is ~30 % slower (prefetch depth 2, 1.5x the LDS-DMA pieces per FLOP) - it loses on
     // every ViT shape, so it only runs when asked for
-    if (forced == 4 && ok4) return 4;
+    if (forced == 4 && ok4 && !(a->flags & DIST_EPI_FP8)) return 4;     // (the e4m3 mode exists in the 8-wave kernel only)
     return ok8 ? 8 : 0;
 }
 

@@ -11,6 +11,8 @@ the rank's clips (clip i with clip b-1-i, so ranks exchange nothing) and the sof
 Only MODE: batch is implemented (every DiST yaml uses it, configs/projects/dist/vit_*.yaml:22); the reference's
 elem / pair modes use `np.bool` (:146,191), which current numpy no longer has.
 """
+from typing import NamedTuple, Optional, Tuple
+
 import numpy as np
 import torch
 
@@ -19,12 +21,12 @@ from ... import ops
 
 def mixup_target(target, num_classes, lam=1.0, smoothing=0.0, device="cuda"):
     """y1 * lam + y2 * (1 - lam) over smoothed one-hot rows of target / target.flip(0) (reference :18-23)."""
-    return ops.mixup_target(_on_gpu(target, "target"), num_classes, lam, smoothing)
+    return ops.mixup_target(_labels_on_gpu(target), num_classes, lam, smoothing)
 
 
 def label_smoothing_target(target, num_classes, smoothing=0.0, device="cuda"):
     """smoothed one-hot rows (reference :25-29) = mixup_target with lam = 1 (y1*1 + y2*0 is exact)."""
-    return ops.mixup_target(_on_gpu(target, "target"), num_classes, 1.0, smoothing)
+    return ops.mixup_target(_labels_on_gpu(target), num_classes, 1.0, smoothing)
 
 
 def label_smoothing(cfg, target):
@@ -34,48 +36,68 @@ def label_smoothing(cfg, target):
     return label_smoothing_target(target, cfg.VIDEO.HEAD.NUM_CLASSES, cfg.AUGMENTATION.LABEL_SMOOTHING)
 
 
-def rand_bbox(img_shape, lam, margin=0.0, count=None):
-    """reference :43-64 (same np.random calls in the same order)"""
-    ratio = np.sqrt(1 - lam)
-    img_h, img_w = img_shape[-2:]
-    cut_h, cut_w = int(img_h * ratio), int(img_w * ratio)
-    margin_y, margin_x = int(margin * cut_h), int(margin * cut_w)
-    cy = np.random.randint(0 + margin_y, img_h - margin_y, size=count)
-    cx = np.random.randint(0 + margin_x, img_w - margin_x, size=count)
-    yl = np.clip(cy - cut_h // 2, 0, img_h)
-    yh = np.clip(cy + cut_h // 2, 0, img_h)
-    xl = np.clip(cx - cut_w // 2, 0, img_w)
-    xh = np.clip(cx + cut_w // 2, 0, img_w)
-    return yl, yh, xl, xh
+class MixPlan(NamedTuple):
+    """What one call does to the batch: kind "none" | "mixup" | "cutmix", the mixing weight that also builds the soft target,
+    and (cutmix) the box [y0, y1) x [x0, x1) that is swapped between clip i and clip b-1-i."""
+    kind: str
+    lam: float
+    box: Optional[Tuple[int, int, int, int]] = None
 
 
-def rand_bbox_minmax(img_shape, minmax, count=None):
-    """reference :67-86"""
-    assert len(minmax) == 2
-    img_h, img_w = img_shape[-2:]
-    cut_h = np.random.randint(int(img_h * minmax[0]), int(img_h * minmax[1]), size=count)
-    cut_w = np.random.randint(int(img_w * minmax[0]), int(img_w * minmax[1]), size=count)
-    yl = np.random.randint(0, img_h - cut_h, size=count)
-    xl = np.random.randint(0, img_w - cut_w, size=count)
-    return yl, yl + cut_h, xl, xl + cut_w
+def _span(centre, extent, limit):
+    """[centre - extent // 2, centre + extent // 2) cut to [0, limit]"""
+    half = extent // 2
+    return max(centre - half, 0), min(centre + half, limit)
 
 
-def cutmix_bbox_and_lam(img_shape, lam, ratio_minmax=None, correct_lam=True, count=None):
-    """reference :89-100"""
-    if ratio_minmax is not None:
-        yl, yu, xl, xu = rand_bbox_minmax(img_shape, ratio_minmax, count=count)
+def draw_plan(height, width, mixup_alpha, cutmix_alpha, mix_prob, switch_prob, minmax=None, enabled=True):
+    """Every random decision of one batch-mode call, drawn from numpy's GLOBAL generator in the reference's order
+    (dataset/utils/mixup.py:160-176 then :43-64 / :67-86; pinned draw by draw by tests/golden/mixup.npz):
+      1. rand()                     apply at all?            (skipped when disabled)
+      2. rand()                     cutmix instead of mixup? (only when both alphas are positive)
+      3. beta(a, a)                 the mixing weight, a = the chosen mode's alpha
+      4. cutmix box: randint(0, H), randint(0, W) -> centre of a box with sides int(H r), int(W r), r = sqrt(1 - lam), clipped by the
+         border; or, with `minmax`, randint for the two side lengths then for the two corners.
+    The weight that reaches the soft target is the area actually swapped (the reference's correct_lam=True, :96-99)."""
+    if not enabled or not (np.random.rand() < mix_prob):
+        return MixPlan("none", 1.0)
+    both = mixup_alpha > 0.0 and cutmix_alpha > 0.0
+    if not both and not (mixup_alpha > 0.0 or cutmix_alpha > 0.0):
+        raise AssertionError("One of mixup_alpha > 0., cutmix_alpha > 0., cutmix_minmax not None should be true.")
+    cut = (np.random.rand() < switch_prob) if both else not (mixup_alpha > 0.0)
+    alpha = cutmix_alpha if cut else mixup_alpha
+    lam = float(np.random.beta(alpha, alpha))
+    if lam == 1.0:
+        return MixPlan("none", 1.0)
+    if not cut:
+        return MixPlan("mixup", lam)
+    if minmax is not None:
+        lo, hi = minmax
+        box_h = int(np.random.randint(int(height * lo), int(height * hi)))
+        box_w = int(np.random.randint(int(width * lo), int(width * hi)))
+        y0 = int(np.random.randint(0, height - box_h))
+        x0 = int(np.random.randint(0, width - box_w))
+        y1, x1 = y0 + box_h, x0 + box_w
     else:
-        yl, yu, xl, xu = rand_bbox(img_shape, lam, count=count)
-    if correct_lam or ratio_minmax is not None:
-        bbox_area = (yu - yl) * (xu - xl)
-        lam = 1.0 - bbox_area / float(img_shape[-2] * img_shape[-1])
-    return (yl, yu, xl, xu), lam
+        r = np.sqrt(1 - lam)
+        box_h, box_w = int(height * r), int(width * r)
+        cy = int(np.random.randint(0, height))
+        cx = int(np.random.randint(0, width))
+        (y0, y1), (x0, x1) = _span(cy, box_h, height), _span(cx, box_w, width)
+    return MixPlan("cutmix", 1.0 - ((y1 - y0) * (x1 - x0)) / float(height * width), (y0, y1, x0, x1))
 
 
 def _on_gpu(t, what):
     if not (torch.is_tensor(t) and t.is_cuda):
         raise RuntimeError(f"Mixup: {what} must be a GPU tensor (the mix runs as HIP kernels; there is no CPU path)")
     return t
+
+
+def _labels_on_gpu(t):
+    """labels arrive from the loader as host tensors in the reference (runs/train.py:92-93): they are moved, the clips are not"""
+    if torch.is_tensor(t) and not t.is_cuda and torch.cuda.is_available():
+        t = t.cuda(non_blocking=True)
+    return _on_gpu(t, "target")
 
 
 class Mixup:
@@ -99,43 +121,25 @@ class Mixup:
         self.correct_lam = True
         self.mixup_enabled = True
 
-    def _params_per_batch(self):
-        """reference :160-176"""
-        lam = 1.0
-        use_cutmix = False
-        if self.mixup_enabled and np.random.rand() < self.mix_prob:
-            if self.mixup_alpha > 0.0 and self.cutmix_alpha > 0.0:
-                use_cutmix = np.random.rand() < self.switch_prob
-                lam_mix = np.random.beta(self.cutmix_alpha, self.cutmix_alpha) if use_cutmix else \
-                    np.random.beta(self.mixup_alpha, self.mixup_alpha)
-            elif self.mixup_alpha > 0.0:
-                lam_mix = np.random.beta(self.mixup_alpha, self.mixup_alpha)
-            elif self.cutmix_alpha > 0.0:
-                use_cutmix = True
-                lam_mix = np.random.beta(self.cutmix_alpha, self.cutmix_alpha)
-            else:
-                assert False, "One of mixup_alpha > 0., cutmix_alpha > 0., cutmix_minmax not None should be true."
-            lam = float(lam_mix)
-        return lam, use_cutmix
+    def plan(self, shape):
+        """the batch's MixPlan for a clip tensor of `shape` [..., H, W] (consumes the global numpy stream like the reference's call)"""
+        return draw_plan(int(shape[-2]), int(shape[-1]), self.mixup_alpha, self.cutmix_alpha, self.mix_prob, self.switch_prob,
+                         minmax=self.cutmix_minmax, enabled=self.mixup_enabled)
 
-    def _mix_batch(self, x):
-        """reference :212-223; x is mixed in place by dist_op_cutmix / dist_op_mixup"""
+    def apply(self, x, plan):
+        """x [b, 3, T, H, W] fp32 on the GPU, mixed in place (reference :212-223): dist_op_cutmix / dist_op_mixup"""
         _on_gpu(x, "video")
-        lam, use_cutmix = self._params_per_batch()
-        if lam == 1.0:
-            return 1.0
-        if use_cutmix:
-            (yl, yh, xl, xh), lam = cutmix_bbox_and_lam(x.shape, lam, ratio_minmax=self.cutmix_minmax, correct_lam=self.correct_lam)
-            ops.cutmix_(x, int(yl), int(yh), int(xl), int(xh))
-        else:
-            ops.mixup_(x, lam)
-        return lam
+        if plan.kind == "cutmix":
+            ops.cutmix_(x, *plan.box)
+        elif plan.kind == "mixup":
+            ops.mixup_(x, plan.lam)
+        return plan.lam
 
     def __call__(self, x, target):
         """reference :303-325 for {"video": tensor}"""
         assert isinstance(x, dict)
         if "video" in x and torch.is_tensor(x["video"]) and "flow" not in x:
-            lam = self._mix_batch(x["video"])
+            lam = self.apply(x["video"], self.plan(x["video"].shape))
         else:
             raise NotImplementedError("Mixup: only {'video': tensor} inputs are on the DiST path")
         if isinstance(target, dict):

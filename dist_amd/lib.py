@@ -70,6 +70,10 @@ class Config(C.Structure):
 
 GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
 
+ABI_VERSION = 7    # include/dist_amd.h DIST_ABI_VERSION: bumped on every struct-layout change
+ABI_MIRRORS = (("dist_gemm_args", GemmArgs), ("dist_gemm_tn_args", GemmTnArgs), ("dist_ln_args", LnArgs), ("dist_ln_bwd_args", LnBwdArgs),
+               ("dist_adamw_seg", AdamwSeg), ("dist_config", Config), ("dist_rowmap", RowMap), ("dist_outmap", OutMap))
+
 
 class DistError(RuntimeError):
     pass
@@ -101,6 +105,14 @@ def load():
     # (device pointers come from torch's allocator); loading ours first binds a second runtime copy.
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
+    # a stale or foreign build (DIST_AMD_LIB) must not be driven through mirrors of another layout: host-only checks, no GPU needed
+    _sig(lib, "dist_abi_version", argtypes=[])
+    _sig(lib, "dist_abi_sizeof", argtypes=[C.c_char_p])
+    if lib.dist_abi_version() != ABI_VERSION:
+        raise DistError(f"{LIB_PATH}: ABI version {lib.dist_abi_version()}, this binding is written for {ABI_VERSION} (stale build? re-run build())")
+    for cname, mirror in ABI_MIRRORS:
+        if lib.dist_abi_sizeof(cname.encode()) != C.sizeof(mirror):
+            raise DistError(f"{LIB_PATH}: sizeof({cname}) = {lib.dist_abi_sizeof(cname.encode())}, the ctypes mirror has {C.sizeof(mirror)}")
     _sig(lib, "dist_strerror", restype=C.c_char_p)
     _sig(lib, "dist_strerror", argtypes=[C.c_int])
     _sig(lib, "dist_abi_sizeof", argtypes=[C.c_char_p])

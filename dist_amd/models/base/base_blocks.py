@@ -28,7 +28,7 @@ class ClipVideoTextIdentity(nn.Module):
         out = x["logits_per_image"].mean(dim=1) if isinstance(x, dict) else x.mean(dim=1)
         if not self.training:
             if isinstance(self.activation, nn.Softmax) and out.is_cuda and out.dim() == 2:
-                out = ops.softmax_rows(out)                      # fp32, same formula as nn.Softmax(dim=-1)
+                out = ops.softmax_rows(out).to(out.dtype)        # computed in fp32, returned in the input dtype like nn.Softmax(dim=-1)
             else:
                 out = self.activation(out)
         return out, x

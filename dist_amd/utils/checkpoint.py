@@ -101,8 +101,13 @@ def load_checkpoint(path, model, optimizer=None, strict=False):
     load_checkpoint.last_mismatch = (list(missing.missing_keys), list(missing.unexpected_keys))
     for what, keys in (("model", missing.missing_keys), ("checkpoint", missing.unexpected_keys)):
         print("Keys in {} not matched: {}{}".format(what, len(keys), " (" + ", ".join(keys[:4]) + (", ..." if len(keys) > 4 else "") + ")" if keys else ""))
-    if strict and (missing.missing_keys or missing.unexpected_keys):
-        raise KeyError(f"checkpoint mismatch: {missing}")
+    if strict:
+        # only what the docstring names: a file that carries dist_net (+ visual) only - what save_checkpoint(full=False) writes - is complete
+        # although the text tower / logit_scale keys of the model are "missing"
+        miss = [k for k in missing.missing_keys if k.startswith(("dist_net.", "visual."))]
+        left = [k for k in missing.unexpected_keys if k.startswith(("dist_net.", "ladder_net."))]
+        if miss or left:
+            raise KeyError(f"checkpoint mismatch: missing {miss[:8]}{' ...' if len(miss) > 8 else ''}, unexpected {left[:8]}{' ...' if len(left) > 8 else ''}")
     eng = clip.engine
     if optimizer is not None and isinstance(ck, dict) and ck.get("optimizer_state"):
         st = ck["optimizer_state"]

@@ -41,7 +41,10 @@ class TestMeter(object):
         self._err.zero_()
 
     def update_stats(self, preds, labels, clip_ids):
-        """preds [N, C], labels [N], clip_ids [N]: device tensors (no host copy, no synchronisation)."""
+        """preds [N, C] on the device; labels [N], clip_ids [N] on the device or - as the reference's loaders yield them - on the
+        host (moved here; no synchronisation either way)."""
+        dev = self.video_preds.device
+        labels, clip_ids = labels.to(dev, non_blocking=True), clip_ids.to(dev, non_blocking=True)
         ops.ensemble_update(self.video_preds, self.video_labels, self.clip_count, preds, labels, clip_ids, self.num_clips,
                             ops.ENSEMBLE_SUM if self.ensemble_method == "sum" else ops.ENSEMBLE_MAX, self._err)
 

@@ -38,6 +38,9 @@ enum {
 };
 
 const char* dist_strerror(int code);
+/* 7 for this header.  Bumped on EVERY layout change of a struct below; a binding compares it, and dist_abi_sizeof() of each
+ * struct it mirrors, before the first dist_create (dist_amd/lib.py does). */
+#define DIST_ABI_VERSION 7
 int dist_abi_version(void);
 /* sizeof() of an argument struct of this header by name ("dist_gemm_args", "dist_gemm_tn_args", "dist_ln_args",
  * "dist_ln_bwd_args", "dist_adamw_seg", "dist_config", "dist_rowmap", "dist_outmap"); -1 for an unknown name.
@@ -314,7 +317,7 @@ int dist_bind(dist_handle* h, float* theta /*dist_net flat fp32*/, float* grads 
 int dist_pack_weights(dist_handle* h, int what, void* stream);
 
 /* VisionTransformer.forward under eval()+no_grad (clip.py:263-300,454-458): video [b,3,T,H,W] fp32
- * -> mid_feat kept inside the workspace ([layers][b,t,L,d]); optional copy-out pointer per layer. */
+ * -> mid_feat kept inside the workspace ([layers][b,t,L,d], read back through dist_debug_tensor("feat.<i>")). */
 int dist_vit_forward(dist_handle* h, const float* video, int b, void* stream);
 /* Software pipelining over batches.  The ViT is frozen (clip.py:454-458: eval() + no_grad), so its forward for batch n+1
  * does not depend on the optimizer step of batch n.  The workspace holds TWO feature slots (patch rows + mid_feat):
@@ -346,9 +349,6 @@ typedef void (*dist_grad_ready_fn)(void* user, int64_t begin, int64_t end);
 int dist_set_grad_ready_hook(dist_handle* h, dist_grad_ready_fn fn, void* user);
 /* SoftTargetCrossEntropy value and dlogits for the logits of the last branch_forward */
 int dist_loss(dist_handle* h, const float* soft_target, int b, float* loss, float* dlogits, void* stream);
-/* measurement hook for bench.py: between begin and end every launch of the dominant kernel (the plain
- * 128x128x64 MFMA GEMM of the frozen ViT) is bracketed by HIP events on its own stream; end() synchronises
- * those events and returns the summed duration, the summed algorithmic FLOPs (2*M*N*K) and the launch count. */
 /* Phase marks: device-side timestamps of the last step (HIP events on the streams the work runs on), for reading the real
  * schedule of the pipelined step without a profiler.  dist_marks_read synchronises the device and returns, per mark, the
  * milliseconds since DIST_MARK_VIT_BEGIN of the same step (NaN for a mark that was not recorded). */
@@ -356,6 +356,9 @@ enum { DIST_MARK_VIT_BEGIN = 0, DIST_MARK_VIT_END = 1, DIST_MARK_FWD_BEGIN = 2, 
        DIST_MARK_BWD_BEGIN = 5, DIST_MARK_BWD_END = 6, DIST_MARK_STEP_END = 7, DIST_NMARKS = 8 };
 int dist_marks_enable(dist_handle* h, int on);
 int dist_marks_read(dist_handle* h, float* ms, int n);
+/* measurement hook for bench.py: between begin and end every launch of the dominant kernel (the 256x256x64
+ * LDS-DMA MFMA GEMM of the frozen ViT, gemm_fast.hip) is bracketed by HIP events on its own stream; end() synchronises
+ * those events and returns the summed duration, the summed algorithmic FLOPs (2*M*N*K) and the launch count. */
 int dist_profile_begin(dist_handle* h);
 int dist_profile_end(dist_handle* h, double* ms_total, double* flops_total, int* launches);
 /* read back an intermediate for tests: name in {"feat.<i>","stem","tn_out.<i>","int_out.<i>","x_temporal.<i>","mid.<i>"} */

@@ -34,7 +34,8 @@ def perform_test(test_loader, model, test_meter, cfg, texts):
         preds, _ = model(inputs)
         if pipe and nxt is not None:
             model.adopt()
-        preds, lab, idx = du.all_gather([preds, labels["supervised"], video_idx])
+        lab, idx = labels["supervised"].to(preds.device, non_blocking=True), video_idx.to(preds.device, non_blocking=True)   # host tensors from a real loader
+        preds, lab, idx = du.all_gather([preds, lab, idx])
         test_meter.update_stats(preds, lab, idx)                # device-side ensemble: no host copy, no synchronisation per iteration
     out = test_meter.finalize_metrics()
     test_meter.reset()

@@ -22,7 +22,9 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert len(syms) >= 30
     for s in syms:
         assert hasattr(l, s), s
-    assert l.dist_abi_version() == 6
+    assert l.dist_abi_version() == lib.ABI_VERSION == 7
+    hdr = open(os.path.join(ROOT, "include", "dist_amd.h")).read()
+    assert "#define DIST_ABI_VERSION 7" in hdr
     # the ctypes mirrors of the argument structs have the library's layout size (checked without a GPU)
     for cname, mirror in (("dist_gemm_args", lib.GemmArgs), ("dist_gemm_tn_args", lib.GemmTnArgs), ("dist_ln_args", lib.LnArgs),
                           ("dist_ln_bwd_args", lib.LnBwdArgs), ("dist_adamw_seg", lib.AdamwSeg), ("dist_config", lib.Config),
@@ -30,6 +32,40 @@ def test_library_builds_loads_and_exports_header_symbols():
         assert l.dist_abi_sizeof(cname.encode()) == ctypes.sizeof(mirror), cname
     assert l.dist_abi_sizeof(b"nope") == -1
     assert l.dist_strerror(-1).decode().startswith("invalid argument")
+
+
+def test_integration_md_stub_matches_the_library():
+    """The ctypes stub INTEGRATION.md shows a maintainer is extracted from the document and checked against the built library:
+    its dist_config mirror has the library's size, its example initializer fills every field, and dist_create accepts it
+    (host-only).  Round 2's stub had 17 of 18 fields: dist_create read 4 bytes past the caller's struct."""
+    import re
+    from dist_amd import lib
+    l = lib.load()
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(import ctypes as C, torch.*?)```", md, re.S).group(1)
+    cls_src = re.search(r"(class dist_config\(C\.Structure\):\n(?:    .*\n|\s*\n)+?)\n", block).group(1)
+    init_src = re.search(r"^cfg = (dist_config\(.*?\))", block, re.M).group(1)
+    ns = {"C": ctypes}
+    exec(cls_src, ns)
+    stub = ns["dist_config"]
+    assert ctypes.sizeof(stub) == l.dist_abi_sizeof(b"dist_config") == ctypes.sizeof(lib.Config)
+    assert [n for n, _ in stub._fields_] == [n for n, _ in lib.Config._fields_]
+    nargs = len(re.findall(r"-?\d+", init_src.split("(", 1)[1]))
+    assert nargs == len(stub._fields_), "the example initializer must fill every field"
+    cfg = eval(init_src, ns)
+    assert "dist_abi_version() == 7" in block and 'dist_abi_sizeof(b"dist_config")' in block
+    h = ctypes.c_void_p()
+    pcfg = ctypes.cast(ctypes.pointer(cfg), ctypes.POINTER(lib.Config))    # the stub's own struct type, handed over as the bytes it is
+    assert l.dist_create(pcfg, ctypes.byref(h)) == 0
+    assert l.dist_param_count(h, 0) == 383
+    l.dist_destroy(h)
+    # garbage in the field an old binding would not have filled is refused, not interpreted
+    for bad in (32, -1, 1 << 20, 16, 17):
+        cfg.vit_fp8 = bad
+        assert l.dist_create(pcfg, ctypes.byref(h)) == -1, bad
+    cfg.vit_fp8 = 31
+    cfg.dtype = 0                                      # fp8 spatial branch on an fp32 engine
+    assert l.dist_create(pcfg, ctypes.byref(h)) == -1
 
 
 def test_engine_tables_without_gpu():

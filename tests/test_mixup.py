@@ -61,6 +61,36 @@ def test_golden_set_covers_mixup_cutmix_identity_and_odd_batches():
     assert {("mixup", 0), ("mixup", 1), ("cutmix", 0), ("cutmix", 1), ("identity", 0)} <= kinds
 
 
+def test_draw_plan_makes_the_reference_draws_in_the_reference_order():
+    """The product's host side (dist_amd.dataset.utils.mixup.draw_plan: one function, its own form) consumes numpy's global
+    stream exactly as the pinned oracle does: same kind, same weight, same box, and the generator is left in the same state -
+    over the golden cases and a sweep of seeds / hyper-parameters / frame sizes (every branch: skipped, mixup only, cutmix only,
+    switch between the two, boxes cut by the border)."""
+    from dist_amd.dataset.utils.mixup import draw_plan
+    cases = [case(ci)[0:1] + case(ci)[3:5] + case(ci)[6:10] for ci in range(NCASES)]
+    for seed in range(200):
+        for H, W in ((224, 224), (7, 5), (64, 96)):
+            for ma, ca, prob, sw in ((0.8, 1.0, 1.0, 0.5), (0.8, 0.0, 1.0, 0.5), (0.0, 1.0, 1.0, 0.5), (0.8, 1.0, 0.5, 0.9), (0.2, 0.3, 0.7, 0.1)):
+                cases.append((seed, H, W, ma, ca, prob, sw))
+    kinds = set()
+    for seed, H, W, ma, ca, prob, sw in cases:
+        np.random.seed(seed)
+        lam, uc = mo.params_per_batch(ma, ca, prob, sw)
+        box = None
+        if lam != 1.0 and uc:
+            box, lam = mo.cutmix_bbox_and_lam((H, W), lam)
+        after_oracle = np.random.rand()
+        np.random.seed(seed)
+        plan = draw_plan(H, W, ma, ca, prob, sw)
+        assert np.random.rand() == after_oracle, "generator state differs after the call"
+        want = "none" if lam == 1.0 and box is None else ("cutmix" if uc else "mixup")
+        assert plan.kind == want and plan.lam == lam and (plan.box == tuple(box) if box is not None else plan.box is None), (seed, H, W, plan, lam, box)
+        kinds.add(plan.kind)
+    assert kinds == {"none", "mixup", "cutmix"}
+    with pytest.raises(AssertionError):
+        np.random.seed(0); draw_plan(8, 8, 0.0, 0.0, 1.0, 0.5)
+
+
 def test_in_place_formula_needs_the_flipped_copy_first():
     """reference :221-222 takes x.flip(0) BEFORE scaling x; `x.mul_(lam).add_(x.flip(0).mul_(1-lam))` scales first and mixes
     lam*x with lam*(1-lam)*flip(x) - the defect the round-1 class had."""
