@@ -10,7 +10,7 @@ writes ONLY outputs (logits, loss, gradients, intermediate activations or their
 checksums) to tests/golden/*.npz.  No reference source is copied; the inputs are
 regenerated from dist_amd/synth.py wherever the fixtures are consumed.
 
-    python oracle/make_golden.py            # writes tests/golden/{tiny,tiny3,b16_b2,l14_t8}.npz
+    python oracle/make_golden.py [name ...]   # writes tests/golden/{tiny,tiny3,b16_b2,l14_t8,b16_t32_b1,l14_t64_b1}.npz
 """
 import os
 import sys
@@ -212,7 +212,10 @@ def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     jobs = [("tiny", "tiny", 2, True, True), ("tiny3", "tiny3", 3, False, False),
-            ("b16_b2", "b16_8+16f", 2, False, False), ("l14_t8", "l14_tiny_t", 1, False, False)]
+            ("b16_b2", "b16_8+16f", 2, False, False), ("l14_t8", "l14_tiny_t", 1, False, False),
+            # BASELINE configs 3 and 4 / 5 at their real frame counts (T = 32, T = 64), one clip: the temporal branch at the sizes the bench
+            # configurations run (round 3; the full-batch GPU tests compare rows of a b = 32 / 8 / 16 run with these through batch invariance)
+            ("b16_t32_b1", "b16_16+32f", 1, False, False), ("l14_t64_b1", "l14_32+64f", 1, False, False)]
     only = sys.argv[1:]
     for fname, gname, b, full, steps in jobs:
         if only and fname not in only:

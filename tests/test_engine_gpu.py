@@ -5,9 +5,13 @@ generated from the reference itself (oracle/make_golden.py).
 Tolerances (written here, as north_star asks):
   * fp32 mode  : logits rtol 1e-3 / atol 1e-4 against the reference goldens and the fp64 oracle
   * bf16 mode  : against the oracle with IDENTICAL bf16 rounding points, logits atol 3e-2 (logit
-                 range ~ +-4); the bf16-vs-fp32 gap is reported in DESIGN.md, not hidden.
+                 range ~ +-4; measured 0.023), gradients 4 % of each tensor's maximum (measured 1.9 %);
+                 against the fp32 reference golden on ViT-B/16: logits 0.025 (measured 0.0116), every
+                 gradient norm within 1.5 % (measured 0.72 %).  Measured values: profiles/r03_parity_gaps.json;
+                 the larger-geometry gates live in tests/test_configs_gpu.py.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -15,6 +19,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _gaps import record  # noqa: E402
 
 
 def build(gname, b, dtype, use_tr=True):
@@ -107,14 +113,17 @@ def test_bf16_vs_oracle_with_same_rounding_points(gpu_lib, use_tr):
     g, eng, sd, video, text, tgt = build("tiny", 2, torch.bfloat16, use_tr)
     loss, logits = eng.forward_backward(video, text, tgt)
     ref = oracle_run(g, sd, 2, bf16=True)
+    record(f"tiny.bf16_same_rounding.tr{int(use_tr)}.logits_maxabs", (logits.cpu().double() - ref["logits"].detach()).abs().max())
+    record(f"tiny.bf16_same_rounding.tr{int(use_tr)}.loss_abs", abs(float(loss) - float(ref["loss"])))
     torch.testing.assert_close(logits.cpu().double(), ref["logits"].detach(), rtol=0, atol=3e-2)
-    assert abs(float(loss) - float(ref["loss"])) < 1e-2
+    assert abs(float(loss) - float(ref["loss"])) < 7e-3              # measured 0.0033
     worst = 0.0
     for n, gr in ref["grads"].items():
         if gr.abs().max() < 1e-6:
             continue
         worst = max(worst, rel_err(eng.view(n, grad=True), gr))
-    assert worst < 0.08, worst
+    record(f"tiny.bf16_same_rounding.tr{int(use_tr)}.grad_worst_relmax", worst)
+    assert worst < 0.04, worst                                       # measured 0.0193
     # and the honest gap to the fp64 oracle without rounding (reported, loosely bounded)
     ref32 = oracle_run(g, sd, 2, bf16=False)
     gap = float((logits.cpu().double() - ref32["logits"].detach()).abs().max())
@@ -142,22 +151,27 @@ def test_b16_logits_vs_reference_golden_fp32(gpu_lib):
 
 def test_b16_bf16_vs_reference_golden(gpu_lib):
     """Same config in bf16 (the LDS-DMA kernels run at these sizes) against the fp32 reference: the
-    honest bf16-vs-fp32 gap, bounded (logits are in +-6; gradient norms within 6 %)."""
+    honest bf16-vs-fp32 gap, gated at ~2x measured (logits are in +-6)."""
     g, eng, sd, video, text, tgt = build("b16_8+16f", 2, torch.bfloat16)
     loss, logits = eng.forward_backward(video, text, tgt)
     gold = np.load(os.path.join(GOLD, "b16_b2.npz"))
     gap = float((logits.cpu().double() - torch.from_numpy(gold["logits"]).double()).abs().max())
     print(f"B/16 bf16 vs fp32 reference logits max-abs gap: {gap:.4f}")
-    assert gap < 0.25 and abs(float(loss) - float(gold["loss"])) < 0.05
+    record("b16_b2.bf16_vs_fp32_golden.logits_maxabs", gap)
+    record("b16_b2.bf16_vs_fp32_golden.loss_abs", abs(float(loss) - float(gold["loss"])))
+    assert gap < 0.025 and abs(float(loss) - float(gold["loss"])) < 0.006      # measured 0.0116 / 0.0025 (logits in +-6)
     assert (logits.cpu().argmax(1) == torch.from_numpy(gold["logits"]).argmax(1)).all()
-    bad = []
+    bad, errs = [], []
     for k in gold.files:
         if k.startswith("gnorm."):
             n = k[6:]
             got, ref = float(eng.view(n, grad=True).double().norm()), float(gold[k])
-            if abs(got - ref) > 0.06 * ref + 1e-6:
+            errs.append(abs(got - ref) / (ref + 1e-12))
+            if abs(got - ref) > 0.015 * ref + 1e-6:                  # measured worst 0.72 %
                 bad.append((n, got, ref))
-    assert len(bad) <= 3, bad[:10]
+    errs.sort(reverse=True)
+    record("b16_b2.bf16_vs_fp32_golden.gnorm_worst", errs[0]); record("b16_b2.bf16_vs_fp32_golden.gnorm_4th", errs[3])
+    assert not bad, bad[:10]
 
 
 def test_full_size_batch_is_consistent_with_the_golden_case(gpu_lib):
@@ -171,11 +185,11 @@ def test_full_size_batch_is_consistent_with_the_golden_case(gpu_lib):
     grads = eng.grads.clone()
     g2, eng2, _, _, _, _ = build("b16_8+16f", 2, torch.bfloat16)
     loss2, logits2 = eng2.forward_backward(video[:2].contiguous(), text, tgt[:2].contiguous())
-    torch.testing.assert_close(logits[:2].float(), logits2.float(), rtol=0, atol=2e-3)     # same kernels, same rows: bf16-exact up to tile-edge order
+    assert torch.equal(logits[:2], logits2)                                                  # same kernels, same rows, same summation order: the same bits
     assert np.array_equal(synth.video(g, 2), video[:2].cpu().numpy())                       # rows 0-1 ARE the golden clips
     gold = np.load(os.path.join(GOLD, "b16_b2.npz"))
     gap = float((logits[:2].cpu().double() - torch.from_numpy(gold["logits"]).double()).abs().max())
-    assert gap < 0.25 and (logits[:2].cpu().argmax(1) == torch.from_numpy(gold["logits"]).argmax(1)).all()
+    assert gap < 0.025 and (logits[:2].cpu().argmax(1) == torch.from_numpy(gold["logits"]).argmax(1)).all()
     assert torch.isfinite(logits).all() and torch.isfinite(grads).all() and float(grads.abs().max()) > 0
     # repeatable: same inputs, same weights -> same logits bit for bit, gradients up to fp32 atomic ordering
     loss_b, logits_b = eng.forward_backward(video, text, tgt)
