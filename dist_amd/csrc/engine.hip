@@ -673,7 +673,7 @@ extern "C" int dist_abi_sizeof(const char* n) {
     if (!n) return -1;
 #define DIST_SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)
     DIST_SZ(dist_gemm_args); DIST_SZ(dist_gemm_tn_args); DIST_SZ(dist_ln_args); DIST_SZ(dist_ln_bwd_args);
-    DIST_SZ(dist_adamw_seg); DIST_SZ(dist_config); DIST_SZ(dist_rowmap); DIST_SZ(dist_outmap);
+    DIST_SZ(dist_adamw_seg); DIST_SZ(dist_config); DIST_SZ(dist_rowmap); DIST_SZ(dist_outmap); DIST_SZ(dist_tnet_args);
 #undef DIST_SZ
     return -1;
 }
@@ -1110,11 +1110,22 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
         const DistLayer& l = h->dl[i];
         DistLayerWs& w = h->lw[i];
         void* Xnext = (i + 1 < nl) ? h->lw[i + 1].X : h->Xlast;
-        // ---- temporal chain: TemporalNet (dist.py:48-65)
-        RUN(ln_fwd(xt, h->theta, l.tn_ln, w.X, w.U, rowsX, w.tn_mean, w.tn_rstd));
-        RUN(gemm(xt, w.U, Ct, x.pk(l.tn_fc1.pk.f), rowsX, Ct, Ct, l.tn_fc1.taps, w.z, Ct, x.th(l.tn_fc1.bias), nullptr, nullptr, w.V,
-                 RM(DIST_RM_SHIFT, T * N, N, 1)));
-        RUN(gemm(xt, w.V, Ct, x.pk(l.tn_fc2.pk.f), rowsX, Ct, Ct, 9, w.p, Ct, x.th(l.tn_fc2.bias), w.X, nullptr, w.Xp, RM(DIST_RM_SPATIAL, h->G, 0, 1)));
+        // ---- temporal chain: TemporalNet (dist.py:48-65): one fused launch (tnet.hip) where the geometry allows, else LayerNorm + two GEMMs
+        if (dist_k_tnet_fwd_eligible(c.dtype, Ct, h->G, l.tn_fc1.taps)) {
+            dist_tnet_args ta;
+            memset(&ta, 0, sizeof(ta));
+            ta.X = w.X; ta.W1 = x.pk(l.tn_fc1.pk.f); ta.W2 = x.pk(l.tn_fc2.pk.f);
+            ta.b1 = x.th(l.tn_fc1.bias); ta.b2 = x.th(l.tn_fc2.bias); ta.ln_w = x.th(l.tn_ln.w); ta.ln_b = x.th(l.tn_ln.b);
+            ta.z = w.z; ta.p = w.p; ta.Xp = w.Xp; ta.U = w.U; ta.V = w.V;       // (U, V: the weight-gradient GEMMs of backward still read them)
+            ta.mean = w.tn_mean; ta.rstd = w.tn_rstd;
+            ta.clips = b; ta.T = T; ta.G = h->G; ta.Ct = Ct; ta.tk = l.tn_fc1.taps; ta.dtype = c.dtype; ta.eps = 1e-5f;
+            RUN(dist_op_temporal_net_fwd(&ta, xt.s));
+        } else {
+            RUN(ln_fwd(xt, h->theta, l.tn_ln, w.X, w.U, rowsX, w.tn_mean, w.tn_rstd));
+            RUN(gemm(xt, w.U, Ct, x.pk(l.tn_fc1.pk.f), rowsX, Ct, Ct, l.tn_fc1.taps, w.z, Ct, x.th(l.tn_fc1.bias), nullptr, nullptr, w.V,
+                     RM(DIST_RM_SHIFT, T * N, N, 1)));
+            RUN(gemm(xt, w.V, Ct, x.pk(l.tn_fc2.pk.f), rowsX, Ct, Ct, 9, w.p, Ct, x.th(l.tn_fc2.bias), w.X, nullptr, w.Xp, RM(DIST_RM_SPATIAL, h->G, 0, 1)));
+        }
         HIP_CHECK_RET(hipEventRecord(ev_xp(i), xt.s));
         // ---- integration chain: mid_feat = input_linear(F_i) + res_feat (dist.py:229)
         HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_feat[i], 0));

@@ -36,5 +36,6 @@ int dist_k_logits_loss(const void* v, const float* text, const float* logit_scal
 bool dist_k_gemm_fast_eligible(const dist_gemm_args* a);
 int dist_k_gemm_fast(const dist_gemm_args* a, hipStream_t s);
 int dist_k_gemm_small(const dist_gemm_args* a, hipStream_t s);       // M < 1024 (gemm_small.hip)
-int dist_k_gemm_small(const dist_gemm_args* a, hipStream_t s);       // M < 1024 (gemm_small.hip)
+// fused TemporalNet (tnet.hip): does dist_op_temporal_net_fwd take this geometry?
+bool dist_k_tnet_fwd_eligible(int dtype, int Ct, int G, int tk);
 

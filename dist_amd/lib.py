@@ -57,6 +57,11 @@ class LnBwdArgs(C.Structure):
                 ("rows", C.c_int64), ("C", C.c_int), ("dtype", C.c_int), ("dx_add", C.c_void_p), ("dx_copy", C.c_void_p)]
 
 
+class TnetArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("X", "W1", "W2", "b1", "b2", "ln_w", "ln_b", "z", "p", "Xp", "U", "V", "mean", "rstd")] + \
+               [(n, C.c_int) for n in ("clips", "T", "G", "Ct", "tk", "dtype")] + [("eps", C.c_float)]
+
+
 class AdamwSeg(C.Structure):
     _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("lr", C.c_float), ("weight_decay", C.c_float)]
 
@@ -72,7 +77,7 @@ GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
 
 ABI_VERSION = 7    # include/dist_amd.h DIST_ABI_VERSION: bumped on every struct-layout change
 ABI_MIRRORS = (("dist_gemm_args", GemmArgs), ("dist_gemm_tn_args", GemmTnArgs), ("dist_ln_args", LnArgs), ("dist_ln_bwd_args", LnBwdArgs),
-               ("dist_adamw_seg", AdamwSeg), ("dist_config", Config), ("dist_rowmap", RowMap), ("dist_outmap", OutMap))
+               ("dist_adamw_seg", AdamwSeg), ("dist_config", Config), ("dist_rowmap", RowMap), ("dist_outmap", OutMap), ("dist_tnet_args", TnetArgs))
 
 
 class DistError(RuntimeError):
@@ -151,6 +156,7 @@ def load():
     _sig(lib, "dist_profile_end", argtypes=[C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)])
     _sig(lib, "dist_debug_tensor", argtypes=[C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)])
     _sig(lib, "dist_op_gemm_nt", argtypes=[C.POINTER(GemmArgs), C.c_void_p])
+    _sig(lib, "dist_op_temporal_net_fwd", argtypes=[C.POINTER(TnetArgs), C.c_void_p])
     _sig(lib, "dist_op_ln_fold", argtypes=[C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p])
     _sig(lib, "dist_op_gemm_tn", argtypes=[C.POINTER(GemmTnArgs), C.c_void_p])
     _sig(lib, "dist_op_layernorm", argtypes=[C.POINTER(LnArgs), C.c_void_p])

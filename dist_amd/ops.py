@@ -77,6 +77,31 @@ def gemm_nt(A, B, M, N, K, *, taps=1, bias=None, res=None, aux=None, amap=None, 
     L.check(lib.dist_op_gemm_nt(C.byref(a), _stream()))
 
 
+def pack_conv_taps(w):
+    """Conv3d weight [Co, Ci, kt, kh, kw] (fp32 master, reference layout) -> the packed forward layout [Co][tap*Ci + ci] in bf16,
+    tap = (t*kh + y)*kw + x - what dist_pack_weights keeps for the row-mapped GEMMs and the fused TemporalNet."""
+    co, ci = w.shape[0], w.shape[1]
+    return w.reshape(co, ci, -1).permute(0, 2, 1).reshape(co, -1).to(torch.bfloat16).contiguous()
+
+
+def temporal_net_fwd(X, W1p, b1, W2p, b2, ln_w, ln_b, clips, T, G, *, tk=3, save_uv=False, eps=1e-5):
+    """Fused TemporalNet forward (dist_op_temporal_net_fwd): X bf16 [clips*T*G*G, Ct]; W1p / W2p from pack_conv_taps.
+    Returns dict(z, p, Xp, mean, rstd[, U, V])."""
+    lib = L.load()
+    rows, Ct = X.shape
+    assert rows == clips * T * G * G and X.dtype == torch.bfloat16 and X.is_contiguous()
+    out = {k: torch.empty_like(X) for k in (("z", "p", "Xp", "U", "V") if save_uv else ("z", "p", "Xp"))}
+    out["mean"] = torch.empty(rows, dtype=torch.float32, device=X.device)
+    out["rstd"] = torch.empty(rows, dtype=torch.float32, device=X.device)
+    a = L.TnetArgs()
+    a.X, a.W1, a.W2, a.b1, a.b2, a.ln_w, a.ln_b = _p(X), _p(W1p), _p(W2p), _p(b1), _p(b2), _p(ln_w), _p(ln_b)
+    a.z, a.p, a.Xp, a.U, a.V = _p(out["z"]), _p(out["p"]), _p(out["Xp"]), _p(out.get("U")), _p(out.get("V"))
+    a.mean, a.rstd = _p(out["mean"]), _p(out["rstd"])
+    a.clips, a.T, a.G, a.Ct, a.tk, a.dtype, a.eps = clips, T, G, Ct, tk, L.BF16, eps
+    L.check(lib.dist_op_temporal_net_fwd(C.byref(a), _stream()))
+    return out
+
+
 def ln_fold(W, bias, gamma, beta):
     """LayerNorm -> Linear fold (dist_op_ln_fold): returns (Wp bf16 [N,K] = W*gamma, colsum fp32 [N], bias' fp32 [N])."""
     lib = L.load()

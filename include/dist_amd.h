@@ -43,7 +43,7 @@ const char* dist_strerror(int code);
 #define DIST_ABI_VERSION 7
 int dist_abi_version(void);
 /* sizeof() of an argument struct of this header by name ("dist_gemm_args", "dist_gemm_tn_args", "dist_ln_args",
- * "dist_ln_bwd_args", "dist_adamw_seg", "dist_config", "dist_rowmap", "dist_outmap"); -1 for an unknown name.
+ * "dist_ln_bwd_args", "dist_adamw_seg", "dist_config", "dist_rowmap", "dist_outmap", "dist_tnet_args"); -1 for an unknown name.
  * Lets a foreign-language binding verify its mirror of the layout without a GPU. */
 int dist_abi_sizeof(const char* struct_name);
 
@@ -196,6 +196,26 @@ int dist_op_attention_out8(const void* qkv, void* out8, const float* out8_scale,
  * scale enters the scores as in_scale^2 and the output as in_scale.  Exactly one of out (bf16 [frames*L][heads*64]) / out8 (as above). */
 int dist_op_attention_fp8(const void* qkv8, const float* in_scale, void* out, void* out8, const float* out8_scale, float* out8_amax,
                           int frames, int L, int heads, void* stream);
+
+/* Fused TemporalNet forward (dist.py:48-65): X' = g(X + conv_{1x3x3}(g(conv_{3x1x1}(LN_C(X))))) on the channels-last temporal map
+ * X [clips*T*G*G][Ct] (rows (b*T + k)*G*G + n) in ONE launch - LayerNorm, the temporal taps, QuickGELU, the nine spatial taps, the
+ * residual and the second QuickGELU; the normalised and the activated tensor live in LDS only.  bf16; Ct in {32, 64, 96}; G*G <= 256;
+ * tk in {1, 3, 5}.  W1 = c_fc1.weight packed as [Ct][tk*Ct] (W1[n][tap*Ct + c] = weight[n][c][tap]), W2 = c_fc2.weight packed as
+ * [Ct][9*Ct] (tap = 3*ky + kx) - the forward layouts dist_pack_weights produces.  Outputs (same shape as X):
+ *   z  = bf16(conv_t(LN(X)) + b1)            (pre-activation of the first QuickGELU; backward needs it)
+ *   p  = bf16(X + conv_s(g(z)) + b2)         (pre-activation of the second)
+ *   Xp = bf16(g(p))                          = TemporalNet(X)
+ *   U  = bf16(LN(X)), V = bf16(g(z))         optional (both or neither; NULL: they never reach memory)
+ *   mean, rstd: fp32 [rows] LayerNorm statistics.
+ * Rounding points are those of the unfused sequence dist_op_layernorm -> dist_op_gemm_nt (ACT2) -> dist_op_gemm_nt (RES | ACT2). */
+typedef struct dist_tnet_args {
+    const void* X; const void* W1; const void* W2;
+    const float* b1; const float* b2; const float* ln_w; const float* ln_b;
+    void* z; void* p; void* Xp; void* U; void* V;
+    float* mean; float* rstd;
+    int clips, T, G, Ct, tk; int dtype; float eps;
+} dist_tnet_args;
+int dist_op_temporal_net_fwd(const dist_tnet_args* a, void* stream);
 
 /* one-query cross attention (CrossAttentionBlockGenral, clip.py:139-147; dist.py:144,158):
  * q [B, C], kv [B*S, 2C] -> o [B, C], probs [B, H, S] (fp32, saved for backward) */
