@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from ... import lib as L
+from ... import ops
 from ...engine import Engine
 from ...utils.registry import Registry
 
@@ -219,7 +220,27 @@ class CLIP(nn.Module):
         pair = getattr(self, "_cur_pair", None)
         video = pair[1] if (pair is not None and pair[0] is video) else video.contiguous().float()
         logits, vid = _DistFunction.apply(self.engine, video, text_features, self.logit_scale, *self._dist_params)
-        return {"logits_per_image": logits, "logits_per_text": logits.t(), "img_logits": None, "vid_logits": vid[:, None, :]}
+        return {"logits_per_image": logits, "logits_per_text": logits.t(), "img_logits": self.image_logits(), "vid_logits": vid[:, None, :]}
+
+    @torch.no_grad()
+    def image_logits(self):
+        """`img_logits` of the reference's output dictionary (clip.py:291-298,503,532): the frozen ViT's own embedding of every sampled
+        frame, ln_post(cls token of the last block) @ visual.proj, [b*t, E] - NOT normalised (the reference only normalises it inside
+        the zero-shot / prediction-fusion branch).  The cls rows come from the engine's saved mid_feat of the last block; LayerNorm and
+        the projection are the HIP operators."""
+        eng = self.engine
+        d, L = eng.cfg.width, (eng.cfg.resolution // eng.cfg.patch) ** 2 + 1
+        feat = eng.debug(f"feat.{eng.cfg.layers - 1}")                       # [b*t*L, d] of the current batch
+        cls = feat.view(-1, L, d)[:, 0, :].contiguous()
+        y = torch.empty_like(cls)
+        ops.layernorm(cls, eng.view("visual.ln_post.weight"), eng.view("visual.ln_post.bias"), y=y)
+        key = eng.visual._version
+        if getattr(self, "_projT_key", None) != key:                          # frozen: transposed working copy made once per load
+            self._projT = eng.view("visual.proj").t().contiguous().to(eng.dtype)
+            self._projT_key = key
+        out = torch.empty(cls.shape[0], eng.cfg.embed_dim, dtype=eng.dtype, device=cls.device)
+        ops.gemm_nt(y, self._projT, cls.shape[0], eng.cfg.embed_dim, d, C_out=out)
+        return out.float()
 
     def load_state_dict(self, state_dict, strict=True, first_init=False):
         out = super().load_state_dict(state_dict, strict=strict)

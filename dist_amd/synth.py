@@ -211,6 +211,40 @@ def state_dict(g, seed=0):
     return sd
 
 
+def text_tower_state_dict(width=64, layers=2, vocab=96, context=77, embed=64, seed=5):
+    """Procedural CLIP text tower (reference models/base/clip.py:359-371,420-435 key names) for the encode_text fixture:
+    small enough that the reference encodes a label set in milliseconds on the CPU."""
+    sd = {"token_embedding.weight": gaussian_like("token_embedding.weight", (vocab, width), 0.3, seed),
+          "positional_embedding": gaussian_like("text.positional_embedding", (context, width), 0.1, seed),
+          "ln_final.weight": (np.float32(1.0) + np.float32(0.1) * uniform("ln_final.weight", (width,), seed)).astype(np.float32),
+          "ln_final.bias": gaussian_like("ln_final.bias", (width,), 0.05, seed),
+          "text_projection": gaussian_like("text_projection", (width, embed), 0.8 / np.sqrt(width), seed)}
+    for i in range(layers):
+        p = f"transformer.resblocks.{i}."
+        for name, shape in (("attn.in_proj_weight", (3 * width, width)), ("attn.out_proj.weight", (width, width)),
+                            ("mlp.c_fc.weight", (4 * width, width)), ("mlp.c_proj.weight", (width, 4 * width))):
+            sd[p + name] = gaussian_like("text." + p + name, shape, 0.8 / np.sqrt(shape[1]), seed)
+        for name, n in (("attn.in_proj_bias", 3 * width), ("attn.out_proj.bias", width), ("mlp.c_fc.bias", 4 * width), ("mlp.c_proj.bias", width),
+                        ("ln_1.bias", width), ("ln_2.bias", width)):
+            sd[p + name] = gaussian_like("text." + p + name, (n,), 0.05, seed)
+        for name in ("ln_1.weight", "ln_2.weight"):
+            sd[p + name] = (np.float32(1.0) + np.float32(0.1) * uniform("text." + p + name, (width,), seed)).astype(np.float32)
+    return sd
+
+
+def label_tokens(K, vocab=96, context=77, seed=6):
+    """[K, context] int64 token rows shaped like CLIP's tokenizer output: start token, 2-9 word tokens, the end token = the LARGEST id
+    of the row (encode_text takes the feature at argmax, reference clip.py:430), zero padding."""
+    u = (uniform("label_tokens", (K, context), seed).astype(np.float64) + 1.0) * 0.5
+    t = np.zeros((K, context), dtype=np.int64)
+    for r in range(K):
+        n = 2 + int(u[r, 0] * 8)
+        t[r, 0] = vocab - 2
+        t[r, 1:1 + n] = 1 + (u[r, 1:1 + n] * (vocab - 4)).astype(np.int64)
+        t[r, 1 + n] = vocab - 1
+    return t
+
+
 def video(g, b, seed=1):
     """Synthetic mean/std-normalised frames [b,3,T,H,W] ~ unit variance."""
     return gaussian_like("video", (b, 3, g.T, g.res, g.res), 1.0, seed)

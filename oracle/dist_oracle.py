@@ -90,6 +90,15 @@ class Oracle:
                 feats.append(x)
         return feats
 
+    def img_logits(self, feats):
+        """`img_logits` of the reference's output dictionary: ln_post(cls token of the last block) @ visual.proj, [b*t, E], not normalised
+        (reference clip.py:291-298 `cls_x`, returned as `img_cls_tokens_ori` at :503,532)."""
+        p = self.p
+        with torch.no_grad():
+            cls = feats[-1][:, :, 0].reshape(-1, self.g.d)
+            y = self.rnd(layer_norm(cls, p["visual.ln_post.weight"], p["visual.ln_post.bias"]))
+            return self.rnd(y @ self.w("visual.proj"))
+
     # ---- e4m3 operands (dist_config.vit_fp8) ---------------------------------------------
     @staticmethod
     def _fp8_rows(a2, per_tensor):
@@ -302,7 +311,7 @@ class Oracle:
         patches = self.patchify(torch.as_tensor(video))
         feats = self.vit(patches)
         logits, vn, keep = self.branch(patches, feats, torch.as_tensor(text_features).to(self.dtype))
-        return {"logits": logits, "vid_logits": vn, "feats": feats, "keep": keep}
+        return {"logits": logits, "vid_logits": vn, "feats": feats, "keep": keep, "img_logits": self.img_logits(feats)}
 
     def loss(self, logits, soft_target):
         """SoftTargetCrossEntropy (reference models/utils/losses.py:29-31)."""

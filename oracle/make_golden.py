@@ -153,7 +153,9 @@ def run(gname, b, full, dtype=torch.float32, with_steps=False):
         h.remove()
 
     res = {"logits": logits.detach().numpy(), "vid_logits": out["vid_logits"].detach().numpy()[:, 0],
-           "loss": np.array(loss.item())}
+           "loss": np.array(loss.item()),
+           # the frozen ViT's own clip-free embedding of every sampled frame: ln_post(cls) @ proj, [b*t, E] (clip.py:291-298,532)
+           "img_logits": out["img_logits"].detach().numpy()}
     # intermediates converted to the build's layout
     L, t = g.L, g.t
     for k, v in inter.items():

@@ -56,6 +56,9 @@ def test_model_forward_backward_matches_reference_golden(gpu_lib):
     assert preds.shape == (2, g.K) and out["logits_per_image"].shape == (2, 1, g.K) and out["vid_logits"].shape == (2, 1, g.E)
     gold = np.load(os.path.join(GOLD, "tiny.npz"))
     torch.testing.assert_close(preds.detach().cpu().double(), torch.from_numpy(gold["logits"]).double(), rtol=1e-3, atol=1e-4)
+    # img_logits: the frozen ViT's own per-frame embedding ln_post(cls) @ proj, [b*t, E] (reference clip.py:291-298,532) - round 2 returned None
+    assert out["img_logits"].shape == (2 * g.t, g.E) and not out["img_logits"].requires_grad
+    torch.testing.assert_close(out["img_logits"].cpu().double(), torch.from_numpy(gold["img_logits"]).double(), rtol=1e-3, atol=1e-4)
     loss, _, _ = losses.calculate_loss(cfg, preds, out, {"supervised": tgt}, 0)
     assert abs(float(loss) - float(gold["loss"])) < 1e-4
     loss.backward()
@@ -69,6 +72,37 @@ def test_model_forward_backward_matches_reference_golden(gpu_lib):
     with torch.no_grad():
         p_eval, _ = model({"video": video, "texts": texts})
     torch.testing.assert_close(p_eval.sum(1).cpu(), torch.ones(2), rtol=1e-4, atol=1e-4)   # head softmax at eval
+
+
+def test_text_tower_matches_the_reference_golden(gpu_lib):
+    """`encode_text` / `cache_text` (reference clip.py:420-452; the frozen text tower runs once per label set and feeds every logit):
+    the reference's own text features for a procedural tower and procedural label tokens (oracle/make_golden_text.py ->
+    tests/golden/text_tiny.npz) against this repository's restatement, built through the same `clip.build_model` shape inference."""
+    from dist_amd import synth
+    from dist_amd.models.base import clip as C
+    g = synth.geometry("tiny")
+    gold = np.load(os.path.join(GOLD, "text_tiny.npz"))
+    sd = {k: torch.from_numpy(v.copy()) for k, v in synth.state_dict(g).items()}
+    sd.update({k: torch.from_numpy(v.copy()) for k, v in synth.text_tower_state_dict(embed=g.E).items()})
+    model = C.build_model(tiny_cfg("TRAIN.FP32_PARITY", "true", "TRAIN.BATCH_SIZE", "2"), dict(sd)).cuda()
+    assert model.context_length == int(gold["context"]) and len(model.transformer) == int(gold["layers"])
+    assert model.transformer[0].attn.num_heads == int(gold["heads"])
+    tokens = torch.from_numpy(synth.label_tokens(g.K)).cuda()
+    with torch.no_grad():
+        feats, eot, _ = model.encode_text(tokens)
+    torch.testing.assert_close(feats.cpu().double(), torch.from_numpy(gold["text_features"]).double(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(eot.cpu().double(), torch.from_numpy(gold["eot_features"]).double(), rtol=1e-4, atol=1e-5)
+    cached, _, _ = model.cache_text(tokens)
+    again, _, _ = model.cache_text(tokens)
+    assert cached.data_ptr() == again.data_ptr()                                   # computed once per label set
+    torch.testing.assert_close(cached.cpu(), feats.cpu().float(), rtol=0, atol=0)
+    # and these features drive the logits of a forward pass
+    video = torch.from_numpy(synth.video(g, 2)).cuda()
+    out = model(video.permute(0, 2, 1, 3, 4).reshape(2 * g.T, 3, g.res, g.res).contiguous(), tokens)
+    v = out["vid_logits"][:, 0].double().cpu()
+    tf = torch.from_numpy(gold["text_features"]).double()
+    want = float(np.exp(np.log(1 / 0.07))) * v @ (tf / tf.norm(dim=1, keepdim=True)).t()
+    torch.testing.assert_close(out["logits_per_image"].double().cpu(), want, rtol=1e-3, atol=1e-4)
 
 
 def test_optimizer_groups_and_fused_step(gpu_lib):
