@@ -59,6 +59,50 @@ class ResidualAttentionBlock(nn.Module):
         return x + self.mlp(self.ln_2(x))
 
 
+class TextTransformer(nn.Module):
+    """The text tower's block stack under the reference's attribute name (`transformer.resblocks.{i}.*`, clip.py:204-215): the
+    OpenAI-CLIP state-dict keys must land on these modules.  (Until round 3 this was a bare nn.Sequential - keys `transformer.{i}.*`
+    - so a non-strict load silently left the text tower at its random initialisation; tests/golden/text_tiny.npz pins it now.)"""
+
+    def __init__(self, width, layers, heads, attn_mask=None):
+        super().__init__()
+        self.width, self.layers = width, layers
+        self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads, attn_mask) for _ in range(layers)])
+
+    def forward(self, x):
+        return self.resblocks(x)
+
+
+def causal_mask(context_length):
+    """additive attention mask of the text tower (clip.py:411-417): -inf above the diagonal"""
+    return torch.empty(context_length, context_length).fill_(float("-inf")).triu_(1)
+
+
+def encode_text_with(m, text):
+    """reference clip.py:420-435 on any module `m` that carries token_embedding, positional_embedding, transformer, ln_final and
+    text_projection: (features [K, E], the end-of-text token's transformer output [K, width])"""
+    x = m.token_embedding(text) + m.positional_embedding
+    x = m.transformer(x.permute(1, 0, 2)).permute(1, 0, 2)                 # NLD -> LND -> NLD
+    eot = x[torch.arange(x.shape[0]), text.argmax(dim=-1)]                  # the end token has the largest id of its row
+    return m.ln_final(eot) @ m.text_projection, eot
+
+
+class TextTower(nn.Module):
+    """The frozen text tower alone (same attribute / state-dict names as on CLIP): used where no GPU engine is needed."""
+
+    def __init__(self, embed_dim, context_length, vocab_size, width, heads, layers):
+        super().__init__()
+        self.context_length = context_length
+        self.transformer = TextTransformer(width, layers, heads, causal_mask(context_length))
+        self.token_embedding = nn.Embedding(vocab_size, width)
+        self.positional_embedding = nn.Parameter(torch.empty(context_length, width).normal_(std=0.01))
+        self.ln_final = LayerNorm(width)
+        self.text_projection = nn.Parameter(torch.empty(width, embed_dim).normal_(std=width ** -0.5))
+
+    def encode_text(self, text):
+        return encode_text_with(self, text)
+
+
 @ATTEN_BLOCK_REGISTRY.register()
 class ResidualAttentionBlockMid(nn.Module):
     """Parameter container of one frozen ViT block (reference clip.py:150-178); the arithmetic
@@ -148,8 +192,7 @@ class CLIP(nn.Module):
         self.dist_net = DiSTNetwork(cfg, d_model=vision_width, width=vision_width, output_dim=embed_dim, engine=self.engine)
         self.logit_scale = nn.Parameter(self.engine.logit_scale.view(()))
         # frozen text tower (clip.py:359-371), plain torch: runs once per label set
-        self.transformer = nn.Sequential(*[ResidualAttentionBlock(transformer_width, transformer_heads, self.build_attention_mask())
-                                           for _ in range(transformer_layers)])
+        self.transformer = TextTransformer(transformer_width, transformer_layers, transformer_heads, self.build_attention_mask())
         self.vocab_size = vocab_size
         self.token_embedding = nn.Embedding(vocab_size, transformer_width)
         self.positional_embedding = nn.Parameter(torch.empty(context_length, transformer_width).normal_(std=0.01))
@@ -169,18 +212,15 @@ class CLIP(nn.Module):
         return getattr(mod, parts[-1])
 
     def build_attention_mask(self):
-        mask = torch.empty(self.context_length, self.context_length).fill_(float("-inf"))
-        return mask.triu_(1)
+        return causal_mask(self.context_length)
 
     @property
     def dtype(self):
         return torch.float32
 
     def encode_text(self, text, others=None):
-        x = self.token_embedding(text) + self.positional_embedding
-        x = self.transformer(x.permute(1, 0, 2)).permute(1, 0, 2)
-        x_logits = x[torch.arange(x.shape[0]), text.argmax(dim=-1)]
-        return self.ln_final(x_logits) @ self.text_projection, x_logits, others
+        feats, eot = encode_text_with(self, text)
+        return feats, eot, others
 
     def cache_text(self, text, others=None):
         """reference clip.py:437-452: text features are computed once (no_grad) and reused."""
@@ -275,7 +315,14 @@ def build_model(cfg, state_dict):
     for key in ("input_resolution", "context_length", "vocab_size"):
         state_dict.pop(key, None)
     sd = {k: (torch.as_tensor(v) if not torch.is_tensor(v) else v) for k, v in state_dict.items()}
-    model.load_state_dict(sd, strict=False, first_init=True)
+    res = model.load_state_dict(sd, strict=False, first_init=True)
+    # non-strict like the reference (the dist_net.* tensors are not in a CLIP checkpoint) - but a frozen-tower key that found no module
+    # is a naming bug, never a choice: refuse instead of training on a randomly initialised tower
+    frozen = ("visual.", "transformer.", "token_embedding.", "ln_final.")
+    lost = [k for k in res.unexpected_keys if k.startswith(frozen) or k in ("positional_embedding", "text_projection", "logit_scale")]
+    unset = [k for k in res.missing_keys if k.startswith(frozen) or k in ("positional_embedding", "text_projection")]
+    if lost or unset:
+        raise L.DistError(f"CLIP state-dict does not match the frozen towers: unexpected {lost[:6]}, missing {unset[:6]}")
     return model.eval()
 
 

@@ -85,8 +85,8 @@ def test_text_tower_matches_the_reference_golden(gpu_lib):
     sd = {k: torch.from_numpy(v.copy()) for k, v in synth.state_dict(g).items()}
     sd.update({k: torch.from_numpy(v.copy()) for k, v in synth.text_tower_state_dict(embed=g.E).items()})
     model = C.build_model(tiny_cfg("TRAIN.FP32_PARITY", "true", "TRAIN.BATCH_SIZE", "2"), dict(sd)).cuda()
-    assert model.context_length == int(gold["context"]) and len(model.transformer) == int(gold["layers"])
-    assert model.transformer[0].attn.num_heads == int(gold["heads"])
+    assert model.context_length == int(gold["context"]) and model.transformer.layers == int(gold["layers"])
+    assert model.transformer.resblocks[0].attn.num_heads == int(gold["heads"])
     tokens = torch.from_numpy(synth.label_tokens(g.K)).cuda()
     with torch.no_grad():
         feats, eot, _ = model.encode_text(tokens)
