@@ -91,8 +91,10 @@ def save_checkpoint(path_to_job, model, optimizer, epoch, cfg, full=False):
 
 def load_checkpoint(path, model, optimizer=None, strict=False):
     """reference utils/checkpoint.py:277-347: non-strict load, the two mismatch lists are reported (and kept in
-    `load_checkpoint.last_mismatch`); `strict=True` raises when a dist_net / visual tensor of the model is missing or a
-    dist_net / ladder_net key of the file is left over."""
+    `load_checkpoint.last_mismatch`).  `strict=True` raises when a dist_net tensor of the model is missing from the file, when the file
+    carries SOME visual.* tensors but not all of them (a dist_net-only file - what `save_checkpoint(full=False)` writes - is complete:
+    the frozen towers keep the CLIP weights they were built from), or when a dist_net / ladder_net key of the file is left over.
+    Text-tower and logit_scale keys never make a strict load fail."""
     assert os.path.exists(path), "Checkpoint '{}' not found".format(path)
     ck = torch.load(path, map_location="cpu")
     sd = normalize_state_dict(ck)
@@ -104,7 +106,8 @@ def load_checkpoint(path, model, optimizer=None, strict=False):
     if strict:
         # only what the docstring names: a file that carries dist_net (+ visual) only - what save_checkpoint(full=False) writes - is complete
         # although the text tower / logit_scale keys of the model are "missing"
-        miss = [k for k in missing.missing_keys if k.startswith(("dist_net.", "visual."))]
+        has_visual = any(k.startswith("visual.") for k in sd)
+        miss = [k for k in missing.missing_keys if k.startswith("dist_net.") or (has_visual and k.startswith("visual."))]
         left = [k for k in missing.unexpected_keys if k.startswith(("dist_net.", "ladder_net."))]
         if miss or left:
             raise KeyError(f"checkpoint mismatch: missing {miss[:8]}{' ...' if len(miss) > 8 else ''}, unexpected {left[:8]}{' ...' if len(left) > 8 else ''}")

@@ -64,8 +64,12 @@ def test_pre_release_checkpoint_loads_completely(gpu_lib, tmp_path):
     assert not [k for k in missing if k.startswith("dist_net.")] and not unexpected
     for n, w in want.items():
         assert torch.equal(eng.view(n), w), n
-    with pytest.raises(KeyError):
-        cu.load_checkpoint(p2, model, strict=True)                              # the frozen tower is not in a dist_net-only file
+    cu.load_checkpoint(p2, model, strict=True)                                  # a complete dist_net-only file is a complete file
+    half = {k: v for k, v in old.items()}
+    half["module.backbone.base_encoder.visual.proj"] = torch.zeros_like(model.backbone.base_encoder.visual.proj)
+    p3 = str(tmp_path / "half_visual.pyth"); torch.save({"model_state": half}, p3)
+    with pytest.raises(KeyError, match="visual"):
+        cu.load_checkpoint(p3, model, strict=True)                              # SOME frozen-ViT tensors but not all of them
     with pytest.raises(AssertionError):
         cu.load_checkpoint(str(tmp_path / "nope.pyth"), model)
 
