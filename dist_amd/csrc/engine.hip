@@ -142,10 +142,12 @@ struct dist_handle {
     // layer-loop scratch, double-buffered by layer parity (the weight-gradient stream lags the data-gradient chain)
     struct BwdSet { void *dMp, *dM, *dXp, *dp, *dXo, *dz, *dU, *dY, *dh2, *dh1, *dzf, *dNa, *dNb; } bs[2];
     void *dR, *dkv, *dkn;
+    float* tnb_scratch = nullptr; long tnb_scratch_elems = 0;   // parameter-gradient partial rows of the fused TemporalNet backward
     float* tn_partial[3] = {nullptr, nullptr, nullptr};   // two-phase dW reduction scratch, one per stream that launches dW GEMMs
     long tn_partial_elems = 0;
     // weight-gradient side stream (created once per handle; host-side objects only)
     hipStream_t side = nullptr, side2 = nullptr, pf = nullptr;   // pf: the handle's own ViT prefetch stream
+    int skip = 0;                              // DIST_AMD_SKIP (measurement knob, results WRONG): 1 = no weight-gradient GEMMs, 2 = no TemporalNet backward data-gradient kernels, 4 = no TemporalNet forward, 8 = no IntegrationNetwork forward GEMMs, 16 = no large-wgrad (in_lin / proj pair / ffn_fc) only
     int serial = 0;                            // DIST_AMD_SERIAL (measurement knob): bit 0 = branch forward, bit 1 = backward on the caller's stream only
     std::vector<hipEvent_t> ev_a;              // chain -> side: "buffer produced"
     std::vector<hipEvent_t> ev_b_dr, ev_b_done; // side -> chain: per layer "dR consumed", "all weight gradients of the layer issued and done"
@@ -464,6 +466,8 @@ size_t layout_ws(dist_handle* h, char* base) {
     h->y_mean = F_(b); h->y_rstd = F_(b); h->logits = F_(b * c.num_classes); h->dlogits = F_(b * c.num_classes); h->loss = F_(4);
     // backward scratch
     h->dR = T_(rowsS, Ci); h->dkv = T_(rowsS, 2 * Ci); h->dkn = T_(rowsS, Ci);
+    h->tnb_scratch_elems = dist_op_temporal_net_bwd_scratch((int)b, c.frames, Ct);
+    h->tnb_scratch = F_(h->tnb_scratch_elems);
     h->tn_partial_elems = 9l << 20;                          // 36 MB each: >= 512 partial tiles of 128 x 128 (+ slack)
     for (int k = 0; k < 3; ++k) h->tn_partial[k] = F_(h->tn_partial_elems);
     for (int k = 0; k < 2; ++k) {
@@ -603,6 +607,8 @@ int wgrad(const Ctx& c, const Lin& l, const void* dY, int ld_dy, const void* X, 
     else if (style == 4) { g.NI = l.K; g.K = l.N; g.so_i = l.N; g.so_tap = 0; g.so_outer = 1; g.inner = 1; }   // [K][N] matrix used as x @ W
     else { const int PP3 = c.h->PP3, PP = PP3 / 3; g.K = PP3; g.so_i = (long)PP3 * l.taps; g.so_tap = PP; g.so_outer = (long)PP * l.taps; g.inner = PP; }
     g.dtype = c.dtype; g.use_tr = c.h->cfg.use_tr;
+    if (c.h->skip & 1) return DIST_OK;
+    if ((c.h->skip & 16) && l.N >= 384 && l.K >= 384) return DIST_OK;
     g.colsum = (with_bias && l.bias >= 0) ? c.gr(l.bias) : nullptr;       // db fused into the same pass over dY
     {   // two-phase reduction scratch of the stream this launch goes to
         dist_handle* h = c.h;
@@ -620,6 +626,7 @@ int wgrad_pair(const Ctx& c, const Lin& l1, const Lin& l2, const void* dY, int l
     g.M = M; g.NI = l1.N; g.K = l1.K + l2.K; g.taps = 1; g.lda = ld_dy; g.ldb = ldx; g.amap = RM(); g.bmap = RM();
     g.so_i = l1.K; g.so_tap = 0; g.so_outer = 1; g.inner = 1;
     g.split_c = l1.K; g.out2 = c.gr(l2.w); g.so_i2 = l2.K;
+    if (c.h->skip & 17) return DIST_OK;
     g.dtype = c.dtype; g.use_tr = c.h->cfg.use_tr;
     g.colsum = c.gr(l1.bias); g.colsum2 = c.gr(l2.bias);
     dist_handle* h = c.h;
@@ -673,7 +680,7 @@ extern "C" int dist_abi_sizeof(const char* n) {
     if (!n) return -1;
 #define DIST_SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)
     DIST_SZ(dist_gemm_args); DIST_SZ(dist_gemm_tn_args); DIST_SZ(dist_ln_args); DIST_SZ(dist_ln_bwd_args);
-    DIST_SZ(dist_adamw_seg); DIST_SZ(dist_config); DIST_SZ(dist_rowmap); DIST_SZ(dist_outmap); DIST_SZ(dist_tnet_args);
+    DIST_SZ(dist_adamw_seg); DIST_SZ(dist_config); DIST_SZ(dist_rowmap); DIST_SZ(dist_outmap); DIST_SZ(dist_tnet_args); DIST_SZ(dist_tnet_bwd_args);
 #undef DIST_SZ
     return -1;
 }
@@ -701,6 +708,7 @@ extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
     build_tables(h);
     h->ws_bytes = layout_ws(h, nullptr);
     if (const char* e = getenv("DIST_AMD_SERIAL")) h->serial = atoi(e);
+    if (const char* e = getenv("DIST_AMD_SKIP")) h->skip = atoi(e);
     if (const char* e = getenv("DIST_AMD_DUMMY")) h->dummy = atoi(e);
     if (const char* e = getenv("DIST_AMD_DUMMY_REPS")) h->dummy_reps = atoi(e);
     *out = h;
@@ -1111,7 +1119,8 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
         DistLayerWs& w = h->lw[i];
         void* Xnext = (i + 1 < nl) ? h->lw[i + 1].X : h->Xlast;
         // ---- temporal chain: TemporalNet (dist.py:48-65): one fused launch (tnet.hip) where the geometry allows, else LayerNorm + two GEMMs
-        if (dist_k_tnet_fwd_eligible(c.dtype, Ct, h->G, l.tn_fc1.taps)) {
+        if (h->skip & 4) {
+        } else if (dist_k_tnet_fwd_eligible(c.dtype, Ct, h->G, l.tn_fc1.taps)) {
             dist_tnet_args ta;
             memset(&ta, 0, sizeof(ta));
             ta.X = w.X; ta.W1 = x.pk(l.tn_fc1.pk.f); ta.W2 = x.pk(l.tn_fc2.pk.f);
@@ -1145,6 +1154,7 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
         RUN(dist_k_cls_rows(w.Mp, w.M, x.th(l.cls_token), (int)bt, L, Ci, t, c.dtype, x.s));
         // IntegrationNetwork (dist.py:16-45)
         RUN(ln_fwd(x, h->theta, l.in_ln, w.Mp, w.Na, rowsS, w.in_mean, w.in_rstd, &l.in_ln_t, w.Nb));
+        if (!(h->skip & 8)) {
         RUN(gemm(x, w.Na, Ci, x.pk(l.ffn_fc.pk.f), rowsS, Ci, Ci, 1, w.zf, Ci + C4, x.th(l.ffn_fc.bias), nullptr, nullptr, w.hf));
         RUN(gemm(x, w.Nb, Ci, x.pk(l.tf_fc1.pk.f), rowsS, C4, Ci, 1, w.h1, C4, x.th(l.tf_fc1.bias), nullptr, nullptr, nullptr));
         RUN(gemm(x, w.h1, C4, x.pk(l.tf_fc2.pk.f), rowsS, C4, C4, l.tf_fc2.taps, w.h2, Ci + C4, x.th(l.tf_fc2.bias), nullptr, nullptr, w.g2,
@@ -1152,6 +1162,7 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
         // R = ffn.c_proj(hf) + temporal_ffn.c_proj(g2): one GEMM over [hf | g2] (K = Ci + C4) with the two weights side by side
         RUN(gemm(x, w.hf, Ci + C4, x.pk(l.pk_proj_f), rowsS, Ci, Ci + C4, 1, w.R, Ci, x.th(l.ffn_proj.bias), nullptr, nullptr, nullptr,
                  RM(), OM(), 0, x.th(l.tf_proj.bias)));
+        }
         if (i == nl / 2 - 1) mark(h, DIST_MARK_FWD_MID, x.s);
     }
     // current_layer_feat = res_feat + updated_mid_feat (dist.py:239)
@@ -1390,7 +1401,24 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         // ---- mid_feat = input_linear(F_i) + R_{i-1}: no dF_i (frozen ViT) ----
         RUN(wgrad(xb, l.in_lin, dM, Ci, h->feat[i], d, rowsS, RM(), RM(), 0, true));
         // ---- TemporalNet backward (dist.py:63-65): X' = g(p), p = X + conv3x3(V) + b, V = g(z), z = conv_t(U), U = LN(X) ----
-        RUN(gemm(x, q.dp, Ct, x.pk(l.tn_fc2.pk.b), rowsX, Ct, Ct, 9, q.dz, Ct, nullptr, nullptr, w.z, nullptr, RM(DIST_RM_SPATIAL, h->G, 0, -1)));
+        // bf16: two fused launches (tnet.hip): dz = conv3x3^T(dp) * g'(z); dX = dp + LN'(conv_t^T(dz)) with the LayerNorm parameter
+        // gradients as per-workgroup partial rows (no atomics); otherwise two row-mapped GEMMs + the LayerNorm backward kernel
+        const bool tn_fused = dist_k_tnet_fwd_eligible(c.dtype, Ct, h->G, l.tn_fc1.taps) &&
+                              !(getenv("DIST_AMD_TNET_BWD_FUSED") && atoi(getenv("DIST_AMD_TNET_BWD_FUSED")) == 0);   // measurement knob
+        if (h->skip & 2) {
+        } else if (tn_fused) {
+            dist_tnet_bwd_args ta;
+            memset(&ta, 0, sizeof(ta));
+            ta.dp = q.dp; ta.z = w.z; ta.X = w.X; ta.mean = w.tn_mean; ta.rstd = w.tn_rstd; ta.ln_w = x.th(l.tn_ln.w);
+            ta.W1b = x.pk(l.tn_fc1.pk.b); ta.W2b = x.pk(l.tn_fc2.pk.b);
+            ta.dz = q.dz; ta.dX = q.dXo; ta.dgamma = x.gr(l.tn_ln.w); ta.dbeta = x.gr(l.tn_ln.b);
+            ta.scratch = h->tnb_scratch; ta.scratch_elems = h->tnb_scratch_elems;
+            ta.clips = b; ta.T = T; ta.G = h->G; ta.Ct = Ct; ta.tk = l.tn_fc1.taps; ta.dtype = c.dtype;
+            ta.phase = 1;                                              // dz first: the weight-gradient streams start on it
+            RUN(dist_op_temporal_net_bwd(&ta, x.s));
+        } else {
+            RUN(gemm(x, q.dp, Ct, x.pk(l.tn_fc2.pk.b), rowsX, Ct, Ct, 9, q.dz, Ct, nullptr, nullptr, w.z, nullptr, RM(DIST_RM_SPATIAL, h->G, 0, -1)));
+        }
         RUN(fork());
         RUN(wgrad(xb, l.tn_fc2, q.dp, Ct, w.V, Ct, rowsX, RM(), RM(DIST_RM_SPATIAL, h->G, 0, 1), 1, true));
         RUN(wgrad(xb2, l.tn_fc1, q.dz, Ct, w.U, Ct, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 1, true));
@@ -1398,9 +1426,22 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         HIP_CHECK_RET(hipEventRecord(h->ev_b_done[i], B));
         if (h->dummy & 2) for (int r = 0; r < h->dummy_reps; ++r) RUN(ln_fwd(x, h->visual, h->vit[0].ln1, h->feat[i], nullptr, rowsS, h->lnstats2, h->lnstats2 + rowsS));
         if (h->dummy & 4) for (int r = 0; r < h->dummy_reps; ++r) RUN(ln_fwd(xb, h->visual, h->vit[0].ln1, h->feat[i], nullptr, rowsS, h->lnstats3, h->lnstats3 + rowsS));
-        RUN(gemm(x, q.dz, Ct, x.pk(l.tn_fc1.pk.b), rowsX, Ct, Ct, l.tn_fc1.taps, q.dU, Ct, nullptr, nullptr, nullptr, nullptr,
-                 RM(DIST_RM_SHIFT, T * N, N, -1)));
-        RUN(ln_bwd(x, l.tn_ln, w.X, w.tn_mean, w.tn_rstd, q.dU, q.dXo, false, rowsX, nullptr, nullptr, q.dp));   // dX_i = dp + LN'(dU)
+        if (!(h->skip & 2) && tn_fused) {
+            dist_tnet_bwd_args ta;
+            memset(&ta, 0, sizeof(ta));
+            ta.dp = q.dp; ta.z = w.z; ta.X = w.X; ta.mean = w.tn_mean; ta.rstd = w.tn_rstd; ta.ln_w = x.th(l.tn_ln.w);
+            ta.W1b = x.pk(l.tn_fc1.pk.b); ta.W2b = x.pk(l.tn_fc2.pk.b);
+            ta.dz = q.dz; ta.dX = q.dXo; ta.dgamma = x.gr(l.tn_ln.w); ta.dbeta = x.gr(l.tn_ln.b);
+            ta.scratch = h->tnb_scratch; ta.scratch_elems = h->tnb_scratch_elems;
+            ta.clips = b; ta.T = T; ta.G = h->G; ta.Ct = Ct; ta.tk = l.tn_fc1.taps; ta.dtype = c.dtype;
+            ta.phase = 2;
+            RUN(dist_op_temporal_net_bwd(&ta, x.s));
+        }
+        if (!(h->skip & 2) && !tn_fused) {
+            RUN(gemm(x, q.dz, Ct, x.pk(l.tn_fc1.pk.b), rowsX, Ct, Ct, l.tn_fc1.taps, q.dU, Ct, nullptr, nullptr, nullptr, nullptr,
+                     RM(DIST_RM_SHIFT, T * N, N, -1)));
+            RUN(ln_bwd(x, l.tn_ln, w.X, w.tn_mean, w.tn_rstd, q.dU, q.dXo, false, rowsX, nullptr, nullptr, q.dp));   // dX_i = dp + LN'(dU)
+        }
         dR = dM;                          // dL/dR_{i-1}
         dXn = q.dXo;
     }

@@ -714,7 +714,8 @@ static int fast_variant(const dist_gemm_args* a) {
     if (!fast_common_ok(a)) return 0;
     static const int forced = [] { const char* e = getenv("DIST_AMD_FAST_NW"); return e ? atoi(e) : 0; }();   // measurement knob
     // (a half-empty last column tile only pays with a deep K loop - bf16 has the branch-GEMM kernels for the rest; fp8 has no other kernel)
-    const bool ok8 = a->N >= 256 && !(a->N % 256 > 0 && (a->N % 256 < 128 || (a->K < 768 && !(a->flags & DIST_EPI_FP8))));
+    static const int kmin = [] { const char* e = getenv("DIST_AMD_FAST_KMIN"); return e ? atoi(e) : 768; }();                 // measurement knob
+    const bool ok8 = a->N >= 256 && !(a->N % 256 > 0 && (a->N % 256 < 128 || (a->K < kmin && !(a->flags & DIST_EPI_FP8))));
     const bool ok4 = a->N >= 128 && a->N % 128 == 0;
     // measured (tools/bench_fastk.py, profiles/r01_fast_gemm_shapes.md): the two-block shape hides ~40 % of the fixed
     // per-block cost but its K loop is ~30 % slower (prefetch depth 2, 1.5x the LDS-DMA pieces per FLOP) - it loses on

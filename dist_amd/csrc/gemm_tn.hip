@@ -281,10 +281,24 @@ __global__ __launch_bounds__(WI * WJ * 64) void gemm_tn_kernel(const dist_gemm_t
     // fragment (a wave instruction would touch 4 x 64-byte pieces); each wave stages its WTI x WTJ sub-tile in LDS and
     // issues the atomics row by row instead, 64 consecutive columns per instruction.
     __syncthreads();                                      // operand tiles / bias scratch are dead
-    {
+    constexpr bool STAGE_FITS = WI * WJ * WTI * (WTJ + 1) * 4 <= 2 * BR * (LDI + LDJ) * (int)sizeof(T);
+    if constexpr (!STAGE_FITS) {
+        // the large tiles (192 x 256: 196 KB of fp32 per block against 122 KB of LDS): straight from the accumulators, a wave instruction
+        // writes 4 rows x 16 consecutive floats - the tile is stored once per block, after ~40 steps of the loop
+        float* pt = p.partial ? p.partial + ((long)ms * tiles_ij + (bid % tiles_ij)) * (BI * BJ) : nullptr;
+#pragma unroll
+        for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wi * WTI + i * 16 + lg * 4 + r, col = wj * WTJ + j * 16 + li;
+                    if (pt) pt[row * BJ + col] = acc[i][j][r];
+                    else if (i0 + row < p.NI && c0 + col < p.K) atomicAdd(tn_dst(p, i0 + row, c0 + col, tap), acc[i][j][r]);
+                }
+    } else {
         constexpr int SLD = WTJ + 1;                      // +1 float: conflict-free column writes
         float* st = reinterpret_cast<float*>(smem) + wid * (WTI * SLD);
-        static_assert(WI * WJ * WTI * SLD * 4 <= 2 * BR * (LDI + LDJ) * (int)sizeof(T), "atomic staging fits in the operand buffers");
 #pragma unroll
         for (int i = 0; i < FI; ++i)
 #pragma unroll
@@ -401,6 +415,18 @@ int dispatch2(const dist_gemm_tn_args& a, hipStream_t s) {
     // alone (conv3x3 dW 95.5 -> 77.4 us, 384x768 dW 71.9 -> 62.0 us); capping the registers at 128 for two 8-wave blocks spills
     // and loses (92 us).  DIST_AMD_TN_W8=0: the 4-wave shapes (measurement knob; they exist for plain and runtime modes only).
     static const int w8 = getenv("DIST_AMD_TN_W8") ? atoi(getenv("DIST_AMD_TN_W8")) : 1;
+    // Large plain gradients (input_linear 384 x 768, the c_proj pair 384 x 480, ffn.c_fc 384 x 384: 63 of the 103 GF of weight gradients
+    // per layer): 192 x 256 / 192 x 192 tiles.  A block's time follows the bytes it moves through registers and LDS per MFMA - the 128 x 128
+    // tile loads 32 KB and does 12 LDS transpose reads per 16 MFMAs per wave; 192 x 256 loads 56 KB and 10 reads per 24 MFMAs per wave:
+    // 1.7x fewer bytes in every path (profiles/r03_tn_big_tiles.md).  DIST_AMD_TN_BIG=0: off (measurement knob).
+    if constexpr (MODES == 0 && std::is_same<T, bf16_t>::value && TR) {
+        static const int big = getenv("DIST_AMD_TN_BIG") ? atoi(getenv("DIST_AMD_TN_BIG")) : 0;
+        if (big && a.NI % 192 == 0 && a.K >= 384 && a.M >= 16384) {
+            const int waste256 = (a.K + 255) / 256 * 256 - a.K, waste192 = (a.K + 191) / 192 * 192 - a.K;
+            if (waste192 * 256 < waste256 * 192 || (big & 2)) return launch<T, 192, 192, 2, 4, TR, MODES>(a, s);
+            return launch<T, 192, 256, 2, 4, TR, MODES>(a, s);
+        }
+    }
     if (w8 || MODES > 0) {
         if (i96 && j96) return launch<T, 96, 96, 3, 2, TR, MODES>(a, s);
         if (i96) return launch<T, 96, 128, 2, 4, TR, MODES>(a, s);

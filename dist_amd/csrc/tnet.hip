@@ -46,6 +46,14 @@ struct TnArgs {
 };
 
 #define TN_SYNC() do { if (!(p.dbg & 128)) __syncthreads(); } while (0)
+// sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15); every lane of the row receives it.  Four v_add_f32_dpp
+DEV float tn_row_sum16(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));   // row_mirror
+    return v;
+}
 DEV int tn_pchunk(const int slot, const int c) { return (c & ~3) | ((c & 3) ^ (((slot >> 2) & 1) << 1)); }
 
 template <int CT, bool SAVE_UV>
@@ -332,6 +340,356 @@ int launch_tnet_fwd2(const TnArgs& a, hipStream_t s) {
 template <int CT>
 int launch_tnet_fwd(const TnArgs& a, hipStream_t s) { return (a.U && a.V) ? launch_tnet_fwd2<CT, true>(a, s) : launch_tnet_fwd2<CT, false>(a, s); }
 
+
+// =====================================================================================================================================
+// Backward of the same block, two launches (the temporal taps of dU need dz of the NEIGHBOUR frames, which other workgroups produce):
+//
+//   tnet_bwd_spatial_kernel   dz = conv_{1x3x3}^T(dp) * g'(z)                 one workgroup per (clip, frame): the dp frame in LDS, nine
+//                             flipped taps over it with the data-gradient weights W2b[ci][tap*Ct + co], g'(z) on the accumulators
+//   tnet_bwd_temporal_kernel  dX = dp + LN'( conv_{3x1x1}^T(dz) )             the dz frames k+1, k, k-1 through LDS one after the other,
+//                             LayerNorm backward on the accumulators (row sums by two lane exchanges), parameter gradients as per-workgroup
+//                             partial rows (plain stores) that tnet_dgb_reduce_kernel adds up: no atomics anywhere
+//
+// dp = dL/dp (already multiplied by g'(p) in the T2I data-gradient epilogue), z / X / mean / rstd as the forward saved them.  The weight
+// gradients dW2 = dp^T V(shifted), dW1 = dz^T U(shifted) stay with the row-split weight-gradient GEMM (gemm_tn.hip).
+// Shared machinery: the LDS tile layout, the weight stream and the tap multiply of the forward kernel, as device functions.
+template <int CT> struct TnK {
+    static constexpr int KBT = CT / 32, NTL = CT / 16, ROWB = CT * 2, CPR = CT / 8, SLOTB = CT * 64, NPIECE = SLOTB / 1024, GPIECES = KBT * NPIECE;
+};
+// one tap (KBT k-blocks of [CT][32]) of a packed weight [CT][ntaps*CT] into ring half `half`; wave-uniform piece distribution
+template <int CT> DEV void tn_issue_tap(char* ring, const int half, const __amdgpu_buffer_rsrc_t r, const unsigned wv, const int wcols, const int tap, const int wid) {
+    using K = TnK<CT>;
+#pragma unroll
+    for (int rr = 0; rr < (K::GPIECES + 7) / 8; ++rr) {
+        const int idx = wid + 8 * rr;
+        if (idx < K::GPIECES) {
+            const int kb = idx / K::NPIECE, j = idx - kb * K::NPIECE;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (tn_lds_ptr)(ring + (half * K::KBT + kb) * K::SLOTB + j * 1024), 16, wv,
+                                                     (j * 16 * wcols + tap * CT + kb * 32) * 2, 0, 0);
+        }
+    }
+}
+template <int CT> DEV void tn_mma_tap(f32x4 (&acc)[2][CT / 16], const char* act, const char* ring, const int half, const unsigned (&ab)[2], const int li, const int cob) {
+    using K = TnK<CT>;
+    const char* bs0 = ring + half * K::KBT * K::SLOTB + li * 64 + cob;
+    constexpr int NH = K::NTL / 2;
+#pragma unroll
+    for (int kb = 0; kb < K::KBT; ++kb) {
+        bf16x8 fa[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(act + ab[i] + kb * 64);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 fb[NH];
+#pragma unroll
+            for (int j = 0; j < NH; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bs0 + kb * K::SLOTB + (h * NH + j) * 1024);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NH; ++j)
+                    acc[i][h * NH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][h * NH + j], 0, 0, 0);
+        }
+    }
+}
+// a whole frame [N][CT] bf16 (contiguous in memory) into the swizzled LDS tile by LDS-DMA: lane l of 1 KB piece j lands at tile byte
+// j*1024 + 16 l, i.e. slot s / physical chunk q, and fetches the logical chunk q ^ swizzle(s) of slot s (the swizzle is an involution);
+// bytes beyond the frame read as zero through the descriptor's bound (they land in the zero slot / the tile's padding)
+template <int CT> DEV void tn_tile_dma(char* act, const bf16_t* frame, const int N, const int wid, const int lane) {
+    using K = TnK<CT>;
+    const int bytes = N * K::ROWB;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(frame), 0, bytes, 0x00020000);
+    const int pieces = (bytes + 1023) >> 10;
+    for (int j = wid; j < pieces; j += 8) {
+        const int off = j * 1024 + lane * 16;
+        const int slot = off / K::ROWB, q = (off - slot * K::ROWB) >> 4;
+        const unsigned src = off < bytes ? (unsigned)(slot * K::ROWB + tn_pchunk(slot, q) * 16) : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (tn_lds_ptr)(act + j * 1024), 16, src, 0, 0, 0);
+    }
+}
+template <int CT> DEV void tn_acc_to_tile(const f32x4 (&acc)[2][CT / 16], char* act, const int N, const int wid, const int li, const int lg) {
+    using K = TnK<CT>;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = (wid + 8 * i) * 16 + li;
+        if (m < N) {
+#pragma unroll
+            for (int j = 0; j < K::NTL; ++j) {
+                bf16x4 o = {(bf16_t)acc[i][j][0], (bf16_t)acc[i][j][1], (bf16_t)acc[i][j][2], (bf16_t)acc[i][j][3]};
+                *reinterpret_cast<bf16x4*>(act + m * K::ROWB + tn_pchunk(m, 2 * j + (lg >> 1)) * 16 + (lg & 1) * 8) = o;
+            }
+        }
+    }
+}
+template <int CT> DEV void tn_tile_out(const char* act, bf16_t* dst, const int N, const int tid) {
+    using K = TnK<CT>;
+    int slot = tid / K::CPR, c = tid - slot * K::CPR;
+    constexpr int DS = 512 / K::CPR, DC = 512 - DS * K::CPR;
+    for (int idx = tid; idx < N * K::CPR; idx += 512) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(act + slot * K::ROWB + tn_pchunk(slot, c) * 16);
+        __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(dst + (long)idx * 8));
+        slot += DS; c += DC;
+        if (c >= K::CPR) { c -= K::CPR; ++slot; }
+    }
+}
+
+struct TnBwdArgs {
+    const bf16_t *dp, *z, *dz_in, *X, *W2b, *W1b;
+    const float *mean, *rstd, *lnw;
+    bf16_t *dz, *dX;
+    float* dgb;              // [2 * Ct][workgroups] partial (dgamma rows, then dbeta rows)
+    int clips, T, G, N, tk, nwg;
+};
+
+template <int CT>
+__global__ __launch_bounds__(512, 4) void tnet_bwd_spatial_kernel(const TnBwdArgs p) {
+    using K = TnK<CT>;
+    constexpr int NTL = K::NTL, ROWB = K::ROWB;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int N = p.N, G = p.G, T = p.T;
+    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    const int clip = xcd + 8 * (qb / T), k = qb - (qb / T) * T;
+    if (clip >= p.clips) return;
+    const int act_bytes = ((N + 1) * ROWB + 1023) & ~1023;
+    char* act = smem;
+    char* ring = smem + act_bytes;
+    const long frame_rows = (long)(clip * T + k) * N;
+
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W2b), 0, CT * 9 * CT * 2, 0x00020000);
+    const int lrow = lane >> 2, lch = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
+    const unsigned wv2 = ((unsigned)lrow * (unsigned)(9 * CT) + lch * 8) * 2u;
+    const int cob = (lg ^ ((4 - ((li >> 2) & 3)) & 3)) * 16;
+
+    tn_issue_tap<CT>(ring, 0, r2, wv2, 9 * CT, 0, wid);
+    tn_tile_dma<CT>(act, p.dp + frame_rows * CT, N, wid, lane);      // (its tail zeroes the zero slot)
+    f32x4 acc[2][NTL];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int my[2], mx[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = (wid + 8 * i) * 16 + li;
+        my[i] = m < N ? m / G : -4; mx[i] = m - (m / G) * G;
+    }
+    if ((N * ROWB) % 1024 == 0) {                                      // the frame ends on a piece boundary: nothing zeroed the zero slot
+        for (int i = tid; i < ROWB / 4; i += 512) reinterpret_cast<unsigned*>(act + N * ROWB)[i] = 0u;
+    }
+    for (int tap = 0; tap < 9; ++tap) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tap + 1 < 9) tn_issue_tap<CT>(ring, (tap + 1) & 1, r2, wv2, 9 * CT, tap + 1, wid);
+        // dz[m] += dp[m - (dy, dx)] . W2b[tap]: the forward tap (dy, dx) seen from the other side
+        const int dy = -(tap / 3 - 1), dx = -(tap - (tap / 3) * 3 - 1);
+        unsigned at[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int y = my[i] + dy, x = mx[i] + dx;
+            const bool ok = y >= 0 && y < G && x >= 0 && x < G;
+            const int s = ok ? y * G + x : N;
+            at[i] = (unsigned)(s * ROWB + ((lg ^ (((s >> 2) & 1) << 1)) << 4));
+        }
+        tn_mma_tap<CT>(acc, act, ring, tap & 1, at, li, cob);
+    }
+    // dz = acc * g'(z): z in the accumulator layout (8-byte pieces straight from memory)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = min((wid + 8 * i) * 16 + li, N - 1);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const bf16x4 zv = *reinterpret_cast<const bf16x4*>(p.z + (frame_rows + m) * CT + j * 16 + lg * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] *= qgelu_grad_t<bf16_t>((float)zv[r]);
+        }
+    }
+    __syncthreads();                                                   // dp tile no longer read
+    tn_acc_to_tile<CT>(acc, act, N, wid, li, lg);
+    __syncthreads();
+    tn_tile_out<CT>(act, p.dz + frame_rows * CT, N, tid);
+}
+
+template <int CT>
+__global__ __launch_bounds__(512, 4) void tnet_bwd_temporal_kernel(const TnBwdArgs p) {
+    using K = TnK<CT>;
+    constexpr int NTL = K::NTL, ROWB = K::ROWB;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int N = p.N, T = p.T;
+    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    const int clip = xcd + 8 * (qb / T), k = qb - (qb / T) * T;
+    const int wg = (xcd + 8 * (qb / T)) * T + k;                       // row of the parameter-gradient partials (also for idle workgroups)
+    const int act_bytes = ((N + 1) * ROWB + 1023) & ~1023;
+    char* act = smem;
+    char* ring = smem + act_bytes;
+    float* gsum = reinterpret_cast<float*>(ring + 2 * K::KBT * K::SLOTB);   // [2 * CT] dgamma | dbeta of this workgroup
+    if (clip >= p.clips) {                                              // idle slot of the XCD-aligned grid: its partial row is zero
+        for (int i = tid; i < 2 * CT; i += 512) p.dgb[(long)i * p.nwg + wg] = 0.f;
+        return;
+    }
+    const long frame_rows = (long)(clip * T + k) * N;
+    const int tk = p.tk, thalf = tk >> 1;
+    // dU[k] = sum_t dz[k - (t - thalf)] . W1b[t]: taps whose source frame exists
+    const int t_first = max(0, k - (T - 1) + thalf), t_last = min(tk - 1, k + thalf);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W1b), 0, CT * tk * CT * 2, 0x00020000);
+    const int lrow = lane >> 2, lch = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
+    const unsigned wv1 = ((unsigned)lrow * (unsigned)(tk * CT) + lch * 8) * 2u;
+    const int cob = (lg ^ ((4 - ((li >> 2) & 3)) & 3)) * 16;
+    for (int i = tid; i < 3 * CT; i += 512) gsum[i] = i < 2 * CT ? 0.f : p.lnw[i - 2 * CT];
+    static_assert(16 * 2 * CT * 4 <= 2 * K::KBT * K::SLOTB, "the (wave, tile) partial rows fit in the weight ring");
+    if ((N * ROWB) % 1024 == 0) {
+        for (int i = tid; i < ROWB / 4; i += 512) reinterpret_cast<unsigned*>(act + N * ROWB)[i] = 0u;
+    }
+    f32x4 acc[2][NTL];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned ab[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = min((wid + 8 * i) * 16 + li, N);
+        ab[i] = (unsigned)(m * ROWB + ((lg ^ (((m >> 2) & 1) << 1)) << 4));
+    }
+    for (int t = t_first; t <= t_last; ++t) {
+        const int g = t - t_first;
+        tn_issue_tap<CT>(ring, g & 1, r1, wv1, tk * CT, t, wid);       // (one tap per interval: the weights arrive beside the frame)
+        tn_tile_dma<CT>(act, p.dz_in + (frame_rows - (long)(t - thalf) * N) * CT, N, wid, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                               // frame + tap complete
+        tn_mma_tap<CT>(acc, act, ring, g & 1, ab, li, cob);
+        __syncthreads();                                               // frame no longer read
+    }
+    // ---- LayerNorm backward on the accumulators: lane (li, lg) holds row m = tile*16 + li, channels j*16 + 4 lg .. + 3 (24 of the 96);
+    // the three other lanes with the same li hold the rest of the row
+    // X[k] comes through the (now free) tile as a whole frame by LDS-DMA and is read from LDS in the accumulator layout (8-byte cells,
+    // twice: row sums, then the result) - gathered straight from memory those reads cost 36 partial-line requests per tile per wave.
+    // LN'(dU) replaces x in its cell (bf16); dp is added on the way out, where both are whole coalesced rows.
+    const float* gam = gsum + 2 * CT;
+    constexpr float invC = 1.f / (float)CT;
+    tn_tile_dma<CT>(act, p.X + frame_rows * CT, N, wid, lane);
+    float rmean[2], rrstd[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = min((wid + 8 * i) * 16 + li, N - 1);
+        rmean[i] = p.mean[frame_rows + m]; rrstd[i] = p.rstd[frame_rows + m];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int mrow = (wid + 8 * i) * 16 + li;
+        const bool live = mrow < N;
+        const int m = min(mrow, N);                                    // rows beyond the plane: the zero slot
+        char* row = act + m * ROWB + (lg & 1) * 8;
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const bf16x4 xv = *reinterpret_cast<const bf16x4*>(row + tn_pchunk(m, 2 * j + (lg >> 1)) * 16);
+            const float4 gv = *reinterpret_cast<const float4*>(gam + j * 16 + lg * 4);
+            const float g4[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float du = live ? acc[i][j][r] : 0.f;
+                acc[i][j][r] = du;
+                const float t = g4[r] * du;
+                a1 += t;
+                a2 += t * (((float)xv[r] - rmean[i]) * rrstd[i]);
+            }
+        }
+        a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
+        a2 += __shfl_xor(a2, 16, 64); a2 += __shfl_xor(a2, 32, 64);
+        const float s1 = a1 * invC, s2 = a2 * invC;
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            char* cell = row + tn_pchunk(m, 2 * j + (lg >> 1)) * 16;
+            const bf16x4 xv = *reinterpret_cast<const bf16x4*>(cell);
+            const float4 gv = *reinterpret_cast<const float4*>(gam + j * 16 + lg * 4);
+            const float g4[4] = {gv.x, gv.y, gv.z, gv.w};
+            float dgm[4], dbt[4], dx[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float du = acc[i][j][r];
+                const float xh = ((float)xv[r] - rmean[i]) * rrstd[i];
+                dgm[r] = du * xh; dbt[r] = du;
+                dx[r] = rrstd[i] * (g4[r] * du - s1 - xh * s2);
+            }
+            if (live) {                                                // in place: this lane is the only reader and writer of the cell
+                bf16x4 o = {(bf16_t)dx[0], (bf16_t)dx[1], (bf16_t)dx[2], (bf16_t)dx[3]};
+                *reinterpret_cast<bf16x4*>(cell) = o;
+            }
+            // parameter gradients: sum over the 16 rows of the tile (the DPP row li = 0..15 of this lg group)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { dgm[r] = tn_row_sum16(dgm[r]); dbt[r] = tn_row_sum16(dbt[r]); }
+            if (li == 0) {                                             // one partial row per (wave, tile) in the dead weight ring: plain stores
+                float* prow = reinterpret_cast<float*>(ring) + (wid * 2 + i) * 2 * CT;
+                *reinterpret_cast<float4*>(prow + j * 16 + lg * 4) = make_float4(dgm[0], dgm[1], dgm[2], dgm[3]);
+                *reinterpret_cast<float4*>(prow + CT + j * 16 + lg * 4) = make_float4(dbt[0], dbt[1], dbt[2], dbt[3]);
+            }
+        }
+    }
+    __syncthreads();
+    {   // dX = dp + LN'(dU): whole rows, 16 bytes per lane
+        const bf16_t* dpf = p.dp + frame_rows * CT;
+        bf16_t* dst = p.dX + frame_rows * CT;
+        int slot = tid / K::CPR, c = tid - slot * K::CPR;
+        constexpr int DS = 512 / K::CPR, DC = 512 - DS * K::CPR;
+        for (int idx = tid; idx < N * K::CPR; idx += 512) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(act + slot * ROWB + tn_pchunk(slot, c) * 16);
+            const bf16x8 d = *reinterpret_cast<const bf16x8*>(dpf + (long)idx * 8);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)v[e] + (float)d[e]);
+            __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(dst + (long)idx * 8));
+            slot += DS; c += DC;
+            if (c >= K::CPR) { c -= K::CPR; ++slot; }
+        }
+    }
+    for (int i = tid; i < 2 * CT; i += 512) {                           // the 16 (wave, tile) rows in a fixed order: bit-repeatable
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a += reinterpret_cast<const float*>(ring)[r * 2 * CT + i];
+        p.dgb[(long)i * p.nwg + wg] = a;                                 // [2 Ct][workgroups]: a channel's partials are one contiguous row
+    }
+}
+
+// dgamma[c] += sum over workgroups of partial[c][wg], dbeta likewise: one wave per channel, fixed order (no atomics, bit-repeatable)
+__global__ __launch_bounds__(64) void tnet_dgb_reduce_kernel(const float* part, int nwg, int CT, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const float* row = part + (long)c * nwg;
+    float a = 0.f;
+    for (int w = lane; w < nwg; w += 64) a += row[w];
+    a = wave_sum(a, 64);
+    if (lane == 0) { if (c < CT) dgamma[c] += a; else dbeta[c - CT] += a; }
+}
+
+template <int CT>
+int launch_tnet_bwd(const TnBwdArgs& aa, float* dgamma, float* dbeta, int phase, hipStream_t s) {
+    const int act_bytes = ((aa.N + 1) * CT * 2 + 1023) & ~1023;
+    const size_t smem = (size_t)act_bytes + 2 * (CT / 32) * CT * 64 + 3 * CT * sizeof(float);
+    if (smem > 160 * 1024) return DIST_ERR_ARG;
+    static size_t attr_done = 0;
+    if (attr_done < smem) {
+        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(tnet_bwd_spatial_kernel<CT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(tnet_bwd_temporal_kernel<CT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_done = smem;
+    }
+    const int groups = (aa.clips + 7) / 8, nwg = groups * 8 * aa.T;
+    TnBwdArgs a = aa;
+    a.nwg = nwg;
+    if (phase != 2) hipLaunchKernelGGL(tnet_bwd_spatial_kernel<CT>, dim3((unsigned)nwg), dim3(512), smem, s, a);
+    if (phase != 1) {
+        hipLaunchKernelGGL(tnet_bwd_temporal_kernel<CT>, dim3((unsigned)nwg), dim3(512), smem, s, a);
+        hipLaunchKernelGGL(tnet_dgb_reduce_kernel, dim3((unsigned)(2 * CT)), dim3(64), 0, s, a.dgb, nwg, CT, dgamma, dbeta);
+    }
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+
 }  // namespace
 
 bool dist_k_tnet_fwd_eligible(int dtype, int Ct, int G, int tk) {
@@ -359,6 +717,31 @@ extern "C" int dist_op_temporal_net_fwd(const dist_tnet_args* a, void* stream) {
         case 32: return launch_tnet_fwd<32>(k, s);
         case 64: return launch_tnet_fwd<64>(k, s);
         case 96: return launch_tnet_fwd<96>(k, s);
+        default: return DIST_ERR_ARG;
+    }
+}
+
+// rows of fp32 scratch dist_op_temporal_net_bwd needs for its parameter-gradient partials
+extern "C" int64_t dist_op_temporal_net_bwd_scratch(int clips, int T, int Ct) { return (int64_t)((clips + 7) / 8) * 8 * T * 2 * Ct; }
+
+extern "C" int dist_op_temporal_net_bwd(const dist_tnet_bwd_args* a, void* stream) {
+    if (!a || !a->dp || !a->z || !a->X || !a->mean || !a->rstd || !a->ln_w || !a->W1b || !a->W2b || !a->dz || !a->dX || !a->dgamma || !a->dbeta || !a->scratch)
+        return DIST_ERR_ARG;
+    if (a->clips <= 0 || a->T <= 0 || a->G <= 0 || a->phase < 0 || a->phase > 2) return DIST_ERR_ARG;
+    if (!dist_k_tnet_fwd_eligible(a->dtype, a->Ct, a->G, a->tk)) return DIST_ERR_ARG;
+    if ((long)a->clips * a->T * a->G * a->G * a->Ct >= (1l << 30)) return DIST_ERR_ARG;
+    if (a->scratch_elems < dist_op_temporal_net_bwd_scratch(a->clips, a->T, a->Ct)) return DIST_ERR_WORKSPACE;
+    TnBwdArgs k;
+    k.dp = static_cast<const bf16_t*>(a->dp); k.z = static_cast<const bf16_t*>(a->z); k.X = static_cast<const bf16_t*>(a->X);
+    k.W1b = static_cast<const bf16_t*>(a->W1b); k.W2b = static_cast<const bf16_t*>(a->W2b);
+    k.mean = a->mean; k.rstd = a->rstd; k.lnw = a->ln_w;
+    k.dz = static_cast<bf16_t*>(a->dz); k.dz_in = k.dz; k.dX = static_cast<bf16_t*>(a->dX); k.dgb = a->scratch;
+    k.clips = a->clips; k.T = a->T; k.G = a->G; k.N = a->G * a->G; k.tk = a->tk;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (a->Ct) {
+        case 32: return launch_tnet_bwd<32>(k, a->dgamma, a->dbeta, a->phase, s);
+        case 64: return launch_tnet_bwd<64>(k, a->dgamma, a->dbeta, a->phase, s);
+        case 96: return launch_tnet_bwd<96>(k, a->dgamma, a->dbeta, a->phase, s);
         default: return DIST_ERR_ARG;
     }
 }

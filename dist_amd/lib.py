@@ -62,6 +62,11 @@ class TnetArgs(C.Structure):
                [(n, C.c_int) for n in ("clips", "T", "G", "Ct", "tk", "dtype")] + [("eps", C.c_float)]
 
 
+class TnetBwdArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dp", "z", "X", "mean", "rstd", "ln_w", "W1b", "W2b", "dz", "dX", "dgamma", "dbeta", "scratch")] + \
+               [("scratch_elems", C.c_int64)] + [(n, C.c_int) for n in ("clips", "T", "G", "Ct", "tk", "dtype", "phase")]
+
+
 class AdamwSeg(C.Structure):
     _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("lr", C.c_float), ("weight_decay", C.c_float)]
 
@@ -77,7 +82,7 @@ GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
 
 ABI_VERSION = 7    # include/dist_amd.h DIST_ABI_VERSION: bumped on every struct-layout change
 ABI_MIRRORS = (("dist_gemm_args", GemmArgs), ("dist_gemm_tn_args", GemmTnArgs), ("dist_ln_args", LnArgs), ("dist_ln_bwd_args", LnBwdArgs),
-               ("dist_adamw_seg", AdamwSeg), ("dist_config", Config), ("dist_rowmap", RowMap), ("dist_outmap", OutMap), ("dist_tnet_args", TnetArgs))
+               ("dist_adamw_seg", AdamwSeg), ("dist_config", Config), ("dist_rowmap", RowMap), ("dist_outmap", OutMap), ("dist_tnet_args", TnetArgs), ("dist_tnet_bwd_args", TnetBwdArgs))
 
 
 class DistError(RuntimeError):
@@ -157,6 +162,8 @@ def load():
     _sig(lib, "dist_debug_tensor", argtypes=[C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)])
     _sig(lib, "dist_op_gemm_nt", argtypes=[C.POINTER(GemmArgs), C.c_void_p])
     _sig(lib, "dist_op_temporal_net_fwd", argtypes=[C.POINTER(TnetArgs), C.c_void_p])
+    _sig(lib, "dist_op_temporal_net_bwd", argtypes=[C.POINTER(TnetBwdArgs), C.c_void_p])
+    _sig(lib, "dist_op_temporal_net_bwd_scratch", argtypes=[C.c_int, C.c_int, C.c_int], restype=C.c_int64)
     _sig(lib, "dist_op_ln_fold", argtypes=[C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p])
     _sig(lib, "dist_op_gemm_tn", argtypes=[C.POINTER(GemmTnArgs), C.c_void_p])
     _sig(lib, "dist_op_layernorm", argtypes=[C.POINTER(LnArgs), C.c_void_p])

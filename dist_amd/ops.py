@@ -102,6 +102,30 @@ def temporal_net_fwd(X, W1p, b1, W2p, b2, ln_w, ln_b, clips, T, G, *, tk=3, save
     return out
 
 
+def pack_conv_taps_dgrad(w):
+    """Conv3d weight [Co, Ci, kt, kh, kw] -> the data-gradient layout [Ci][tap*Co + co] in bf16 (PACK_B of dist_pack_weights)."""
+    co, ci = w.shape[0], w.shape[1]
+    return w.reshape(co, ci, -1).permute(1, 2, 0).reshape(ci, -1).to(torch.bfloat16).contiguous()
+
+
+def temporal_net_bwd(dp, z, X, mean, rstd, ln_w, W1b, W2b, clips, T, G, *, tk=3, dgamma=None, dbeta=None):
+    """Fused TemporalNet data-gradient backward (dist_op_temporal_net_bwd).  Returns dict(dz, dX, dgamma, dbeta); dgamma / dbeta are
+    ACCUMULATED into when given."""
+    lib = L.load()
+    rows, Ct = X.shape
+    out = {"dz": torch.empty_like(X), "dX": torch.empty_like(X),
+           "dgamma": dgamma if dgamma is not None else torch.zeros(Ct, dtype=torch.float32, device=X.device),
+           "dbeta": dbeta if dbeta is not None else torch.zeros(Ct, dtype=torch.float32, device=X.device)}
+    n = lib.dist_op_temporal_net_bwd_scratch(clips, T, Ct)
+    scratch = torch.empty(n, dtype=torch.float32, device=X.device)
+    a = L.TnetBwdArgs()
+    a.dp, a.z, a.X, a.mean, a.rstd, a.ln_w, a.W1b, a.W2b = _p(dp), _p(z), _p(X), _p(mean), _p(rstd), _p(ln_w), _p(W1b), _p(W2b)
+    a.dz, a.dX, a.dgamma, a.dbeta, a.scratch, a.scratch_elems = _p(out["dz"]), _p(out["dX"]), _p(out["dgamma"]), _p(out["dbeta"]), _p(scratch), n
+    a.clips, a.T, a.G, a.Ct, a.tk, a.dtype = clips, T, G, Ct, tk, L.BF16
+    L.check(lib.dist_op_temporal_net_bwd(C.byref(a), _stream()))
+    return out
+
+
 def ln_fold(W, bias, gamma, beta):
     """LayerNorm -> Linear fold (dist_op_ln_fold): returns (Wp bf16 [N,K] = W*gamma, colsum fp32 [N], bias' fp32 [N])."""
     lib = L.load()

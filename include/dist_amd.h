@@ -43,7 +43,7 @@ const char* dist_strerror(int code);
 #define DIST_ABI_VERSION 7
 int dist_abi_version(void);
 /* sizeof() of an argument struct of this header by name ("dist_gemm_args", "dist_gemm_tn_args", "dist_ln_args",
- * "dist_ln_bwd_args", "dist_adamw_seg", "dist_config", "dist_rowmap", "dist_outmap", "dist_tnet_args"); -1 for an unknown name.
+ * "dist_ln_bwd_args", "dist_adamw_seg", "dist_config", "dist_rowmap", "dist_outmap", "dist_tnet_args", "dist_tnet_bwd_args"); -1 for an unknown name.
  * Lets a foreign-language binding verify its mirror of the layout without a GPU. */
 int dist_abi_sizeof(const char* struct_name);
 
@@ -216,6 +216,24 @@ typedef struct dist_tnet_args {
     int clips, T, G, Ct, tk; int dtype; float eps;
 } dist_tnet_args;
 int dist_op_temporal_net_fwd(const dist_tnet_args* a, void* stream);
+/* Data-gradient backward of the same block (autograd in the reference, runs/train.py:110), two fused launches + a small reduction:
+ *   dz = conv_{1x3x3}^T(dp) * g'(z)                (dp = dL/dp: the incoming gradient already multiplied by g'(p); nine flipped taps over the
+ *                                                   frame in LDS, W2b = c_fc2.weight in the data-gradient layout [Ct][9*Ct], W2b[ci][tap*Ct + co])
+ *   dX = dp + bf16(LN'(conv_{3x1x1}^T(dz)))        (W1b [Ct][tk*Ct] likewise; LayerNorm backward on the accumulators, dp added as whole rows)
+ *   dgamma += sum_rows dU * xhat, dbeta += sum_rows dU   (per-workgroup partial rows in `scratch`, summed in a fixed order: no atomics)
+ * dz is an output (the weight-gradient GEMM dW1 = dz^T U needs it) and is re-read by the second launch.  The weight gradients themselves
+ * (dW1, dW2, db1 = colsum dz, db2 = colsum dp) stay with dist_op_gemm_tn.  scratch: fp32, >= dist_op_temporal_net_bwd_scratch() elements. */
+typedef struct dist_tnet_bwd_args {
+    const void* dp; const void* z; const void* X; const float* mean; const float* rstd; const float* ln_w;
+    const void* W1b; const void* W2b;
+    void* dz; void* dX; float* dgamma; float* dbeta;
+    float* scratch; int64_t scratch_elems;
+    int clips, T, G, Ct, tk; int dtype;
+    int phase;               /* 0 = everything; 1 = only dz (first launch); 2 = only dX, dgamma, dbeta from the dz of an earlier phase-1 call
+                              * (lets the caller start the weight-gradient GEMMs that read dz on another stream in between) */
+} dist_tnet_bwd_args;
+int64_t dist_op_temporal_net_bwd_scratch(int clips, int T, int Ct);
+int dist_op_temporal_net_bwd(const dist_tnet_bwd_args* a, void* stream);
 
 /* one-query cross attention (CrossAttentionBlockGenral, clip.py:139-147; dist.py:144,158):
  * q [B, C], kv [B*S, 2C] -> o [B, C], probs [B, H, S] (fp32, saved for backward) */

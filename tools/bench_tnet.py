@@ -53,5 +53,47 @@ def main():
         del Xs, bufs
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--bwd" not in sys.argv:
     main()
+
+
+def bench_bwd():
+    """the data-gradient backward: fused (two launches + reduce) vs the unfused sequence (two row-mapped GEMMs + LayerNorm backward)"""
+    dt = torch.bfloat16
+    NSET = 6
+    for (clips, T, G, tag) in [(32, 16, 14, "config 2: b=32 T=16 14x14"), (8, 64, 16, "config 4: b=8 T=64 16x16")]:
+        Ct, N = 96, G * G
+        rows = clips * T * N
+        mk = lambda: [(torch.randn(rows, Ct, device="cuda") * 0.7).to(dt) for _ in range(NSET)]
+        Xs, zs, dps = mk(), mk(), mk()
+        W1 = torch.randn(Ct, Ct, 3, 1, 1, device="cuda") * 0.05; W2 = torch.randn(Ct, Ct, 1, 3, 3, device="cuda") * 0.03
+        W1b, W2b = ops.pack_conv_taps_dgrad(W1), ops.pack_conv_taps_dgrad(W2)
+        lw = torch.randn(Ct, device="cuda") * 0.1 + 1
+        mean, rstd = torch.randn(rows, device="cuda") * 0.1, torch.rand(rows, device="cuda") + 0.5
+        dzs, dUs, dXs = [torch.empty(rows, Ct, device="cuda", dtype=dt) for _ in range(NSET)], [torch.empty(rows, Ct, device="cuda", dtype=dt) for _ in range(2)], \
+            [torch.empty(rows, Ct, device="cuda", dtype=dt) for _ in range(NSET)]
+        dg, db = torch.zeros(Ct, device="cuda"), torch.zeros(Ct, device="cuda")
+        n = L.load().dist_op_temporal_net_bwd_scratch(clips, T, Ct)
+        scratch = torch.empty(n, device="cuda")
+
+        def fused(i, phase=0):
+            a = L.TnetBwdArgs()
+            a.dp, a.z, a.X, a.mean, a.rstd, a.ln_w, a.W1b, a.W2b = (ops._p(v) for v in (dps[i], zs[i], Xs[i], mean, rstd, lw, W1b, W2b))
+            a.dz, a.dX, a.dgamma, a.dbeta, a.scratch, a.scratch_elems = ops._p(dzs[i]), ops._p(dXs[i]), ops._p(dg), ops._p(db), ops._p(scratch), n
+            a.clips, a.T, a.G, a.Ct, a.tk, a.dtype, a.phase = clips, T, G, Ct, 3, L.BF16, phase
+            L.check(L.load().dist_op_temporal_net_bwd(a, ops._stream()))
+
+        def unfused(i, part=0):
+            if part in (0, 1):
+                ops.gemm_nt(dps[i], W2b, rows, Ct, Ct, taps=9, aux=zs[i], amap=ops.rowmap(L.RM_SPATIAL, G, 0, -1), C_out=dzs[i])
+            if part in (0, 2):
+                ops.gemm_nt(dzs[i], W1b, rows, Ct, Ct, taps=3, amap=ops.rowmap(L.RM_SHIFT, T * N, N, -1), C_out=dUs[i % 2])
+                ops.layernorm_bwd(Xs[i], mean, rstd, dUs[i % 2], lw, dx=dXs[i], dw=dg, db=db, dx_add=dps[i])
+        for name, fn in (("unfused: conv3x3^T * g'", lambda i: unfused(i, 1)), ("unfused: conv_t^T + LN bwd", lambda i: unfused(i, 2)),
+                         ("fused phase 1 (dz)", lambda i: fused(i, 1)), ("fused phase 2 (dX, dg, db)", lambda i: fused(i, 2)), ("fused, all", lambda i: fused(i, 0))):
+            t = timeit_rot([(lambda i=i: fn(i)) for i in range(NSET)])
+            print(f"{tag}: {name:28s} {t * 1e6:8.1f} us", flush=True)
+
+
+if __name__ == "__main__" and "--bwd" in sys.argv:
+    bench_bwd()
