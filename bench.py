@@ -68,9 +68,43 @@ def cpu_baseline(gname, seconds_budget=12.0):
     out = {"value": round(b / dt, 4), "unit": "clips/s", "cores": threads, "kind": "port",
            "sample": f"{gname} b={b} fp32 fwd+bwd, torch-CPU oracle, median of {n} iterations ({dt:.2f} s each), host has {cores} usable cores"}
     if cores > threads:
-        dta, na = sample(cores, seconds_budget)
-        out["all_cores"] = {"value": round(b / dta, 4), "unit": "clips/s", "cores": cores,
-                            "sample": f"same workload on all {cores} usable cores, median of {na} iterations ({dta:.2f} s each)"}
+        # BASELINE.md section 3 asks for "all host cores".  On a 256-core host 256 OpenMP threads on this b = 2 problem take MINUTES per
+        # iteration (642 s measured in round 3: every small operator pays a 256-way fork / join), so the leg runs in its own process
+        # under a hard limit and reports what it measured - or that it did not finish - instead of stretching the bench.
+        import subprocess
+        code = ("import sys, os, time, json, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+                "from dist_amd import synth; from dist_oracle import Oracle\n"
+                "g = synth.geometry(%r); torch.set_num_threads(%d)\n"
+                "o = Oracle(g, synth.state_dict(g), dtype=torch.float32)\n"
+                "v, t, y = synth.video(g, 2), synth.text_features(g), synth.soft_target(g, 2)[0]\n"
+                "ts = []\n"
+                "for i in range(4):\n"
+                "    t0 = time.time(); o.forward_backward(v, t, y); ts.append(time.time() - t0); print(json.dumps(ts), flush=True)\n") % (
+                    ROOT, os.path.join(ROOT, "oracle"), gname, cores)
+        limit = 45.0
+        ts = []
+        try:
+            pr = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                                  env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+            try:
+                so, _ = pr.communicate(timeout=limit)
+            except subprocess.TimeoutExpired:
+                pr.kill()                                   # the exact child we started
+                so, _ = pr.communicate()
+            lines = [ln for ln in (so or "").splitlines() if ln.startswith("[")]
+            ts = json.loads(lines[-1]) if lines else []
+        except Exception:
+            ts = []
+        timed = ts[1:] if len(ts) > 1 else ts
+        if timed:
+            dta = sorted(timed)[len(timed) // 2]
+            out["all_cores"] = {"value": round(b / dta, 4), "unit": "clips/s", "cores": cores,
+                                "sample": f"same workload on all {cores} usable cores (own process, {limit:.0f} s limit), median of {len(timed)} iterations ({dta:.2f} s each)"}
+        else:
+            out["all_cores"] = {"value": None, "unit": "clips/s", "cores": cores,
+                                "sample": f"same workload on all {cores} usable cores: no iteration finished within {limit:.0f} s "
+                                          f"(round 3 measured 642 s per iteration with 256 threads: fork / join of every small operator); "
+                                          f"the {threads}-thread figure is the faster one"}
     return out
 
 
