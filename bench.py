@@ -250,7 +250,7 @@ def main():
         # HBM bytes per launch of this kernel: PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes, corrected
         # as MI355X_MICROARCH.md prescribes), collected offline by tools/pmc_pass.sh and committed; null when the file is absent
         traffic = None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_fast_gemm.json")
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_fast_gemm.json")
         if args.config == "b16_8+16f" and os.path.exists(pmc):
             with open(pmc) as f:
                 traffic = json.load(f).get("traffic_bytes_per_launch_avg")
@@ -261,7 +261,7 @@ def main():
                 prof_avg = json.load(f).get("dominant_kernel_avg_us")
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "bytes per launch, mean of the four ViT GEMM shapes (48 of the launches), profiles/r02_pmc_fast_gemm.json",
+                "traffic_note": "bytes per launch, mean of the four ViT GEMM shapes (48 of the launches), profiles/r03_pmc_fast_gemm.{md,json}",
                 "kernel": "gemm_fast8p_kernel 256x256x64 LDS-DMA, two wave groups (ViT QKV/out/MLP + large DiST Linears; the strided patch embedding on the 256x256x32 loop)", "launches_per_step": lps,
                 "avg_launch_us": round(avg_us, 1), "profile_avg_us": prof_avg,
                 "profile_note": "average duration of the same kernel in profiles/r03_bench_kernel_stats.{md,json} (rocprofv3 --kernel-trace --stats of this command); "
@@ -319,13 +319,13 @@ def main():
             out["path_mfma_frac"] = round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4)
         # whole-step HBM-side traffic from the committed PMC passes (tools/pmc_step.sh: FETCH_SIZE x2 + WRITE_SIZE over every kernel of
         # one step, Infinity-Cache hits included) against this run's step time; null when the file is absent or the config differs
-        tj = os.path.join(ROOT, "profiles", "r02_pmc_step_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r03_pmc_step_traffic.json")
         if args.config == "b16_8+16f" and b == 32 and os.path.exists(tj):
             with open(tj) as f:
                 tr = json.load(f)
             gbps = tr["bytes_per_step"] / (dt / args.steps) / 1e9
             out["hbm"] = {"bytes_per_step_per_gpu": tr["bytes_per_step"], "achieved_gbps_per_gpu": round(gbps, 1), "peak_gbps": 8000.0,
-                          "frac": round(gbps / 8000.0, 4), "source": "profiles/r02_pmc_step_traffic.{md,json}"}
+                          "frac": round(gbps / 8000.0, 4), "source": "profiles/r03_pmc_step_traffic.{md,json}"}
         if reducer is not None:
             import torch.distributed as tdist
             out["reducer"] = {"backend": tdist.get_backend(), "world": world, "collectives_per_step": reducer.n_collectives,

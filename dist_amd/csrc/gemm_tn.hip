@@ -392,7 +392,8 @@ int launch(const dist_gemm_tn_args& a, hipStream_t s) {
     if (!two_phase) b.partial = nullptr;
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * msplit)), dim3(WI * WJ * 64), smem, s, b, chunk, tiles_i, tiles_c);
     HIP_CHECK_RET(hipGetLastError());
-    if (two_phase) {
+    static const bool skip_reduce = getenv("DIST_AMD_TN_SKIP_REDUCE") && atoi(getenv("DIST_AMD_TN_SKIP_REDUCE"));   // measurement knob (results WRONG): what the second phase holds of the step
+    if (two_phase && !skip_reduce) {
         const long total = tiles * (long)(BI * BJ);
         const long gx = (total + (a.colsum ? (long)tiles_i * BI : 0) + NT - 1) / NT;
         long groups = (1024 + gx - 1) / gx;               // ~1024 blocks in flight ...
