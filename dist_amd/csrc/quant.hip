@@ -68,7 +68,7 @@ __global__ __launch_bounds__(NT) void fp8_rowsum_kernel(const unsigned char* __r
 __global__ void fp8_scale_update_kernel(float* __restrict__ amax, float* __restrict__ scale, const int n, const float margin) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float t = fmaxf(amax[i], 1e-30f) * margin * (1.0f / 448.f);
+    const float t = fmaxf(amax[i], 5.9604645e-8f /* 2^-24 */) * margin * (1.0f / 448.f);   // (an all-zero tensor must not give a scale whose square underflows in the attention scores)
     int e;
     const float f = frexpf(t, &e);                         // t = f * 2^e, f in [0.5, 1)
     scale[i] = ldexpf(1.0f, f == 0.5f ? e - 1 : e);        // smallest power of two >= t

@@ -42,6 +42,7 @@ struct TnArgs {
     bf16_t *z, *p, *Xp, *U, *V;
     float *mean, *rstd;
     int clips, T, G, N, tk; float eps;
+    int stagger;  // DIST_AMD_TNET_STAGGER: the second workgroup of a CU starts this many s_sleep(127) (3.4 us each) late
     int dbg;      // measurement knob DIST_AMD_TNET_DBG (results are WRONG with any bit set): 1 = no weight DMA, 2 = no MFMAs, 4 = no row loads, 8 = no stores, 16 = no LayerNorm math / U tile, 32 = no stream-out, 64 = no accumulator -> tile, 128 = no block barriers
 };
 
@@ -82,6 +83,11 @@ __global__ __launch_bounds__(512, 4) void tnet_fwd_kernel(const TnArgs p) {
     char* ring = smem + act_bytes;                                   // [2][KBT][CT][32] bf16
     float* par = reinterpret_cast<float*>(ring + 2 * KBT * SLOTB);  // gamma, beta, b1, b2
     const int MT = (N + 15) >> 4;
+    // The two workgroups of a CU would walk the same phases in step (LayerNorm VALU phases together, MFMA phases together).  Workgroups
+    // are dispatched to an XCD's 32 CUs in order, so the 32 that follow the first 32 of an XCD are the second tenants: they start late.
+    if (p.stagger > 0 && ((qb >> 5) & 1)) {
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     // ---- parameters and the zero slot
     for (int i = tid; i < 4 * CT; i += 512) {
@@ -710,7 +716,8 @@ extern "C" int dist_op_temporal_net_fwd(const dist_tnet_args* a, void* stream) {
     k.U = static_cast<bf16_t*>(a->U); k.V = static_cast<bf16_t*>(a->V);
     k.mean = a->mean; k.rstd = a->rstd;
     static const int dbg = getenv("DIST_AMD_TNET_DBG") ? atoi(getenv("DIST_AMD_TNET_DBG")) : 0;
-    k.dbg = dbg;
+    static const int stagger = getenv("DIST_AMD_TNET_STAGGER") ? atoi(getenv("DIST_AMD_TNET_STAGGER")) : 0;
+    k.dbg = dbg; k.stagger = stagger;
     k.clips = a->clips; k.T = a->T; k.G = a->G; k.N = a->G * a->G; k.tk = a->tk; k.eps = a->eps;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (a->Ct) {

@@ -119,7 +119,7 @@ int dist_op_gemm_nt(const dist_gemm_args* a, void* stream);
  * x [rows][ld] of `dtype` (bf16 / fp32), K % 8 == 0, K <= 8192, ld % 8 == 0; q [rows][ldq] bytes, ldq % 8 == 0 (% 16 for a GEMM operand).  Used once per frozen weight at
  * pack time (per output channel) and per GEMM input row at run time (per token). */
 int dist_op_quant_rows_fp8(const void* x, int dtype, int64_t rows, int K, int ld, void* q, int ldq, float* scale, void* stream);
-/* per-tensor scales for DIST_EPI_OUT8 from collected maxima: for i < n: scale[i] = 2^ceil(log2(max(amax[i], 1e-30) * margin / 448)),
+/* per-tensor scales for DIST_EPI_OUT8 from collected maxima: for i < n: scale[i] = 2^ceil(log2(max(amax[i], 2^-24) * margin / 448)),
  * then amax[i] = 0 (ready to collect the next pass).  dist_op_amax: *amax = max(*amax, max |x|) over a bf16 / fp32 tensor (the
  * calibration pass of a tensor no DIST_EPI_OUT8 producer has written yet). */
 int dist_op_fp8_scale_update(float* amax, float* scale, int n, float margin, void* stream);

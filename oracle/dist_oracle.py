@@ -107,7 +107,7 @@ class Oracle:
         import fp8_oracle as fo
         if not per_tensor:
             return fo.quant_rows(a2)
-        t = max(float(a2.abs().max()), 1e-30) * 4.0 / 448.0
+        t = max(float(a2.abs().max()), 2.0 ** -24) * 4.0 / 448.0
         sc = 2.0 ** int(math.ceil(math.log2(t)))
         q = (a2.float() / sc).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
         return q, torch.full((a2.shape[0],), sc, dtype=torch.float32)

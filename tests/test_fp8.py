@@ -255,9 +255,9 @@ def test_scale_update_and_amax_ops(gpu_lib):
     amax = torch.tensor([0.0, 448.0, 449.0, 1.0, 3.3e4, 112.0], device="cuda")
     scale = torch.zeros(6, device="cuda")
     ops.fp8_scale_update(amax, scale, 4.0)
-    want = [2.0 ** -96, 4.0, 8.0, 2.0 ** -6, 512.0, 1.0]                       # smallest power of two >= amax * 4 / 448
+    want = [2.0 ** -30, 4.0, 8.0, 2.0 ** -6, 512.0, 1.0]                       # smallest power of two >= max(amax, 2^-24) * 4 / 448
     got = scale.cpu().tolist()
-    assert got[1:] == want[1:] and got[0] <= 2.0 ** -90 and float(amax.abs().sum()) == 0
+    assert got == want and float(amax.abs().sum()) == 0                      # (an all-zero tensor: a floor whose square is a normal fp32 number)
     x = rnd((1000, 768), 5, 3.0)
     a = torch.zeros(1, device="cuda")
     ops.amax_(x, a)
