@@ -468,7 +468,7 @@ size_t layout_ws(dist_handle* h, char* base) {
     h->dR = T_(rowsS, Ci); h->dkv = T_(rowsS, 2 * Ci); h->dkn = T_(rowsS, Ci);
     h->tnb_scratch_elems = dist_op_temporal_net_bwd_scratch((int)b, c.frames, Ct);
     h->tnb_scratch = F_(h->tnb_scratch_elems);
-    h->tn_partial_elems = 9l << 20;                          // 36 MB each: >= 512 partial tiles of 128 x 128 (+ slack)
+    h->tn_partial_elems = 16l << 20;                         // 64 MB each: 256 partial tiles of 192 x 256 (the LDS-DMA weight-gradient kernel) + slack
     for (int k = 0; k < 3; ++k) h->tn_partial[k] = F_(h->tn_partial_elems);
     for (int k = 0; k < 2; ++k) {
         dist_handle::BwdSet& q = h->bs[k];

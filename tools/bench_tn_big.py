@@ -22,7 +22,7 @@ M = 50432
 for (NI, K, tag) in [(384, 768, "in_lin"), (384, 480, "proj pair"), (384, 384, "ffn_fc"), (96, 384, "tf_fc1")]:
     As = [torch.randn(M, NI, device="cuda").to(dt) for _ in range(NSET)]
     Bs = [torch.randn(M, K, device="cuda").to(dt) for _ in range(NSET)]
-    out = torch.zeros(NI, K, device="cuda"); cs = torch.zeros(NI, device="cuda"); part = torch.empty(9 << 20, device="cuda")
+    out = torch.zeros(NI, K, device="cuda"); cs = torch.zeros(NI, device="cuda"); part = torch.empty(16 << 20, device="cuda")
     fns = [(lambda a=a, b=b: ops.gemm_tn(a, b, out, M, NI, K, colsum=cs, partial=part)) for a, b in zip(As, Bs)]
     t = timeit_rot(fns)
     byts = (M * NI + M * K) * 2
