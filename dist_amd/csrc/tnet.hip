@@ -481,9 +481,8 @@ __global__ __launch_bounds__(512, 4) void tnet_bwd_spatial_kernel(const TnBwdArg
         const int m = (wid + 8 * i) * 16 + li;
         my[i] = m < N ? m / G : -4; mx[i] = m - (m / G) * G;
     }
-    if ((N * ROWB) % 1024 == 0) {                                      // the frame ends on a piece boundary: nothing zeroed the zero slot
-        for (int i = tid; i < ROWB / 4; i += 512) reinterpret_cast<unsigned*>(act + N * ROWB)[i] = 0u;
-    }
+    // the zero slot (the DMA's last piece zero-fills only what lies inside that piece; zeros over zeros where both write)
+    for (int i = tid; i < ROWB / 4; i += 512) reinterpret_cast<unsigned*>(act + N * ROWB)[i] = 0u;
     for (int tap = 0; tap < 9; ++tap) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -547,9 +546,7 @@ __global__ __launch_bounds__(512, 4) void tnet_bwd_temporal_kernel(const TnBwdAr
     const int cob = (lg ^ ((4 - ((li >> 2) & 3)) & 3)) * 16;
     for (int i = tid; i < 3 * CT; i += 512) gsum[i] = i < 2 * CT ? 0.f : p.lnw[i - 2 * CT];
     static_assert(16 * 2 * CT * 4 <= 2 * K::KBT * K::SLOTB, "the (wave, tile) partial rows fit in the weight ring");
-    if ((N * ROWB) % 1024 == 0) {
-        for (int i = tid; i < ROWB / 4; i += 512) reinterpret_cast<unsigned*>(act + N * ROWB)[i] = 0u;
-    }
+    for (int i = tid; i < ROWB / 4; i += 512) reinterpret_cast<unsigned*>(act + N * ROWB)[i] = 0u;     // the zero slot
     f32x4 acc[2][NTL];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
