@@ -147,7 +147,7 @@ struct dist_handle {
     long tn_partial_elems = 0;
     // weight-gradient side stream (created once per handle; host-side objects only)
     hipStream_t side = nullptr, side2 = nullptr, pf = nullptr;   // pf: the handle's own ViT prefetch stream
-    int skip = 0;                              // DIST_AMD_SKIP (measurement knob, results WRONG): 1 = no weight-gradient GEMMs, 2 = no TemporalNet backward data-gradient kernels, 4 = no TemporalNet forward, 8 = no IntegrationNetwork forward GEMMs, 16 = no large-wgrad (in_lin / proj pair / ffn_fc) only
+    int skip = 0;                              // DIST_AMD_SKIP (measurement knob, results WRONG): 1 = no weight-gradient GEMMs, 2 = no TemporalNet backward data-gradient kernels, 4 = no TemporalNet forward, 8 = no IntegrationNetwork forward GEMMs, 16 = no large-wgrad (in_lin / proj pair / ffn_fc) only, 32 = no ViT attention, 64 = no ViT MLP (fc + proj GEMMs)
     int serial = 0;                            // DIST_AMD_SERIAL (measurement knob): bit 0 = branch forward, bit 1 = backward on the caller's stream only
     std::vector<hipEvent_t> ev_a;              // chain -> side: "buffer produced"
     std::vector<hipEvent_t> ev_b_dr, ev_b_done; // side -> chain: per layer "dR consumed", "all weight gradients of the layer issued and done"
@@ -929,7 +929,7 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
             RUN(gemm(x, h->hbuf, d, x.pk(v.qkv.pk.f), rowsS, 3 * d, d, 1, h->qkv, 64, x.vs(v.qkv.bias), nullptr, nullptr, nullptr, RM(), OM(DIST_OM_HEADS, L, h->heads)));
         }
         if (fused) RUN(dist_op_attention_fp8(h->qkv, h->f8_scale + 5 * i + 4, nullptr, h->aq, h->f8_scale + 5 * i + 3, h->f8_amax + 5 * i + 3, b * h->t, L, h->heads, stream));
-        else RUN(dist_op_attention(h->qkv, h->att, b * h->t, L, h->heads, DIST_QKV_HEADS, c.dtype, stream));
+        else if (!(h->skip & 32)) RUN(dist_op_attention(h->qkv, h->att, b * h->t, L, h->heads, DIST_QKV_HEADS, c.dtype, stream));
         int done8 = 0;
         if (f8 & 2) {
             if (fused) {                                   // the attention kernel left the e4m3 image in h->aq
@@ -963,7 +963,8 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
                 }
                 if (folded < 0) return fail(h, folded, "fp8 MLP GEMM failed");
             }
-            if (!folded) folded = gemm_lnfold(x, h->xa, d, x.pk(v.pk_fold_fc), rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, h->lnstats, v.cs_fc, h->mlp);
+            if (!folded && !(h->skip & 64)) folded = gemm_lnfold(x, h->xa, d, x.pk(v.pk_fold_fc), rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, h->lnstats, v.cs_fc, h->mlp);
+            if (h->skip & 64) folded = 1;
             if (folded < 0) return fail(h, folded, "folded MLP GEMM failed");
         }
         if (!folded) {
