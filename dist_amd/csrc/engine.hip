@@ -155,6 +155,7 @@ struct dist_handle {
     std::vector<hipEvent_t> ev_feat;           // chain -> side: ViT layer i output (mid_feat[i]) is complete
     void *dv, *dzp, *dy, *du, *ds, *dc, *dzu, *dun, *do2, *dq2, *dkv2, *dqn2, *dkn2, *dzs, *dsn, *do_, *dq, *dqn;
     int fwd_b = 0, branch_b = 0;
+    bool inference = false, branch_infer = false;   // dist_set_inference: the next branch forwards keep nothing for a backward pass
     const float* text = nullptr;               // borrowed: text features of the last branch_forward
     // gradient-ready hook + the slices it reports
     dist_grad_ready_fn grad_hook = nullptr; void* grad_hook_user = nullptr;
@@ -1126,7 +1127,8 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
             memset(&ta, 0, sizeof(ta));
             ta.X = w.X; ta.W1 = x.pk(l.tn_fc1.pk.f); ta.W2 = x.pk(l.tn_fc2.pk.f);
             ta.b1 = x.th(l.tn_fc1.bias); ta.b2 = x.th(l.tn_fc2.bias); ta.ln_w = x.th(l.tn_ln.w); ta.ln_b = x.th(l.tn_ln.b);
-            ta.z = w.z; ta.p = w.p; ta.Xp = w.Xp; ta.U = w.U; ta.V = w.V;       // (U, V: the weight-gradient GEMMs of backward still read them)
+            ta.z = w.z; ta.p = w.p; ta.Xp = w.Xp;
+            if (!h->inference) { ta.U = w.U; ta.V = w.V; }                      // (U, V: the weight-gradient GEMMs of backward read them)
             ta.mean = w.tn_mean; ta.rstd = w.tn_rstd;
             ta.clips = b; ta.T = T; ta.G = h->G; ta.Ct = Ct; ta.tk = l.tn_fc1.taps; ta.dtype = c.dtype; ta.eps = 1e-5f;
             RUN(dist_op_temporal_net_fwd(&ta, xt.s));
@@ -1156,9 +1158,10 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
         // IntegrationNetwork (dist.py:16-45)
         RUN(ln_fwd(x, h->theta, l.in_ln, w.Mp, w.Na, rowsS, w.in_mean, w.in_rstd, &l.in_ln_t, w.Nb));
         if (!(h->skip & 8)) {
-        RUN(gemm(x, w.Na, Ci, x.pk(l.ffn_fc.pk.f), rowsS, Ci, Ci, 1, w.zf, Ci + C4, x.th(l.ffn_fc.bias), nullptr, nullptr, w.hf));
+        // (inference: the pre-activations zf / h2 are what backward needs - only the activated tensors are written)
+        RUN(gemm(x, w.Na, Ci, x.pk(l.ffn_fc.pk.f), rowsS, Ci, Ci, 1, h->inference ? nullptr : w.zf, Ci + C4, x.th(l.ffn_fc.bias), nullptr, nullptr, w.hf));
         RUN(gemm(x, w.Nb, Ci, x.pk(l.tf_fc1.pk.f), rowsS, C4, Ci, 1, w.h1, C4, x.th(l.tf_fc1.bias), nullptr, nullptr, nullptr));
-        RUN(gemm(x, w.h1, C4, x.pk(l.tf_fc2.pk.f), rowsS, C4, C4, l.tf_fc2.taps, w.h2, Ci + C4, x.th(l.tf_fc2.bias), nullptr, nullptr, w.g2,
+        RUN(gemm(x, w.h1, C4, x.pk(l.tf_fc2.pk.f), rowsS, C4, C4, l.tf_fc2.taps, h->inference ? nullptr : w.h2, Ci + C4, x.th(l.tf_fc2.bias), nullptr, nullptr, w.g2,
                  RM(DIST_RM_SHIFT, t * L, L, 1)));
         // R = ffn.c_proj(hf) + temporal_ffn.c_proj(g2): one GEMM over [hf | g2] (K = Ci + C4) with the two weights side by side
         RUN(gemm(x, w.hf, Ci + C4, x.pk(l.pk_proj_f), rowsS, Ci, Ci + C4, 1, w.R, Ci, x.th(l.ffn_proj.bias), nullptr, nullptr, nullptr,
@@ -1209,6 +1212,7 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
                            b, c.embed_dim, c.num_classes, c.dtype, A));
     if (logits) HIP_CHECK_RET(hipMemcpyAsync(logits, h->logits, (size_t)b * c.num_classes * sizeof(float), hipMemcpyDeviceToDevice, A));
     h->branch_b = b;
+    h->branch_infer = h->inference;
     h->text = text_features;
     return DIST_OK;
 }
@@ -1278,6 +1282,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
     if (!h || !dlogits) return DIST_ERR_ARG;
     if (!h->grads || !h->dlogit_scale) return fail(h, DIST_ERR_UNBOUND, "dist_branch_backward needs grads and dlogit_scale bound");
     if (h->branch_b != b || !h->text) return fail(h, DIST_ERR_STATE, "dist_branch_backward(b=%d) needs dist_branch_forward with the same batch first", b);
+    if (h->branch_infer) return fail(h, DIST_ERR_STATE, "dist_branch_backward after an inference-mode forward (dist_set_inference): nothing was kept for it");
     const dist_config& c = h->cfg;
     Ctx x{h, static_cast<hipStream_t>(stream), c.dtype};
     const int d = c.width, Ci = c.integration_dim, Ct = c.temporal_dim, C4 = h->C4, N = h->N, L = h->L, T = c.frames, t = h->t, al = c.alpha;
@@ -1458,6 +1463,12 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         for (; hook_next >= 0; --hook_next) h->grad_hook(h->grad_hook_user, h->layer_begin[hook_next], h->layer_end[hook_next]);
         h->grad_hook(h->grad_hook_user, 0, h->layer_begin[0]);
     }
+    return DIST_OK;
+}
+
+extern "C" int dist_set_inference(dist_handle* h, int on) {
+    if (!h) return DIST_ERR_ARG;
+    h->inference = on != 0;
     return DIST_OK;
 }
 

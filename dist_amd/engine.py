@@ -169,6 +169,10 @@ class Engine:
         self.b = self._pf_video.shape[0]
         self._cur_video, self._cur_ver, self._pf_video = self._pf_video, self._pf_ver, None
 
+    def set_inference(self, on=True):
+        """forward passes keep nothing for a backward pass (dist_set_inference); `backward` then raises until a training-mode forward ran"""
+        L.check(self.lib.dist_set_inference(self.h, int(bool(on))), self.h)
+
     def branch_forward(self, text_features):
         assert text_features.dtype == torch.float32 and text_features.is_contiguous()
         self._text = text_features            # keep alive: the engine borrows the pointer until backward

@@ -154,6 +154,7 @@ def load():
     _sig(lib, "dist_branch_forward", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_branch_backward", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p])
     _sig(lib, "dist_loss", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
+    _sig(lib, "dist_set_inference", argtypes=[C.c_void_p, C.c_int])
     _sig(lib, "dist_set_grad_ready_hook", argtypes=[C.c_void_p, GRAD_HOOK, C.c_void_p])
     _sig(lib, "dist_marks_enable", argtypes=[C.c_void_p, C.c_int])
     _sig(lib, "dist_marks_read", argtypes=[C.c_void_p, C.POINTER(C.c_float), C.c_int])

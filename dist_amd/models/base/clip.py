@@ -259,6 +259,11 @@ class CLIP(nn.Module):
         text_features, _, others = self.cache_text(text, others)
         pair = getattr(self, "_cur_pair", None)
         video = pair[1] if (pair is not None and pair[0] is video) else video.contiguous().float()
+        # under torch.no_grad() (eval_epoch, perform_test) the engine keeps nothing for a backward pass (dist_set_inference)
+        infer = not torch.is_grad_enabled()
+        if infer != getattr(self, "_infer", False):
+            self.engine.set_inference(infer)
+            self._infer = infer
         logits, vid = _DistFunction.apply(self.engine, video, text_features, self.logit_scale, *self._dist_params)
         return {"logits_per_image": logits, "logits_per_text": logits.t(), "img_logits": self.image_logits(), "vid_logits": vid[:, None, :]}
 

@@ -375,6 +375,12 @@ int dist_vit_adopt(dist_handle* h);
 /* DiSTNetwork.forward + cosine logits (dist.py:222-247, clip.py:509-518): -> logits [b,K] fp32,
  * vid_logits [b,E] fp32 (L2-normalised video embedding) */
 int dist_branch_forward(dist_handle* h, const float* text_features, int b, float* logits, float* vid_logits, void* stream);
+/* Inference mode (the reference's `torch.no_grad()` evaluation loops, runs/train.py:205-260, runs/test.py:24-178): while on, dist_branch_forward
+ * writes nothing that only a backward pass would read (the TemporalNet's normalised / activated tensors, the pre-activations of the
+ * IntegrationNetwork's two QuickGELUs: 87 MB per layer at the bench geometry), and dist_branch_backward refuses to run behind such a
+ * forward (DIST_ERR_STATE).  Those two QuickGELUs then act on the fp32 accumulators instead of the stored bf16 pre-activations: the logits
+ * agree with a training-mode forward to bf16 rounding (0.005 on a +-6 range), not bit for bit. */
+int dist_set_inference(dist_handle* h, int on);
 /* backward of the branch given dlogits [b,K] fp32 (autograd in the reference, runs/train.py:110);
  * accumulates into the bound flat grads buffer (zeroed first when zero_grads != 0). */
 int dist_branch_backward(dist_handle* h, const float* dlogits, int b, int zero_grads, void* stream);
