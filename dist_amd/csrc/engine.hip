@@ -142,6 +142,7 @@ struct dist_handle {
     // layer-loop scratch, double-buffered by layer parity (the weight-gradient stream lags the data-gradient chain)
     struct BwdSet { void *dMp, *dM, *dXp, *dp, *dXo, *dz, *dU, *dY, *dh2, *dh1, *dzf, *dNa, *dNb; } bs[2];
     void *dR, *dkv, *dkn;
+    float* ln_partial = nullptr; long ln_partial_elems = 0;     // per-block parameter-gradient sums of the LayerNorm backward (two-phase, no atomics)
     float* tnb_scratch = nullptr; long tnb_scratch_elems = 0;   // parameter-gradient partial rows of the fused TemporalNet backward
     float* tn_partial[3] = {nullptr, nullptr, nullptr};   // two-phase dW reduction scratch, one per stream that launches dW GEMMs
     long tn_partial_elems = 0;
@@ -467,6 +468,8 @@ size_t layout_ws(dist_handle* h, char* base) {
     h->y_mean = F_(b); h->y_rstd = F_(b); h->logits = F_(b * c.num_classes); h->dlogits = F_(b * c.num_classes); h->loss = F_(4);
     // backward scratch
     h->dR = T_(rowsS, Ci); h->dkv = T_(rowsS, 2 * Ci); h->dkn = T_(rowsS, Ci);
+    h->ln_partial_elems = dist_op_layernorm_bwd_scratch(rowsS > rowsX ? rowsS : rowsX, Ci > Ct ? Ci : Ct);
+    h->ln_partial = F_(h->ln_partial_elems);
     h->tnb_scratch_elems = dist_op_temporal_net_bwd_scratch((int)b, c.frames, Ct);
     h->tnb_scratch = F_(h->tnb_scratch_elems);
     h->tn_partial_elems = 16l << 20;                         // 64 MB each: 256 partial tiles of 192 x 256 (the LDS-DMA weight-gradient kernel) + slack
@@ -657,6 +660,11 @@ int ln_bwd(const Ctx& c, const LNp& l, const void* x, const float* mean, const f
     if (l2) { a.dy2 = dy2; a.w2 = c.th(l2->w); a.dw2 = c.gr(l2->w); a.db2 = c.gr(l2->b); }
     a.rows = rows; a.C = l.C; a.dtype = c.dtype;
     a.dx_add = dx_add; a.dx_copy = dx_copy;
+    // Two-phase parameter gradients (dist_ln_bwd_args.partial): measured in the step and NOT the default - 20.03 -> 20.20 ms with the same grid
+    // caps, 20.2 with 512 blocks (three alternations): the second launch sits on the data-gradient chain and costs more than the same-line
+    // atomics it removes.  DIST_AMD_LN_TWO_PHASE=1 turns it on (the data-gradient chain owns the scratch: its launches are serial).
+    static const bool two_phase = getenv("DIST_AMD_LN_TWO_PHASE") && atoi(getenv("DIST_AMD_LN_TWO_PHASE")) == 1;
+    if (two_phase && c.s != c.h->side && c.s != c.h->side2) { a.partial = c.h->ln_partial; a.partial_elems = c.h->ln_partial_elems; }
     return dist_op_layernorm_bwd(&a, c.s);
 }
 
@@ -676,7 +684,8 @@ extern "C" const char* dist_strerror(int code) {
 // 5: dist_gemm_args.rowstats, marks, mixup, evaluation side; 6: fp8 operands (a_scale / b_scale, DIST_EPI_FP8);
 // 7: dist_config.vit_fp8 and dist_gemm_args.C8 / ldc8 / out8_scale / out8_amax (both structs grew after 6 without a bump), vit_fp8 range-checked.
 // Rule: EVERY change of a public struct's layout bumps this number (dist_amd/lib.py and tests/test_abi_and_host.py pin it).
-extern "C" int dist_abi_version(void) { return 7; }
+// 8: dist_ln_bwd_args.partial / partial_elems (two-phase LayerNorm parameter gradients), dist_tnet_args / dist_tnet_bwd_args, dist_set_inference.
+extern "C" int dist_abi_version(void) { return 8; }
 extern "C" int dist_abi_sizeof(const char* n) {
     if (!n) return -1;
 #define DIST_SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)

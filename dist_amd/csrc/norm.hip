@@ -210,6 +210,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const dist_ln_bwd_args p) {
     // block reduction of the per-lane parameter-gradient sums, one array at a time: lanes that own the same columns
     // (same lr) are first summed inside the wave by shuffles, then across the 4 waves through a [4][C] LDS image
     // (plain stores; LDS atomics on C addresses from every lane serialised thousands of updates per block)
+    int which = 0;                                         // index of the array being reduced (two-phase layout)
     auto reduce_out = [&](auto& a, float* __restrict__ dst) {
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it)
@@ -233,8 +234,14 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const dist_ln_bwd_args p) {
             }
         }
         __syncthreads();
-        for (int c = tid; c < C; c += NT) atomicAdd(dst + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+        if (p.partial) {                                   // two-phase: this block's row of array `which`, plain stores
+            float* prow = p.partial + ((long)which * gridDim.x + blockIdx.x) * C;
+            for (int c = tid; c < C; c += NT) prow[c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        } else {
+            for (int c = tid; c < C; c += NT) atomicAdd(dst + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+        }
         __syncthreads();
+        ++which;
     };
     if (p.dw) reduce_out(aw, p.dw);
     if (p.db) reduce_out(ab, p.db);
@@ -242,6 +249,21 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const dist_ln_bwd_args p) {
         if (p.dw2) reduce_out(aw2, p.dw2);
         if (p.db2) reduce_out(ab2, p.db2);
     }
+}
+
+// second phase of the parameter gradients: array a (dw, db, dw2, db2 in the order they were requested), channel c: the `nblk` per-block
+// sums in block order, four independent accumulators; one thread per (array, channel)
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int C, float* d0, float* d1, float* d2, float* d3) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int a = e / C, c = e - a * C;
+    float* dst = a == 0 ? d0 : (a == 1 ? d1 : (a == 2 ? d2 : d3));
+    if (a > 3 || !dst) return;
+    const float* col = part + (long)a * nblk * C + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nblk; b += 4) { s0 += col[(long)b * C]; s1 += col[(long)(b + 1) * C]; s2 += col[(long)(b + 2) * C]; s3 += col[(long)(b + 3) * C]; }
+    for (; b < nblk; ++b) s0 += col[(long)b * C];
+    dst[c] += (s0 + s1) + (s2 + s3);
 }
 
 int grid_for(long rows, int rpb) {
@@ -322,10 +344,23 @@ extern "C" int dist_op_layernorm_bwd(const dist_ln_bwd_args* a, void* stream) {
     // dual-input 62 -> 52 us at 256 blocks, single-input 42 -> 33 us at 384); without them 1024 blocks stream best
     const bool want_w = a->dw || a->db || a->dw2 || a->db2;
     static const int gcap_env = getenv("DIST_AMD_LN_GCAP") ? atoi(getenv("DIST_AMD_LN_GCAP")) : 0;     // measurement knob
-    const long gcap = gcap_env > 0 ? gcap_env : (!want_w ? 1024 : (a->dy2 ? 256 : 384));
+    const bool two_phase_on = true;                        // (whoever passes `partial` asks for it; the engine does so only under DIST_AMD_LN_TWO_PHASE=1)
+    // two-phase parameter gradients (round 3): per-block sums to `partial`, a second launch adds them in block order - no same-line atomics at
+    // the end of every block, so the grid no longer has to be capped for them, and the sums are bit-repeatable
+    const int narr = (a->dw ? 1 : 0) + (a->db ? 1 : 0) + (a->dw2 ? 1 : 0) + (a->db2 ? 1 : 0);
+    long gcap = gcap_env > 0 ? gcap_env : (!want_w ? 1024 : (a->dy2 ? 256 : 384));
+    bool two_phase = want_w && two_phase_on && a->partial != nullptr;
+    if (two_phase) {
+        static const int gcap2_env = getenv("DIST_AMD_LN_GCAP2") ? atoi(getenv("DIST_AMD_LN_GCAP2")) : 0;   // measurement knob
+        const long gcap2 = gcap2_env > 0 ? gcap2_env : gcap;       // (512 blocks: +0.4 ms in the step - the caps found for the atomics stay)
+        if ((g > gcap2 ? gcap2 : g) * 4 * a->C <= a->partial_elems) gcap = gcap2; else two_phase = false;
+    }
     if (g > gcap) g = gcap;
     const int grid = (int)g;
     const bool dual = a->dy2 != nullptr;
+    dist_ln_bwd_args local = *a;
+    if (!two_phase) local.partial = nullptr;
+    a = &local;
     if (a->dtype == DIST_BF16) {
         if (dual) launch_by_lpr<bf16_t>(lpr, grid, s, *a, ln_bwd_kernel<bf16_t, 4, true>, ln_bwd_kernel<bf16_t, 16, true>, ln_bwd_kernel<bf16_t, 32, true>, ln_bwd_kernel<bf16_t, 64, true>);
         else launch_by_lpr<bf16_t>(lpr, grid, s, *a, ln_bwd_kernel<bf16_t, 4, false>, ln_bwd_kernel<bf16_t, 16, false>, ln_bwd_kernel<bf16_t, 32, false>, ln_bwd_kernel<bf16_t, 64, false>);
@@ -333,6 +368,23 @@ extern "C" int dist_op_layernorm_bwd(const dist_ln_bwd_args* a, void* stream) {
         if (dual) launch_by_lpr<float>(lpr, grid, s, *a, ln_bwd_kernel<float, 4, true>, ln_bwd_kernel<float, 16, true>, ln_bwd_kernel<float, 32, true>, ln_bwd_kernel<float, 64, true>);
         else launch_by_lpr<float>(lpr, grid, s, *a, ln_bwd_kernel<float, 4, false>, ln_bwd_kernel<float, 16, false>, ln_bwd_kernel<float, 32, false>, ln_bwd_kernel<float, 64, false>);
     }
+    if (two_phase) {                                       // arrays in the order the kernel stored them
+        float* d[4] = {nullptr, nullptr, nullptr, nullptr};
+        int k = 0;
+        if (a->dw) d[k++] = a->dw;
+        if (a->db) d[k++] = a->db;
+        if (a->dw2) d[k++] = a->dw2;
+        if (a->db2) d[k++] = a->db2;
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((narr * a->C + 255) / 256)), dim3(256), 0, s, a->partial, grid, a->C, d[0], d[1], d[2], d[3]);
+    }
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
+}
+
+extern "C" int64_t dist_op_layernorm_bwd_scratch(int64_t rows, int C) {
+    if (rows <= 0 || C <= 0) return 0;
+    const int rpb = NT / lanes_per_row(C);
+    long g = (rows + rpb - 1) / rpb;
+    if (g > 512) g = 512;
+    return g * 4 * (int64_t)C;
 }

@@ -54,7 +54,8 @@ class LnBwdArgs(C.Structure):
                 ("dy", C.c_void_p), ("w", C.c_void_p), ("dy2", C.c_void_p), ("w2", C.c_void_p),
                 ("dx", C.c_void_p), ("accumulate_dx", C.c_int),
                 ("dw", C.c_void_p), ("db", C.c_void_p), ("dw2", C.c_void_p), ("db2", C.c_void_p),
-                ("rows", C.c_int64), ("C", C.c_int), ("dtype", C.c_int), ("dx_add", C.c_void_p), ("dx_copy", C.c_void_p)]
+                ("rows", C.c_int64), ("C", C.c_int), ("dtype", C.c_int), ("dx_add", C.c_void_p), ("dx_copy", C.c_void_p),
+                ("partial", C.c_void_p), ("partial_elems", C.c_int64)]
 
 
 class TnetArgs(C.Structure):
@@ -80,7 +81,7 @@ class Config(C.Structure):
 
 GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
 
-ABI_VERSION = 7    # include/dist_amd.h DIST_ABI_VERSION: bumped on every struct-layout change
+ABI_VERSION = 8    # include/dist_amd.h DIST_ABI_VERSION: bumped on every struct-layout change
 ABI_MIRRORS = (("dist_gemm_args", GemmArgs), ("dist_gemm_tn_args", GemmTnArgs), ("dist_ln_args", LnArgs), ("dist_ln_bwd_args", LnBwdArgs),
                ("dist_adamw_seg", AdamwSeg), ("dist_config", Config), ("dist_rowmap", RowMap), ("dist_outmap", OutMap), ("dist_tnet_args", TnetArgs), ("dist_tnet_bwd_args", TnetBwdArgs))
 
@@ -170,6 +171,7 @@ def load():
     _sig(lib, "dist_op_layernorm", argtypes=[C.POINTER(LnArgs), C.c_void_p])
     _sig(lib, "dist_op_ln_stats_from_partials", argtypes=[C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_op_layernorm_bwd", argtypes=[C.POINTER(LnBwdArgs), C.c_void_p])
+    _sig(lib, "dist_op_layernorm_bwd_scratch", argtypes=[C.c_int64, C.c_int], restype=C.c_int64)
     _sig(lib, "dist_op_attention", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p])
     _sig(lib, "dist_op_attention_out8", argtypes=[C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p])
     _sig(lib, "dist_op_attention_fp8", argtypes=[C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_void_p])

@@ -179,7 +179,7 @@ def ln_stats_from_partials(part, C_, eps=1e-5):
 
 
 def layernorm_bwd(x, mean, rstd, dy, w, *, dy2=None, w2=None, dx=None, accumulate=False, dw=None, db=None, dw2=None, db2=None,
-                  dx_add=None, dx_copy=None):
+                  dx_add=None, dx_copy=None, two_phase=False):
     lib = L.load()
     rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
     a = L.LnBwdArgs()
@@ -189,6 +189,10 @@ def layernorm_bwd(x, mean, rstd, dy, w, *, dy2=None, w2=None, dx=None, accumulat
     a.dw, a.db, a.dw2, a.db2 = _p(dw), _p(db), _p(dw2), _p(db2)
     a.rows, a.C, a.dtype = rows, Cc, _dt(x)
     a.dx_add, a.dx_copy = _p(dx_add), _p(dx_copy)
+    if two_phase:                                   # parameter gradients through per-block partial sums + a fixed-order reduction (no atomics)
+        n = lib.dist_op_layernorm_bwd_scratch(rows, Cc)
+        scratch = torch.empty(n, dtype=torch.float32, device=x.device)
+        a.partial, a.partial_elems = _p(scratch), n
     L.check(lib.dist_op_layernorm_bwd(C.byref(a), _stream()))
 
 

@@ -38,9 +38,9 @@ enum {
 };
 
 const char* dist_strerror(int code);
-/* 7 for this header.  Bumped on EVERY layout change of a struct below; a binding compares it, and dist_abi_sizeof() of each
+/* 8 for this header (8: dist_ln_bwd_args.partial / partial_elems).  Bumped on EVERY layout change of a struct below; a binding compares it, and dist_abi_sizeof() of each
  * struct it mirrors, before the first dist_create (dist_amd/lib.py does). */
-#define DIST_ABI_VERSION 7
+#define DIST_ABI_VERSION 8
 int dist_abi_version(void);
 /* sizeof() of an argument struct of this header by name ("dist_gemm_args", "dist_gemm_tn_args", "dist_ln_args",
  * "dist_ln_bwd_args", "dist_adamw_seg", "dist_config", "dist_rowmap", "dist_outmap", "dist_tnet_args", "dist_tnet_bwd_args"); -1 for an unknown name.
@@ -176,7 +176,12 @@ typedef struct dist_ln_bwd_args {
     int64_t rows; int C; int dtype;
     const void* dx_add;      /* optional: dx = dx_add + LN'(...) (out-of-place accumulate; overrides accumulate_dx) */
     void* dx_copy;           /* optional: second copy of dx */
+    float* partial;          /* optional fp32 scratch (ABI 8): when it holds >= dist_op_layernorm_bwd_scratch(rows, C) elements the per-block parameter-
+                              * gradient sums are stored there with plain stores and added up by a second small launch in a fixed order (bit-repeatable,
+                              * no same-address atomics at the end of every block); NULL / too small: fp32 atomics as before */
+    int64_t partial_elems;
 } dist_ln_bwd_args;
+int64_t dist_op_layernorm_bwd_scratch(int64_t rows, int C);
 int dist_op_layernorm_bwd(const dist_ln_bwd_args* a, void* stream);
 
 /* per-frame multi-head self-attention -> [frames*L, d]

@@ -329,7 +329,7 @@ def test_layernorm_fwd_bwd(gpu_lib, dtype, rows, C):
     torch.testing.assert_close(y.double(), ry, **tol(dtype))
     torch.testing.assert_close(y2.double(), ry2, **tol(dtype))
     dy, dy2 = rnd((rows, C), dtype, 6), rnd((rows, C), dtype, 7)
-    (ry * dy.double() + ry2 * dy2.double()).sum().backward()
+    (ry * dy.double() + ry2 * dy2.double()).sum().backward(retain_graph=True)
     dx0 = rnd((rows, C), dtype, 8)
     dx = dx0.clone()
     dw, db, dw2, db2 = [torch.zeros(C, device="cuda") for _ in range(4)]
@@ -337,6 +337,25 @@ def test_layernorm_fwd_bwd(gpu_lib, dtype, rows, C):
     torch.testing.assert_close(dx.double(), xd.grad + dx0.double(), **tol(dtype, 4.0))
     for got, ref in ((dw, wd.grad), (db, bd.grad), (dw2, w2d.grad), (db2, b2d.grad)):
         torch.testing.assert_close(got.double(), ref, rtol=1e-3, atol=2e-3 * rows ** 0.5)
+    # two-phase parameter gradients (ABI 8: per-block partial sums + a fixed-order reduction, no atomics): same values, accumulated INTO the
+    # given buffers, and bit-repeatable
+    pre = 0.5
+    outs = []
+    for _ in range(2):
+        dx_t = dx0.clone()
+        g4 = [torch.full((C,), pre, device="cuda") for _ in range(4)]
+        ops.layernorm_bwd(x, mean, rstd, dy, w, dy2=dy2, w2=w2, dx=dx_t, accumulate=True, dw=g4[0], db=g4[1], dw2=g4[2], db2=g4[3], two_phase=True)
+        outs.append(g4)
+    torch.testing.assert_close(dx_t.double(), xd.grad + dx0.double(), **tol(dtype, 4.0))
+    for got, again, ref in zip(outs[0], outs[1], (wd.grad, bd.grad, w2d.grad, b2d.grad)):
+        torch.testing.assert_close(got.double() - pre, ref, rtol=1e-3, atol=2e-3 * rows ** 0.5)
+        assert torch.equal(got, again)
+    g2 = [torch.zeros(C, device="cuda") for _ in range(2)]          # a subset of the arrays (single-input form)
+    ops.layernorm_bwd(x, mean, rstd, dy, w, dx=dx_t, dw=g2[0], db=g2[1], two_phase=True)
+    single = (ry * dy.double()).sum()
+    gw, gb = torch.autograd.grad(single, (wd, bd))
+    torch.testing.assert_close(g2[0].double(), gw, rtol=1e-3, atol=2e-3 * rows ** 0.5)
+    torch.testing.assert_close(g2[1].double(), gb, rtol=1e-3, atol=2e-3 * rows ** 0.5)
     # out-of-place accumulate + second copy (used by the two-stream backward)
     dxo, dxc = torch.empty_like(x), torch.empty_like(x)
     ops.layernorm_bwd(x, mean, rstd, dy, w, dy2=dy2, w2=w2, dx=dxo, dx_add=dx0, dx_copy=dxc)
