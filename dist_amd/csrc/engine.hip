@@ -471,7 +471,7 @@ size_t layout_ws(dist_handle* h, char* base) {
     h->ln_partial_elems = dist_op_layernorm_bwd_scratch(rowsS > rowsX ? rowsS : rowsX, Ci > Ct ? Ci : Ct);
     h->ln_partial = F_(h->ln_partial_elems);
     h->tnb_scratch_elems = dist_op_temporal_net_bwd_scratch((int)b, c.frames, Ct);
-    h->tnb_scratch = F_(h->tnb_scratch_elems);
+    h->tnb_scratch = F_(h->tnb_scratch_elems * c.layers);        // one partial table per layer
     h->tn_partial_elems = 16l << 20;                         // 64 MB each: 256 partial tiles of 192 x 256 (the LDS-DMA weight-gradient kernel) + slack
     for (int k = 0; k < 3; ++k) h->tn_partial[k] = F_(h->tn_partial_elems);
     for (int k = 0; k < 2; ++k) {
@@ -1447,9 +1447,13 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
             ta.dp = q.dp; ta.z = w.z; ta.X = w.X; ta.mean = w.tn_mean; ta.rstd = w.tn_rstd; ta.ln_w = x.th(l.tn_ln.w);
             ta.W1b = x.pk(l.tn_fc1.pk.b); ta.W2b = x.pk(l.tn_fc2.pk.b);
             ta.dz = q.dz; ta.dX = q.dXo; ta.dgamma = x.gr(l.tn_ln.w); ta.dbeta = x.gr(l.tn_ln.b);
-            ta.scratch = h->tnb_scratch; ta.scratch_elems = h->tnb_scratch_elems;
+            ta.scratch = h->tnb_scratch + (long)i * h->tnb_scratch_elems; ta.scratch_elems = h->tnb_scratch_elems;
             ta.clips = b; ta.T = T; ta.G = h->G; ta.Ct = Ct; ta.tk = l.tn_fc1.taps; ta.dtype = c.dtype;
             ta.phase = 2;
+            // measurement knob: leave the LayerNorm parameter gradients unsummed (phase 3).  The step does not change (19.64 vs 19.70 ms),
+            // so one multi-layer dist_op_temporal_net_bwd_reduce at the end of backward would buy nothing: the per-layer sum stays here
+            static const bool no_reduce = getenv("DIST_AMD_TNET_BWD_NOREDUCE") && atoi(getenv("DIST_AMD_TNET_BWD_NOREDUCE"));
+            if (no_reduce) ta.phase = 3;
             RUN(dist_op_temporal_net_bwd(&ta, x.s));
         }
         if (!(h->skip & 2) && !tn_fused) {

@@ -670,6 +670,18 @@ __global__ __launch_bounds__(64) void tnet_dgb_reduce_kernel(const float* part, 
     if (lane == 0) { if (c < CT) dgamma[c] += a; else dbeta[c - CT] += a; }
 }
 
+// the same reduction for SEVERAL layers in one launch (the engine defers the per-layer reductions to the end of backward: every launch on the
+// data-gradient chain costs the step ~10 us): blockIdx.y = layer, its partial table at part + y * stride, its destinations from the table
+struct TnDgbMulti { float* dgamma[32]; float* dbeta[32]; };
+__global__ __launch_bounds__(64) void tnet_dgb_reduce_multi_kernel(const float* part, long stride, int nwg, int CT, TnDgbMulti dst) {
+    const int c = blockIdx.x, lane = threadIdx.x, layer = blockIdx.y;
+    const float* row = part + (long)layer * stride + (long)c * nwg;
+    float a = 0.f;
+    for (int w = lane; w < nwg; w += 64) a += row[w];
+    a = wave_sum(a, 64);
+    if (lane == 0) { if (c < CT) dst.dgamma[layer][c] += a; else dst.dbeta[layer][c - CT] += a; }
+}
+
 template <int CT>
 int launch_tnet_bwd(const TnBwdArgs& aa, float* dgamma, float* dbeta, int phase, hipStream_t s) {
     const int act_bytes = ((aa.N + 1) * CT * 2 + 1023) & ~1023;
@@ -684,10 +696,10 @@ int launch_tnet_bwd(const TnBwdArgs& aa, float* dgamma, float* dbeta, int phase,
     const int groups = (aa.clips + 7) / 8, nwg = groups * 8 * aa.T;
     TnBwdArgs a = aa;
     a.nwg = nwg;
-    if (phase != 2) hipLaunchKernelGGL(tnet_bwd_spatial_kernel<CT>, dim3((unsigned)nwg), dim3(512), smem, s, a);
+    if (phase == 0 || phase == 1) hipLaunchKernelGGL(tnet_bwd_spatial_kernel<CT>, dim3((unsigned)nwg), dim3(512), smem, s, a);
     if (phase != 1) {
         hipLaunchKernelGGL(tnet_bwd_temporal_kernel<CT>, dim3((unsigned)nwg), dim3(512), smem, s, a);
-        hipLaunchKernelGGL(tnet_dgb_reduce_kernel, dim3((unsigned)(2 * CT)), dim3(64), 0, s, a.dgb, nwg, CT, dgamma, dbeta);
+        if (phase != 3) hipLaunchKernelGGL(tnet_dgb_reduce_kernel, dim3((unsigned)(2 * CT)), dim3(64), 0, s, a.dgb, nwg, CT, dgamma, dbeta);
     }
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
@@ -731,7 +743,7 @@ extern "C" int64_t dist_op_temporal_net_bwd_scratch(int clips, int T, int Ct) { 
 extern "C" int dist_op_temporal_net_bwd(const dist_tnet_bwd_args* a, void* stream) {
     if (!a || !a->dp || !a->z || !a->X || !a->mean || !a->rstd || !a->ln_w || !a->W1b || !a->W2b || !a->dz || !a->dX || !a->dgamma || !a->dbeta || !a->scratch)
         return DIST_ERR_ARG;
-    if (a->clips <= 0 || a->T <= 0 || a->G <= 0 || a->phase < 0 || a->phase > 2) return DIST_ERR_ARG;
+    if (a->clips <= 0 || a->T <= 0 || a->G <= 0 || a->phase < 0 || a->phase > 3) return DIST_ERR_ARG;
     if (!dist_k_tnet_fwd_eligible(a->dtype, a->Ct, a->G, a->tk)) return DIST_ERR_ARG;
     if ((long)a->clips * a->T * a->G * a->G * a->Ct >= (1l << 30)) return DIST_ERR_ARG;
     if (a->scratch_elems < dist_op_temporal_net_bwd_scratch(a->clips, a->T, a->Ct)) return DIST_ERR_WORKSPACE;
@@ -748,4 +760,18 @@ extern "C" int dist_op_temporal_net_bwd(const dist_tnet_bwd_args* a, void* strea
         case 96: return launch_tnet_bwd<96>(k, a->dgamma, a->dbeta, a->phase, s);
         default: return DIST_ERR_ARG;
     }
+}
+
+extern "C" int dist_op_temporal_net_bwd_reduce(const float* scratch, int64_t layer_stride, int layers, int clips, int T, int Ct,
+                                               float* const* dgamma, float* const* dbeta, void* stream) {
+    if (!scratch || !dgamma || !dbeta || layers <= 0 || layers > 32 || clips <= 0 || T <= 0 || Ct <= 0) return DIST_ERR_ARG;
+    if (layer_stride < dist_op_temporal_net_bwd_scratch(clips, T, Ct)) return DIST_ERR_ARG;
+    TnDgbMulti d;
+    for (int i = 0; i < 32; ++i) { d.dgamma[i] = i < layers ? dgamma[i] : nullptr; d.dbeta[i] = i < layers ? dbeta[i] : nullptr; }
+    for (int i = 0; i < layers; ++i) if (!d.dgamma[i] || !d.dbeta[i]) return DIST_ERR_ARG;
+    const int nwg = (clips + 7) / 8 * 8 * T;
+    hipLaunchKernelGGL(tnet_dgb_reduce_multi_kernel, dim3((unsigned)(2 * Ct), (unsigned)layers), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       scratch, (long)layer_stride, nwg, Ct, d);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
 }

@@ -165,6 +165,7 @@ def load():
     _sig(lib, "dist_op_gemm_nt", argtypes=[C.POINTER(GemmArgs), C.c_void_p])
     _sig(lib, "dist_op_temporal_net_fwd", argtypes=[C.POINTER(TnetArgs), C.c_void_p])
     _sig(lib, "dist_op_temporal_net_bwd", argtypes=[C.POINTER(TnetBwdArgs), C.c_void_p])
+    _sig(lib, "dist_op_temporal_net_bwd_reduce", argtypes=[C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_op_temporal_net_bwd_scratch", argtypes=[C.c_int, C.c_int, C.c_int], restype=C.c_int64)
     _sig(lib, "dist_op_ln_fold", argtypes=[C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p])
     _sig(lib, "dist_op_gemm_tn", argtypes=[C.POINTER(GemmTnArgs), C.c_void_p])

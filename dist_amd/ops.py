@@ -108,22 +108,36 @@ def pack_conv_taps_dgrad(w):
     return w.reshape(co, ci, -1).permute(1, 2, 0).reshape(ci, -1).to(torch.bfloat16).contiguous()
 
 
-def temporal_net_bwd(dp, z, X, mean, rstd, ln_w, W1b, W2b, clips, T, G, *, tk=3, dgamma=None, dbeta=None):
-    """Fused TemporalNet data-gradient backward (dist_op_temporal_net_bwd).  Returns dict(dz, dX, dgamma, dbeta); dgamma / dbeta are
-    ACCUMULATED into when given."""
+def temporal_net_bwd(dp, z, X, mean, rstd, ln_w, W1b, W2b, clips, T, G, *, tk=3, dgamma=None, dbeta=None, scratch=None, phase=0, dz=None):
+    """Fused TemporalNet data-gradient backward (dist_op_temporal_net_bwd).  Returns dict(dz, dX, dgamma, dbeta, scratch); dgamma / dbeta
+    are ACCUMULATED into when given.  phase 0 = everything; 1 = dz only; 2 = dX + parameter gradients; 3 = dX with the parameter
+    gradients left as partial rows in `scratch` for temporal_net_bwd_reduce.  `dz` (phases 2, 3): the dz an earlier phase-1 call returned."""
     lib = L.load()
     rows, Ct = X.shape
-    out = {"dz": torch.empty_like(X), "dX": torch.empty_like(X),
+    out = {"dz": dz if dz is not None else torch.empty_like(X), "dX": torch.empty_like(X),
            "dgamma": dgamma if dgamma is not None else torch.zeros(Ct, dtype=torch.float32, device=X.device),
            "dbeta": dbeta if dbeta is not None else torch.zeros(Ct, dtype=torch.float32, device=X.device)}
     n = lib.dist_op_temporal_net_bwd_scratch(clips, T, Ct)
-    scratch = torch.empty(n, dtype=torch.float32, device=X.device)
+    if scratch is None:
+        scratch = torch.empty(n, dtype=torch.float32, device=X.device)
+    out["scratch"] = scratch
     a = L.TnetBwdArgs()
     a.dp, a.z, a.X, a.mean, a.rstd, a.ln_w, a.W1b, a.W2b = _p(dp), _p(z), _p(X), _p(mean), _p(rstd), _p(ln_w), _p(W1b), _p(W2b)
     a.dz, a.dX, a.dgamma, a.dbeta, a.scratch, a.scratch_elems = _p(out["dz"]), _p(out["dX"]), _p(out["dgamma"]), _p(out["dbeta"]), _p(scratch), n
-    a.clips, a.T, a.G, a.Ct, a.tk, a.dtype = clips, T, G, Ct, tk, L.BF16
+    a.clips, a.T, a.G, a.Ct, a.tk, a.dtype, a.phase = clips, T, G, Ct, tk, L.BF16, phase
     L.check(lib.dist_op_temporal_net_bwd(C.byref(a), _stream()))
     return out
+
+
+def temporal_net_bwd_reduce(scratch, layers, clips, T, Ct, dgammas, dbetas):
+    """Sum the partial rows `layers` phase-3 launches left in `scratch` ([layers, dist_op_temporal_net_bwd_scratch] floats) INTO
+    dgammas[l] / dbetas[l] (dist_op_temporal_net_bwd_reduce): one launch for every layer."""
+    lib = L.load()
+    n = lib.dist_op_temporal_net_bwd_scratch(clips, T, Ct)
+    FP = C.POINTER(C.c_float)
+    dg = (FP * layers)(*[C.cast(_p(t), FP) for t in dgammas])
+    db = (FP * layers)(*[C.cast(_p(t), FP) for t in dbetas])
+    L.check(lib.dist_op_temporal_net_bwd_reduce(_p(scratch), n, layers, clips, T, Ct, dg, db, _stream()))
 
 
 def ln_fold(W, bias, gamma, beta):

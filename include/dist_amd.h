@@ -235,10 +235,15 @@ typedef struct dist_tnet_bwd_args {
     float* scratch; int64_t scratch_elems;
     int clips, T, G, Ct, tk; int dtype;
     int phase;               /* 0 = everything; 1 = only dz (first launch); 2 = only dX, dgamma, dbeta from the dz of an earlier phase-1 call
-                              * (lets the caller start the weight-gradient GEMMs that read dz on another stream in between) */
+                              * (lets the caller start the weight-gradient GEMMs that read dz on another stream in between); 3 = as 2, but the
+                              * parameter-gradient partials stay in `scratch` for a later dist_op_temporal_net_bwd_reduce over several layers */
 } dist_tnet_bwd_args;
 int64_t dist_op_temporal_net_bwd_scratch(int clips, int T, int Ct);
 int dist_op_temporal_net_bwd(const dist_tnet_bwd_args* a, void* stream);
+/* dgamma[l][c] += / dbeta[l][c] += the partial rows that phase-3 calls of `layers` (<= 32) layers left at scratch + l * layer_stride: ONE launch
+ * for all of them (every launch on a serial chain costs ~10 us of step; same fixed summation order as the per-layer form) */
+int dist_op_temporal_net_bwd_reduce(const float* scratch, int64_t layer_stride, int layers, int clips, int T, int Ct,
+                                    float* const* dgamma, float* const* dbeta, void* stream);
 
 /* one-query cross attention (CrossAttentionBlockGenral, clip.py:139-147; dist.py:144,158):
  * q [B, C], kv [B*S, 2C] -> o [B, C], probs [B, H, S] (fp32, saved for backward) */

@@ -242,3 +242,37 @@ def test_fused_temporal_net_backward_matches_the_unfused_sequence(gpu_lib):
     for k, ref in (("dgamma", dg), ("dbeta", db)):
         err = float((a[k] - ref).abs().max() / (ref.abs().max() + 1e-9))
         assert err < 8e-3, (k, err)
+
+
+def test_fused_temporal_net_backward_phases_and_the_multi_layer_reduce(gpu_lib):
+    """phase 1 (dz) + phase 2 (dX, dgamma, dbeta) == phase 0 bit for bit; phase 3 leaves the partial rows in the layer's scratch slice
+    and ONE dist_op_temporal_net_bwd_reduce over two layers gives the same sums as the per-layer form, accumulated into the buffers"""
+    from dist_amd import lib as L, ops
+    clips, T, G, Ct = 2, 4, 14, 96
+    lib = L.load()
+    n = lib.dist_op_temporal_net_bwd_scratch(clips, T, Ct)
+    scratch = torch.zeros(2 * n, dtype=torch.float32, device="cuda")
+    whole, dgs, dbs = [], [], []
+    for layer in range(2):
+        t = make(clips, T, G, Ct, 3, seed=40 + layer)
+        X, W1, b1, W2, b2, lnw, lnb = (v.cuda() for v in t)
+        fwd = run_fused(t, clips, T, G, 3, save_uv=False)
+        dp = (torch.randn(X.shape, device="cuda") * 0.5).to(torch.bfloat16)
+        W1b, W2b = ops.pack_conv_taps_dgrad(W1), ops.pack_conv_taps_dgrad(W2)
+        args = (dp, fwd["z"], X, fwd["mean"], fwd["rstd"], lnw, W1b, W2b, clips, T, G)
+        a = ops.temporal_net_bwd(*args)
+        p1 = ops.temporal_net_bwd(*args, phase=1)
+        assert torch.equal(p1["dz"], a["dz"])
+        p2 = ops.temporal_net_bwd(*args, phase=2, dz=p1["dz"])
+        for k in ("dX", "dgamma", "dbeta"):
+            assert torch.equal(p2[k], a[k]), k
+        p3 = ops.temporal_net_bwd(*args, phase=3, dz=p1["dz"], scratch=scratch[layer * n:(layer + 1) * n])
+        assert torch.equal(p3["dX"], a["dX"])
+        assert float(p3["dgamma"].abs().max()) == 0.0 and float(p3["dbeta"].abs().max()) == 0.0      # not summed yet
+        whole.append(a)
+        dgs.append(torch.full((Ct,), 0.5, device="cuda")); dbs.append(torch.full((Ct,), -0.5, device="cuda"))
+    ops.temporal_net_bwd_reduce(scratch, 2, clips, T, Ct, dgs, dbs)
+    torch.cuda.synchronize()
+    for layer in range(2):
+        assert torch.equal(dgs[layer], whole[layer]["dgamma"] + 0.5), layer
+        assert torch.equal(dbs[layer], whole[layer]["dbeta"] - 0.5), layer
