@@ -5,7 +5,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdist_amd.so")
-SOURCES = ["gemm_nt.hip", "gemm_fast.hip", "gemm_small.hip", "gemm_tn.hip", "tnet.hip", "norm.hip", "attn.hip", "misc.hip", "metrics.hip", "quant.hip", "engine.hip"]
+SOURCES = ["gemm_nt.hip", "gemm_fast.hip", "gemm_small.hip", "gemm_tn.hip", "tnet.hip", "integ.hip", "norm.hip", "attn.hip", "misc.hip", "metrics.hip", "quant.hip", "engine.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "dist_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
@@ -31,7 +31,7 @@ def build_library(force=False, verbose=True):
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + os.environ.get("DIST_AMD_BUILD_DEFS", "").split() + ["-c", s, "-o", o]     # e.g. -DDIST_INTEG_ABLATE (tools/integ_ablate.sh)
             if verbose:
                 print("[dist_amd.build]", " ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -58,6 +58,8 @@ struct DistLayer {
     Lin in_lin, i2t, t2i; long cls_token = -1;
     LNp in_ln, in_ln_t; Lin ffn_fc, ffn_proj, tf_fc1, tf_fc2, tf_proj;   // IntegrationNetwork
     long pk_proj_f = -1, pk_proj_b = -1;     // the two c_proj weights side by side: [Ci][Ci+C4] forward, [Ci+C4][Ci] data-gradient
+    // fused IntegrationNetwork forward (integ.hip): MFMA-operand-ordered weights with the two LayerNorms folded in (workspace pointers)
+    void *ig_W1 = nullptr, *ig_W2 = nullptr, *ig_W3 = nullptr; float *ig_b1 = nullptr, *ig_b2 = nullptr, *ig_b3 = nullptr;
 };
 struct XAttn { LNp ln1; Lin q, kv, out; };   // CrossAttentionBlockGenral (in_proj split into q / kv rows)
 struct AdaLayer { long pos = -1; XAttn sp, tm; LNp ln_sp, ln_tm; Lin sp_fc, sp_proj, tm_fc, tm_proj; };
@@ -144,6 +146,7 @@ struct dist_handle {
     void *dR, *dkv, *dkn;
     float* ln_partial = nullptr; long ln_partial_elems = 0;     // per-block parameter-gradient sums of the LayerNorm backward (two-phase, no atomics)
     float* tnb_scratch = nullptr; long tnb_scratch_elems = 0;   // parameter-gradient partial rows of the fused TemporalNet backward
+    bool ig_on = false; void* ig_descs = nullptr;               // fused IntegrationNetwork forward: taken for this geometry; its pack descriptors (device)
     float* tn_partial[3] = {nullptr, nullptr, nullptr};   // two-phase dW reduction scratch, one per stream that launches dW GEMMs
     long tn_partial_elems = 0;
     // weight-gradient side stream (created once per handle; host-side objects only)
@@ -472,6 +475,16 @@ size_t layout_ws(dist_handle* h, char* base) {
     h->ln_partial = F_(h->ln_partial_elems);
     h->tnb_scratch_elems = dist_op_temporal_net_bwd_scratch((int)b, c.frames, Ct);
     h->tnb_scratch = F_(h->tnb_scratch_elems * c.layers);        // one partial table per layer
+    h->ig_on = dist_k_integ_eligible(c.dtype, Ci, C4, h->t, c.temporal_kernel) && !(getenv("DIST_AMD_INTEG_FUSED") && atoi(getenv("DIST_AMD_INTEG_FUSED")) == 0);
+    if (h->ig_on) {
+        for (int i = 0; i < c.layers; ++i) {
+            DistLayer& l = h->dl[i];
+            l.ig_W1 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 0) * 2); l.ig_W2 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 1) * 2);
+            l.ig_W3 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 2) * 2);
+            l.ig_b1 = F_(dist_op_integration_pack_elems(Ci, C4, 3)); l.ig_b2 = F_(dist_op_integration_pack_elems(Ci, C4, 4)); l.ig_b3 = F_(dist_op_integration_pack_elems(Ci, C4, 5));
+        }
+        h->ig_descs = a.take((size_t)dist_k_integ_pack_desc_bytes() * c.layers);
+    }
     h->tn_partial_elems = 16l << 20;                         // 64 MB each: 256 partial tiles of 192 x 256 (the LDS-DMA weight-gradient kernel) + slack
     for (int k = 0; k < 3; ++k) h->tn_partial[k] = F_(h->tn_partial_elems);
     for (int k = 0; k < 2; ++k) {
@@ -690,7 +703,7 @@ extern "C" int dist_abi_sizeof(const char* n) {
     if (!n) return -1;
 #define DIST_SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)
     DIST_SZ(dist_gemm_args); DIST_SZ(dist_gemm_tn_args); DIST_SZ(dist_ln_args); DIST_SZ(dist_ln_bwd_args);
-    DIST_SZ(dist_adamw_seg); DIST_SZ(dist_config); DIST_SZ(dist_rowmap); DIST_SZ(dist_outmap); DIST_SZ(dist_tnet_args); DIST_SZ(dist_tnet_bwd_args);
+    DIST_SZ(dist_adamw_seg); DIST_SZ(dist_config); DIST_SZ(dist_rowmap); DIST_SZ(dist_outmap); DIST_SZ(dist_tnet_args); DIST_SZ(dist_tnet_bwd_args); DIST_SZ(dist_integ_args); DIST_SZ(dist_integ_pack_args);
 #undef DIST_SZ
     return -1;
 }
@@ -801,6 +814,23 @@ extern "C" int dist_bind(dist_handle* h, float* theta, float* grads, const float
     HIP_CHECK_RET(hipMemcpy(p + off, h->blk_desc.data(), h->blk_desc.size() * sizeof(int), hipMemcpyHostToDevice));
     off = (off + h->blk_desc.size() * sizeof(int) + 255) & ~(size_t)255;
     HIP_CHECK_RET(hipMemcpy(p + off, h->blk_first.data(), h->blk_first.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (h->ig_on) {                                        // the all-layers pack of the fused IntegrationNetwork forward reads its descriptors from the workspace
+        const size_t db = (size_t)dist_k_integ_pack_desc_bytes();
+        std::vector<char> host(db * h->dl.size());
+        for (size_t i = 0; i < h->dl.size(); ++i) {
+            const DistLayer& l = h->dl[i];
+            dist_integ_pack_args a;
+            memset(&a, 0, sizeof(a));
+            a.ffn_fc_w = theta + l.ffn_fc.w; a.ffn_fc_b = theta + l.ffn_fc.bias; a.ln_w = theta + l.in_ln.w; a.ln_b = theta + l.in_ln.b;
+            a.tf_fc1_w = theta + l.tf_fc1.w; a.tf_fc1_b = theta + l.tf_fc1.bias; a.ln_t_w = theta + l.in_ln_t.w; a.ln_t_b = theta + l.in_ln_t.b;
+            a.tf_fc2_w = theta + l.tf_fc2.w; a.tf_fc2_b = theta + l.tf_fc2.bias;
+            a.ffn_proj_w = theta + l.ffn_proj.w; a.ffn_proj_b = theta + l.ffn_proj.bias; a.tf_proj_w = theta + l.tf_proj.w; a.tf_proj_b = theta + l.tf_proj.bias;
+            a.W1 = l.ig_W1; a.W2 = l.ig_W2; a.W3 = l.ig_W3; a.b1 = l.ig_b1; a.b2 = l.ig_b2; a.b3 = l.ig_b3;
+            a.Ci = h->cfg.integration_dim; a.C4 = h->C4;
+            dist_k_integ_pack_desc(&a, host.data() + i * db);
+        }
+        HIP_CHECK_RET(hipMemcpy(h->ig_descs, host.data(), host.size(), hipMemcpyHostToDevice));
+    }
     h->fwd_b = h->branch_b = 0;
     h->slot[0].b = h->slot[1].b = 0; h->slot[0].prefetched = h->slot[1].prefetched = false;
     h->use_slot(0);
@@ -823,6 +853,7 @@ extern "C" int dist_pack_weights(dist_handle* h, int what, void* stream) {
     else if (what == 2) { first = h->nblk_visual; count = nblk - h->nblk_visual; }
     else if (what != 3) return fail(h, DIST_ERR_ARG, "dist_pack_weights: what must be 1, 2 or 3");
     RUN(dist_k_pack(descs, blk_desc, blk_first, first, count, h->theta, h->visual, dst, h->cfg.dtype, s));
+    if ((what & 2) && h->ig_on) RUN(dist_k_integ_pack(h->ig_descs, nullptr, h->cfg.layers, h->cfg.integration_dim, h->C4, s));
     // frozen ViT: ln_1 -> attn.in_proj and ln_2 -> mlp.c_fc folded (W diag(gamma), column sums, folded biases); DIST_AMD_LNFOLD=0: off
     static const bool fold_on = !(getenv("DIST_AMD_LNFOLD") && atoi(getenv("DIST_AMD_LNFOLD")) == 0);
     // (only a pack of the frozen weights touches the fold: the per-step re-pack of the trainable weights, what = 2, used to reset
@@ -1164,7 +1195,21 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
         RUN(gemm(x, w.Xp, Ct, x.pk(l.t2i.pk.f), rowsQ, Ci, Ct, al, w.Mp, Ci, x.th(l.t2i.bias), w.M, nullptr, nullptr,
                  RM(DIST_RM_STRIDED, al, N), OM(DIST_OM_INSERTCLS, N)));
         RUN(dist_k_cls_rows(w.Mp, w.M, x.th(l.cls_token), (int)bt, L, Ci, t, c.dtype, x.s));
-        // IntegrationNetwork (dist.py:16-45)
+        // IntegrationNetwork (dist.py:16-45): one fused launch (integ.hip) where the geometry allows, else LayerNorm + four GEMMs
+        if (h->ig_on) {
+            if (!(h->skip & 8)) {
+                dist_integ_args ia;
+                memset(&ia, 0, sizeof(ia));
+                ia.Mp = w.Mp; ia.W1 = l.ig_W1; ia.W2 = l.ig_W2; ia.W3 = l.ig_W3; ia.b1 = l.ig_b1; ia.b2 = l.ig_b2; ia.b3 = l.ig_b3;
+                ia.R = w.R;
+                if (!h->inference) {                                            // (what backward reads)
+                    ia.ln_w = x.th(l.in_ln.w); ia.ln_b = x.th(l.in_ln.b); ia.ln_t_w = x.th(l.in_ln_t.w); ia.ln_t_b = x.th(l.in_ln_t.b);
+                    ia.Na = w.Na; ia.Nb = w.Nb; ia.mean = w.in_mean; ia.rstd = w.in_rstd; ia.zf_h2 = w.zf; ia.hf_g2 = w.hf; ia.h1 = w.h1;
+                }
+                ia.clips = (int)b; ia.t = t; ia.L = L; ia.Ci = Ci; ia.C4 = C4; ia.tk = l.tf_fc2.taps; ia.dtype = c.dtype; ia.eps = 1e-5f;
+                RUN(dist_op_integration_fwd(&ia, x.s));
+            }
+        } else {
         RUN(ln_fwd(x, h->theta, l.in_ln, w.Mp, w.Na, rowsS, w.in_mean, w.in_rstd, &l.in_ln_t, w.Nb));
         if (!(h->skip & 8)) {
         // (inference: the pre-activations zf / h2 are what backward needs - only the activated tensors are written)
@@ -1175,6 +1220,7 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
         // R = ffn.c_proj(hf) + temporal_ffn.c_proj(g2): one GEMM over [hf | g2] (K = Ci + C4) with the two weights side by side
         RUN(gemm(x, w.hf, Ci + C4, x.pk(l.pk_proj_f), rowsS, Ci, Ci + C4, 1, w.R, Ci, x.th(l.ffn_proj.bias), nullptr, nullptr, nullptr,
                  RM(), OM(), 0, x.th(l.tf_proj.bias)));
+        }
         }
         if (i == nl / 2 - 1) mark(h, DIST_MARK_FWD_MID, x.s);
     }

@@ -1,0 +1,498 @@
+// Fused IntegrationNetwork forward (reference models/module_zoo/branches/dist.py:16-45):
+//
+//     R = ffn.c_proj( g( ffn.c_fc( ln(M') ) ) )  +  temporal_ffn.c_proj( g( conv_{3x1x1}( temporal_ffn.c_fc1( ln_temporal(M') ) ) ) )
+//
+// on the token rows M'[(clip*t + frame)*L + token][Ci].  ONE launch per layer instead of LayerNorm (two outputs) + four GEMMs: the
+// normalised rows, the hidden activations hf / g2 and the 96-wide temporal intermediate h1 are read back from LDS, not from HBM
+// (the unfused sequence reads 174 MB per layer at the bench size, this kernel 39 MB; what backward needs is still written).
+//
+// Work decomposition: one workgroup (8 waves) per (clip, group of TOK = BM / t tokens): its BM rows are ALL t frames of those tokens, so
+// the temporal taps of temporal_ffn.c_fc2 (rows +-L apart in memory) are rows +-TOK of the same tile.
+//
+//   stage 0  rows -> registers (8 lanes per row) -> statistics -> xhat = (x - mean) rstd as bf16 in LDS (region A, [BM][Ci]);
+//            training: the two affine outputs Na / Nb (what the weight-gradient GEMMs of backward read) and mean / rstd go to HBM
+//   stage 1  [zf | h1] = xhat [Wa diag(ga) ; Wb diag(gb)]^T + [ba + Wa beta_a ; bb + Wb beta_b]      (LayerNorm folded into the weights,
+//            dist_op_integration_pack) - N = Ci + C4 columns split over the waves by PAIRS of 16-column blocks
+//            hf = g(zf) replaces xhat in region A, h1 goes to region B
+//   stage 2  h2 = sum_d h1[row + d TOK] W2[d]^T + b2 (frames outside the clip contribute nothing), g2 = g(h2) -> region C   (6 waves)
+//   stage 3  R = [hf | g2] [Wp | Wt]^T + bp + bt
+//
+// MFMA orientation: the WEIGHTS are the A operand (16 output columns x 32 k) and the activations the B operand (32 k x 16 tile rows),
+// so a lane of the result holds four consecutive output COLUMNS of one tile row.  Each pair of MFMAs works on a permuted set of 32
+// weight rows (n = 32 p + 8 (m / 4) + 4 q + m % 4 for row m of MFMA q) so that the two results of a lane are 8 consecutive columns:
+// one 16-byte store to HBM / LDS per (pair, 16-row block), no transposition through LDS.  The weights come in exactly this
+// fragment order (1 KB per MFMA operand, dist_op_integration_pack) straight from L2 into registers - no LDS, no barrier in the K loops.
+//
+// LDS: region A rows of Ci bf16, 16-byte chunk c of row r at chunk c ^ (r & 15) (768-byte rows alias to the same banks: the XOR makes
+// the 16 lanes of every ds_read_b128 service group hit 16 different chunks); regions B / C rows of C4 bf16 with the chunk map of
+// tnet.hip.  BM = 128: 154 KB, one workgroup per CU; BM = 64: 78 KB, two.
+//
+// Rounding points: xhat, zf, hf = g(bf16 zf), h1, h2, g2 = g(bf16 h2), R are rounded to bf16 (the unfused sequence rounds Na / Nb instead
+// of xhat and multiplies by the unfolded weights: same precision, different rounding - see tests/test_integ_gpu.py for the measured gap).
+#include <stdlib.h>
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+struct IgArgs {
+    const bf16_t* Mp;
+    const bf16_t *W1, *W2, *W3;
+    const float *b1, *b2, *b3;
+    const float *ga, *ba, *gb, *bb;
+    bf16_t *R, *Na, *Nb, *zfh2, *hfg2, *h1;
+    float *mean, *rstd;
+    int clips, t, L, groups, tokshift;
+    float eps;
+};
+
+DEV int ig_pchunk(const int row, const int c) { return (c & ~3) | ((c & 3) ^ (((row >> 2) & 1) << 1)); }
+// sum over the 8 lanes that share a row in stage 0 (lanes 8 k .. 8 k + 7)
+DEV float ig_sum8(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));   // row_half_mirror
+    return v;
+}
+DEV f32x4 ig_mma(const bf16x8& w, const bf16x8& x, const f32x4& acc) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc, 0, 0, 0); }
+DEV bf16x8 ig_ldw(const bf16_t* base, const long frag, const int lane) { return *reinterpret_cast<const bf16x8*>(base + (frag * 64 + lane) * 8); }
+#define IG_LDW(base, frag) ((DBG & 1) ? bf16x8{(bf16_t)(float)lane, 0, 0, 0, 0, 0, 0, 0} : ig_ldw(base, frag, lane))
+#define IG_MMA(w, x, acc) ((DBG & 2) ? (acc) : ig_mma(w, x, acc))
+#define IG_GELU(x) ((DBG & 4) ? (x) : qgelu_t<bf16_t>(x))
+#define IG_LDS(ptr) ((DBG & 16) ? bf16x8{(bf16_t)(float)li, 0, 0, 0, 0, 0, 0, 0} : *reinterpret_cast<const bf16x8*>(ptr))
+#define IG_ST(v, ptr) do { if (!(DBG & 8)) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(ptr)); } while (0)
+DEV void ig_load8(const float* p, float (&o)[8]) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+
+template <int CI, int C4, int BM, bool TRAIN, int DBG>
+__global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_fwd_kernel(const IgArgs p) {
+    constexpr int CC = CI + C4;
+    constexpr int CPR = CI / 8;                  // 16-byte chunks per region-A row
+    constexpr int CPB = C4 / 8;                  // ... per region-B / C row
+    constexpr int LCH = CPR / 8;                 // chunks per lane in stage 0 (8 lanes per row)
+    constexpr int RPW = BM / 8;                  // rows per wave in stage 0
+    constexpr int NPASS = RPW / 8;
+    constexpr int RB = BM / 16, RBH = RB / 2;    // 16-row blocks (the N dimension of the MFMAs)
+    constexpr int KS1 = CI / 32, NP1 = CC / 32;
+    constexpr int KT = C4 / 32, KS2 = 3 * KT, NP2 = C4 / 32;
+    constexpr int KS3 = CC / 32, NP3 = CI / 32;
+    static_assert(CPR % 16 == 0 && C4 % 32 == 0 && NP1 <= 16 && NP2 * 2 <= 8 && NP3 == 12 && (BM == 64 || BM == 128), "geometry");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* const regA = smem;                               // [BM][CI]  xhat, then hf
+    char* const regB = smem + BM * CI * 2;                 // [BM][C4]  h1
+    char* const regC = regB + BM * C4 * 2;                 // [BM][C4]  g2
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int clip = blockIdx.x / p.groups, grp = blockIdx.x - clip * p.groups;
+    const int tsh = p.tokshift, TOK = 1 << tsh, tokmask = TOK - 1;
+    const int L = p.L, t = p.t;
+    // tile row r = frame * TOK + token slot; global row of it, or -1 for a token slot beyond L (last group of a clip)
+    auto grow_of = [&](const int r) -> int {
+        const int f = r >> tsh, j = (grp << tsh) + (r & tokmask);
+        return j < L ? (clip * t + f) * L + j : -1;
+    };
+
+    // ---------------- stage 0: rows -> LayerNorm statistics -> xhat tile (+ Na, Nb, mean, rstd)
+    {
+        const int lq = lane & 7, lrow = lane >> 3;
+        bf16x8 raw[NPASS][LCH];
+        int grow0[NPASS];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = wid * RPW + ps * 8 + lrow;
+            const int f = r >> tsh, j = (grp << tsh) + (r & tokmask);
+            grow0[ps] = j < L ? (clip * t + f) * L + j : -1;
+            const bf16_t* src = p.Mp + (long)((clip * t + f) * L + min(j, L - 1)) * CI;       // (clamped: a slot beyond L computes on real numbers)
+#pragma unroll
+            for (int m = 0; m < LCH; ++m) raw[ps][m] = (DBG & 32) ? bf16x8{(bf16_t)(float)(lane + m), 1, 0, 2, 0, 0, 0, 0} : *reinterpret_cast<const bf16x8*>(src + (lq + 8 * m) * 8);
+        }
+        float mean[NPASS], rstd[NPASS];
+        constexpr float invC = 1.f / (float)CI;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < LCH; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += (float)raw[ps][m][e];
+            mean[ps] = ig_sum8(s) * invC;
+            float q = 0.f;
+#pragma unroll
+            for (int m = 0; m < LCH; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)raw[ps][m][e] - mean[ps]; q += d * d; }
+            rstd[ps] = rsqrtf(ig_sum8(q) * invC + p.eps);
+            if (TRAIN && lq == 0 && grow0[ps] >= 0) { p.mean[grow0[ps]] = mean[ps]; p.rstd[grow0[ps]] = rstd[ps]; }
+        }
+#pragma unroll
+        for (int m = 0; m < LCH; ++m) {
+            const int c = lq + 8 * m;
+            float wa[8], ba[8], wb[8], bb[8];
+            if (TRAIN) { ig_load8(p.ga + c * 8, wa); ig_load8(p.ba + c * 8, ba); ig_load8(p.gb + c * 8, wb); ig_load8(p.bb + c * 8, bb); }
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int r = wid * RPW + ps * 8 + lrow;
+                float xh[8];
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xh[e] = ((float)raw[ps][m][e] - mean[ps]) * rstd[ps]; o[e] = (bf16_t)xh[e]; }
+                *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + ((c ^ (r & 15)) << 4)) = o;
+                if (TRAIN && grow0[ps] >= 0) {
+                    bf16x8 na, nb;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { na[e] = (bf16_t)(xh[e] * wa[e] + ba[e]); nb[e] = (bf16_t)(xh[e] * wb[e] + bb[e]); }
+                    IG_ST(na, p.Na + (long)grow0[ps] * CI + c * 8);
+                    IG_ST(nb, p.Nb + (long)grow0[ps] * CI + c * 8);
+                }
+            }
+        }
+    }
+    int grow[RB];                                          // global row of tile row rb * 16 + li
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) grow[rb] = grow_of(rb * 16 + li);
+    __syncthreads();
+
+    // ---------------- stage 1: [zf | h1] = xhat W1^T, pairs 2 wid and 2 wid + 1 (the last wave has one pair when NP1 is odd)
+    {
+        // (NP1 odd: the last wave's second pair repeats its first one and is dropped in the epilogue - no branch inside the K loop)
+        const int pA = 2 * wid, pB = min(2 * wid + 1, NP1 - 1);
+        f32x4 acc[4][RB];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[f][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 wb[2][4];
+        auto ldw = [&](bf16x8 (&w)[4], const int ks) __attribute__((always_inline)) {
+            w[0] = IG_LDW(p.W1, ((long)pA * KS1 + ks) * 2); w[1] = IG_LDW(p.W1, ((long)pA * KS1 + ks) * 2 + 1);
+            w[2] = IG_LDW(p.W1, ((long)pB * KS1 + ks) * 2); w[3] = IG_LDW(p.W1, ((long)pB * KS1 + ks) * 2 + 1);
+        };
+        ldw(wb[0], 0);
+        if (KS1 > 1) ldw(wb[1], 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            bf16x8 (&w)[4] = wb[ks & 1];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const bf16x8 a = IG_LDS(regA + (rb * 16 + li) * (CI * 2) + (((ks * 4 + lg) ^ li) << 4));
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc[f][rb] = IG_MMA(w[f], a, acc[f][rb]);
+            }
+            if (ks + 2 < KS1) ldw(w, ks + 2);
+            __builtin_amdgcn_sched_barrier(0);             // (the loads stay HERE, a whole k-step ahead of their use: the scheduler would sink them to it)
+        }
+        __syncthreads();                                   // every wave has read xhat: region A becomes hf
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int pr = pp ? 2 * wid + 1 : pA;
+            if (pr >= NP1) continue;
+            const int n0 = pr * 32 + lg * 8;
+            float bv[8];
+            ig_load8(p.b1 + n0, bv);
+            const bool is_zf = pr < NP3;                   // (Ci / 32 pairs of zf, then the h1 pairs)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int r = rb * 16 + li;
+                bf16x8 zb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { zb[e] = (bf16_t)(acc[pp * 2][rb][e] + bv[e]); zb[4 + e] = (bf16_t)(acc[pp * 2 + 1][rb][e] + bv[4 + e]); }
+                if (is_zf) {
+                    bf16x8 hf;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hf[e] = (bf16_t)IG_GELU((float)zb[e]);
+                    *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((pr * 4 + lg) ^ li) << 4)) = hf;
+                    if (TRAIN && grow[rb] >= 0) {
+                        IG_ST(zb, p.zfh2 + (long)grow[rb] * CC + n0);
+                        IG_ST(hf, p.hfg2 + (long)grow[rb] * CC + n0);
+                    }
+                } else {
+                    *reinterpret_cast<bf16x8*>(regB + r * (C4 * 2) + (ig_pchunk(r, (pr - NP3) * 4 + lg) << 4)) = zb;
+                    if (TRAIN && grow[rb] >= 0) IG_ST(zb, p.h1 + (long)grow[rb] * C4 + (n0 - CI));
+                }
+            }
+        }
+    }
+    // the temporal weights of this wave's stage-2 item travel while the workgroup meets at the barrier
+    const bool s2 = wid < NP2 * 2;
+    const int p2 = s2 ? wid % NP2 : 0, half2 = s2 ? wid / NP2 : 0;
+    bf16x8 w2[KS2][2];
+    if (s2) {
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) { w2[ks][0] = IG_LDW(p.W2, ((long)p2 * KS2 + ks) * 2); w2[ks][1] = IG_LDW(p.W2, ((long)p2 * KS2 + ks) * 2 + 1); }
+    }
+    __syncthreads();                                       // hf in region A, h1 in region B
+
+    // ---------------- stage 2: h2 = conv_t(h1) + b2, g2 = g(h2) -> region C; item = (pair p2, half of the 16-row blocks)
+    if (s2) {
+        f32x4 a2[2][RBH];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int rb = 0; rb < RBH; ++rb) a2[q][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+#pragma unroll
+            for (int rbh = 0; rbh < RBH; ++rbh) {
+                const int r = (half2 * RBH + rbh) * 16 + li;
+                const int f = (r >> tsh) + tap - 1;
+                const bool ok = (unsigned)f < (unsigned)t;
+                const int rs = ok ? r + (tap - 1) * TOK : r;
+#pragma unroll
+                for (int k3 = 0; k3 < KT; ++k3) {
+                    bf16x8 a = IG_LDS(regB + rs * (C4 * 2) + (ig_pchunk(rs, k3 * 4 + lg) << 4));
+                    if (!ok) a = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    a2[0][rbh] = IG_MMA(w2[tap * KT + k3][0], a, a2[0][rbh]);
+                    a2[1][rbh] = IG_MMA(w2[tap * KT + k3][1], a, a2[1][rbh]);
+                }
+            }
+        }
+        const int n0 = p2 * 32 + lg * 8;
+        float bv[8];
+        ig_load8(p.b2 + n0, bv);
+#pragma unroll
+        for (int rbh = 0; rbh < RBH; ++rbh) {
+            const int r = (half2 * RBH + rbh) * 16 + li;
+            const int gr = grow_of(r);
+            bf16x8 hb, gb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { hb[e] = (bf16_t)(a2[0][rbh][e] + bv[e]); hb[4 + e] = (bf16_t)(a2[1][rbh][e] + bv[4 + e]); }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gb[e] = (bf16_t)IG_GELU((float)hb[e]);
+            *reinterpret_cast<bf16x8*>(regC + r * (C4 * 2) + (ig_pchunk(r, p2 * 4 + lg) << 4)) = gb;
+            if (TRAIN && gr >= 0) {
+                IG_ST(hb, p.zfh2 + (long)gr * CC + CI + n0);
+                IG_ST(gb, p.hfg2 + (long)gr * CC + CI + n0);
+            }
+        }
+    }
+
+    // ---------------- stage 3: R = [hf | g2] W3^T + b3.  Waves 2m, 2m+1 share pairs 3m .. 3m+2: one full pair each and half the
+    // 16-row blocks of the middle one.  The blocks are walked from this wave's half on, so the first RBH of them are the shared pair's.
+    {
+        const int m3 = wid >> 1, odd = wid & 1;
+        const int pF = 3 * m3 + (odd ? 2 : 0), pH = 3 * m3 + 1;
+        f32x4 aF[2][RB], aH[2][RBH];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) aF[q][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rb = 0; rb < RBH; ++rb) aH[q][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        bf16x8 wb[2][4];
+        auto ldw = [&](bf16x8 (&w)[4], const int ks) __attribute__((always_inline)) {
+            w[0] = IG_LDW(p.W3, ((long)pF * KS3 + ks) * 2); w[1] = IG_LDW(p.W3, ((long)pF * KS3 + ks) * 2 + 1);
+            w[2] = IG_LDW(p.W3, ((long)pH * KS3 + ks) * 2); w[3] = IG_LDW(p.W3, ((long)pH * KS3 + ks) * 2 + 1);
+        };
+        ldw(wb[0], 0);
+        ldw(wb[1], 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KS3; ++ks) {
+            if (ks == KS1) __syncthreads();                // g2 is complete in region C (the stage-2 waves pass here after writing it)
+            bf16x8 (&w)[4] = wb[ks & 1];
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr) {
+                const int rb = (rr + odd * RBH) & (RB - 1);
+                const int r = rb * 16 + li;
+                bf16x8 a;
+                if (ks < KS1) a = IG_LDS(regA + r * (CI * 2) + (((ks * 4 + lg) ^ li) << 4));
+                else a = IG_LDS(regC + r * (C4 * 2) + (ig_pchunk(r, (ks - KS1) * 4 + lg) << 4));
+                aF[0][rr] = IG_MMA(w[0], a, aF[0][rr]);
+                aF[1][rr] = IG_MMA(w[1], a, aF[1][rr]);
+                if (rr < RBH) { aH[0][rr] = IG_MMA(w[2], a, aH[0][rr]); aH[1][rr] = IG_MMA(w[3], a, aH[1][rr]); }
+            }
+            if (ks + 2 < KS3) ldw(w, ks + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float bF[8], bH[8];
+        ig_load8(p.b3 + pF * 32 + lg * 8, bF);
+        ig_load8(p.b3 + pH * 32 + lg * 8, bH);
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            const int rb = (rr + odd * RBH) & (RB - 1);
+            const int gr = grow_of(rb * 16 + li);
+            if (gr < 0) continue;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)(aF[0][rr][e] + bF[e]); o[4 + e] = (bf16_t)(aF[1][rr][e] + bF[4 + e]); }
+            IG_ST(o, p.R + (long)gr * CI + pF * 32 + lg * 8);
+            if (rr < RBH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)(aH[0][rr][e] + bH[e]); o[4 + e] = (bf16_t)(aH[1][rr][e] + bH[4 + e]); }
+                IG_ST(o, p.R + (long)gr * CI + pH * 32 + lg * 8);
+            }
+        }
+    }
+}
+
+// ---- weights into MFMA-operand order -----------------------------------------------------------------------------------------------
+// matrix [N][K] (N, K multiples of 32) -> fragments ((p * K/32 + ks) * 2 + q) of 64 lanes x 8 bf16: lane l holds row
+// n = 32 p + 8 ((l & 15) / 4) + 4 q + (l & 3), columns k = 32 ks + 8 (l / 16) .. + 7
+struct IgPack {
+    const float *Wa, *ba, *ga, *bta;         // ffn.c_fc [Ci][Ci], bias, ln weight / bias
+    const float *Wb, *bb, *gb, *btb;         // temporal_ffn.c_fc1 [C4][Ci], bias, ln_temporal weight / bias
+    const float *W2, *b2;                    // temporal_ffn.c_fc2 [C4][C4][3], bias
+    const float *Wp, *bp, *Wt, *bt;          // ffn.c_proj [Ci][Ci], temporal_ffn.c_proj [Ci][C4], biases
+    bf16_t *W1o, *W2o, *W3o; float *b1o, *b2o, *b3o;
+};
+
+template <int CI, int C4>
+__global__ __launch_bounds__(256) void integ_pack_kernel(const IgPack* __restrict__ descs, const IgPack one) {
+    constexpr int CC = CI + C4;
+    constexpr int KS1 = CI / 32, NP1 = CC / 32, KS2 = 3 * C4 / 32, NP2 = C4 / 32, KS3 = CC / 32, NP3 = CI / 32;
+    constexpr int F1 = NP1 * KS1 * 2, F2 = NP2 * KS2 * 2, F3 = NP3 * KS3 * 2;      // fragments per matrix
+    constexpr int PIECES = (F1 + F2 + F3) * 64;
+    constexpr int PBLK = (PIECES + 255) / 256;
+    constexpr int NB = CC + C4 + CI;                                              // bias outputs, one wave each
+    const IgPack& d = descs ? descs[blockIdx.y] : one;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < PBLK) {
+        int piece = blockIdx.x * 256 + tid;
+        if (piece >= PIECES) return;
+        int which = 0;
+        if (piece >= F1 * 64) { piece -= F1 * 64; which = 1; if (piece >= F2 * 64) { piece -= F2 * 64; which = 2; } }
+        const int KS = which == 0 ? KS1 : (which == 1 ? KS2 : KS3);
+        const int l = piece & 63, frag = piece >> 6, q = frag & 1, pk = frag >> 1, ks = pk % KS, pr = pk / KS;
+        const int n = 32 * pr + 8 * ((l & 15) >> 2) + 4 * q + (l & 3), k0 = 32 * ks + 8 * (l >> 4);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e;
+            float v;
+            if (which == 0) v = n < CI ? d.Wa[(long)n * CI + k] * d.ga[k] : d.Wb[(long)(n - CI) * CI + k] * d.gb[k];
+            else if (which == 1) { const int tap = k / C4, ci = k - tap * C4; v = d.W2[((long)n * C4 + ci) * 3 + tap]; }
+            else v = k < CI ? d.Wp[(long)n * CI + k] : d.Wt[(long)n * C4 + (k - CI)];
+            o[e] = (bf16_t)v;
+        }
+        bf16_t* dst = which == 0 ? d.W1o : (which == 1 ? d.W2o : d.W3o);
+        *reinterpret_cast<bf16x8*>(dst + (long)piece * 8) = o;
+        return;
+    }
+    // biases: b1 = [ba + Wa beta_a ; bb + Wb beta_b] (the LayerNorm shift through the weights), b2, b3 = bp + bt
+    const int w = ((int)blockIdx.x - PBLK) * 4 + (tid >> 6), lane = tid & 63;
+    if (w >= NB) return;
+    if (w < CC) {
+        const float* row = w < CI ? d.Wa + (long)w * CI : d.Wb + (long)(w - CI) * CI;
+        const float* beta = w < CI ? d.bta : d.btb;
+        float s = 0.f;
+        for (int k = lane; k < CI; k += 64) s += row[k] * beta[k];
+        s = wave_sum(s, 64);
+        if (lane == 0) d.b1o[w] = s + (w < CI ? d.ba[w] : d.bb[w - CI]);
+    } else if (w < CC + C4) {
+        if (lane == 0) d.b2o[w - CC] = d.b2[w - CC];
+    } else {
+        if (lane == 0) d.b3o[w - CC - C4] = d.bp[w - CC - C4] + d.bt[w - CC - C4];
+    }
+}
+
+// DBG: timing-only ablation (results WRONG with any bit set): 1 = no weight loads, 2 = no MFMAs, 4 = no QuickGELU, 8 = no global stores,
+// 16 = no LDS fragment reads, 32 = no row loads.  Only DBG = 0 is compiled unless the file is built with -DDIST_INTEG_ABLATE
+// (tools/integ_ablate.sh), which adds the variants DIST_AMD_INTEG_DBG can select.
+template <int CI, int C4, int BM, bool TRAIN, int DBG>
+int launch_integ_v(const IgArgs& a, hipStream_t s) {
+    const int smem = BM * CI * 2 + 2 * BM * C4 * 2;
+    static bool attr = false;
+    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)integ_fwd_kernel<CI, C4, BM, TRAIN, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr = true; }
+    hipLaunchKernelGGL((integ_fwd_kernel<CI, C4, BM, TRAIN, DBG>), dim3((unsigned)(a.clips * a.groups)), dim3(512), smem, s, a);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+template <int CI, int C4, int BM>
+int launch_integ(const IgArgs& a, const bool train, hipStream_t s) {
+#ifdef DIST_INTEG_ABLATE
+    static const int dbg = getenv("DIST_AMD_INTEG_DBG") ? atoi(getenv("DIST_AMD_INTEG_DBG")) : 0;
+#define IG_VARIANT(D) if (dbg == D) return train ? launch_integ_v<CI, C4, BM, true, D>(a, s) : launch_integ_v<CI, C4, BM, false, D>(a, s);
+    IG_VARIANT(1) IG_VARIANT(2) IG_VARIANT(4) IG_VARIANT(8) IG_VARIANT(16) IG_VARIANT(32) IG_VARIANT(3) IG_VARIANT(19) IG_VARIANT(23) IG_VARIANT(63) IG_VARIANT(59)
+#undef IG_VARIANT
+#endif
+    return train ? launch_integ_v<CI, C4, BM, true, 0>(a, s) : launch_integ_v<CI, C4, BM, false, 0>(a, s);
+}
+
+}  // namespace
+
+bool dist_k_integ_eligible(int dtype, int Ci, int C4, int t, int tk) {
+    return dtype == DIST_BF16 && Ci == 384 && C4 == 96 && tk == 3 && (t == 4 || t == 8 || t == 16 || t == 32);
+}
+
+extern "C" int64_t dist_op_integration_pack_elems(int Ci, int C4, int which) {
+    const int64_t CC = Ci + C4;
+    switch (which) {
+        case 0: return CC * Ci;                 // W1 (bf16 elements)
+        case 1: return (int64_t)C4 * 3 * C4;    // W2
+        case 2: return (int64_t)Ci * CC;        // W3
+        case 3: return CC;                      // b1 (floats)
+        case 4: return C4;                      // b2
+        case 5: return Ci;                      // b3
+        default: return -1;
+    }
+}
+
+static IgPack ig_pack_of(const dist_integ_pack_args& a) {
+    IgPack d;
+    d.Wa = a.ffn_fc_w; d.ba = a.ffn_fc_b; d.ga = a.ln_w; d.bta = a.ln_b;
+    d.Wb = a.tf_fc1_w; d.bb = a.tf_fc1_b; d.gb = a.ln_t_w; d.btb = a.ln_t_b;
+    d.W2 = a.tf_fc2_w; d.b2 = a.tf_fc2_b;
+    d.Wp = a.ffn_proj_w; d.bp = a.ffn_proj_b; d.Wt = a.tf_proj_w; d.bt = a.tf_proj_b;
+    d.W1o = static_cast<bf16_t*>(a.W1); d.W2o = static_cast<bf16_t*>(a.W2); d.W3o = static_cast<bf16_t*>(a.W3);
+    d.b1o = a.b1; d.b2o = a.b2; d.b3o = a.b3;
+    return d;
+}
+
+int64_t dist_k_integ_pack_desc_bytes() { return (int64_t)sizeof(IgPack); }
+void dist_k_integ_pack_desc(const dist_integ_pack_args* a, void* out) { *static_cast<IgPack*>(out) = ig_pack_of(*a); }
+
+// `descs_dev`: n descriptors (dist_k_integ_pack_desc) in device memory, or nullptr with n == 1 and `one` passed by value
+int dist_k_integ_pack(const void* descs_dev, const dist_integ_pack_args* one, int n, int Ci, int C4, hipStream_t s) {
+    if (Ci != 384 || C4 != 96 || n <= 0) return DIST_ERR_ARG;
+    constexpr int CI = 384, C4c = 96, CC = CI + C4c;
+    constexpr int PIECES = ((CC / 32) * (CI / 32) * 2 + (C4c / 32) * (3 * C4c / 32) * 2 + (CI / 32) * (CC / 32) * 2) * 64;
+    const int pblk = (PIECES + 255) / 256, bblk = (CC + C4c + CI + 3) / 4;
+    IgPack d{};
+    if (!descs_dev) { if (!one || n != 1) return DIST_ERR_ARG; d = ig_pack_of(*one); }
+    hipLaunchKernelGGL((integ_pack_kernel<CI, C4c>), dim3((unsigned)(pblk + bblk), (unsigned)n), dim3(256), 0, s, static_cast<const IgPack*>(descs_dev), d);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+
+extern "C" int dist_op_integration_pack(const dist_integ_pack_args* a, void* stream) {
+    if (!a || !a->ffn_fc_w || !a->ffn_fc_b || !a->ln_w || !a->ln_b || !a->tf_fc1_w || !a->tf_fc1_b || !a->ln_t_w || !a->ln_t_b || !a->tf_fc2_w ||
+        !a->tf_fc2_b || !a->ffn_proj_w || !a->ffn_proj_b || !a->tf_proj_w || !a->tf_proj_b || !a->W1 || !a->W2 || !a->W3 || !a->b1 || !a->b2 || !a->b3)
+        return DIST_ERR_ARG;
+    if (!dist_k_integ_eligible(DIST_BF16, a->Ci, a->C4, 8, 3)) return DIST_ERR_ARG;
+    return dist_k_integ_pack(nullptr, a, 1, a->Ci, a->C4, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dist_op_integration_fwd(const dist_integ_args* a, void* stream) {
+    if (!a || !a->Mp || !a->W1 || !a->W2 || !a->W3 || !a->b1 || !a->b2 || !a->b3 || !a->R) return DIST_ERR_ARG;
+    if (a->clips <= 0 || a->t <= 0 || a->L <= 0) return DIST_ERR_ARG;
+    if (!dist_k_integ_eligible(a->dtype, a->Ci, a->C4, a->t, a->tk)) return DIST_ERR_ARG;
+    const bool train = a->Na || a->Nb || a->zf_h2 || a->hf_g2 || a->h1 || a->mean || a->rstd;
+    if (train && !(a->Na && a->Nb && a->zf_h2 && a->hf_g2 && a->h1 && a->mean && a->rstd && a->ln_w && a->ln_b && a->ln_t_w && a->ln_t_b))
+        return DIST_ERR_ARG;                               // the tensors backward reads come all or none
+    static const int bm_env = getenv("DIST_AMD_INTEG_BM") ? atoi(getenv("DIST_AMD_INTEG_BM")) : 0;     // measurement knob: 64 / 128
+    int BM = bm_env == 64 || bm_env == 128 ? bm_env : 128;
+    if (BM / a->t < 1 || (BM % a->t)) return DIST_ERR_ARG;
+    IgArgs k;
+    k.Mp = static_cast<const bf16_t*>(a->Mp);
+    k.W1 = static_cast<const bf16_t*>(a->W1); k.W2 = static_cast<const bf16_t*>(a->W2); k.W3 = static_cast<const bf16_t*>(a->W3);
+    k.b1 = a->b1; k.b2 = a->b2; k.b3 = a->b3;
+    k.ga = a->ln_w; k.ba = a->ln_b; k.gb = a->ln_t_w; k.bb = a->ln_t_b;
+    k.R = static_cast<bf16_t*>(a->R); k.Na = static_cast<bf16_t*>(a->Na); k.Nb = static_cast<bf16_t*>(a->Nb);
+    k.zfh2 = static_cast<bf16_t*>(a->zf_h2); k.hfg2 = static_cast<bf16_t*>(a->hf_g2); k.h1 = static_cast<bf16_t*>(a->h1);
+    k.mean = a->mean; k.rstd = a->rstd;
+    k.clips = a->clips; k.t = a->t; k.L = a->L;
+    const int TOK = BM / a->t;
+    int sh = 0;
+    while ((1 << sh) < TOK) ++sh;
+    k.tokshift = sh;
+    k.groups = (a->L + TOK - 1) / TOK;
+    k.eps = a->eps > 0.f ? a->eps : 1e-5f;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (BM == 128) return launch_integ<384, 96, 128>(k, train, s);
+    return launch_integ<384, 96, 64>(k, train, s);
+}

@@ -38,4 +38,10 @@ int dist_k_gemm_fast(const dist_gemm_args* a, hipStream_t s);
 int dist_k_gemm_small(const dist_gemm_args* a, hipStream_t s);       // M < 1024 (gemm_small.hip)
 // fused TemporalNet (tnet.hip): does dist_op_temporal_net_fwd take this geometry?
 bool dist_k_tnet_fwd_eligible(int dtype, int Ct, int G, int tk);
+// fused IntegrationNetwork forward (integ.hip): eligibility, and the all-layers form of dist_op_integration_pack (`descs_dev`: n descriptors
+// written by dist_k_integ_pack_desc, in device memory)
+bool dist_k_integ_eligible(int dtype, int Ci, int C4, int t, int tk);
+int64_t dist_k_integ_pack_desc_bytes();
+void dist_k_integ_pack_desc(const dist_integ_pack_args* a, void* out);
+int dist_k_integ_pack(const void* descs_dev, const dist_integ_pack_args* one, int n, int Ci, int C4, hipStream_t s);
 

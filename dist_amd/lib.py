@@ -68,6 +68,18 @@ class TnetBwdArgs(C.Structure):
                [("scratch_elems", C.c_int64)] + [(n, C.c_int) for n in ("clips", "T", "G", "Ct", "tk", "dtype", "phase")]
 
 
+class IntegArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("Mp", "W1", "W2", "W3", "b1", "b2", "b3", "ln_w", "ln_b", "ln_t_w", "ln_t_b", "R", "Na", "Nb", "mean", "rstd",
+                                          "zf_h2", "hf_g2", "h1")] + \
+               [(n, C.c_int) for n in ("clips", "t", "L", "Ci", "C4", "tk", "dtype")] + [("eps", C.c_float)]
+
+
+class IntegPackArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ffn_fc_w", "ffn_fc_b", "ln_w", "ln_b", "tf_fc1_w", "tf_fc1_b", "ln_t_w", "ln_t_b", "tf_fc2_w", "tf_fc2_b",
+                                          "ffn_proj_w", "ffn_proj_b", "tf_proj_w", "tf_proj_b", "W1", "W2", "W3", "b1", "b2", "b3")] + \
+               [("Ci", C.c_int), ("C4", C.c_int)]
+
+
 class AdamwSeg(C.Structure):
     _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("lr", C.c_float), ("weight_decay", C.c_float)]
 
@@ -83,7 +95,8 @@ GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
 
 ABI_VERSION = 8    # include/dist_amd.h DIST_ABI_VERSION: bumped on every struct-layout change
 ABI_MIRRORS = (("dist_gemm_args", GemmArgs), ("dist_gemm_tn_args", GemmTnArgs), ("dist_ln_args", LnArgs), ("dist_ln_bwd_args", LnBwdArgs),
-               ("dist_adamw_seg", AdamwSeg), ("dist_config", Config), ("dist_rowmap", RowMap), ("dist_outmap", OutMap), ("dist_tnet_args", TnetArgs), ("dist_tnet_bwd_args", TnetBwdArgs))
+               ("dist_adamw_seg", AdamwSeg), ("dist_config", Config), ("dist_rowmap", RowMap), ("dist_outmap", OutMap), ("dist_tnet_args", TnetArgs), ("dist_tnet_bwd_args", TnetBwdArgs),
+               ("dist_integ_args", IntegArgs), ("dist_integ_pack_args", IntegPackArgs))
 
 
 class DistError(RuntimeError):
@@ -166,6 +179,9 @@ def load():
     _sig(lib, "dist_op_temporal_net_fwd", argtypes=[C.POINTER(TnetArgs), C.c_void_p])
     _sig(lib, "dist_op_temporal_net_bwd", argtypes=[C.POINTER(TnetBwdArgs), C.c_void_p])
     _sig(lib, "dist_op_temporal_net_bwd_reduce", argtypes=[C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
+    _sig(lib, "dist_op_integration_fwd", argtypes=[C.POINTER(IntegArgs), C.c_void_p])
+    _sig(lib, "dist_op_integration_pack", argtypes=[C.POINTER(IntegPackArgs), C.c_void_p])
+    _sig(lib, "dist_op_integration_pack_elems", argtypes=[C.c_int, C.c_int, C.c_int], restype=C.c_int64)
     _sig(lib, "dist_op_temporal_net_bwd_scratch", argtypes=[C.c_int, C.c_int, C.c_int], restype=C.c_int64)
     _sig(lib, "dist_op_ln_fold", argtypes=[C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p])
     _sig(lib, "dist_op_gemm_tn", argtypes=[C.POINTER(GemmTnArgs), C.c_void_p])

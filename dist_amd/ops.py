@@ -37,7 +37,7 @@ def outmap(mode=L.OM_PLAIN, p0=0, p1=0, p2=0):
 
 
 def gemm_nt(A, B, M, N, K, *, taps=1, bias=None, res=None, aux=None, amap=None, omap=None,
-            C_out=None, C2_out=None, lda=None, ldc=None, mulg_post=False, lnfold=None, rowstats=None, fp8=None, out8=None, act_only8=False):
+            C_out=None, C2_out=None, lda=None, ldc=None, ldc2=None, mulg_post=False, lnfold=None, rowstats=None, fp8=None, out8=None, act_only8=False):
     """C[omap(m)][n] = epi(sum_tap sum_k A[amap(m,tap)][k] B[n][tap*K+k]); returns None (writes C_out / C2_out)."""
     lib = L.load()
     a = L.GemmArgs()
@@ -48,7 +48,7 @@ def gemm_nt(A, B, M, N, K, *, taps=1, bias=None, res=None, aux=None, amap=None, 
     a.ldb = B.shape[-1]
     ldo = ldc if ldc is not None else (C_out.shape[-1] if C_out is not None else (C2_out.shape[-1] if C2_out is not None else N))
     a.ldc = ldo
-    a.ldc2 = C2_out.shape[-1] if C2_out is not None else ldo
+    a.ldc2 = ldc2 if ldc2 is not None else (C2_out.shape[-1] if C2_out is not None else ldo)
     a.ldres = res.shape[-1] if res is not None else ldo
     a.ldaux = aux.shape[-1] if aux is not None else ldo
     a.amap = amap or rowmap()
@@ -138,6 +138,54 @@ def temporal_net_bwd_reduce(scratch, layers, clips, T, Ct, dgammas, dbetas):
     dg = (FP * layers)(*[C.cast(_p(t), FP) for t in dgammas])
     db = (FP * layers)(*[C.cast(_p(t), FP) for t in dbetas])
     L.check(lib.dist_op_temporal_net_bwd_reduce(_p(scratch), n, layers, clips, T, Ct, dg, db, _stream()))
+
+
+def integration_pack(w):
+    """fp32 master weights of one IntegrationNetwork (dict with the reference's parameter names below `integration_nets.i.`) -> the operands
+    of integration_fwd (dist_op_integration_pack): dict(W1, W2, W3 bf16; b1, b2, b3 fp32)."""
+    lib = L.load()
+    Ci, C4 = w["ffn.c_fc.weight"].shape[0], w["temporal_ffn.c_fc1.weight"].shape[0]
+    dev = w["ffn.c_fc.weight"].device
+    n = [lib.dist_op_integration_pack_elems(Ci, C4, k) for k in range(6)]
+    out = {"W1": torch.empty(n[0], dtype=torch.bfloat16, device=dev), "W2": torch.empty(n[1], dtype=torch.bfloat16, device=dev),
+           "W3": torch.empty(n[2], dtype=torch.bfloat16, device=dev), "b1": torch.empty(n[3], dtype=torch.float32, device=dev),
+           "b2": torch.empty(n[4], dtype=torch.float32, device=dev), "b3": torch.empty(n[5], dtype=torch.float32, device=dev)}
+    keep = [w[k].float().contiguous() for k in ("ffn.c_fc.weight", "ffn.c_fc.bias", "ln.weight", "ln.bias", "temporal_ffn.c_fc1.weight", "temporal_ffn.c_fc1.bias",
+                                                "ln_temporal.weight", "ln_temporal.bias", "temporal_ffn.c_fc2.weight", "temporal_ffn.c_fc2.bias",
+                                                "ffn.c_proj.weight", "ffn.c_proj.bias", "temporal_ffn.c_proj.weight", "temporal_ffn.c_proj.bias")]
+    a = L.IntegPackArgs()
+    (a.ffn_fc_w, a.ffn_fc_b, a.ln_w, a.ln_b, a.tf_fc1_w, a.tf_fc1_b, a.ln_t_w, a.ln_t_b, a.tf_fc2_w, a.tf_fc2_b,
+     a.ffn_proj_w, a.ffn_proj_b, a.tf_proj_w, a.tf_proj_b) = [_p(t) for t in keep]
+    a.W1, a.W2, a.W3, a.b1, a.b2, a.b3 = _p(out["W1"]), _p(out["W2"]), _p(out["W3"]), _p(out["b1"]), _p(out["b2"]), _p(out["b3"])
+    a.Ci, a.C4 = Ci, C4
+    L.check(lib.dist_op_integration_pack(C.byref(a), _stream()))
+    torch.cuda.current_stream().synchronize()          # (the fp32 copies in `keep` must outlive the launch)
+    return out
+
+
+def integration_fwd(Mp, pk, clips, t, Ltok, *, ln=None, train=True, tk=3, eps=1e-5, out=None):
+    """Fused IntegrationNetwork forward (dist_op_integration_fwd) on Mp [clips*t*Ltok, Ci] (bf16).  `pk` from integration_pack; `ln` =
+    (ln.weight, ln.bias, ln_temporal.weight, ln_temporal.bias) fp32, needed when train (the tensors backward reads are written).
+    Returns dict(R [, Na, Nb, mean, rstd, zf_h2, hf_g2, h1])."""
+    lib = L.load()
+    rows, Ci = Mp.shape
+    C4 = pk["b2"].numel()
+    reuse = out is not None                           # (buffers of an earlier call with the same shapes)
+    out = out if reuse else {"R": torch.empty_like(Mp)}
+    a = L.IntegArgs()
+    a.Mp, a.W1, a.W2, a.W3, a.b1, a.b2, a.b3 = _p(Mp), _p(pk["W1"]), _p(pk["W2"]), _p(pk["W3"]), _p(pk["b1"]), _p(pk["b2"]), _p(pk["b3"])
+    a.R = _p(out["R"])
+    if train:
+        if not reuse:
+            out.update(Na=torch.empty_like(Mp), Nb=torch.empty_like(Mp), mean=torch.empty(rows, dtype=torch.float32, device=Mp.device),
+                       rstd=torch.empty(rows, dtype=torch.float32, device=Mp.device),
+                       zf_h2=torch.empty(rows, Ci + C4, dtype=Mp.dtype, device=Mp.device), hf_g2=torch.empty(rows, Ci + C4, dtype=Mp.dtype, device=Mp.device),
+                       h1=torch.empty(rows, C4, dtype=Mp.dtype, device=Mp.device))
+        a.ln_w, a.ln_b, a.ln_t_w, a.ln_t_b = [_p(v) for v in ln]
+        a.Na, a.Nb, a.mean, a.rstd, a.zf_h2, a.hf_g2, a.h1 = [_p(out[k]) for k in ("Na", "Nb", "mean", "rstd", "zf_h2", "hf_g2", "h1")]
+    a.clips, a.t, a.L, a.Ci, a.C4, a.tk, a.dtype, a.eps = clips, t, Ltok, Ci, C4, tk, L.BF16, eps
+    L.check(lib.dist_op_integration_fwd(C.byref(a), _stream()))
+    return out
 
 
 def ln_fold(W, bias, gamma, beta):

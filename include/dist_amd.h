@@ -43,7 +43,7 @@ const char* dist_strerror(int code);
 #define DIST_ABI_VERSION 8
 int dist_abi_version(void);
 /* sizeof() of an argument struct of this header by name ("dist_gemm_args", "dist_gemm_tn_args", "dist_ln_args",
- * "dist_ln_bwd_args", "dist_adamw_seg", "dist_config", "dist_rowmap", "dist_outmap", "dist_tnet_args", "dist_tnet_bwd_args"); -1 for an unknown name.
+ * "dist_ln_bwd_args", "dist_adamw_seg", "dist_config", "dist_rowmap", "dist_outmap", "dist_tnet_args", "dist_tnet_bwd_args", "dist_integ_args", "dist_integ_pack_args"); -1 for an unknown name.
  * Lets a foreign-language binding verify its mirror of the layout without a GPU. */
 int dist_abi_sizeof(const char* struct_name);
 
@@ -244,6 +244,35 @@ int dist_op_temporal_net_bwd(const dist_tnet_bwd_args* a, void* stream);
  * for all of them (every launch on a serial chain costs ~10 us of step; same fixed summation order as the per-layer form) */
 int dist_op_temporal_net_bwd_reduce(const float* scratch, int64_t layer_stride, int layers, int clips, int T, int Ct,
                                     float* const* dgamma, float* const* dbeta, void* stream);
+
+/* Fused IntegrationNetwork forward (reference models/module_zoo/branches/dist.py:16-45; integ.hip), bf16, Ci = 384, C4 = 96, 3 temporal taps,
+ * t in {4, 8, 16, 32} - DIST_ERR_ARG otherwise (dist_op_layernorm + four dist_op_gemm_nt calls do the same):
+ *   R = ffn.c_proj(g(ffn.c_fc(ln(M')))) + temporal_ffn.c_proj(g(conv_{3x1x1}(temporal_ffn.c_fc1(ln_temporal(M')))))
+ * on M'[(clip*t + frame)*L + token][Ci].  W1 / W2 / W3 / b1 / b2 / b3 come from dist_op_integration_pack (the two LayerNorms folded into the
+ * first pair of weights; MFMA-operand order).  The tensors backward reads are written when given (all or none): Na / Nb (the two affine
+ * LayerNorm outputs), mean / rstd, zf_h2 = [ffn.c_fc output | temporal conv output] and hf_g2 = their activations (rows of Ci + C4), h1. */
+typedef struct dist_integ_args {
+    const void* Mp;
+    const void* W1; const void* W2; const void* W3;
+    const float* b1; const float* b2; const float* b3;
+    const float* ln_w; const float* ln_b; const float* ln_t_w; const float* ln_t_b;   /* only read when Na / Nb are written */
+    void* R;
+    void* Na; void* Nb; float* mean; float* rstd; void* zf_h2; void* hf_g2; void* h1;
+    int clips, t, L, Ci, C4, tk; int dtype; float eps;
+} dist_integ_args;
+int dist_op_integration_fwd(const dist_integ_args* a, void* stream);
+/* fp32 master weights of one IntegrationNetwork (torch layouts: Linear [out][in], Conv3d [out][in][3][1][1]) -> the operands above.
+ * Sizes: dist_op_integration_pack_elems(Ci, C4, which) with which = 0..5 for W1, W2, W3 (bf16 elements), b1, b2, b3 (floats). */
+typedef struct dist_integ_pack_args {
+    const float* ffn_fc_w; const float* ffn_fc_b; const float* ln_w; const float* ln_b;
+    const float* tf_fc1_w; const float* tf_fc1_b; const float* ln_t_w; const float* ln_t_b;
+    const float* tf_fc2_w; const float* tf_fc2_b;
+    const float* ffn_proj_w; const float* ffn_proj_b; const float* tf_proj_w; const float* tf_proj_b;
+    void* W1; void* W2; void* W3; float* b1; float* b2; float* b3;
+    int Ci, C4;
+} dist_integ_pack_args;
+int64_t dist_op_integration_pack_elems(int Ci, int C4, int which);
+int dist_op_integration_pack(const dist_integ_pack_args* a, void* stream);
 
 /* one-query cross attention (CrossAttentionBlockGenral, clip.py:139-147; dist.py:144,158):
  * q [B, C], kv [B*S, 2C] -> o [B, C], probs [B, H, S] (fp32, saved for backward) */
