@@ -146,7 +146,8 @@ struct dist_handle {
     void *dR, *dkv, *dkn;
     float* ln_partial = nullptr; long ln_partial_elems = 0;     // per-block parameter-gradient sums of the LayerNorm backward (two-phase, no atomics)
     float* tnb_scratch = nullptr; long tnb_scratch_elems = 0;   // parameter-gradient partial rows of the fused TemporalNet backward
-    bool ig_on = false; void* ig_descs = nullptr;               // fused IntegrationNetwork forward: taken for this geometry; its pack descriptors (device)
+    bool ig_on = false, ig_xhat = false; void* ig_descs = nullptr;   // ig_xhat: the forward keeps xhat (in the Na buffer) instead of Na / Nb; the weight gradients of the two folded Linears are unfolded afterwards
+                  // fused IntegrationNetwork forward: taken for this geometry; its pack descriptors (device)
     float* tn_partial[3] = {nullptr, nullptr, nullptr};   // two-phase dW reduction scratch, one per stream that launches dW GEMMs
     long tn_partial_elems = 0;
     // weight-gradient side stream (created once per handle; host-side objects only)
@@ -476,6 +477,7 @@ size_t layout_ws(dist_handle* h, char* base) {
     h->tnb_scratch_elems = dist_op_temporal_net_bwd_scratch((int)b, c.frames, Ct);
     h->tnb_scratch = F_(h->tnb_scratch_elems * c.layers);        // one partial table per layer
     h->ig_on = dist_k_integ_eligible(c.dtype, Ci, C4, h->t, c.temporal_kernel) && !(getenv("DIST_AMD_INTEG_FUSED") && atoi(getenv("DIST_AMD_INTEG_FUSED")) == 0);
+    h->ig_xhat = h->ig_on && !(getenv("DIST_AMD_INTEG_XHAT") && atoi(getenv("DIST_AMD_INTEG_XHAT")) == 0);
     if (h->ig_on) {
         for (int i = 0; i < c.layers; ++i) {
             DistLayer& l = h->dl[i];
@@ -665,12 +667,12 @@ int ln_fwd(const Ctx& c, const float* wbase, const LNp& l, const void* x, void* 
     return dist_op_layernorm(&a, c.s);
 }
 int ln_bwd(const Ctx& c, const LNp& l, const void* x, const float* mean, const float* rstd, const void* dy, void* dx, bool accumulate,
-           long rows, const LNp* l2 = nullptr, const void* dy2 = nullptr, const void* dx_add = nullptr, void* dx_copy = nullptr) {
+           long rows, const LNp* l2 = nullptr, const void* dy2 = nullptr, const void* dx_add = nullptr, void* dx_copy = nullptr, bool param_grads = true) {
     dist_ln_bwd_args a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.mean = mean; a.rstd = rstd; a.dy = dy; a.w = c.th(l.w); a.dx = dx; a.accumulate_dx = accumulate ? 1 : 0;
-    a.dw = c.gr(l.w); a.db = c.gr(l.b);
-    if (l2) { a.dy2 = dy2; a.w2 = c.th(l2->w); a.dw2 = c.gr(l2->w); a.db2 = c.gr(l2->b); }
+    if (param_grads) { a.dw = c.gr(l.w); a.db = c.gr(l.b); }
+    if (l2) { a.dy2 = dy2; a.w2 = c.th(l2->w); if (param_grads) { a.dw2 = c.gr(l2->w); a.db2 = c.gr(l2->b); } }
     a.rows = rows; a.C = l.C; a.dtype = c.dtype;
     a.dx_add = dx_add; a.dx_copy = dx_copy;
     // Two-phase parameter gradients (dist_ln_bwd_args.partial): measured in the step and NOT the default - 20.03 -> 20.20 ms with the same grid
@@ -703,7 +705,7 @@ extern "C" int dist_abi_sizeof(const char* n) {
     if (!n) return -1;
 #define DIST_SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)
     DIST_SZ(dist_gemm_args); DIST_SZ(dist_gemm_tn_args); DIST_SZ(dist_ln_args); DIST_SZ(dist_ln_bwd_args);
-    DIST_SZ(dist_adamw_seg); DIST_SZ(dist_config); DIST_SZ(dist_rowmap); DIST_SZ(dist_outmap); DIST_SZ(dist_tnet_args); DIST_SZ(dist_tnet_bwd_args); DIST_SZ(dist_integ_args); DIST_SZ(dist_integ_pack_args);
+    DIST_SZ(dist_adamw_seg); DIST_SZ(dist_config); DIST_SZ(dist_rowmap); DIST_SZ(dist_outmap); DIST_SZ(dist_tnet_args); DIST_SZ(dist_tnet_bwd_args); DIST_SZ(dist_integ_args); DIST_SZ(dist_integ_pack_args); DIST_SZ(dist_integ_unfold_args);
 #undef DIST_SZ
     return -1;
 }
@@ -1203,8 +1205,12 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
                 ia.Mp = w.Mp; ia.W1 = l.ig_W1; ia.W2 = l.ig_W2; ia.W3 = l.ig_W3; ia.b1 = l.ig_b1; ia.b2 = l.ig_b2; ia.b3 = l.ig_b3;
                 ia.R = w.R;
                 if (!h->inference) {                                            // (what backward reads)
-                    ia.ln_w = x.th(l.in_ln.w); ia.ln_b = x.th(l.in_ln.b); ia.ln_t_w = x.th(l.in_ln_t.w); ia.ln_t_b = x.th(l.in_ln_t.b);
-                    ia.Na = w.Na; ia.Nb = w.Nb; ia.mean = w.in_mean; ia.rstd = w.in_rstd; ia.zf_h2 = w.zf; ia.hf_g2 = w.hf; ia.h1 = w.h1;
+                    if (h->ig_xhat) ia.Xhat = w.Na;
+                    else {
+                        ia.ln_w = x.th(l.in_ln.w); ia.ln_b = x.th(l.in_ln.b); ia.ln_t_w = x.th(l.in_ln_t.w); ia.ln_t_b = x.th(l.in_ln_t.b);
+                        ia.Na = w.Na; ia.Nb = w.Nb;
+                    }
+                    ia.mean = w.in_mean; ia.rstd = w.in_rstd; ia.zf_h2 = w.zf; ia.hf_g2 = w.hf; ia.h1 = w.h1;
                 }
                 ia.clips = (int)b; ia.t = t; ia.L = L; ia.Ci = Ci; ia.C4 = C4; ia.tk = l.tf_fc2.taps; ia.dtype = c.dtype; ia.eps = 1e-5f;
                 RUN(dist_op_integration_fwd(&ia, x.s));
@@ -1436,11 +1442,11 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         RUN(gemm(x, q.dh2, Cc, x.pk(l.tf_fc2.pk.b), rowsS, C4, C4, l.tf_fc2.taps, q.dh1, C4, nullptr, nullptr, nullptr, nullptr,
                  RM(DIST_RM_SHIFT, t * L, L, -1)));
         RUN(fork());
-        RUN(wgrad(xb2, l.tf_fc1, q.dh1, C4, w.Nb, Ci, rowsS, RM(), RM(), 0, true));
+        RUN(wgrad(xb2, l.tf_fc1, q.dh1, C4, h->ig_xhat ? w.Na : w.Nb, Ci, rowsS, RM(), RM(), 0, true));     // (ig_xhat: w.Na holds xhat, see the unfold below)
         RUN(lin_dx(h, x, l.ffn_fc, q.dzf, rowsS, q.dNa, nullptr, nullptr, Cc));
         RUN(lin_dx(h, x, l.tf_fc1, q.dh1, rowsS, q.dNb));
         // dM' = LN'(dNa, dNb) (+ dFz for the last layer); a second copy becomes dM (updated in place by the I2T term)
-        RUN(ln_bwd(x, l.in_ln, w.Mp, w.in_mean, w.in_rstd, q.dNa, q.dMp, false, rowsS, &l.in_ln_t, q.dNb, last ? dR : nullptr, last ? nullptr : q.dM));
+        RUN(ln_bwd(x, l.in_ln, w.Mp, w.in_mean, w.in_rstd, q.dNa, q.dMp, false, rowsS, &l.in_ln_t, q.dNb, last ? dR : nullptr, last ? nullptr : q.dM, !h->ig_xhat));
         // ---- T2I backward (dist.py:81-86): M' = M + [cls_token ; conv_strided(X')] ----
         RUN(fork());
         RUN(dist_k_cls_rows_bwd(q.dMp, x.gr(l.cls_token), (int)bt, L, Ci, t, c.dtype, B));
@@ -1484,6 +1490,15 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         RUN(wgrad(xb, l.tn_fc2, q.dp, Ct, w.V, Ct, rowsX, RM(), RM(DIST_RM_SPATIAL, h->G, 0, 1), 1, true));
         RUN(wgrad(xb2, l.tn_fc1, q.dz, Ct, w.U, Ct, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 1, true));
         RUN(merge_b2());
+        if (h->ig_xhat && !(h->skip & 1)) {   // the weight gradients of ffn.c_fc / temporal_ffn.c_fc1 were taken against xhat: unfold them (+ the two LayerNorms' gradients)
+            dist_integ_unfold_args ua;
+            ua.ffn_fc_w = x.th(l.ffn_fc.w); ua.ln_w = x.th(l.in_ln.w); ua.ln_b = x.th(l.in_ln.b);
+            ua.d_ffn_fc_w = x.gr(l.ffn_fc.w); ua.d_ffn_fc_b = x.gr(l.ffn_fc.bias); ua.d_ln_w = x.gr(l.in_ln.w); ua.d_ln_b = x.gr(l.in_ln.b);
+            ua.tf_fc1_w = x.th(l.tf_fc1.w); ua.ln_t_w = x.th(l.in_ln_t.w); ua.ln_t_b = x.th(l.in_ln_t.b);
+            ua.d_tf_fc1_w = x.gr(l.tf_fc1.w); ua.d_tf_fc1_b = x.gr(l.tf_fc1.bias); ua.d_ln_t_w = x.gr(l.in_ln_t.w); ua.d_ln_t_b = x.gr(l.in_ln_t.b);
+            ua.Ci = Ci; ua.C4 = C4;
+            RUN(dist_op_integration_unfold(&ua, B));
+        }
         HIP_CHECK_RET(hipEventRecord(h->ev_b_done[i], B));
         if (h->dummy & 2) for (int r = 0; r < h->dummy_reps; ++r) RUN(ln_fwd(x, h->visual, h->vit[0].ln1, h->feat[i], nullptr, rowsS, h->lnstats2, h->lnstats2 + rowsS));
         if (h->dummy & 4) for (int r = 0; r < h->dummy_reps; ++r) RUN(ln_fwd(xb, h->visual, h->vit[0].ln1, h->feat[i], nullptr, rowsS, h->lnstats3, h->lnstats3 + rowsS));

@@ -40,7 +40,7 @@ struct IgArgs {
     const bf16_t *W1, *W2, *W3;
     const float *b1, *b2, *b3;
     const float *ga, *ba, *gb, *bb;
-    bf16_t *R, *Na, *Nb, *zfh2, *hfg2, *h1;
+    bf16_t *R, *Na, *Nb, *Xh, *zfh2, *hfg2, *h1;
     float *mean, *rstd;
     int clips, t, L, groups, tokshift;
     float eps;
@@ -66,8 +66,9 @@ DEV void ig_load8(const float* p, float (&o)[8]) {
     o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
 }
 
-template <int CI, int C4, int BM, bool TRAIN, int DBG>
+template <int CI, int C4, int BM, int MODE, int DBG>
 __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_fwd_kernel(const IgArgs p) {
+    constexpr bool TRAIN = MODE != 0;            // MODE 1: the two affine LayerNorm outputs Na / Nb are written, MODE 2: xhat itself (one tensor)
     constexpr int CC = CI + C4;
     constexpr int CPR = CI / 8;                  // 16-byte chunks per region-A row
     constexpr int CPB = C4 / 8;                  // ... per region-B / C row
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_fwd_kernel(con
         for (int m = 0; m < LCH; ++m) {
             const int c = lq + 8 * m;
             float wa[8], ba[8], wb[8], bb[8];
-            if (TRAIN) { ig_load8(p.ga + c * 8, wa); ig_load8(p.ba + c * 8, ba); ig_load8(p.gb + c * 8, wb); ig_load8(p.bb + c * 8, bb); }
+            if (MODE == 1) { ig_load8(p.ga + c * 8, wa); ig_load8(p.ba + c * 8, ba); ig_load8(p.gb + c * 8, wb); ig_load8(p.bb + c * 8, bb); }
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int r = wid * RPW + ps * 8 + lrow;
@@ -141,7 +142,8 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_fwd_kernel(con
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { xh[e] = ((float)raw[ps][m][e] - mean[ps]) * rstd[ps]; o[e] = (bf16_t)xh[e]; }
                 *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + ((c ^ (r & 15)) << 4)) = o;
-                if (TRAIN && grow0[ps] >= 0) {
+                if (MODE == 2 && grow0[ps] >= 0) IG_ST(o, p.Xh + (long)grow0[ps] * CI + c * 8);
+                if (MODE == 1 && grow0[ps] >= 0) {
                     bf16x8 na, nb;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { na[e] = (bf16_t)(xh[e] * wa[e] + ba[e]); nb[e] = (bf16_t)(xh[e] * wb[e] + bb[e]); }
@@ -393,24 +395,51 @@ __global__ __launch_bounds__(256) void integ_pack_kernel(const IgPack* __restric
 // DBG: timing-only ablation (results WRONG with any bit set): 1 = no weight loads, 2 = no MFMAs, 4 = no QuickGELU, 8 = no global stores,
 // 16 = no LDS fragment reads, 32 = no row loads.  Only DBG = 0 is compiled unless the file is built with -DDIST_INTEG_ABLATE
 // (tools/integ_ablate.sh), which adds the variants DIST_AMD_INTEG_DBG can select.
-template <int CI, int C4, int BM, bool TRAIN, int DBG>
+// ---- LayerNorm fold, backward side ----------------------------------------------------------------------------------------------------
+// The weight-gradient GEMM of a folded Linear z = W (xhat gamma + beta) + b reads xhat, so it leaves G' = dz^T xhat in W's gradient slot.
+// In place:  dW = G' diag(gamma) + db beta^T,  and  dgamma[k] += sum_n W[n][k] G'[n][k],  dbeta[k] += sum_n W[n][k] db[n].
+// One block per 64 columns k (the lanes of a wave walk consecutive k: coalesced), its 4 waves split the rows n; fixed summation order.
+struct IgUnfold { const float *W, *gamma, *beta; float *G; const float* db; float *dgamma, *dbeta; int N, K; };
+__global__ __launch_bounds__(256) void integ_unfold_kernel(const IgUnfold a, const IgUnfold b) {
+    const int nba = a.K / 64;
+    const IgUnfold& d = (int)blockIdx.x < nba ? a : b;
+    const int k = ((int)blockIdx.x < nba ? blockIdx.x : blockIdx.x - nba) * 64 + (threadIdx.x & 63), wv = threadIdx.x >> 6;
+    __shared__ float red[2][4][64];
+    const float g = d.gamma[k], be = d.beta[k];
+    float sg = 0.f, sb = 0.f;
+    const int n0 = wv * (d.N / 4), n1 = n0 + d.N / 4;
+    for (int n = n0; n < n1; ++n) {
+        const float w = d.W[(long)n * d.K + k], gp = d.G[(long)n * d.K + k], dbn = d.db[n];
+        sg += w * gp; sb += w * dbn;
+        d.G[(long)n * d.K + k] = gp * g + dbn * be;
+    }
+    red[0][wv][threadIdx.x & 63] = sg; red[1][wv][threadIdx.x & 63] = sb;
+    __syncthreads();
+    if (wv == 0) {
+        const int l = threadIdx.x;
+        d.dgamma[k] += (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+        d.dbeta[k] += (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+    }
+}
+
+template <int CI, int C4, int BM, int MODE, int DBG>
 int launch_integ_v(const IgArgs& a, hipStream_t s) {
     const int smem = BM * CI * 2 + 2 * BM * C4 * 2;
     static bool attr = false;
-    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)integ_fwd_kernel<CI, C4, BM, TRAIN, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr = true; }
-    hipLaunchKernelGGL((integ_fwd_kernel<CI, C4, BM, TRAIN, DBG>), dim3((unsigned)(a.clips * a.groups)), dim3(512), smem, s, a);
+    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)integ_fwd_kernel<CI, C4, BM, MODE, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr = true; }
+    hipLaunchKernelGGL((integ_fwd_kernel<CI, C4, BM, MODE, DBG>), dim3((unsigned)(a.clips * a.groups)), dim3(512), smem, s, a);
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
 }
 template <int CI, int C4, int BM>
-int launch_integ(const IgArgs& a, const bool train, hipStream_t s) {
+int launch_integ(const IgArgs& a, const int mode, hipStream_t s) {
 #ifdef DIST_INTEG_ABLATE
     static const int dbg = getenv("DIST_AMD_INTEG_DBG") ? atoi(getenv("DIST_AMD_INTEG_DBG")) : 0;
-#define IG_VARIANT(D) if (dbg == D) return train ? launch_integ_v<CI, C4, BM, true, D>(a, s) : launch_integ_v<CI, C4, BM, false, D>(a, s);
+#define IG_VARIANT(D) if (dbg == D) return mode ? launch_integ_v<CI, C4, BM, 1, D>(a, s) : launch_integ_v<CI, C4, BM, 0, D>(a, s);
     IG_VARIANT(1) IG_VARIANT(2) IG_VARIANT(4) IG_VARIANT(8) IG_VARIANT(16) IG_VARIANT(32) IG_VARIANT(3) IG_VARIANT(19) IG_VARIANT(23) IG_VARIANT(63) IG_VARIANT(59)
 #undef IG_VARIANT
 #endif
-    return train ? launch_integ_v<CI, C4, BM, true, 0>(a, s) : launch_integ_v<CI, C4, BM, false, 0>(a, s);
+    return mode == 2 ? launch_integ_v<CI, C4, BM, 2, 0>(a, s) : (mode == 1 ? launch_integ_v<CI, C4, BM, 1, 0>(a, s) : launch_integ_v<CI, C4, BM, 0, 0>(a, s));
 }
 
 }  // namespace
@@ -467,13 +496,28 @@ extern "C" int dist_op_integration_pack(const dist_integ_pack_args* a, void* str
     return dist_k_integ_pack(nullptr, a, 1, a->Ci, a->C4, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int dist_op_integration_unfold(const dist_integ_unfold_args* a, void* stream) {
+    if (!a || !a->ffn_fc_w || !a->ln_w || !a->ln_b || !a->d_ffn_fc_w || !a->d_ffn_fc_b || !a->d_ln_w || !a->d_ln_b || !a->tf_fc1_w || !a->ln_t_w ||
+        !a->ln_t_b || !a->d_tf_fc1_w || !a->d_tf_fc1_b || !a->d_ln_t_w || !a->d_ln_t_b) return DIST_ERR_ARG;
+    if (a->Ci <= 0 || a->Ci % 64 || a->C4 <= 0 || a->C4 % 4) return DIST_ERR_ARG;
+    IgUnfold x{a->ffn_fc_w, a->ln_w, a->ln_b, a->d_ffn_fc_w, a->d_ffn_fc_b, a->d_ln_w, a->d_ln_b, a->Ci, a->Ci};
+    IgUnfold y{a->tf_fc1_w, a->ln_t_w, a->ln_t_b, a->d_tf_fc1_w, a->d_tf_fc1_b, a->d_ln_t_w, a->d_ln_t_b, a->C4, a->Ci};
+    hipLaunchKernelGGL(integ_unfold_kernel, dim3((unsigned)(2 * a->Ci / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+
 extern "C" int dist_op_integration_fwd(const dist_integ_args* a, void* stream) {
     if (!a || !a->Mp || !a->W1 || !a->W2 || !a->W3 || !a->b1 || !a->b2 || !a->b3 || !a->R) return DIST_ERR_ARG;
     if (a->clips <= 0 || a->t <= 0 || a->L <= 0) return DIST_ERR_ARG;
     if (!dist_k_integ_eligible(a->dtype, a->Ci, a->C4, a->t, a->tk)) return DIST_ERR_ARG;
-    const bool train = a->Na || a->Nb || a->zf_h2 || a->hf_g2 || a->h1 || a->mean || a->rstd;
-    if (train && !(a->Na && a->Nb && a->zf_h2 && a->hf_g2 && a->h1 && a->mean && a->rstd && a->ln_w && a->ln_b && a->ln_t_w && a->ln_t_b))
-        return DIST_ERR_ARG;                               // the tensors backward reads come all or none
+    const bool train = a->Na || a->Nb || a->Xhat || a->zf_h2 || a->hf_g2 || a->h1 || a->mean || a->rstd;
+    int mode = 0;
+    if (train) {                                           // the tensors backward reads come all or none; the normalised rows either as xhat or as Na + Nb
+        if (!(a->zf_h2 && a->hf_g2 && a->h1 && a->mean && a->rstd)) return DIST_ERR_ARG;
+        if (a->Xhat) { if (a->Na || a->Nb) return DIST_ERR_ARG; mode = 2; }
+        else { if (!(a->Na && a->Nb && a->ln_w && a->ln_b && a->ln_t_w && a->ln_t_b)) return DIST_ERR_ARG; mode = 1; }
+    }
     static const int bm_env = getenv("DIST_AMD_INTEG_BM") ? atoi(getenv("DIST_AMD_INTEG_BM")) : 0;     // measurement knob: 64 / 128
     int BM = bm_env == 64 || bm_env == 128 ? bm_env : 128;
     if (BM / a->t < 1 || (BM % a->t)) return DIST_ERR_ARG;
@@ -482,7 +526,7 @@ extern "C" int dist_op_integration_fwd(const dist_integ_args* a, void* stream) {
     k.W1 = static_cast<const bf16_t*>(a->W1); k.W2 = static_cast<const bf16_t*>(a->W2); k.W3 = static_cast<const bf16_t*>(a->W3);
     k.b1 = a->b1; k.b2 = a->b2; k.b3 = a->b3;
     k.ga = a->ln_w; k.ba = a->ln_b; k.gb = a->ln_t_w; k.bb = a->ln_t_b;
-    k.R = static_cast<bf16_t*>(a->R); k.Na = static_cast<bf16_t*>(a->Na); k.Nb = static_cast<bf16_t*>(a->Nb);
+    k.R = static_cast<bf16_t*>(a->R); k.Na = static_cast<bf16_t*>(a->Na); k.Nb = static_cast<bf16_t*>(a->Nb); k.Xh = static_cast<bf16_t*>(a->Xhat);
     k.zfh2 = static_cast<bf16_t*>(a->zf_h2); k.hfg2 = static_cast<bf16_t*>(a->hf_g2); k.h1 = static_cast<bf16_t*>(a->h1);
     k.mean = a->mean; k.rstd = a->rstd;
     k.clips = a->clips; k.t = a->t; k.L = a->L;
@@ -493,6 +537,6 @@ extern "C" int dist_op_integration_fwd(const dist_integ_args* a, void* stream) {
     k.groups = (a->L + TOK - 1) / TOK;
     k.eps = a->eps > 0.f ? a->eps : 1e-5f;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (BM == 128) return launch_integ<384, 96, 128>(k, train, s);
-    return launch_integ<384, 96, 64>(k, train, s);
+    if (BM == 128) return launch_integ<384, 96, 128>(k, mode, s);
+    return launch_integ<384, 96, 64>(k, mode, s);
 }

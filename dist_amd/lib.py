@@ -71,7 +71,12 @@ class TnetBwdArgs(C.Structure):
 class IntegArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("Mp", "W1", "W2", "W3", "b1", "b2", "b3", "ln_w", "ln_b", "ln_t_w", "ln_t_b", "R", "Na", "Nb", "mean", "rstd",
                                           "zf_h2", "hf_g2", "h1")] + \
-               [(n, C.c_int) for n in ("clips", "t", "L", "Ci", "C4", "tk", "dtype")] + [("eps", C.c_float)]
+               [(n, C.c_int) for n in ("clips", "t", "L", "Ci", "C4", "tk", "dtype")] + [("eps", C.c_float), ("Xhat", C.c_void_p)]
+
+
+class IntegUnfoldArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ffn_fc_w", "ln_w", "ln_b", "d_ffn_fc_w", "d_ffn_fc_b", "d_ln_w", "d_ln_b",
+                                          "tf_fc1_w", "ln_t_w", "ln_t_b", "d_tf_fc1_w", "d_tf_fc1_b", "d_ln_t_w", "d_ln_t_b")] + [("Ci", C.c_int), ("C4", C.c_int)]
 
 
 class IntegPackArgs(C.Structure):
@@ -96,7 +101,7 @@ GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
 ABI_VERSION = 8    # include/dist_amd.h DIST_ABI_VERSION: bumped on every struct-layout change
 ABI_MIRRORS = (("dist_gemm_args", GemmArgs), ("dist_gemm_tn_args", GemmTnArgs), ("dist_ln_args", LnArgs), ("dist_ln_bwd_args", LnBwdArgs),
                ("dist_adamw_seg", AdamwSeg), ("dist_config", Config), ("dist_rowmap", RowMap), ("dist_outmap", OutMap), ("dist_tnet_args", TnetArgs), ("dist_tnet_bwd_args", TnetBwdArgs),
-               ("dist_integ_args", IntegArgs), ("dist_integ_pack_args", IntegPackArgs))
+               ("dist_integ_args", IntegArgs), ("dist_integ_pack_args", IntegPackArgs), ("dist_integ_unfold_args", IntegUnfoldArgs))
 
 
 class DistError(RuntimeError):
@@ -180,6 +185,7 @@ def load():
     _sig(lib, "dist_op_temporal_net_bwd", argtypes=[C.POINTER(TnetBwdArgs), C.c_void_p])
     _sig(lib, "dist_op_temporal_net_bwd_reduce", argtypes=[C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_op_integration_fwd", argtypes=[C.POINTER(IntegArgs), C.c_void_p])
+    _sig(lib, "dist_op_integration_unfold", argtypes=[C.POINTER(IntegUnfoldArgs), C.c_void_p])
     _sig(lib, "dist_op_integration_pack", argtypes=[C.POINTER(IntegPackArgs), C.c_void_p])
     _sig(lib, "dist_op_integration_pack_elems", argtypes=[C.c_int, C.c_int, C.c_int], restype=C.c_int64)
     _sig(lib, "dist_op_temporal_net_bwd_scratch", argtypes=[C.c_int, C.c_int, C.c_int], restype=C.c_int64)

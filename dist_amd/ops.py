@@ -163,10 +163,11 @@ def integration_pack(w):
     return out
 
 
-def integration_fwd(Mp, pk, clips, t, Ltok, *, ln=None, train=True, tk=3, eps=1e-5, out=None):
+def integration_fwd(Mp, pk, clips, t, Ltok, *, ln=None, train=True, tk=3, eps=1e-5, out=None, xhat=False):
     """Fused IntegrationNetwork forward (dist_op_integration_fwd) on Mp [clips*t*Ltok, Ci] (bf16).  `pk` from integration_pack; `ln` =
-    (ln.weight, ln.bias, ln_temporal.weight, ln_temporal.bias) fp32, needed when train (the tensors backward reads are written).
-    Returns dict(R [, Na, Nb, mean, rstd, zf_h2, hf_g2, h1])."""
+    (ln.weight, ln.bias, ln_temporal.weight, ln_temporal.bias) fp32, needed when train (the tensors backward reads are written) unless
+    xhat=True (the normalised rows themselves are kept instead of the two affine outputs).
+    Returns dict(R [, Na, Nb | Xhat, mean, rstd, zf_h2, hf_g2, h1])."""
     lib = L.load()
     rows, Ci = Mp.shape
     C4 = pk["b2"].numel()
@@ -177,15 +178,33 @@ def integration_fwd(Mp, pk, clips, t, Ltok, *, ln=None, train=True, tk=3, eps=1e
     a.R = _p(out["R"])
     if train:
         if not reuse:
-            out.update(Na=torch.empty_like(Mp), Nb=torch.empty_like(Mp), mean=torch.empty(rows, dtype=torch.float32, device=Mp.device),
+            out.update(mean=torch.empty(rows, dtype=torch.float32, device=Mp.device),
                        rstd=torch.empty(rows, dtype=torch.float32, device=Mp.device),
                        zf_h2=torch.empty(rows, Ci + C4, dtype=Mp.dtype, device=Mp.device), hf_g2=torch.empty(rows, Ci + C4, dtype=Mp.dtype, device=Mp.device),
                        h1=torch.empty(rows, C4, dtype=Mp.dtype, device=Mp.device))
-        a.ln_w, a.ln_b, a.ln_t_w, a.ln_t_b = [_p(v) for v in ln]
-        a.Na, a.Nb, a.mean, a.rstd, a.zf_h2, a.hf_g2, a.h1 = [_p(out[k]) for k in ("Na", "Nb", "mean", "rstd", "zf_h2", "hf_g2", "h1")]
+            out.update({"Xhat": torch.empty_like(Mp)} if xhat else {"Na": torch.empty_like(Mp), "Nb": torch.empty_like(Mp)})
+        if xhat:
+            a.Xhat = _p(out["Xhat"])
+        else:
+            a.ln_w, a.ln_b, a.ln_t_w, a.ln_t_b = [_p(v) for v in ln]
+            a.Na, a.Nb = _p(out["Na"]), _p(out["Nb"])
+        a.mean, a.rstd, a.zf_h2, a.hf_g2, a.h1 = [_p(out[k]) for k in ("mean", "rstd", "zf_h2", "hf_g2", "h1")]
     a.clips, a.t, a.L, a.Ci, a.C4, a.tk, a.dtype, a.eps = clips, t, Ltok, Ci, C4, tk, L.BF16, eps
     L.check(lib.dist_op_integration_fwd(C.byref(a), _stream()))
     return out
+
+
+def integration_unfold(w, g):
+    """backward side of the LayerNorm fold (dist_op_integration_unfold), in place on the fp32 gradient dict `g` (same keys as the weights `w`):
+    g["ffn.c_fc.weight"] / g["temporal_ffn.c_fc1.weight"] hold dz^T xhat on entry."""
+    a = L.IntegUnfoldArgs()
+    a.ffn_fc_w, a.ln_w, a.ln_b = _p(w["ffn.c_fc.weight"]), _p(w["ln.weight"]), _p(w["ln.bias"])
+    a.d_ffn_fc_w, a.d_ffn_fc_b, a.d_ln_w, a.d_ln_b = _p(g["ffn.c_fc.weight"]), _p(g["ffn.c_fc.bias"]), _p(g["ln.weight"]), _p(g["ln.bias"])
+    a.tf_fc1_w, a.ln_t_w, a.ln_t_b = _p(w["temporal_ffn.c_fc1.weight"]), _p(w["ln_temporal.weight"]), _p(w["ln_temporal.bias"])
+    a.d_tf_fc1_w, a.d_tf_fc1_b, a.d_ln_t_w, a.d_ln_t_b = (_p(g["temporal_ffn.c_fc1.weight"]), _p(g["temporal_ffn.c_fc1.bias"]),
+                                                          _p(g["ln_temporal.weight"]), _p(g["ln_temporal.bias"]))
+    a.Ci, a.C4 = w["ffn.c_fc.weight"].shape[0], w["temporal_ffn.c_fc1.weight"].shape[0]
+    L.check(L.load().dist_op_integration_unfold(C.byref(a), _stream()))
 
 
 def ln_fold(W, bias, gamma, beta):

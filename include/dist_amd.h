@@ -43,7 +43,7 @@ const char* dist_strerror(int code);
 #define DIST_ABI_VERSION 8
 int dist_abi_version(void);
 /* sizeof() of an argument struct of this header by name ("dist_gemm_args", "dist_gemm_tn_args", "dist_ln_args",
- * "dist_ln_bwd_args", "dist_adamw_seg", "dist_config", "dist_rowmap", "dist_outmap", "dist_tnet_args", "dist_tnet_bwd_args", "dist_integ_args", "dist_integ_pack_args"); -1 for an unknown name.
+ * "dist_ln_bwd_args", "dist_adamw_seg", "dist_config", "dist_rowmap", "dist_outmap", "dist_tnet_args", "dist_tnet_bwd_args", "dist_integ_args", "dist_integ_pack_args", "dist_integ_unfold_args"); -1 for an unknown name.
  * Lets a foreign-language binding verify its mirror of the layout without a GPU. */
 int dist_abi_sizeof(const char* struct_name);
 
@@ -250,7 +250,7 @@ int dist_op_temporal_net_bwd_reduce(const float* scratch, int64_t layer_stride, 
  *   R = ffn.c_proj(g(ffn.c_fc(ln(M')))) + temporal_ffn.c_proj(g(conv_{3x1x1}(temporal_ffn.c_fc1(ln_temporal(M')))))
  * on M'[(clip*t + frame)*L + token][Ci].  W1 / W2 / W3 / b1 / b2 / b3 come from dist_op_integration_pack (the two LayerNorms folded into the
  * first pair of weights; MFMA-operand order).  The tensors backward reads are written when given (all or none): Na / Nb (the two affine
- * LayerNorm outputs), mean / rstd, zf_h2 = [ffn.c_fc output | temporal conv output] and hf_g2 = their activations (rows of Ci + C4), h1. */
+ * LayerNorm outputs) or Xhat, mean / rstd, zf_h2 = [ffn.c_fc output | temporal conv output] and hf_g2 = their activations (rows of Ci + C4), h1. */
 typedef struct dist_integ_args {
     const void* Mp;
     const void* W1; const void* W2; const void* W3;
@@ -259,6 +259,8 @@ typedef struct dist_integ_args {
     void* R;
     void* Na; void* Nb; float* mean; float* rstd; void* zf_h2; void* hf_g2; void* h1;
     int clips, t, L, Ci, C4, tk; int dtype; float eps;
+    void* Xhat;              /* instead of Na / Nb: the normalised rows (x - mean) rstd themselves, ONE tensor - for a backward pass whose weight-gradient
+                              * GEMMs read xhat and whose results dist_op_integration_unfold turns into the gradients of W, gamma and beta */
 } dist_integ_args;
 int dist_op_integration_fwd(const dist_integ_args* a, void* stream);
 /* fp32 master weights of one IntegrationNetwork (torch layouts: Linear [out][in], Conv3d [out][in][3][1][1]) -> the operands above.
@@ -272,6 +274,15 @@ typedef struct dist_integ_pack_args {
     int Ci, C4;
 } dist_integ_pack_args;
 int64_t dist_op_integration_pack_elems(int Ci, int C4, int which);
+/* backward side of the LayerNorm fold.  On entry d_ffn_fc_w / d_tf_fc1_w hold G' = dz^T xhat (dist_op_gemm_tn with B = Xhat) and d_*_b the bias
+ * gradients; on exit they hold the gradients of the unfolded weights, dW = G' diag(gamma) + db beta^T, and
+ * d_ln_w[k] += sum_n W[n][k] G'[n][k], d_ln_b[k] += sum_n W[n][k] db[n] (likewise ln_temporal through temporal_ffn.c_fc1).  fp32, fixed order. */
+typedef struct dist_integ_unfold_args {
+    const float* ffn_fc_w; const float* ln_w; const float* ln_b; float* d_ffn_fc_w; const float* d_ffn_fc_b; float* d_ln_w; float* d_ln_b;
+    const float* tf_fc1_w; const float* ln_t_w; const float* ln_t_b; float* d_tf_fc1_w; const float* d_tf_fc1_b; float* d_ln_t_w; float* d_ln_t_b;
+    int Ci, C4;
+} dist_integ_unfold_args;
+int dist_op_integration_unfold(const dist_integ_unfold_args* a, void* stream);
 int dist_op_integration_pack(const dist_integ_pack_args* a, void* stream);
 
 /* one-query cross attention (CrossAttentionBlockGenral, clip.py:139-147; dist.py:144,158):
