@@ -60,6 +60,7 @@ struct DistLayer {
     long pk_proj_f = -1, pk_proj_b = -1;     // the two c_proj weights side by side: [Ci][Ci+C4] forward, [Ci+C4][Ci] data-gradient
     // fused IntegrationNetwork forward (integ.hip): MFMA-operand-ordered weights with the two LayerNorms folded in (workspace pointers)
     void *ig_W1 = nullptr, *ig_W2 = nullptr, *ig_W3 = nullptr; float *ig_b1 = nullptr, *ig_b2 = nullptr, *ig_b3 = nullptr;
+    void *ig_B1 = nullptr, *ig_B2 = nullptr, *ig_B3 = nullptr;      // ... and the data-gradient side (fused backward)
 };
 struct XAttn { LNp ln1; Lin q, kv, out; };   // CrossAttentionBlockGenral (in_proj split into q / kv rows)
 struct AdaLayer { long pos = -1; XAttn sp, tm; LNp ln_sp, ln_tm; Lin sp_fc, sp_proj, tm_fc, tm_proj; };
@@ -146,7 +147,7 @@ struct dist_handle {
     void *dR, *dkv, *dkn;
     float* ln_partial = nullptr; long ln_partial_elems = 0;     // per-block parameter-gradient sums of the LayerNorm backward (two-phase, no atomics)
     float* tnb_scratch = nullptr; long tnb_scratch_elems = 0;   // parameter-gradient partial rows of the fused TemporalNet backward
-    bool ig_on = false, ig_xhat = false; void* ig_descs = nullptr;   // ig_xhat: the forward keeps xhat (in the Na buffer) instead of Na / Nb; the weight gradients of the two folded Linears are unfolded afterwards
+    bool ig_on = false, ig_xhat = false, ig_bwd = false; void* ig_descs = nullptr;   // ig_xhat: the forward keeps xhat (in the Na buffer) instead of Na / Nb; the weight gradients of the two folded Linears are unfolded afterwards
                   // fused IntegrationNetwork forward: taken for this geometry; its pack descriptors (device)
     float* tn_partial[3] = {nullptr, nullptr, nullptr};   // two-phase dW reduction scratch, one per stream that launches dW GEMMs
     long tn_partial_elems = 0;
@@ -478,11 +479,16 @@ size_t layout_ws(dist_handle* h, char* base) {
     h->tnb_scratch = F_(h->tnb_scratch_elems * c.layers);        // one partial table per layer
     h->ig_on = dist_k_integ_eligible(c.dtype, Ci, C4, h->t, c.temporal_kernel) && !(getenv("DIST_AMD_INTEG_FUSED") && atoi(getenv("DIST_AMD_INTEG_FUSED")) == 0);
     h->ig_xhat = h->ig_on && !(getenv("DIST_AMD_INTEG_XHAT") && atoi(getenv("DIST_AMD_INTEG_XHAT")) == 0);
+    h->ig_bwd = h->ig_xhat && !(getenv("DIST_AMD_INTEG_BWD_FUSED") && atoi(getenv("DIST_AMD_INTEG_BWD_FUSED")) == 0);
     if (h->ig_on) {
         for (int i = 0; i < c.layers; ++i) {
             DistLayer& l = h->dl[i];
             l.ig_W1 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 0) * 2); l.ig_W2 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 1) * 2);
             l.ig_W3 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 2) * 2);
+            if (h->ig_bwd) {
+                l.ig_B1 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 0) * 2); l.ig_B2 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 1) * 2);
+                l.ig_B3 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 2) * 2);
+            }
             l.ig_b1 = F_(dist_op_integration_pack_elems(Ci, C4, 3)); l.ig_b2 = F_(dist_op_integration_pack_elems(Ci, C4, 4)); l.ig_b3 = F_(dist_op_integration_pack_elems(Ci, C4, 5));
         }
         h->ig_descs = a.take((size_t)dist_k_integ_pack_desc_bytes() * c.layers);
@@ -705,7 +711,7 @@ extern "C" int dist_abi_sizeof(const char* n) {
     if (!n) return -1;
 #define DIST_SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)
     DIST_SZ(dist_gemm_args); DIST_SZ(dist_gemm_tn_args); DIST_SZ(dist_ln_args); DIST_SZ(dist_ln_bwd_args);
-    DIST_SZ(dist_adamw_seg); DIST_SZ(dist_config); DIST_SZ(dist_rowmap); DIST_SZ(dist_outmap); DIST_SZ(dist_tnet_args); DIST_SZ(dist_tnet_bwd_args); DIST_SZ(dist_integ_args); DIST_SZ(dist_integ_pack_args); DIST_SZ(dist_integ_unfold_args);
+    DIST_SZ(dist_adamw_seg); DIST_SZ(dist_config); DIST_SZ(dist_rowmap); DIST_SZ(dist_outmap); DIST_SZ(dist_tnet_args); DIST_SZ(dist_tnet_bwd_args); DIST_SZ(dist_integ_args); DIST_SZ(dist_integ_pack_args); DIST_SZ(dist_integ_unfold_args); DIST_SZ(dist_integ_bwd_args);
 #undef DIST_SZ
     return -1;
 }
@@ -828,6 +834,7 @@ extern "C" int dist_bind(dist_handle* h, float* theta, float* grads, const float
             a.tf_fc2_w = theta + l.tf_fc2.w; a.tf_fc2_b = theta + l.tf_fc2.bias;
             a.ffn_proj_w = theta + l.ffn_proj.w; a.ffn_proj_b = theta + l.ffn_proj.bias; a.tf_proj_w = theta + l.tf_proj.w; a.tf_proj_b = theta + l.tf_proj.bias;
             a.W1 = l.ig_W1; a.W2 = l.ig_W2; a.W3 = l.ig_W3; a.b1 = l.ig_b1; a.b2 = l.ig_b2; a.b3 = l.ig_b3;
+            a.B1 = l.ig_B1; a.B2 = l.ig_B2; a.B3 = l.ig_B3;
             a.Ci = h->cfg.integration_dim; a.C4 = h->C4;
             dist_k_integ_pack_desc(&a, host.data() + i * db);
         }
@@ -1434,6 +1441,19 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         RUN(wgrad_pair(xb, l.ffn_proj, l.tf_proj, dR, Ci, w.hf, Cc, rowsS));
         RUN(merge_b2());
         HIP_CHECK_RET(hipEventRecord(h->ev_b_dr[i], B));
+        if (h->ig_bwd) {
+            // one fused launch (integ.hip): [dzf | dh2], dh1 and dM' = LN'(dzf Wa' + dh1 Wb') (+ dFz for the last layer; a second copy becomes dM)
+            dist_integ_bwd_args ba;
+            memset(&ba, 0, sizeof(ba));
+            ba.dR = dR; ba.zf_h2 = w.zf; ba.Xhat = w.Na; ba.rstd = w.in_rstd; ba.B1 = l.ig_B1; ba.B2 = l.ig_B2; ba.B3 = l.ig_B3;
+            ba.dzf_dh2 = q.dzf; ba.dh1 = q.dh1; ba.dMp = q.dMp; ba.dM_copy = last ? nullptr : q.dM; ba.add_dR = last ? 1 : 0;
+            ba.clips = (int)b; ba.t = t; ba.L = L; ba.Ci = Ci; ba.C4 = C4; ba.tk = l.tf_fc2.taps; ba.dtype = c.dtype;
+            RUN(dist_op_integration_bwd(&ba, x.s));
+            RUN(fork());
+            RUN(wgrad(xb, l.ffn_fc, q.dzf, Cc, w.Na, Ci, rowsS, RM(), RM(), 0, true));
+            RUN(wgrad(xb2, l.tf_fc2, q.dh2, Cc, w.h1, C4, rowsS, RM(), RM(DIST_RM_SHIFT, t * L, L, 1), 1, true));
+            RUN(wgrad(xb2, l.tf_fc1, q.dh1, C4, w.Na, Ci, rowsS, RM(), RM(), 0, true));
+        } else {
         // [dzf | dh2] = (dR [Wp ; W3]) * g'([zf | h2]): one data-gradient GEMM for the two projections
         RUN(gemm(x, dR, Ci, x.pk(l.pk_proj_b), rowsS, Cc, Ci, 1, q.dzf, Cc, nullptr, nullptr, w.zf, nullptr));
         RUN(fork());
@@ -1447,6 +1467,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         RUN(lin_dx(h, x, l.tf_fc1, q.dh1, rowsS, q.dNb));
         // dM' = LN'(dNa, dNb) (+ dFz for the last layer); a second copy becomes dM (updated in place by the I2T term)
         RUN(ln_bwd(x, l.in_ln, w.Mp, w.in_mean, w.in_rstd, q.dNa, q.dMp, false, rowsS, &l.in_ln_t, q.dNb, last ? dR : nullptr, last ? nullptr : q.dM, !h->ig_xhat));
+        }
         // ---- T2I backward (dist.py:81-86): M' = M + [cls_token ; conv_strided(X')] ----
         RUN(fork());
         RUN(dist_k_cls_rows_bwd(q.dMp, x.gr(l.cls_token), (int)bt, L, Ci, t, c.dtype, B));

@@ -332,6 +332,296 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_fwd_kernel(con
     }
 }
 
+// ---- fused data-gradient backward -----------------------------------------------------------------------------------------------------
+// dM' = LN'( dzf Wa' + dh1 Wb' ),  dh1 = conv_t^T(dh2),  [dzf | dh2] = (dR [Wp | Wt]) * g'([zf | h2])          (dist.py:40-45 through autograd)
+// The same three GEMM shapes as the forward kernel on the same tile (t frames x TOK tokens), with the transposed weights (B1 / B2 / B3 of
+// dist_op_integration_pack): stage 1 N = Ci + C4 over dR, stage 2 the temporal taps with the opposite shift, stage 3 K = Ci + C4 over
+// [dzf | dh1] with the LayerNorm weights folded in, so its accumulators ARE dxhat and the LayerNorm backward
+//     dx = rstd (dxhat - mean_k dxhat - xhat mean_k(dxhat xhat))
+// runs on them in registers: row sums over a lane's columns, over the 4 lanes of a row (ds_bpermute), over the 8 waves through LDS.
+// Written: [dzf | dh2] and dh1 (the weight-gradient GEMMs read them), dM' (+ a second copy, + dR for the last layer).  The LayerNorm
+// parameter gradients come from dist_op_integration_unfold, not from here.
+struct IgBwdArgs {
+    const bf16_t *dR, *zfh2, *Xh; const float* rstd;
+    const bf16_t *W1, *W2, *W3;
+    bf16_t *dzfh2, *dh1, *dMp, *dM;
+    int add_dR;
+    int clips, t, L, groups, tokshift;
+};
+
+template <int CI, int C4, int BM>
+__global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_bwd_kernel(const IgBwdArgs p) {
+    constexpr int DBG = 0;
+    constexpr int CC = CI + C4;
+    constexpr int CPR = CI / 8, LCH = CPR / 8, RPW = BM / 8, NPASS = RPW / 8;
+    constexpr int RB = BM / 16, RBH = RB / 2;
+    constexpr int KS1 = CI / 32, NP1 = CC / 32;
+    constexpr int KT = C4 / 32, KS2 = 3 * KT, NP2 = C4 / 32;
+    constexpr int KS3 = CC / 32, NP3 = CI / 32;
+    static_assert(CPR % 16 == 0 && C4 % 32 == 0 && NP1 <= 16 && NP2 * 2 <= 8 && NP3 == 12 && (BM == 64 || BM == 128), "geometry");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* const regA = smem;                               // [BM][CI]  dR, then dzf
+    char* const regB = smem + BM * CI * 2;                 // [BM][C4]  dh2
+    char* const regC = regB + BM * C4 * 2;                 // [BM][C4]  dh1
+    float* const red = reinterpret_cast<float*>(regC + BM * C4 * 2);   // [8 waves][BM][2] partial row sums, then [BM][2] totals
+    float* const tot = red + 8 * BM * 2;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int clip = blockIdx.x / p.groups, grp = blockIdx.x - clip * p.groups;
+    const int tsh = p.tokshift, TOK = 1 << tsh, tokmask = TOK - 1;
+    const int L = p.L, t = p.t;
+    auto grow_of = [&](const int r) -> int {
+        const int f = r >> tsh, j = (grp << tsh) + (r & tokmask);
+        return j < L ? (clip * t + f) * L + j : -1;
+    };
+
+    // ---------------- stage 0: dR rows -> region A
+    {
+        const int lq = lane & 7, lrow = lane >> 3;
+        bf16x8 raw[NPASS][LCH];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = wid * RPW + ps * 8 + lrow;
+            const int f = r >> tsh, j = (grp << tsh) + (r & tokmask);
+            const bf16_t* src = p.dR + (long)((clip * t + f) * L + min(j, L - 1)) * CI;
+#pragma unroll
+            for (int m = 0; m < LCH; ++m) raw[ps][m] = *reinterpret_cast<const bf16x8*>(src + (lq + 8 * m) * 8);
+        }
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = wid * RPW + ps * 8 + lrow;
+#pragma unroll
+            for (int m = 0; m < LCH; ++m) *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((lq + 8 * m) ^ (r & 15)) << 4)) = raw[ps][m];
+        }
+    }
+    int grow[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) grow[rb] = grow_of(rb * 16 + li);
+    __syncthreads();
+
+    // ---------------- stage 1: [dzf | dh2] = (dR B1^T) * g'([zf | h2])
+    {
+        const int pA = 2 * wid, pB = min(2 * wid + 1, NP1 - 1);
+        f32x4 acc[4][RB];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[f][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 wb[2][4];
+        auto ldw = [&](bf16x8 (&w)[4], const int ks) __attribute__((always_inline)) {
+            w[0] = IG_LDW(p.W1, ((long)pA * KS1 + ks) * 2); w[1] = IG_LDW(p.W1, ((long)pA * KS1 + ks) * 2 + 1);
+            w[2] = IG_LDW(p.W1, ((long)pB * KS1 + ks) * 2); w[3] = IG_LDW(p.W1, ((long)pB * KS1 + ks) * 2 + 1);
+        };
+        ldw(wb[0], 0);
+        ldw(wb[1], 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            bf16x8 (&w)[4] = wb[ks & 1];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const bf16x8 a = IG_LDS(regA + (rb * 16 + li) * (CI * 2) + (((ks * 4 + lg) ^ li) << 4));
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc[f][rb] = IG_MMA(w[f], a, acc[f][rb]);
+            }
+            if (ks + 2 < KS1) ldw(w, ks + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                   // every wave has read dR: region A becomes dzf
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int pr = pp ? 2 * wid + 1 : pA;
+            if (pr >= NP1) continue;
+            const int n0 = pr * 32 + lg * 8;
+            bf16x8 zv[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                zv[rb] = grow[rb] >= 0 ? *reinterpret_cast<const bf16x8*>(p.zfh2 + (long)grow[rb] * CC + n0) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int r = rb * 16 + li;
+                bf16x8 dv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dv[e] = (bf16_t)(acc[pp * 2][rb][e] * qgelu_grad_t<bf16_t>((float)zv[rb][e]));
+                    dv[4 + e] = (bf16_t)(acc[pp * 2 + 1][rb][e] * qgelu_grad_t<bf16_t>((float)zv[rb][4 + e]));
+                }
+                if (pr < NP3) *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((pr * 4 + lg) ^ li) << 4)) = dv;
+                else *reinterpret_cast<bf16x8*>(regB + r * (C4 * 2) + (ig_pchunk(r, (pr - NP3) * 4 + lg) << 4)) = dv;
+                if (grow[rb] >= 0) IG_ST(dv, p.dzfh2 + (long)grow[rb] * CC + n0);
+            }
+        }
+    }
+    const bool s2 = wid < NP2 * 2;
+    const int p2 = s2 ? wid % NP2 : 0, half2 = s2 ? wid / NP2 : 0;
+    bf16x8 w2[KS2][2];
+    if (s2) {
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) { w2[ks][0] = IG_LDW(p.W2, ((long)p2 * KS2 + ks) * 2); w2[ks][1] = IG_LDW(p.W2, ((long)p2 * KS2 + ks) * 2 + 1); }
+    }
+    __syncthreads();                                       // dzf in region A, dh2 in region B
+
+    // ---------------- stage 2: dh1[r] = sum_tap dh2[r - (tap - 1) TOK] W2[tap] -> region C
+    if (s2) {
+        f32x4 a2[2][RBH];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int rb = 0; rb < RBH; ++rb) a2[q][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+#pragma unroll
+            for (int rbh = 0; rbh < RBH; ++rbh) {
+                const int r = (half2 * RBH + rbh) * 16 + li;
+                const int f = (r >> tsh) - (tap - 1);
+                const bool ok = (unsigned)f < (unsigned)t;
+                const int rs = ok ? r - (tap - 1) * TOK : r;
+#pragma unroll
+                for (int k3 = 0; k3 < KT; ++k3) {
+                    bf16x8 a = IG_LDS(regB + rs * (C4 * 2) + (ig_pchunk(rs, k3 * 4 + lg) << 4));
+                    if (!ok) a = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    a2[0][rbh] = IG_MMA(w2[tap * KT + k3][0], a, a2[0][rbh]);
+                    a2[1][rbh] = IG_MMA(w2[tap * KT + k3][1], a, a2[1][rbh]);
+                }
+            }
+        }
+        const int n0 = p2 * 32 + lg * 8;
+#pragma unroll
+        for (int rbh = 0; rbh < RBH; ++rbh) {
+            const int r = (half2 * RBH + rbh) * 16 + li;
+            const int gr = grow_of(r);
+            bf16x8 hb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { hb[e] = (bf16_t)a2[0][rbh][e]; hb[4 + e] = (bf16_t)a2[1][rbh][e]; }
+            *reinterpret_cast<bf16x8*>(regC + r * (C4 * 2) + (ig_pchunk(r, p2 * 4 + lg) << 4)) = hb;
+            if (gr >= 0) IG_ST(hb, p.dh1 + (long)gr * C4 + n0);
+        }
+    }
+
+    // ---------------- stage 3: dxhat = [dzf | dh1] B3^T, then the LayerNorm backward on the accumulators
+    {
+        const int m3 = wid >> 1, odd = wid & 1;
+        const int pF = 3 * m3 + (odd ? 2 : 0), pH = 3 * m3 + 1;
+        f32x4 aF[2][RB], aH[2][RBH];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) aF[q][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rb = 0; rb < RBH; ++rb) aH[q][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        bf16x8 wb[2][4];
+        auto ldw = [&](bf16x8 (&w)[4], const int ks) __attribute__((always_inline)) {
+            w[0] = IG_LDW(p.W3, ((long)pF * KS3 + ks) * 2); w[1] = IG_LDW(p.W3, ((long)pF * KS3 + ks) * 2 + 1);
+            w[2] = IG_LDW(p.W3, ((long)pH * KS3 + ks) * 2); w[3] = IG_LDW(p.W3, ((long)pH * KS3 + ks) * 2 + 1);
+        };
+        ldw(wb[0], 0);
+        ldw(wb[1], 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KS3; ++ks) {
+            if (ks == KS1) __syncthreads();                // dh1 is complete in region C
+            bf16x8 (&w)[4] = wb[ks & 1];
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr) {
+                const int rb = (rr + odd * RBH) & (RB - 1);
+                const int r = rb * 16 + li;
+                bf16x8 a;
+                if (ks < KS1) a = IG_LDS(regA + r * (CI * 2) + (((ks * 4 + lg) ^ li) << 4));
+                else a = IG_LDS(regC + r * (C4 * 2) + (ig_pchunk(r, (ks - KS1) * 4 + lg) << 4));
+                aF[0][rr] = IG_MMA(w[0], a, aF[0][rr]);
+                aF[1][rr] = IG_MMA(w[1], a, aF[1][rr]);
+                if (rr < RBH) { aH[0][rr] = IG_MMA(w[2], a, aH[0][rr]); aH[1][rr] = IG_MMA(w[3], a, aH[1][rr]); }
+            }
+            if (ks + 2 < KS3) ldw(w, ks + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // xhat at this lane's (row, 8 columns) positions; partial row sums S1 = sum dxhat, S2 = sum dxhat xhat
+        int gro[RB];
+        bf16x8 xF[RB], xH[RBH];
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            gro[rr] = grow_of((((rr + odd * RBH) & (RB - 1)) * 16) + li);
+            const long base = (long)max(gro[rr], 0) * CI;
+            xF[rr] = *reinterpret_cast<const bf16x8*>(p.Xh + base + pF * 32 + lg * 8);
+            if (rr < RBH) xH[rr] = *reinterpret_cast<const bf16x8*>(p.Xh + base + pH * 32 + lg * 8);
+        }
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            float s1 = 0.f, s2v = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1 += aF[0][rr][e] + aF[1][rr][e];
+                s2v += aF[0][rr][e] * (float)xF[rr][e] + aF[1][rr][e] * (float)xF[rr][4 + e];
+            }
+            if (rr < RBH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s1 += aH[0][rr][e] + aH[1][rr][e];
+                    s2v += aH[0][rr][e] * (float)xH[rr][e] + aH[1][rr][e] * (float)xH[rr][4 + e];
+                }
+            }
+            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+            s2v += __shfl_xor(s2v, 16, 64); s2v += __shfl_xor(s2v, 32, 64);
+            if (lg == 0) {
+                const int r = (((rr + odd * RBH) & (RB - 1)) * 16) + li;
+                reinterpret_cast<float2*>(red)[wid * BM + r] = make_float2(s1, s2v);
+            }
+        }
+        __syncthreads();
+        if (tid < BM) {
+            float a1 = 0.f, a2s = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) { const float2 v = reinterpret_cast<const float2*>(red)[w8 * BM + tid]; a1 += v.x; a2s += v.y; }
+            reinterpret_cast<float2*>(tot)[tid] = make_float2(a1, a2s);
+        }
+        __syncthreads();
+        constexpr float invC = 1.f / (float)CI;
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            const int gr = gro[rr];
+            if (gr < 0) continue;
+            const int r = (((rr + odd * RBH) & (RB - 1)) * 16) + li;
+            const float2 cs = reinterpret_cast<const float2*>(tot)[r];
+            const float rs = p.rstd[gr], m1 = cs.x * invC, m2 = cs.y * invC;
+            bf16x8 o;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = rs * (aF[0][rr][e] - m1 - (float)xF[rr][e] * m2);
+                v[4 + e] = rs * (aF[1][rr][e] - m1 - (float)xF[rr][4 + e] * m2);
+            }
+            if (p.add_dR) {
+                const bf16x8 d = *reinterpret_cast<const bf16x8*>(p.dR + (long)gr * CI + pF * 32 + lg * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)d[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+            IG_ST(o, p.dMp + (long)gr * CI + pF * 32 + lg * 8);
+            if (p.dM) IG_ST(o, p.dM + (long)gr * CI + pF * 32 + lg * 8);
+            if (rr < RBH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = rs * (aH[0][rr][e] - m1 - (float)xH[rr][e] * m2);
+                    v[4 + e] = rs * (aH[1][rr][e] - m1 - (float)xH[rr][4 + e] * m2);
+                }
+                if (p.add_dR) {
+                    const bf16x8 d = *reinterpret_cast<const bf16x8*>(p.dR + (long)gr * CI + pH * 32 + lg * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)d[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                IG_ST(o, p.dMp + (long)gr * CI + pH * 32 + lg * 8);
+                if (p.dM) IG_ST(o, p.dM + (long)gr * CI + pH * 32 + lg * 8);
+            }
+        }
+    }
+}
+
 // ---- weights into MFMA-operand order -----------------------------------------------------------------------------------------------
 // matrix [N][K] (N, K multiples of 32) -> fragments ((p * K/32 + ks) * 2 + q) of 64 lanes x 8 bf16: lane l holds row
 // n = 32 p + 8 ((l & 15) / 4) + 4 q + (l & 3), columns k = 32 ks + 8 (l / 16) .. + 7
@@ -341,6 +631,7 @@ struct IgPack {
     const float *W2, *b2;                    // temporal_ffn.c_fc2 [C4][C4][3], bias
     const float *Wp, *bp, *Wt, *bt;          // ffn.c_proj [Ci][Ci], temporal_ffn.c_proj [Ci][C4], biases
     bf16_t *W1o, *W2o, *W3o; float *b1o, *b2o, *b3o;
+    bf16_t *B1o, *B2o, *B3o;                 // optional: the data-gradient operands of integ_bwd_kernel (same shapes, transposed weights)
 };
 
 template <int CI, int C4>
@@ -353,8 +644,10 @@ __global__ __launch_bounds__(256) void integ_pack_kernel(const IgPack* __restric
     constexpr int NB = CC + C4 + CI;                                              // bias outputs, one wave each
     const IgPack& d = descs ? descs[blockIdx.y] : one;
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x < PBLK) {
-        int piece = blockIdx.x * 256 + tid;
+    if ((int)blockIdx.x < 2 * PBLK) {
+        const bool bwd = (int)blockIdx.x >= PBLK;          // second half of the piece blocks: B1 [CC][CI], B2 [C4][3 C4], B3 [CI][CC]
+        if (bwd && !d.B1o) return;
+        int piece = ((int)blockIdx.x - (bwd ? PBLK : 0)) * 256 + tid;
         if (piece >= PIECES) return;
         int which = 0;
         if (piece >= F1 * 64) { piece -= F1 * 64; which = 1; if (piece >= F2 * 64) { piece -= F2 * 64; which = 2; } }
@@ -366,17 +659,23 @@ __global__ __launch_bounds__(256) void integ_pack_kernel(const IgPack* __restric
         for (int e = 0; e < 8; ++e) {
             const int k = k0 + e;
             float v;
-            if (which == 0) v = n < CI ? d.Wa[(long)n * CI + k] * d.ga[k] : d.Wb[(long)(n - CI) * CI + k] * d.gb[k];
-            else if (which == 1) { const int tap = k / C4, ci = k - tap * C4; v = d.W2[((long)n * C4 + ci) * 3 + tap]; }
-            else v = k < CI ? d.Wp[(long)n * CI + k] : d.Wt[(long)n * C4 + (k - CI)];
+            if (!bwd) {
+                if (which == 0) v = n < CI ? d.Wa[(long)n * CI + k] * d.ga[k] : d.Wb[(long)(n - CI) * CI + k] * d.gb[k];
+                else if (which == 1) { const int tap = k / C4, ci = k - tap * C4; v = d.W2[((long)n * C4 + ci) * 3 + tap]; }
+                else v = k < CI ? d.Wp[(long)n * CI + k] : d.Wt[(long)n * C4 + (k - CI)];
+            } else {
+                if (which == 0) v = n < CI ? d.Wp[(long)k * CI + n] : d.Wt[(long)k * C4 + (n - CI)];                       // B1[n][k] = [Wp | Wt][k][n]
+                else if (which == 1) { const int tap = k / C4, co = k - tap * C4; v = d.W2[((long)co * C4 + n) * 3 + tap]; }  // B2[ci][tap C4 + co] = W2[co][ci][tap]
+                else v = k < CI ? d.Wa[(long)k * CI + n] * d.ga[n] : d.Wb[(long)(k - CI) * CI + n] * d.gb[n];              // B3[k'][n'] = [Wa' ; Wb'][n'][k']
+            }
             o[e] = (bf16_t)v;
         }
-        bf16_t* dst = which == 0 ? d.W1o : (which == 1 ? d.W2o : d.W3o);
+        bf16_t* dst = bwd ? (which == 0 ? d.B1o : (which == 1 ? d.B2o : d.B3o)) : (which == 0 ? d.W1o : (which == 1 ? d.W2o : d.W3o));
         *reinterpret_cast<bf16x8*>(dst + (long)piece * 8) = o;
         return;
     }
     // biases: b1 = [ba + Wa beta_a ; bb + Wb beta_b] (the LayerNorm shift through the weights), b2, b3 = bp + bt
-    const int w = ((int)blockIdx.x - PBLK) * 4 + (tid >> 6), lane = tid & 63;
+    const int w = ((int)blockIdx.x - 2 * PBLK) * 4 + (tid >> 6), lane = tid & 63;
     if (w >= NB) return;
     if (w < CC) {
         const float* row = w < CI ? d.Wa + (long)w * CI : d.Wb + (long)(w - CI) * CI;
@@ -469,6 +768,7 @@ static IgPack ig_pack_of(const dist_integ_pack_args& a) {
     d.Wp = a.ffn_proj_w; d.bp = a.ffn_proj_b; d.Wt = a.tf_proj_w; d.bt = a.tf_proj_b;
     d.W1o = static_cast<bf16_t*>(a.W1); d.W2o = static_cast<bf16_t*>(a.W2); d.W3o = static_cast<bf16_t*>(a.W3);
     d.b1o = a.b1; d.b2o = a.b2; d.b3o = a.b3;
+    d.B1o = static_cast<bf16_t*>(a.B1); d.B2o = static_cast<bf16_t*>(a.B2); d.B3o = static_cast<bf16_t*>(a.B3);
     return d;
 }
 
@@ -483,7 +783,7 @@ int dist_k_integ_pack(const void* descs_dev, const dist_integ_pack_args* one, in
     const int pblk = (PIECES + 255) / 256, bblk = (CC + C4c + CI + 3) / 4;
     IgPack d{};
     if (!descs_dev) { if (!one || n != 1) return DIST_ERR_ARG; d = ig_pack_of(*one); }
-    hipLaunchKernelGGL((integ_pack_kernel<CI, C4c>), dim3((unsigned)(pblk + bblk), (unsigned)n), dim3(256), 0, s, static_cast<const IgPack*>(descs_dev), d);
+    hipLaunchKernelGGL((integ_pack_kernel<CI, C4c>), dim3((unsigned)(2 * pblk + bblk), (unsigned)n), dim3(256), 0, s, static_cast<const IgPack*>(descs_dev), d);
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
 }
@@ -494,6 +794,31 @@ extern "C" int dist_op_integration_pack(const dist_integ_pack_args* a, void* str
         return DIST_ERR_ARG;
     if (!dist_k_integ_eligible(DIST_BF16, a->Ci, a->C4, 8, 3)) return DIST_ERR_ARG;
     return dist_k_integ_pack(nullptr, a, 1, a->Ci, a->C4, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dist_op_integration_bwd(const dist_integ_bwd_args* a, void* stream) {
+    if (!a || !a->dR || !a->zf_h2 || !a->Xhat || !a->rstd || !a->B1 || !a->B2 || !a->B3 || !a->dzf_dh2 || !a->dh1 || !a->dMp) return DIST_ERR_ARG;
+    if (a->clips <= 0 || a->t <= 0 || a->L <= 0) return DIST_ERR_ARG;
+    if (!dist_k_integ_eligible(a->dtype, a->Ci, a->C4, a->t, a->tk)) return DIST_ERR_ARG;
+    constexpr int BM = 128;
+    if (BM % a->t) return DIST_ERR_ARG;
+    IgBwdArgs k;
+    k.dR = static_cast<const bf16_t*>(a->dR); k.zfh2 = static_cast<const bf16_t*>(a->zf_h2); k.Xh = static_cast<const bf16_t*>(a->Xhat); k.rstd = a->rstd;
+    k.W1 = static_cast<const bf16_t*>(a->B1); k.W2 = static_cast<const bf16_t*>(a->B2); k.W3 = static_cast<const bf16_t*>(a->B3);
+    k.dzfh2 = static_cast<bf16_t*>(a->dzf_dh2); k.dh1 = static_cast<bf16_t*>(a->dh1); k.dMp = static_cast<bf16_t*>(a->dMp); k.dM = static_cast<bf16_t*>(a->dM_copy);
+    k.add_dR = a->add_dR ? 1 : 0;
+    k.clips = a->clips; k.t = a->t; k.L = a->L;
+    const int TOK = BM / a->t;
+    int sh = 0;
+    while ((1 << sh) < TOK) ++sh;
+    k.tokshift = sh;
+    k.groups = (a->L + TOK - 1) / TOK;
+    const int smem = BM * 384 * 2 + 2 * BM * 96 * 2 + 9 * BM * 2 * 4;
+    static bool attr = false;
+    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)integ_bwd_kernel<384, 96, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr = true; }
+    hipLaunchKernelGGL((integ_bwd_kernel<384, 96, BM>), dim3((unsigned)(k.clips * k.groups)), dim3(512), smem, static_cast<hipStream_t>(stream), k);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
 }
 
 extern "C" int dist_op_integration_unfold(const dist_integ_unfold_args* a, void* stream) {

@@ -82,7 +82,12 @@ class IntegUnfoldArgs(C.Structure):
 class IntegPackArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ffn_fc_w", "ffn_fc_b", "ln_w", "ln_b", "tf_fc1_w", "tf_fc1_b", "ln_t_w", "ln_t_b", "tf_fc2_w", "tf_fc2_b",
                                           "ffn_proj_w", "ffn_proj_b", "tf_proj_w", "tf_proj_b", "W1", "W2", "W3", "b1", "b2", "b3")] + \
-               [("Ci", C.c_int), ("C4", C.c_int)]
+               [("Ci", C.c_int), ("C4", C.c_int)] + [(n, C.c_void_p) for n in ("B1", "B2", "B3")]
+
+
+class IntegBwdArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dR", "zf_h2", "Xhat", "rstd", "B1", "B2", "B3", "dzf_dh2", "dh1", "dMp", "dM_copy")] + \
+               [(n, C.c_int) for n in ("add_dR", "clips", "t", "L", "Ci", "C4", "tk", "dtype")]
 
 
 class AdamwSeg(C.Structure):
@@ -101,7 +106,7 @@ GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
 ABI_VERSION = 8    # include/dist_amd.h DIST_ABI_VERSION: bumped on every struct-layout change
 ABI_MIRRORS = (("dist_gemm_args", GemmArgs), ("dist_gemm_tn_args", GemmTnArgs), ("dist_ln_args", LnArgs), ("dist_ln_bwd_args", LnBwdArgs),
                ("dist_adamw_seg", AdamwSeg), ("dist_config", Config), ("dist_rowmap", RowMap), ("dist_outmap", OutMap), ("dist_tnet_args", TnetArgs), ("dist_tnet_bwd_args", TnetBwdArgs),
-               ("dist_integ_args", IntegArgs), ("dist_integ_pack_args", IntegPackArgs), ("dist_integ_unfold_args", IntegUnfoldArgs))
+               ("dist_integ_args", IntegArgs), ("dist_integ_pack_args", IntegPackArgs), ("dist_integ_unfold_args", IntegUnfoldArgs), ("dist_integ_bwd_args", IntegBwdArgs))
 
 
 class DistError(RuntimeError):
@@ -185,6 +190,7 @@ def load():
     _sig(lib, "dist_op_temporal_net_bwd", argtypes=[C.POINTER(TnetBwdArgs), C.c_void_p])
     _sig(lib, "dist_op_temporal_net_bwd_reduce", argtypes=[C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_op_integration_fwd", argtypes=[C.POINTER(IntegArgs), C.c_void_p])
+    _sig(lib, "dist_op_integration_bwd", argtypes=[C.POINTER(IntegBwdArgs), C.c_void_p])
     _sig(lib, "dist_op_integration_unfold", argtypes=[C.POINTER(IntegUnfoldArgs), C.c_void_p])
     _sig(lib, "dist_op_integration_pack", argtypes=[C.POINTER(IntegPackArgs), C.c_void_p])
     _sig(lib, "dist_op_integration_pack_elems", argtypes=[C.c_int, C.c_int, C.c_int], restype=C.c_int64)

@@ -140,9 +140,9 @@ def temporal_net_bwd_reduce(scratch, layers, clips, T, Ct, dgammas, dbetas):
     L.check(lib.dist_op_temporal_net_bwd_reduce(_p(scratch), n, layers, clips, T, Ct, dg, db, _stream()))
 
 
-def integration_pack(w):
+def integration_pack(w, bwd=False):
     """fp32 master weights of one IntegrationNetwork (dict with the reference's parameter names below `integration_nets.i.`) -> the operands
-    of integration_fwd (dist_op_integration_pack): dict(W1, W2, W3 bf16; b1, b2, b3 fp32)."""
+    of integration_fwd (dist_op_integration_pack): dict(W1, W2, W3 bf16; b1, b2, b3 fp32 [; B1, B2, B3 bf16 for integration_bwd])."""
     lib = L.load()
     Ci, C4 = w["ffn.c_fc.weight"].shape[0], w["temporal_ffn.c_fc1.weight"].shape[0]
     dev = w["ffn.c_fc.weight"].device
@@ -150,6 +150,8 @@ def integration_pack(w):
     out = {"W1": torch.empty(n[0], dtype=torch.bfloat16, device=dev), "W2": torch.empty(n[1], dtype=torch.bfloat16, device=dev),
            "W3": torch.empty(n[2], dtype=torch.bfloat16, device=dev), "b1": torch.empty(n[3], dtype=torch.float32, device=dev),
            "b2": torch.empty(n[4], dtype=torch.float32, device=dev), "b3": torch.empty(n[5], dtype=torch.float32, device=dev)}
+    if bwd:
+        out.update({f"B{k + 1}": torch.empty(n[k], dtype=torch.bfloat16, device=dev) for k in range(3)})
     keep = [w[k].float().contiguous() for k in ("ffn.c_fc.weight", "ffn.c_fc.bias", "ln.weight", "ln.bias", "temporal_ffn.c_fc1.weight", "temporal_ffn.c_fc1.bias",
                                                 "ln_temporal.weight", "ln_temporal.bias", "temporal_ffn.c_fc2.weight", "temporal_ffn.c_fc2.bias",
                                                 "ffn.c_proj.weight", "ffn.c_proj.bias", "temporal_ffn.c_proj.weight", "temporal_ffn.c_proj.bias")]
@@ -158,6 +160,8 @@ def integration_pack(w):
      a.ffn_proj_w, a.ffn_proj_b, a.tf_proj_w, a.tf_proj_b) = [_p(t) for t in keep]
     a.W1, a.W2, a.W3, a.b1, a.b2, a.b3 = _p(out["W1"]), _p(out["W2"]), _p(out["W3"]), _p(out["b1"]), _p(out["b2"]), _p(out["b3"])
     a.Ci, a.C4 = Ci, C4
+    if bwd:
+        a.B1, a.B2, a.B3 = _p(out["B1"]), _p(out["B2"]), _p(out["B3"])
     L.check(lib.dist_op_integration_pack(C.byref(a), _stream()))
     torch.cuda.current_stream().synchronize()          # (the fp32 copies in `keep` must outlive the launch)
     return out
@@ -191,6 +195,24 @@ def integration_fwd(Mp, pk, clips, t, Ltok, *, ln=None, train=True, tk=3, eps=1e
         a.mean, a.rstd, a.zf_h2, a.hf_g2, a.h1 = [_p(out[k]) for k in ("mean", "rstd", "zf_h2", "hf_g2", "h1")]
     a.clips, a.t, a.L, a.Ci, a.C4, a.tk, a.dtype, a.eps = clips, t, Ltok, Ci, C4, tk, L.BF16, eps
     L.check(lib.dist_op_integration_fwd(C.byref(a), _stream()))
+    return out
+
+
+def integration_bwd(dR, saved, pk, clips, t, Ltok, *, add_dR=False, copy=False, tk=3):
+    """Fused IntegrationNetwork data-gradient backward (dist_op_integration_bwd).  `saved`: what integration_fwd(..., xhat=True) returned;
+    `pk` from integration_pack(w, bwd=True).  Returns dict(dzf_dh2, dh1, dMp [, dM])."""
+    rows, Ci = dR.shape
+    C4 = saved["h1"].shape[1]
+    out = {"dzf_dh2": torch.empty(rows, Ci + C4, dtype=dR.dtype, device=dR.device), "dh1": torch.empty(rows, C4, dtype=dR.dtype, device=dR.device),
+           "dMp": torch.empty_like(dR)}
+    if copy:
+        out["dM"] = torch.empty_like(dR)
+    a = L.IntegBwdArgs()
+    a.dR, a.zf_h2, a.Xhat, a.rstd = _p(dR), _p(saved["zf_h2"]), _p(saved["Xhat"]), _p(saved["rstd"])
+    a.B1, a.B2, a.B3 = _p(pk["B1"]), _p(pk["B2"]), _p(pk["B3"])
+    a.dzf_dh2, a.dh1, a.dMp, a.dM_copy = _p(out["dzf_dh2"]), _p(out["dh1"]), _p(out["dMp"]), _p(out.get("dM"))
+    a.add_dR, a.clips, a.t, a.L, a.Ci, a.C4, a.tk, a.dtype = int(add_dR), clips, t, Ltok, Ci, C4, tk, L.BF16
+    L.check(L.load().dist_op_integration_bwd(C.byref(a), _stream()))
     return out
 
 

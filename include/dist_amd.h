@@ -43,7 +43,7 @@ const char* dist_strerror(int code);
 #define DIST_ABI_VERSION 8
 int dist_abi_version(void);
 /* sizeof() of an argument struct of this header by name ("dist_gemm_args", "dist_gemm_tn_args", "dist_ln_args",
- * "dist_ln_bwd_args", "dist_adamw_seg", "dist_config", "dist_rowmap", "dist_outmap", "dist_tnet_args", "dist_tnet_bwd_args", "dist_integ_args", "dist_integ_pack_args", "dist_integ_unfold_args"); -1 for an unknown name.
+ * "dist_ln_bwd_args", "dist_adamw_seg", "dist_config", "dist_rowmap", "dist_outmap", "dist_tnet_args", "dist_tnet_bwd_args", "dist_integ_args", "dist_integ_pack_args", "dist_integ_unfold_args", "dist_integ_bwd_args"); -1 for an unknown name.
  * Lets a foreign-language binding verify its mirror of the layout without a GPU. */
 int dist_abi_sizeof(const char* struct_name);
 
@@ -272,8 +272,21 @@ typedef struct dist_integ_pack_args {
     const float* ffn_proj_w; const float* ffn_proj_b; const float* tf_proj_w; const float* tf_proj_b;
     void* W1; void* W2; void* W3; float* b1; float* b2; float* b3;
     int Ci, C4;
+    void* B1; void* B2; void* B3;   /* optional (all or none): the operands of dist_op_integration_bwd, sized like W1 / W2 / W3 */
 } dist_integ_pack_args;
 int64_t dist_op_integration_pack_elems(int Ci, int C4, int which);
+/* Fused data-gradient backward of the IntegrationNetwork (integ.hip), same geometries as dist_op_integration_fwd:
+ *   [dzf | dh2] = (dR [Wp | Wt]) * g'([zf | h2]);  dh1 = conv_t^T(dh2);  dM' = LN'(dzf Wa' + dh1 Wb') (+ dR when add_dR: the last layer's residual)
+ * dzf_dh2 (rows of Ci + C4) and dh1 are outputs because the weight-gradient GEMMs read them; dM_copy (optional) receives a second copy of dM'.
+ * Xhat / rstd / zf_h2: what dist_op_integration_fwd saved.  The parameter gradients of the two LayerNorms come from dist_op_integration_unfold. */
+typedef struct dist_integ_bwd_args {
+    const void* dR; const void* zf_h2; const void* Xhat; const float* rstd;
+    const void* B1; const void* B2; const void* B3;
+    void* dzf_dh2; void* dh1; void* dMp; void* dM_copy;
+    int add_dR;
+    int clips, t, L, Ci, C4, tk; int dtype;
+} dist_integ_bwd_args;
+int dist_op_integration_bwd(const dist_integ_bwd_args* a, void* stream);
 /* backward side of the LayerNorm fold.  On entry d_ffn_fc_w / d_tf_fc1_w hold G' = dz^T xhat (dist_op_gemm_tn with B = Xhat) and d_*_b the bias
  * gradients; on exit they hold the gradients of the unfolded weights, dW = G' diag(gamma) + db beta^T, and
  * d_ln_w[k] += sum_n W[n][k] G'[n][k], d_ln_b[k] += sum_n W[n][k] db[n] (likewise ln_temporal through temporal_ffn.c_fc1).  fp32, fixed order. */

@@ -202,3 +202,58 @@ def test_fused_integration_xhat_form(gpu_lib):
     d = (a["R"].float() - b["R"].float()).abs()
     assert float(d.max()) <= 2 ** -6 and float((d.sum(1) > 0).float().mean()) < 0.02          # (separately compiled instantiations, see above)
     assert torch.equal(a["mean"], b["mean"])
+
+
+def reference_grads(w, Mp, dR, clips, t, Ltok):
+    """fp64 autograd through `reference`: gradients of sum(R * dR) w.r.t. M', zf, h2, h1"""
+    d = {k: v.double() for k, v in w.items()}
+    x = Mp.double().clone().requires_grad_(True)
+    mean = x.mean(-1, keepdim=True)
+    rstd = (((x - mean) ** 2).mean(-1, keepdim=True) + 1e-5).rsqrt()
+    xh = (x - mean) * rstd
+    zf = (xh * d["ln.weight"] + d["ln.bias"]) @ d["ffn.c_fc.weight"].t() + d["ffn.c_fc.bias"]
+    h1 = (xh * d["ln_temporal.weight"] + d["ln_temporal.bias"]) @ d["temporal_ffn.c_fc1.weight"].reshape(C4, CI).t() + d["temporal_ffn.c_fc1.bias"]
+    h1v = h1.reshape(clips, t, Ltok, C4)
+    W2 = d["temporal_ffn.c_fc2.weight"].reshape(C4, C4, 3)
+    h2 = d["temporal_ffn.c_fc2.bias"].expand_as(h1v)
+    for tap in range(3):
+        dd = tap - 1
+        lo, hi = max(0, -dd), min(t, t - dd)
+        sh = torch.zeros_like(h1v)
+        sh = torch.cat([torch.zeros_like(h1v[:, :lo]), h1v[:, lo + dd:hi + dd], torch.zeros_like(h1v[:, hi:])], dim=1)
+        h2 = h2 + sh @ W2[:, :, tap].t()
+    h2 = h2.reshape(-1, C4)
+    for v in (zf, h1, h2):
+        v.retain_grad()
+    R = qgelu(zf) @ d["ffn.c_proj.weight"].t() + qgelu(h2) @ d["temporal_ffn.c_proj.weight"].reshape(CI, C4).t()
+    (R * dR.double()).sum().backward()
+    return {"dMp": x.grad, "dzf": zf.grad, "dh2": h2.grad, "dh1": h1.grad}
+
+
+@pytest.mark.parametrize("clips,t,Ltok", [(1, 8, 16), (2, 8, 197), (1, 8, 5), (2, 16, 37), (1, 4, 50), (1, 32, 9)])
+def test_fused_integration_backward_vs_fp64_autograd(gpu_lib, clips, t, Ltok):
+    from dist_amd import ops
+    w, Mp = make(clips, t, Ltok, seed=clips * 100 + t + Ltok)
+    g = torch.Generator().manual_seed(4)
+    dR = (torch.randn(Mp.shape, generator=g) * 0.5).to(torch.bfloat16)
+    wc = {k: v.cuda() for k, v in w.items()}
+    pk = ops.integration_pack(wc, bwd=True)
+    saved = ops.integration_fwd(Mp.cuda(), pk, clips, t, Ltok, xhat=True)
+    out = ops.integration_bwd(dR.cuda(), saved, pk, clips, t, Ltok, copy=True)
+    torch.cuda.synchronize()
+    ref = reference_grads(w, Mp, dR, clips, t, Ltok)
+    gaps = {"dzf": rel(out["dzf_dh2"][:, :CI], ref["dzf"]), "dh2": rel(out["dzf_dh2"][:, CI:], ref["dh2"]), "dh1": rel(out["dh1"], ref["dh1"]),
+            "dMp": rel(out["dMp"], ref["dMp"])}
+    record(f"integ.bwd.vs_fp64.{clips}x{t}x{Ltok}", max(gaps.values()))
+    for k, v in gaps.items():
+        assert v < 1.5e-2, (k, v, gaps)
+    mean_err = float((out["dMp"].double().cpu() - ref["dMp"]).abs().mean() / ref["dMp"].abs().mean())
+    assert mean_err < 8e-3, mean_err
+    assert torch.equal(out["dM"], out["dMp"])
+    plus = ops.integration_bwd(dR.cuda(), saved, pk, clips, t, Ltok, add_dR=True)
+    torch.cuda.synchronize()
+    assert rel(plus["dMp"], ref["dMp"] + dR.double()) < 1.5e-2
+    again = ops.integration_bwd(dR.cuda(), saved, pk, clips, t, Ltok, copy=True)
+    torch.cuda.synchronize()
+    for k in out:
+        assert torch.equal(out[k], again[k]), k
