@@ -50,10 +50,13 @@ DEV void frag_load_e4m3(Frag<float>&, const unsigned char*) {}
 // qkv8 (bf16 instantiation, head-major layout only): q | k | v arrive as e4m3 bytes with ONE scale in_scale[0] (a DIST_EPI_OUT8 image of the
 // in_proj output): they are widened to bf16 on their way into LDS / the query fragments, the products stay bf16 MFMAs, the scale enters the
 // scores as scale^2 and the output as scale.
-template <typename T, int NT>
-__global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int heads, int Lp, int hm,
+// NSLAB = 0: online softmax over 32-key slabs (any L).  NSLAB = Lp / 32 (bf16): whole-row softmax - every score of a 16-query tile stays in
+// registers (2 NSLAB accumulator quads), ONE row maximum, no running maximum / rescale of the output per slab: ~190 VALU + 8 NSLAB exponentials per tile
+// instead of 130 VALU + 9 exponentials per SLAB (the slab loop was VALU-bound: 91 us for 155 MB at L = 197).
+template <typename T, int NT, int NSLAB>
+__global__ __launch_bounds__(NT, (NSLAB > 0 ? 4 : 1)) void attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int heads, int Lp, int hm,
                                                   unsigned char* __restrict__ out8, const float* __restrict__ out8_scale, float* __restrict__ out8_amax,
-                                                  const unsigned char* __restrict__ qkv8, const float* __restrict__ in_scale) {
+                                                  const unsigned char* __restrict__ qkv8, const float* __restrict__ in_scale, const int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KLD = HD + KPAD, VLD = Lp + KPAD;
     constexpr bool TRV = sizeof(T) == 2;         // bf16: V stays row-major and is gathered with LDS transpose reads
@@ -107,7 +110,8 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
     // per loop iteration
     constexpr int KV_IT = 6;                                  // covers Lp * 8 vectors up to Lp = 336 (L = 257 -> Lp = 288)
     const int n_it = (Lp * (HD / 8) + NT - 1) / NT;           // block-uniform
-    if (in8) {
+    if (dbg & 2) {
+    } else if (in8) {
         // e4m3 rows are 64 bytes: 16-byte loads carry two 8-element vectors (8-byte loads run at little more than half the rate)
         constexpr int P_IT = KV_IT / 2;
         const int np = (Lp * (HD / 16) + NT - 1) / NT;
@@ -169,7 +173,133 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
     }
     load_q(wid, qrow, fq);
     __syncthreads();
+    if (dbg & 1) return;                                   // measurement knob DIST_AMD_ATTN_DBG: 1 = staging only, 2 = no K / V staging loads
 
+    // normalise one tile's output and store it (bf16 rows / e4m3 rows / fp32 rows)
+    auto finish = [&](const f32x4 (&ou)[4], const float l_in, const int qr) __attribute__((always_inline)) {
+            float l = l_in;
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            const float inv = s_in / l;
+            if (TRV && out8) {
+                // e4m3 output (the A operand of a DIST_EPI_FP8 out-projection): e4m3(clamp(bf16(o) / scale)) with the caller's per-tensor
+                // scale, INSTEAD of the bf16 rows; same lane exchange as below on one dword (4 columns) per fragment
+                const float si = 1.0f / out8_scale[0];
+                float am = 0.f;
+                auto pk4 = [&](int j) __attribute__((always_inline)) -> int {
+                    float y[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = (float)(bf16_t)(ou[j][r] * inv);
+                        am = fmaxf(am, fabsf(v));
+                        y[r] = fminf(fmaxf(v * si, -448.f), 448.f);
+                    }
+                    int w = 0;
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], w, false);
+                    return __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], w, true);
+                };
+                const int a = pk4(0), b = pk4(1), c = pk4(2), d4 = pk4(3);
+                const bool odd = lg & 1;
+                const int r0 = __shfl_xor(odd ? a : c, 16, 64), r1 = __shfl_xor(odd ? b : d4, 16, 64);
+                if (qr < L) {
+                    unsigned char* orow = out8 + ((long)f * L + qr) * d + h * HD + (odd ? 32 : 0) + (lg >> 1) * 8;
+                    *reinterpret_cast<int2*>(orow) = odd ? make_int2(r0, c) : make_int2(a, r0);
+                    *reinterpret_cast<int2*>(orow + 16) = odd ? make_int2(r1, d4) : make_int2(b, r1);
+                }
+                if (out8_amax) {
+                    am = qr < L ? am : 0.f;
+                    am = wave_max(am, 64);
+                    if (lane == 0 && am > *static_cast<const volatile float*>(out8_amax)) atomicMax(reinterpret_cast<unsigned*>(out8_amax), __float_as_uint(am));
+                }
+            } else if (TRV) {
+                // a lane holds 4 consecutive columns per 16-column fragment (8 bytes of bf16): lanes lg and lg ^ 1 swap
+                // two fragments each, so every lane ends up with 8 consecutive columns of two fragments and writes two
+                // 16-byte pieces instead of four 8-byte ones (the epilogue is store-issue-bound)
+                auto pk2 = [&](int j, int half) __attribute__((always_inline)) -> unsigned {
+                    union { bf16_t b[2]; unsigned w; } cv;
+                    cv.b[0] = (bf16_t)(ou[j][2 * half] * inv); cv.b[1] = (bf16_t)(ou[j][2 * half + 1] * inv);
+                    return cv.w;
+                };
+                // scalars, not an array: with an array hipcc turns the selects below into lane-indexed stack accesses
+                const unsigned a0 = pk2(0, 0), a1 = pk2(0, 1), b0 = pk2(1, 0), b1 = pk2(1, 1);
+                const unsigned c0 = pk2(2, 0), c1 = pk2(2, 1), d0 = pk2(3, 0), d1 = pk2(3, 1);
+                const bool odd = lg & 1;
+                // even lg keeps fragments 0, 1 and sends 2, 3; odd lg keeps 2, 3 and sends 0, 1
+                const unsigned r00 = __shfl_xor(odd ? a0 : c0, 16, 64), r01 = __shfl_xor(odd ? a1 : c1, 16, 64);
+                const unsigned r10 = __shfl_xor(odd ? b0 : d0, 16, 64), r11 = __shfl_xor(odd ? b1 : d1, 16, 64);
+                if (qr < L) {
+                    T* orow = out + ((long)f * L + qr) * d + h * HD + (odd ? 32 : 0) + (lg >> 1) * 8;
+                    const unsigned k00 = odd ? c0 : a0, k01 = odd ? c1 : a1, k10 = odd ? d0 : b0, k11 = odd ? d1 : b1;
+                    store16_nt(orow, odd ? make_uint4(r00, r01, k00, k01) : make_uint4(k00, k01, r00, r01));
+                    store16_nt(orow + 16, odd ? make_uint4(r10, r11, k10, k11) : make_uint4(k10, k11, r10, r11));
+                }
+            } else if (qr < L) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v4[4] = {ou[j][0] * inv, ou[j][1] * inv, ou[j][2] * inv, ou[j][3] * inv};
+                    store4(out + ((long)f * L + qr) * d + h * HD + j * 16 + lg * 4, v4);
+                }
+            }
+    };
+
+    if constexpr (NSLAB > 0 && TRV) {
+        for (int qt0 = wid; qt0 < nq; qt0 += 2 * NW) {
+            if (qt0 != wid) load_q(qt0, qrow, fq);
+            const bool two = qt0 + NW < nq;               // wave-uniform
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !two) continue;
+                // scores of ALL keys for this lane's query: st[kt][r] = key 16 kt + 4 lg + r
+                f32x4 st[2 * NSLAB];
+#pragma unroll
+                for (int kt = 0; kt < 2 * NSLAB; ++kt) {
+                    const T* kp = Ks + (kt * 16 + li) * KLD + lg * 8;
+                    Frag<T> k0, k1;
+                    frag_load(k0, kp);
+                    frag_load(k1, kp + 32);
+                    st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    mma16(k0, fq[u][0], st[kt]);
+                    mma16(k1, fq[u][1], st[kt]);
+                }
+                // keys >= L live in the last slab only (Lp - 32 < L <= Lp)
+#pragma unroll
+                for (int kt = 2 * NSLAB - 2; kt < 2 * NSLAB; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[kt][r] = (kt * 16 + lg * 4 + r) < L ? st[kt][r] : -1e30f;
+                float mx = -1e30f;
+#pragma unroll
+                for (int kt = 0; kt < 2 * NSLAB; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(st[kt][0], st[kt][1])), fmaxf(st[kt][2], st[kt][3]));
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m = mx * sc_qk;                // raw products: the scale (> 0) commutes with the maximum
+                f32x4 ou[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ou[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                float ps = 0.f;
+#pragma unroll
+                for (int sl = 0; sl < NSLAB; ++sl) {
+                    Frag<T> fp;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pv = __builtin_amdgcn_exp2f(fmaf(st[2 * sl + t][r], sc_qk, -m));   // a masked key holds -1e30: exactly 0
+                            ps += pv;
+                            frag_set(fp, t * 4 + r, pv);
+                        }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        Frag<T> fv;
+                        v_frag_tr(fv, Vt + (sl * 32 + 4 * lg + (li >> 2)) * KLD + j * 16 + (li & 3) * 4, 16 * KLD);
+                        mma16(fv, fp, ou[j]);
+                    }
+                }
+                finish(ou, ps, qrow[u]);
+                __builtin_amdgcn_sched_barrier(0);        // (one tile after the other: interleaved, the two tiles' scores need 256 registers)
+            }
+        }
+        return;
+    }
     // each wave walks TWO 16-query tiles at once (qt, qt + NW): two independent score -> softmax -> PV dependency
     // chains per wave, so the shuffle / exp / MFMA latencies of one tile are covered by the other
     for (int qt0 = wid; qt0 < nq; qt0 += 2 * NW) {
@@ -245,71 +375,7 @@ __global__ __launch_bounds__(NT) void attn_kernel(const T* __restrict__ qkv, T* 
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            float l = lrun[u];
-            l += __shfl_xor(l, 16, 64);
-            l += __shfl_xor(l, 32, 64);
-            const float inv = s_in / l;
-            if (TRV && out8) {
-                // e4m3 output (the A operand of a DIST_EPI_FP8 out-projection): e4m3(clamp(bf16(o) / scale)) with the caller's per-tensor
-                // scale, INSTEAD of the bf16 rows; same lane exchange as below on one dword (4 columns) per fragment
-                const float si = 1.0f / out8_scale[0];
-                float am = 0.f;
-                auto pk4 = [&](int j) __attribute__((always_inline)) -> int {
-                    float y[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = (float)(bf16_t)(o[u][j][r] * inv);
-                        am = fmaxf(am, fabsf(v));
-                        y[r] = fminf(fmaxf(v * si, -448.f), 448.f);
-                    }
-                    int w = 0;
-                    w = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], w, false);
-                    return __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], w, true);
-                };
-                const int a = pk4(0), b = pk4(1), c = pk4(2), d4 = pk4(3);
-                const bool odd = lg & 1;
-                const int r0 = __shfl_xor(odd ? a : c, 16, 64), r1 = __shfl_xor(odd ? b : d4, 16, 64);
-                if (qrow[u] < L) {
-                    unsigned char* orow = out8 + ((long)f * L + qrow[u]) * d + h * HD + (odd ? 32 : 0) + (lg >> 1) * 8;
-                    *reinterpret_cast<int2*>(orow) = odd ? make_int2(r0, c) : make_int2(a, r0);
-                    *reinterpret_cast<int2*>(orow + 16) = odd ? make_int2(r1, d4) : make_int2(b, r1);
-                }
-                if (out8_amax) {
-                    am = qrow[u] < L ? am : 0.f;
-                    am = wave_max(am, 64);
-                    if (lane == 0 && am > *static_cast<const volatile float*>(out8_amax)) atomicMax(reinterpret_cast<unsigned*>(out8_amax), __float_as_uint(am));
-                }
-            } else if (TRV) {
-                // a lane holds 4 consecutive columns per 16-column fragment (8 bytes of bf16): lanes lg and lg ^ 1 swap
-                // two fragments each, so every lane ends up with 8 consecutive columns of two fragments and writes two
-                // 16-byte pieces instead of four 8-byte ones (the epilogue is store-issue-bound)
-                auto pk2 = [&](int j, int half) __attribute__((always_inline)) -> unsigned {
-                    union { bf16_t b[2]; unsigned w; } cv;
-                    cv.b[0] = (bf16_t)(o[u][j][2 * half] * inv); cv.b[1] = (bf16_t)(o[u][j][2 * half + 1] * inv);
-                    return cv.w;
-                };
-                // scalars, not an array: with an array hipcc turns the selects below into lane-indexed stack accesses
-                const unsigned a0 = pk2(0, 0), a1 = pk2(0, 1), b0 = pk2(1, 0), b1 = pk2(1, 1);
-                const unsigned c0 = pk2(2, 0), c1 = pk2(2, 1), d0 = pk2(3, 0), d1 = pk2(3, 1);
-                const bool odd = lg & 1;
-                // even lg keeps fragments 0, 1 and sends 2, 3; odd lg keeps 2, 3 and sends 0, 1
-                const unsigned r00 = __shfl_xor(odd ? a0 : c0, 16, 64), r01 = __shfl_xor(odd ? a1 : c1, 16, 64);
-                const unsigned r10 = __shfl_xor(odd ? b0 : d0, 16, 64), r11 = __shfl_xor(odd ? b1 : d1, 16, 64);
-                if (qrow[u] < L) {
-                    T* orow = out + ((long)f * L + qrow[u]) * d + h * HD + (odd ? 32 : 0) + (lg >> 1) * 8;
-                    const unsigned k00 = odd ? c0 : a0, k01 = odd ? c1 : a1, k10 = odd ? d0 : b0, k11 = odd ? d1 : b1;
-                    store16_nt(orow, odd ? make_uint4(r00, r01, k00, k01) : make_uint4(k00, k01, r00, r01));
-                    store16_nt(orow + 16, odd ? make_uint4(r10, r11, k10, k11) : make_uint4(k10, k11, r10, r11));
-                }
-            } else if (qrow[u] < L) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v4[4] = {o[u][j][0] * inv, o[u][j][1] * inv, o[u][j][2] * inv, o[u][j][3] * inv};
-                    store4(out + ((long)f * L + qrow[u]) * d + h * HD + j * 16 + lg * 4, v4);
-                }
-            }
-        }
+        for (int u = 0; u < 2; ++u) finish(o[u], lrun[u], qrow[u]);
     }
 }
 
@@ -447,6 +513,7 @@ int launch_attn(const void* qkv, void* out, int frames, int L, int heads, int hm
                                        : ((size_t)Lp * (HD + KPAD) + (size_t)HD * (Lp + KPAD)) * sizeof(T);
     if (smem > 160 * 1024) return DIST_ERR_ARG;
     const int nq = (L + 15) / 16;
+    static const int dbg_env = getenv("DIST_AMD_ATTN_DBG") ? atoi(getenv("DIST_AMD_ATTN_DBG")) : 0;
     static const int nt_env = getenv("DIST_AMD_ATTN_NT") ? atoi(getenv("DIST_AMD_ATTN_NT")) : 0;      // measurement knob: 448 / 576
     // nine waves only where two 7-wave workgroups do not fit a CU's LDS anyway (L = 257: 234 us with nine waves and one workgroup per CU,
     // 190 us with seven waves and two - tools/bench_attn.py)
@@ -454,19 +521,31 @@ int launch_attn(const void* qkv, void* out, int frames, int L, int heads, int hm
     if (nine) {
         static size_t attr9 = 0;
         if (smem > attr9) {
-            HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<T, NT9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<T, NT9, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             attr9 = smem;
         }
-        hipLaunchKernelGGL((attn_kernel<T, NT9>), dim3(frames * heads), dim3(NT9), smem, s, static_cast<const T*>(qkv), static_cast<T*>(out), L, heads, Lp, hm,
-                           out8, out8_scale, out8_amax, qkv8, in_scale);
+        hipLaunchKernelGGL((attn_kernel<T, NT9, 0>), dim3(frames * heads), dim3(NT9), smem, s, static_cast<const T*>(qkv), static_cast<T*>(out), L, heads, Lp, hm,
+                           out8, out8_scale, out8_amax, qkv8, in_scale, dbg_env);
     } else {
-        static size_t attr7 = 0;
-        if (smem > attr7) {
-            HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<T, NT7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr7 = smem;
+        // whole-row softmax where the scores of a query tile fit the register budget of two workgroups per CU (Lp = 224: L = 193 .. 224, the ViT-B/16 plane + cls)
+        static const int full_env = getenv("DIST_AMD_ATTN_FULLROW") ? atoi(getenv("DIST_AMD_ATTN_FULLROW")) : 1;      // measurement knob: 0 = online softmax
+        const bool full7 = sizeof(T) == 2 && Lp == 224 && full_env;
+        static size_t attr7 = 0, attr7f = 0;
+        if (full7) {
+            if (smem > attr7f) {
+                HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<T, NT7, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                attr7f = smem;
+            }
+            hipLaunchKernelGGL((attn_kernel<T, NT7, 7>), dim3(frames * heads), dim3(NT7), smem, s, static_cast<const T*>(qkv), static_cast<T*>(out), L, heads, Lp, hm,
+                               out8, out8_scale, out8_amax, qkv8, in_scale, dbg_env);
+        } else {
+            if (smem > attr7) {
+                HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<T, NT7, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                attr7 = smem;
+            }
+            hipLaunchKernelGGL((attn_kernel<T, NT7, 0>), dim3(frames * heads), dim3(NT7), smem, s, static_cast<const T*>(qkv), static_cast<T*>(out), L, heads, Lp, hm,
+                               out8, out8_scale, out8_amax, qkv8, in_scale, dbg_env);
         }
-        hipLaunchKernelGGL((attn_kernel<T, NT7>), dim3(frames * heads), dim3(NT7), smem, s, static_cast<const T*>(qkv), static_cast<T*>(out), L, heads, Lp, hm,
-                           out8, out8_scale, out8_amax, qkv8, in_scale);
     }
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
