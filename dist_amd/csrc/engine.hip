@@ -153,6 +153,9 @@ struct dist_handle {
     long tn_partial_elems = 0;
     // weight-gradient side stream (created once per handle; host-side objects only)
     hipStream_t side = nullptr, side2 = nullptr, pf = nullptr;   // pf: the handle's own ViT prefetch stream
+    hipStream_t chain2 = nullptr;                                // backward: the temporal data-gradient chain (T2I data gradient + TemporalNet backward), beside the integration chain
+    std::vector<hipEvent_t> ev_dmp, ev_dx;                       // chain -> chain2: dM'_i written; chain2 -> chain: dX_i written
+    hipEvent_t ev_c2 = nullptr;
     int skip = 0;                              // DIST_AMD_SKIP (measurement knob, results WRONG): 1 = no weight-gradient GEMMs, 2 = no TemporalNet backward data-gradient kernels, 4 = no TemporalNet forward, 8 = no IntegrationNetwork forward GEMMs, 16 = no large-wgrad (in_lin / proj pair / ffn_fc) only, 32 = no ViT attention, 64 = no ViT MLP (fc + proj GEMMs)
     int serial = 0;                            // DIST_AMD_SERIAL (measurement knob): bit 0 = branch forward, bit 1 = backward on the caller's stream only
     std::vector<hipEvent_t> ev_a;              // chain -> side: "buffer produced"
@@ -758,12 +761,17 @@ static int ensure_streams(dist_handle* h) {
     const int prio = (pe && atoi(pe) == 0) ? 0 : least;
     bool ok = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio) == hipSuccess &&
               hipStreamCreateWithPriority(&h->side2, hipStreamNonBlocking, prio) == hipSuccess &&
-              hipStreamCreateWithPriority(&h->pf, hipStreamNonBlocking, least) == hipSuccess;
+              hipStreamCreateWithPriority(&h->pf, hipStreamNonBlocking, least) == hipSuccess &&
+              hipStreamCreateWithPriority(&h->chain2, hipStreamNonBlocking, 0) == hipSuccess;        // (default priority, like the caller's stream: it is half of the critical chain)
     auto mk = [&](hipEvent_t& e) { ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
     h->ev_a.resize(10 * c.layers + 4); h->ev_b_dr.resize(c.layers); h->ev_b_done.resize(c.layers);
     for (auto& e : h->ev_a) mk(e);
     for (auto& e : h->ev_b_dr) mk(e);
     for (auto& e : h->ev_b_done) mk(e);
+    h->ev_dmp.resize(c.layers); h->ev_dx.resize(c.layers);
+    for (auto& e : h->ev_dmp) mk(e);
+    for (auto& e : h->ev_dx) mk(e);
+    mk(h->ev_c2);
     for (int k = 0; k < 2; ++k) {
         h->slot[k].ev_feat.resize(c.layers + 1);
         for (auto& e : h->slot[k].ev_feat) mk(e);
@@ -781,6 +789,10 @@ extern "C" void dist_destroy(dist_handle* h) {
     for (hipEvent_t e : h->ev_a) if (e) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_b_dr) if (e) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_b_done) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_dmp) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_dx) if (e) hipEventDestroy(e);
+    if (h->ev_c2) hipEventDestroy(h->ev_c2);
+    if (h->chain2) hipStreamDestroy(h->chain2);
     for (int k = 0; k < 2; ++k) {
         for (hipEvent_t e : h->slot[k].ev_feat) if (e) hipEventDestroy(e);
         if (h->slot[k].ev_pre) hipEventDestroy(h->slot[k].ev_pre);
@@ -1405,7 +1417,23 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
     // version are out-of-place here (dM = copy of dM' from the LayerNorm backward, dX_out = dp + LN'(dU)).
     hipStream_t A = x.s, B = (h->serial & 2) ? A : h->side, B2 = (h->serial & 2) ? A : h->side2;
     Ctx xb{h, B, c.dtype}, xb2{h, B2, c.dtype};          // two weight-gradient streams: independent dW GEMMs also overlap each other
+    // Two data-gradient chains (round 3): the integration chain (fused IntegrationNetwork backward, I2T data gradient) stays on A, the temporal
+    // chain (T2I data gradient + TemporalNet backward of the SAME layer) runs on `Tc` one layer behind it: layer i's temporal chain needs dM'_i
+    // and dX_{i+1}, the integration chain of layer i-1 needs dM_i = dM'_i + I2T^T(dX_{i+1}) - not dX_i.  DIST_AMD_BWD_TCHAIN=0: one chain.
+    // Measured: 18.78 -> 20.23 ms with the fifth stream (any fifth ACTIVE stream costs that much on this system, profiles/r01_streams_and_queues.md),
+    // so the default is one chain.  DIST_AMD_BWD_TCHAIN=1: own stream; 2: the second weight-gradient stream carries the temporal chain instead.
+    static const int tchain_env = getenv("DIST_AMD_BWD_TCHAIN") ? atoi(getenv("DIST_AMD_BWD_TCHAIN")) : 0;
+    const bool tchain = tchain_env > 0 && !(h->serial & 2) && h->chain2;
+    hipStream_t Tc = tchain ? (tchain_env == 2 ? h->side2 : h->chain2) : A;
+    if (tchain && tchain_env == 2) { B2 = B; xb2.s = B; }
+    Ctx xt{h, Tc, c.dtype};
     int evn = 0;
+    auto fork_t = [&]() -> int {         // B and B2 wait for everything enqueued on the temporal chain so far
+        if (!tchain) return DIST_OK;
+        if (hipEventRecord(h->ev_c2, Tc) != hipSuccess || hipStreamWaitEvent(B, h->ev_c2, 0) != hipSuccess || hipStreamWaitEvent(B2, h->ev_c2, 0) != hipSuccess)
+            return DIST_ERR_STATE;
+        return DIST_OK;
+    };
     auto fork = [&]() -> int {           // B and B2 wait for everything enqueued on A so far
         hipEvent_t e = h->ev_a[evn++];
         if (hipEventRecord(e, A) != hipSuccess || hipStreamWaitEvent(B, e, 0) != hipSuccess || hipStreamWaitEvent(B2, e, 0) != hipSuccess)
@@ -1475,11 +1503,16 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         // dX' = dX_next (identity, absent for the last layer) + conv^T(dQ): column block a of row (bj,n) -> frame bj*alpha+a
         // ... and straight through X' = g(p): dp = (dX_next + conv^T(dQ)) * g'(p) in the same epilogue (no dX' tensor, no
         // separate activation-backward pass)
-        RUN(gemm(x, q.dMp, Ci, x.pk(l.t2i.pk.b), rowsQ, al * Ct, Ci, 1, q.dp, Ct, nullptr, last ? nullptr : dXn, w.p, nullptr,
+        if (tchain) {
+            HIP_CHECK_RET(hipEventRecord(h->ev_dmp[i], A));
+            HIP_CHECK_RET(hipStreamWaitEvent(Tc, h->ev_dmp[i], 0));
+        }
+        RUN(gemm(xt, q.dMp, Ci, x.pk(l.t2i.pk.b), rowsQ, al * Ct, Ci, 1, q.dp, Ct, nullptr, last ? nullptr : dXn, w.p, nullptr,
                  RM(DIST_RM_SKIPCLS, N), OM(DIST_OM_SPLITCOLS, al, N, Ct), DIST_EPI_MULG_POST));
         // ---- I2T backward (dist.py:100-105): X_next = X' + upsample(Linear(M[1:])) ----
         const void* dM = q.dMp;            // last layer: no I2T path, dM = dM'
         if (!last) {
+            if (tchain) HIP_CHECK_RET(hipStreamWaitEvent(A, h->ev_dx[i + 1], 0));       // dX_{i+1} comes from the temporal chain
             RUN(dist_k_pair_sum(dXn, q.dY, bt, N * Ct, al, c.dtype, A));
             RUN(gemm(x, q.dY, Ct, x.pk(l.i2t.pk.b), rowsQ, Ci, Ct, 1, q.dM, Ci, nullptr, q.dM, nullptr, nullptr, RM(), OM(DIST_OM_INSERTCLS, N)));
             dM = q.dM;
@@ -1503,11 +1536,12 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
             ta.scratch = h->tnb_scratch; ta.scratch_elems = h->tnb_scratch_elems;
             ta.clips = b; ta.T = T; ta.G = h->G; ta.Ct = Ct; ta.tk = l.tn_fc1.taps; ta.dtype = c.dtype;
             ta.phase = 1;                                              // dz first: the weight-gradient streams start on it
-            RUN(dist_op_temporal_net_bwd(&ta, x.s));
+            RUN(dist_op_temporal_net_bwd(&ta, xt.s));
         } else {
-            RUN(gemm(x, q.dp, Ct, x.pk(l.tn_fc2.pk.b), rowsX, Ct, Ct, 9, q.dz, Ct, nullptr, nullptr, w.z, nullptr, RM(DIST_RM_SPATIAL, h->G, 0, -1)));
+            RUN(gemm(xt, q.dp, Ct, x.pk(l.tn_fc2.pk.b), rowsX, Ct, Ct, 9, q.dz, Ct, nullptr, nullptr, w.z, nullptr, RM(DIST_RM_SPATIAL, h->G, 0, -1)));
         }
         RUN(fork());
+        RUN(fork_t());
         RUN(wgrad(xb, l.tn_fc2, q.dp, Ct, w.V, Ct, rowsX, RM(), RM(DIST_RM_SPATIAL, h->G, 0, 1), 1, true));
         RUN(wgrad(xb2, l.tn_fc1, q.dz, Ct, w.U, Ct, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 1, true));
         RUN(merge_b2());
@@ -1536,18 +1570,20 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
             // so one multi-layer dist_op_temporal_net_bwd_reduce at the end of backward would buy nothing: the per-layer sum stays here
             static const bool no_reduce = getenv("DIST_AMD_TNET_BWD_NOREDUCE") && atoi(getenv("DIST_AMD_TNET_BWD_NOREDUCE"));
             if (no_reduce) ta.phase = 3;
-            RUN(dist_op_temporal_net_bwd(&ta, x.s));
+            RUN(dist_op_temporal_net_bwd(&ta, xt.s));
         }
         if (!(h->skip & 2) && !tn_fused) {
-            RUN(gemm(x, q.dz, Ct, x.pk(l.tn_fc1.pk.b), rowsX, Ct, Ct, l.tn_fc1.taps, q.dU, Ct, nullptr, nullptr, nullptr, nullptr,
+            RUN(gemm(xt, q.dz, Ct, x.pk(l.tn_fc1.pk.b), rowsX, Ct, Ct, l.tn_fc1.taps, q.dU, Ct, nullptr, nullptr, nullptr, nullptr,
                      RM(DIST_RM_SHIFT, T * N, N, -1)));
-            RUN(ln_bwd(x, l.tn_ln, w.X, w.tn_mean, w.tn_rstd, q.dU, q.dXo, false, rowsX, nullptr, nullptr, q.dp));   // dX_i = dp + LN'(dU)
+            RUN(ln_bwd(xt, l.tn_ln, w.X, w.tn_mean, w.tn_rstd, q.dU, q.dXo, false, rowsX, nullptr, nullptr, q.dp));   // dX_i = dp + LN'(dU)
         }
+        if (tchain) HIP_CHECK_RET(hipEventRecord(h->ev_dx[i], Tc));
         dR = dM;                          // dL/dR_{i-1}
         dXn = q.dXo;
     }
     // temporal stem (dist.py:178-181): no input gradient
     RUN(fork());
+    RUN(fork_t());
     RUN(wgrad(xb, h->stem, dXn, Ct, h->patches, h->Kp, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 3, true));
     RUN(merge_b2());
     // join: the caller's stream continues only after every weight gradient is complete
