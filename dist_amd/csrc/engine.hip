@@ -61,6 +61,7 @@ struct DistLayer {
     // fused IntegrationNetwork forward (integ.hip): MFMA-operand-ordered weights with the two LayerNorms folded in (workspace pointers)
     void *ig_W1 = nullptr, *ig_W2 = nullptr, *ig_W3 = nullptr; float *ig_b1 = nullptr, *ig_b2 = nullptr, *ig_b3 = nullptr;
     void *ig_B1 = nullptr, *ig_B2 = nullptr, *ig_B3 = nullptr;      // ... and the data-gradient side (fused backward)
+    void* ig_Wt = nullptr;                                          // ... and the T2I weight (T2I formed in front of the fused forward)
 };
 struct XAttn { LNp ln1; Lin q, kv, out; };   // CrossAttentionBlockGenral (in_proj split into q / kv rows)
 struct AdaLayer { long pos = -1; XAttn sp, tm; LNp ln_sp, ln_tm; Lin sp_fc, sp_proj, tm_fc, tm_proj; };
@@ -147,7 +148,7 @@ struct dist_handle {
     void *dR, *dkv, *dkn;
     float* ln_partial = nullptr; long ln_partial_elems = 0;     // per-block parameter-gradient sums of the LayerNorm backward (two-phase, no atomics)
     float* tnb_scratch = nullptr; long tnb_scratch_elems = 0;   // parameter-gradient partial rows of the fused TemporalNet backward
-    bool ig_on = false, ig_xhat = false, ig_bwd = false; void* ig_descs = nullptr;   // ig_xhat: the forward keeps xhat (in the Na buffer) instead of Na / Nb; the weight gradients of the two folded Linears are unfolded afterwards
+    bool ig_on = false, ig_xhat = false, ig_bwd = false, ig_t2i = false, keep_mid = false; void* ig_descs = nullptr;   // ig_xhat: the forward keeps xhat (in the Na buffer) instead of Na / Nb; the weight gradients of the two folded Linears are unfolded afterwards
                   // fused IntegrationNetwork forward: taken for this geometry; its pack descriptors (device)
     float* tn_partial[3] = {nullptr, nullptr, nullptr};   // two-phase dW reduction scratch, one per stream that launches dW GEMMs
     long tn_partial_elems = 0;
@@ -483,11 +484,15 @@ size_t layout_ws(dist_handle* h, char* base) {
     h->ig_on = dist_k_integ_eligible(c.dtype, Ci, C4, h->t, c.temporal_kernel) && !(getenv("DIST_AMD_INTEG_FUSED") && atoi(getenv("DIST_AMD_INTEG_FUSED")) == 0);
     h->ig_xhat = h->ig_on && !(getenv("DIST_AMD_INTEG_XHAT") && atoi(getenv("DIST_AMD_INTEG_XHAT")) == 0);
     h->ig_bwd = h->ig_xhat && !(getenv("DIST_AMD_INTEG_BWD_FUSED") && atoi(getenv("DIST_AMD_INTEG_BWD_FUSED")) == 0);
+    // T2I (dist.py:68-86) formed in front of the fused forward instead of a GEMM + a cls-row kernel + a round trip of M' (alpha = 2, temporal width = C4)
+    h->ig_t2i = h->ig_xhat && c.alpha == 2 && Ct == C4 && !(getenv("DIST_AMD_INTEG_T2I") && atoi(getenv("DIST_AMD_INTEG_T2I")) == 0);
+    h->keep_mid = getenv("DIST_AMD_KEEP_MID") && atoi(getenv("DIST_AMD_KEEP_MID"));     // debugging: M' of every layer stays readable (dist_debug_tensor "mid.i")
     if (h->ig_on) {
         for (int i = 0; i < c.layers; ++i) {
             DistLayer& l = h->dl[i];
             l.ig_W1 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 0) * 2); l.ig_W2 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 1) * 2);
             l.ig_W3 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 2) * 2);
+            if (h->ig_t2i) l.ig_Wt = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 6) * 2);
             if (h->ig_bwd) {
                 l.ig_B1 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 0) * 2); l.ig_B2 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 1) * 2);
                 l.ig_B3 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 2) * 2);
@@ -847,6 +852,7 @@ extern "C" int dist_bind(dist_handle* h, float* theta, float* grads, const float
             a.ffn_proj_w = theta + l.ffn_proj.w; a.ffn_proj_b = theta + l.ffn_proj.bias; a.tf_proj_w = theta + l.tf_proj.w; a.tf_proj_b = theta + l.tf_proj.bias;
             a.W1 = l.ig_W1; a.W2 = l.ig_W2; a.W3 = l.ig_W3; a.b1 = l.ig_b1; a.b2 = l.ig_b2; a.b3 = l.ig_b3;
             a.B1 = l.ig_B1; a.B2 = l.ig_B2; a.B3 = l.ig_B3;
+            if (h->ig_t2i) { a.t2i_w = theta + l.t2i.w; a.Wt = l.ig_Wt; }
             a.Ci = h->cfg.integration_dim; a.C4 = h->C4;
             dist_k_integ_pack_desc(&a, host.data() + i * db);
         }
@@ -1213,15 +1219,22 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
         }
         // T2I (dist.py:68-86,232): strided temporal conv into the patch rows of M', learnable cls row
         HIP_CHECK_RET(hipStreamWaitEvent(x.s, ev_xp(i), 0));
+        const bool t2i_in_front = h->ig_t2i && !(h->skip & 8);
+        if (!t2i_in_front) {
         RUN(gemm(x, w.Xp, Ct, x.pk(l.t2i.pk.f), rowsQ, Ci, Ct, al, w.Mp, Ci, x.th(l.t2i.bias), w.M, nullptr, nullptr,
                  RM(DIST_RM_STRIDED, al, N), OM(DIST_OM_INSERTCLS, N)));
         RUN(dist_k_cls_rows(w.Mp, w.M, x.th(l.cls_token), (int)bt, L, Ci, t, c.dtype, x.s));
+        }
         // IntegrationNetwork (dist.py:16-45): one fused launch (integ.hip) where the geometry allows, else LayerNorm + four GEMMs
         if (h->ig_on) {
             if (!(h->skip & 8)) {
                 dist_integ_args ia;
                 memset(&ia, 0, sizeof(ia));
-                ia.Mp = w.Mp; ia.W1 = l.ig_W1; ia.W2 = l.ig_W2; ia.W3 = l.ig_W3; ia.b1 = l.ig_b1; ia.b2 = l.ig_b2; ia.b3 = l.ig_b3;
+                if (t2i_in_front) {       // M' is formed in the kernel; it is written out only where something else reads it (the last layer's residual, the unfused backward)
+                    ia.t2i_M = w.M; ia.t2i_Xp = w.Xp; ia.t2i_W = l.ig_Wt; ia.t2i_bias = x.th(l.t2i.bias); ia.t2i_cls = x.th(l.cls_token);
+                    if (i == nl - 1 || !h->ig_bwd || h->keep_mid) ia.Mp_out = w.Mp;
+                } else ia.Mp = w.Mp;
+                ia.W1 = l.ig_W1; ia.W2 = l.ig_W2; ia.W3 = l.ig_W3; ia.b1 = l.ig_b1; ia.b2 = l.ig_b2; ia.b3 = l.ig_b3;
                 ia.R = w.R;
                 if (!h->inference) {                                            // (what backward reads)
                     if (h->ig_xhat) ia.Xhat = w.Na;

@@ -44,6 +44,8 @@ struct IgArgs {
     float *mean, *rstd;
     int clips, t, L, groups, tokshift;
     float eps;
+    // T2I in front (template T2I): M' = M + [cls_token ; conv_strided(X')] is formed here instead of being read
+    const bf16_t *M, *Xp, *Wt; const float *bt, *cls; bf16_t* Mpo;
 };
 
 DEV int ig_pchunk(const int row, const int c) { return (c & ~3) | ((c & 3) ^ (((row >> 2) & 1) << 1)); }
@@ -66,7 +68,7 @@ DEV void ig_load8(const float* p, float (&o)[8]) {
     o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
 }
 
-template <int CI, int C4, int BM, int MODE, int DBG>
+template <int CI, int C4, int BM, int MODE, int DBG, bool T2I>
 __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_fwd_kernel(const IgArgs p) {
     constexpr bool TRAIN = MODE != 0;            // MODE 1: the two affine LayerNorm outputs Na / Nb are written, MODE 2: xhat itself (one tensor)
     constexpr int CC = CI + C4;
@@ -97,6 +99,150 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_fwd_kernel(con
         return j < L ? (clip * t + f) * L + j : -1;
     };
 
+    if constexpr (T2I) {
+        // ---------------- stage -1 (T2I, dist.py:68-86): M' = M + [cls_token_f ; X'(frames 2f, 2f+1; position j-1) Wt^T + bt], then the LayerNorm
+        // statistics of M' across the waves.  X' rows of the two frames go to regions B (a = 0) and C (a = 1): K = 2 C4, six k-steps.
+        static_assert(!T2I || (BM == 128 && MODE != 1), "T2I in front: 128-row tiles, xhat form");
+        constexpr int KST = 2 * C4 / 32;
+        float* const red = reinterpret_cast<float*>(regC + BM * C4 * 2);   // [8][BM][2] partial row sums, then [BM][2] (mean, rstd)
+        float* const tot = red + 8 * BM * 2;
+        const int N = L - 1, T = 2 * t;
+        {
+            const int lq4 = lane & 3, lrow = lane >> 2;
+            const int r = wid * 16 + lrow, f = r >> tsh, j = (grp << tsh) + (r & tokmask);
+            const bool ok = j >= 1 && j < L;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const bf16_t* src = p.Xp + ((long)(clip * T + 2 * f + a) * N + (ok ? j - 1 : 0)) * C4;
+                char* dst = (a ? regC : regB) + r * (C4 * 2);
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const int c = lq4 + 4 * m;
+                    bf16x8 v = *reinterpret_cast<const bf16x8*>(src + c * 8);
+                    if (!ok) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    *reinterpret_cast<bf16x8*>(dst + (ig_pchunk(r, c) << 4)) = v;
+                }
+            }
+        }
+        const int m3 = wid >> 1, odd = wid & 1;
+        const int pF = 3 * m3 + (odd ? 2 : 0), pH = 3 * m3 + 1;
+        // M at this lane's (row, 8 columns) positions (rows beyond L are clamped: finite numbers, never stored)
+        bf16x8 mF[RB], mH[RBH];
+        int gro[RB];
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            const int r = (((rr + odd * RBH) & (RB - 1)) * 16) + li;
+            const int f = r >> tsh, j = (grp << tsh) + (r & tokmask);
+            gro[rr] = j < L ? (clip * t + f) * L + j : -1;
+            const long base = (long)((clip * t + f) * L + min(j, L - 1)) * CI;
+            mF[rr] = *reinterpret_cast<const bf16x8*>(p.M + base + pF * 32 + lg * 8);
+            if (rr < RBH) mH[rr] = *reinterpret_cast<const bf16x8*>(p.M + base + pH * 32 + lg * 8);
+        }
+        __syncthreads();
+        f32x4 aF[2][RB], aH[2][RBH];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) aF[q][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rb = 0; rb < RBH; ++rb) aH[q][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        {
+            bf16x8 wb[2][4];
+            auto ldw = [&](bf16x8 (&w)[4], const int ks) __attribute__((always_inline)) {
+                w[0] = IG_LDW(p.Wt, ((long)pF * KST + ks) * 2); w[1] = IG_LDW(p.Wt, ((long)pF * KST + ks) * 2 + 1);
+                w[2] = IG_LDW(p.Wt, ((long)pH * KST + ks) * 2); w[3] = IG_LDW(p.Wt, ((long)pH * KST + ks) * 2 + 1);
+            };
+            ldw(wb[0], 0);
+            ldw(wb[1], 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KST; ++ks) {
+                bf16x8 (&w)[4] = wb[ks & 1];
+#pragma unroll
+                for (int rr = 0; rr < RB; ++rr) {
+                    const int r = (((rr + odd * RBH) & (RB - 1)) * 16) + li;
+                    const bf16x8 a = IG_LDS((ks < KST / 2 ? regB : regC) + r * (C4 * 2) + (ig_pchunk(r, (ks % (KST / 2)) * 4 + lg) << 4));
+                    aF[0][rr] = IG_MMA(w[0], a, aF[0][rr]);
+                    aF[1][rr] = IG_MMA(w[1], a, aF[1][rr]);
+                    if (rr < RBH) { aH[0][rr] = IG_MMA(w[2], a, aH[0][rr]); aH[1][rr] = IG_MMA(w[3], a, aH[1][rr]); }
+                }
+                if (ks + 2 < KST) ldw(w, ks + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        float bF[8], bH[8];
+        ig_load8(p.bt + pF * 32 + lg * 8, bF);
+        ig_load8(p.bt + pH * 32 + lg * 8, bH);
+        // M' (rounded to bf16 as the unfused GEMM stores it) replaces M in the registers; partial row sums of M' and M'^2
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            const int r = (((rr + odd * RBH) & (RB - 1)) * 16) + li;
+            const int f = r >> tsh, j = (grp << tsh) + (r & tokmask);
+            const bool is_cls = j == 0;
+            float s1 = 0.f, s2 = 0.f;
+            {
+                float cl[8];
+                if (is_cls) ig_load8(p.cls + (long)f * CI + pF * 32 + lg * 8, cl);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float add = is_cls ? cl[e] : (e < 4 ? aF[0][rr][e] : aF[1][rr][e - 4]) + bF[e];
+                    const bf16_t v = (bf16_t)((float)mF[rr][e] + add);
+                    mF[rr][e] = v;
+                    s1 += (float)v; s2 += (float)v * (float)v;
+                }
+            }
+            if (rr < RBH) {
+                float cl[8];
+                if (is_cls) ig_load8(p.cls + (long)f * CI + pH * 32 + lg * 8, cl);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float add = is_cls ? cl[e] : (e < 4 ? aH[0][rr][e] : aH[1][rr][e - 4]) + bH[e];
+                    const bf16_t v = (bf16_t)((float)mH[rr][e] + add);
+                    mH[rr][e] = v;
+                    s1 += (float)v; s2 += (float)v * (float)v;
+                }
+            }
+            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (lg == 0) reinterpret_cast<float2*>(red)[wid * BM + r] = make_float2(s1, s2);
+        }
+        __syncthreads();
+        if (tid < BM) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) { const float2 v = reinterpret_cast<const float2*>(red)[w8 * BM + tid]; a1 += v.x; a2 += v.y; }
+            constexpr float invC = 1.f / (float)CI;
+            const float mu = a1 * invC;
+            const float rs = rsqrtf(fmaxf(a2 * invC - mu * mu, 0.f) + p.eps);
+            reinterpret_cast<float2*>(tot)[tid] = make_float2(mu, rs);
+            const int gr = grow_of(tid);
+            if (TRAIN && gr >= 0) { p.mean[gr] = mu; p.rstd[gr] = rs; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            const int r = (((rr + odd * RBH) & (RB - 1)) * 16) + li;
+            const float2 st = reinterpret_cast<const float2*>(tot)[r];
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(((float)mF[rr][e] - st.x) * st.y);
+            *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((pF * 4 + lg) ^ li) << 4)) = o;
+            if (gro[rr] >= 0) {
+                if (MODE == 2) IG_ST(o, p.Xh + (long)gro[rr] * CI + pF * 32 + lg * 8);
+                if (p.Mpo) IG_ST(mF[rr], p.Mpo + (long)gro[rr] * CI + pF * 32 + lg * 8);
+            }
+            if (rr < RBH) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(((float)mH[rr][e] - st.x) * st.y);
+                *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((pH * 4 + lg) ^ li) << 4)) = o;
+                if (gro[rr] >= 0) {
+                    if (MODE == 2) IG_ST(o, p.Xh + (long)gro[rr] * CI + pH * 32 + lg * 8);
+                    if (p.Mpo) IG_ST(mH[rr], p.Mpo + (long)gro[rr] * CI + pH * 32 + lg * 8);
+                }
+            }
+        }
+    } else
     // ---------------- stage 0: rows -> LayerNorm statistics -> xhat tile (+ Na, Nb, mean, rstd)
     {
         const int lq = lane & 7, lrow = lane >> 3;
@@ -632,6 +778,7 @@ struct IgPack {
     const float *Wp, *bp, *Wt, *bt;          // ffn.c_proj [Ci][Ci], temporal_ffn.c_proj [Ci][C4], biases
     bf16_t *W1o, *W2o, *W3o; float *b1o, *b2o, *b3o;
     bf16_t *B1o, *B2o, *B3o;                 // optional: the data-gradient operands of integ_bwd_kernel (same shapes, transposed weights)
+    const float* Wt2i; bf16_t* Wto;          // optional: temporal2integration linear_fuse [Ci][C4][2] -> [Ci][2 C4] in fragment order (T2I in front of the forward)
 };
 
 template <int CI, int C4>
@@ -674,8 +821,24 @@ __global__ __launch_bounds__(256) void integ_pack_kernel(const IgPack* __restric
         *reinterpret_cast<bf16x8*>(dst + (long)piece * 8) = o;
         return;
     }
+    constexpr int KST = 2 * C4 / 32, FT = NP3 * KST * 2, TBLK = (FT * 64 + 255) / 256;
+    if ((int)blockIdx.x < 2 * PBLK + TBLK) {               // T2I weight: Wt[n][a C4 + c] = W[n][c][a]
+        if (!d.Wto) return;
+        const int piece = ((int)blockIdx.x - 2 * PBLK) * 256 + tid;
+        if (piece >= FT * 64) return;
+        const int l = piece & 63, frag = piece >> 6, q = frag & 1, pk = frag >> 1, ks = pk % KST, pr = pk / KST;
+        const int n = 32 * pr + 8 * ((l & 15) >> 2) + 4 * q + (l & 3), k0 = 32 * ks + 8 * (l >> 4);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e, a = k / C4, c = k - a * C4;
+            o[e] = (bf16_t)d.Wt2i[((long)n * C4 + c) * 2 + a];
+        }
+        *reinterpret_cast<bf16x8*>(d.Wto + (long)piece * 8) = o;
+        return;
+    }
     // biases: b1 = [ba + Wa beta_a ; bb + Wb beta_b] (the LayerNorm shift through the weights), b2, b3 = bp + bt
-    const int w = ((int)blockIdx.x - 2 * PBLK) * 4 + (tid >> 6), lane = tid & 63;
+    const int w = ((int)blockIdx.x - 2 * PBLK - TBLK) * 4 + (tid >> 6), lane = tid & 63;
     if (w >= NB) return;
     if (w < CC) {
         const float* row = w < CI ? d.Wa + (long)w * CI : d.Wb + (long)(w - CI) * CI;
@@ -735,12 +898,12 @@ __global__ __launch_bounds__(1024) void integ_unfold_kernel(const IgUnfold a, co
     }
 }
 
-template <int CI, int C4, int BM, int MODE, int DBG>
+template <int CI, int C4, int BM, int MODE, int DBG, bool T2I = false>
 int launch_integ_v(const IgArgs& a, hipStream_t s) {
-    const int smem = BM * CI * 2 + 2 * BM * C4 * 2;
+    const int smem = BM * CI * 2 + 2 * BM * C4 * 2 + (T2I ? 9 * BM * 2 * 4 : 0);
     static bool attr = false;
-    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)integ_fwd_kernel<CI, C4, BM, MODE, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr = true; }
-    hipLaunchKernelGGL((integ_fwd_kernel<CI, C4, BM, MODE, DBG>), dim3((unsigned)(a.clips * a.groups)), dim3(512), smem, s, a);
+    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)integ_fwd_kernel<CI, C4, BM, MODE, DBG, T2I>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr = true; }
+    hipLaunchKernelGGL((integ_fwd_kernel<CI, C4, BM, MODE, DBG, T2I>), dim3((unsigned)(a.clips * a.groups)), dim3(512), smem, s, a);
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
 }
@@ -752,6 +915,11 @@ int launch_integ(const IgArgs& a, const int mode, hipStream_t s) {
     IG_VARIANT(1) IG_VARIANT(2) IG_VARIANT(4) IG_VARIANT(8) IG_VARIANT(16) IG_VARIANT(32) IG_VARIANT(3) IG_VARIANT(19) IG_VARIANT(23) IG_VARIANT(63) IG_VARIANT(59)
 #undef IG_VARIANT
 #endif
+    if constexpr (BM == 128) {
+        if (a.Xp && mode == 2) return launch_integ_v<CI, C4, BM, 2, 0, true>(a, s);
+        if (a.Xp && mode == 0) return launch_integ_v<CI, C4, BM, 0, 0, true>(a, s);
+    }
+    if (a.Xp) return DIST_ERR_ARG;
     return mode == 2 ? launch_integ_v<CI, C4, BM, 2, 0>(a, s) : (mode == 1 ? launch_integ_v<CI, C4, BM, 1, 0>(a, s) : launch_integ_v<CI, C4, BM, 0, 0>(a, s));
 }
 
@@ -770,6 +938,7 @@ extern "C" int64_t dist_op_integration_pack_elems(int Ci, int C4, int which) {
         case 3: return CC;                      // b1 (floats)
         case 4: return C4;                      // b2
         case 5: return Ci;                      // b3
+        case 6: return (int64_t)Ci * 2 * C4;    // Wt (bf16 elements): the T2I weight in front of the forward
         default: return -1;
     }
 }
@@ -783,6 +952,7 @@ static IgPack ig_pack_of(const dist_integ_pack_args& a) {
     d.W1o = static_cast<bf16_t*>(a.W1); d.W2o = static_cast<bf16_t*>(a.W2); d.W3o = static_cast<bf16_t*>(a.W3);
     d.b1o = a.b1; d.b2o = a.b2; d.b3o = a.b3;
     d.B1o = static_cast<bf16_t*>(a.B1); d.B2o = static_cast<bf16_t*>(a.B2); d.B3o = static_cast<bf16_t*>(a.B3);
+    d.Wt2i = a.t2i_w; d.Wto = static_cast<bf16_t*>(a.Wt);
     return d;
 }
 
@@ -794,10 +964,10 @@ int dist_k_integ_pack(const void* descs_dev, const dist_integ_pack_args* one, in
     if (Ci != 384 || C4 != 96 || n <= 0) return DIST_ERR_ARG;
     constexpr int CI = 384, C4c = 96, CC = CI + C4c;
     constexpr int PIECES = ((CC / 32) * (CI / 32) * 2 + (C4c / 32) * (3 * C4c / 32) * 2 + (CI / 32) * (CC / 32) * 2) * 64;
-    const int pblk = (PIECES + 255) / 256, bblk = (CC + C4c + CI + 3) / 4;
+    const int pblk = (PIECES + 255) / 256, bblk = (CC + C4c + CI + 3) / 4, tblk = ((CI / 32) * (2 * C4c / 32) * 2 * 64 + 255) / 256;
     IgPack d{};
     if (!descs_dev) { if (!one || n != 1) return DIST_ERR_ARG; d = ig_pack_of(*one); }
-    hipLaunchKernelGGL((integ_pack_kernel<CI, C4c>), dim3((unsigned)(2 * pblk + bblk), (unsigned)n), dim3(256), 0, s, static_cast<const IgPack*>(descs_dev), d);
+    hipLaunchKernelGGL((integ_pack_kernel<CI, C4c>), dim3((unsigned)(2 * pblk + tblk + bblk), (unsigned)n), dim3(256), 0, s, static_cast<const IgPack*>(descs_dev), d);
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
 }
@@ -847,7 +1017,9 @@ extern "C" int dist_op_integration_unfold(const dist_integ_unfold_args* a, void*
 }
 
 extern "C" int dist_op_integration_fwd(const dist_integ_args* a, void* stream) {
-    if (!a || !a->Mp || !a->W1 || !a->W2 || !a->W3 || !a->b1 || !a->b2 || !a->b3 || !a->R) return DIST_ERR_ARG;
+    if (!a || !a->W1 || !a->W2 || !a->W3 || !a->b1 || !a->b2 || !a->b3 || !a->R) return DIST_ERR_ARG;
+    const bool t2i = a->t2i_Xp != nullptr;              // M' is formed in the kernel: M, X', the packed T2I weight, its bias, the cls tokens instead of Mp
+    if (t2i ? !(a->t2i_M && a->t2i_W && a->t2i_bias && a->t2i_cls) : !a->Mp) return DIST_ERR_ARG;
     if (a->clips <= 0 || a->t <= 0 || a->L <= 0) return DIST_ERR_ARG;
     if (!dist_k_integ_eligible(a->dtype, a->Ci, a->C4, a->t, a->tk)) return DIST_ERR_ARG;
     const bool train = a->Na || a->Nb || a->Xhat || a->zf_h2 || a->hf_g2 || a->h1 || a->mean || a->rstd;
@@ -869,6 +1041,9 @@ extern "C" int dist_op_integration_fwd(const dist_integ_args* a, void* stream) {
     k.zfh2 = static_cast<bf16_t*>(a->zf_h2); k.hfg2 = static_cast<bf16_t*>(a->hf_g2); k.h1 = static_cast<bf16_t*>(a->h1);
     k.mean = a->mean; k.rstd = a->rstd;
     k.clips = a->clips; k.t = a->t; k.L = a->L;
+    k.M = static_cast<const bf16_t*>(a->t2i_M); k.Xp = static_cast<const bf16_t*>(a->t2i_Xp); k.Wt = static_cast<const bf16_t*>(a->t2i_W);
+    k.bt = a->t2i_bias; k.cls = a->t2i_cls; k.Mpo = static_cast<bf16_t*>(a->Mp_out);
+    if (t2i && (BM != 128 || a->Na)) return DIST_ERR_ARG;
     const int TOK = BM / a->t;
     int sh = 0;
     while ((1 << sh) < TOK) ++sh;

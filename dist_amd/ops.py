@@ -140,7 +140,7 @@ def temporal_net_bwd_reduce(scratch, layers, clips, T, Ct, dgammas, dbetas):
     L.check(lib.dist_op_temporal_net_bwd_reduce(_p(scratch), n, layers, clips, T, Ct, dg, db, _stream()))
 
 
-def integration_pack(w, bwd=False):
+def integration_pack(w, bwd=False, t2i_w=None):
     """fp32 master weights of one IntegrationNetwork (dict with the reference's parameter names below `integration_nets.i.`) -> the operands
     of integration_fwd (dist_op_integration_pack): dict(W1, W2, W3 bf16; b1, b2, b3 fp32 [; B1, B2, B3 bf16 for integration_bwd])."""
     lib = L.load()
@@ -162,12 +162,16 @@ def integration_pack(w, bwd=False):
     a.Ci, a.C4 = Ci, C4
     if bwd:
         a.B1, a.B2, a.B3 = _p(out["B1"]), _p(out["B2"]), _p(out["B3"])
+    if t2i_w is not None:                               # temporal2integration linear_fuse.weight [Ci][C4][2][1][1] -> the T2I operand in front of the forward
+        keep.append(t2i_w.float().contiguous())
+        out["Wt"] = torch.empty(lib.dist_op_integration_pack_elems(Ci, C4, 6), dtype=torch.bfloat16, device=dev)
+        a.t2i_w, a.Wt = _p(keep[-1]), _p(out["Wt"])
     L.check(lib.dist_op_integration_pack(C.byref(a), _stream()))
     torch.cuda.current_stream().synchronize()          # (the fp32 copies in `keep` must outlive the launch)
     return out
 
 
-def integration_fwd(Mp, pk, clips, t, Ltok, *, ln=None, train=True, tk=3, eps=1e-5, out=None, xhat=False):
+def integration_fwd(Mp, pk, clips, t, Ltok, *, ln=None, train=True, tk=3, eps=1e-5, out=None, xhat=False, t2i=None):
     """Fused IntegrationNetwork forward (dist_op_integration_fwd) on Mp [clips*t*Ltok, Ci] (bf16).  `pk` from integration_pack; `ln` =
     (ln.weight, ln.bias, ln_temporal.weight, ln_temporal.bias) fp32, needed when train (the tensors backward reads are written) unless
     xhat=True (the normalised rows themselves are kept instead of the two affine outputs).
@@ -193,6 +197,12 @@ def integration_fwd(Mp, pk, clips, t, Ltok, *, ln=None, train=True, tk=3, eps=1e
             a.ln_w, a.ln_b, a.ln_t_w, a.ln_t_b = [_p(v) for v in ln]
             a.Na, a.Nb = _p(out["Na"]), _p(out["Nb"])
         a.mean, a.rstd, a.zf_h2, a.hf_g2, a.h1 = [_p(out[k]) for k in ("mean", "rstd", "zf_h2", "hf_g2", "h1")]
+    if t2i is not None:                                 # (Xp, bias, cls_tokens): `Mp` is M, and M' = M + [cls ; conv_strided(Xp)] is formed in the kernel (returned as "Mp")
+        Xp, tb, cls = t2i
+        if "Mp" not in out:
+            out["Mp"] = torch.empty_like(Mp)
+        a.Mp = None
+        a.t2i_M, a.t2i_Xp, a.t2i_W, a.t2i_bias, a.t2i_cls, a.Mp_out = _p(Mp), _p(Xp), _p(pk["Wt"]), _p(tb), _p(cls), _p(out["Mp"])
     a.clips, a.t, a.L, a.Ci, a.C4, a.tk, a.dtype, a.eps = clips, t, Ltok, Ci, C4, tk, L.BF16, eps
     L.check(lib.dist_op_integration_fwd(C.byref(a), _stream()))
     return out

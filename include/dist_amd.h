@@ -259,6 +259,10 @@ typedef struct dist_integ_args {
     void* R;
     void* Na; void* Nb; float* mean; float* rstd; void* zf_h2; void* hf_g2; void* h1;
     int clips, t, L, Ci, C4, tk; int dtype; float eps;
+    /* T2I in front (dist.py:68-86, alpha = 2, temporal width = C4): t2i_Xp != NULL makes the kernel form M' = M + [cls_token ; conv_strided(X')] itself
+     * instead of reading Mp - M [rows][Ci], X' [clips*2t*(L-1)][C4], t2i_W from dist_op_integration_pack (Wt), bias [Ci], cls tokens [t][Ci] (fp32);
+     * Mp_out (optional) receives M'.  Xhat / inference forms only. */
+    const void* t2i_M; const void* t2i_Xp; const void* t2i_W; const float* t2i_bias; const float* t2i_cls; void* Mp_out;
     void* Xhat;              /* instead of Na / Nb: the normalised rows (x - mean) rstd themselves, ONE tensor - for a backward pass whose weight-gradient
                               * GEMMs read xhat and whose results dist_op_integration_unfold turns into the gradients of W, gamma and beta */
 } dist_integ_args;
@@ -273,6 +277,7 @@ typedef struct dist_integ_pack_args {
     void* W1; void* W2; void* W3; float* b1; float* b2; float* b3;
     int Ci, C4;
     void* B1; void* B2; void* B3;   /* optional (all or none): the operands of dist_op_integration_bwd, sized like W1 / W2 / W3 */
+    const float* t2i_w; void* Wt;   /* optional: temporal2integration_nets.i.linear_fuse.weight [Ci][C4][2][1][1] -> the t2i_W operand (which = 6 elements) */
 } dist_integ_pack_args;
 int64_t dist_op_integration_pack_elems(int Ci, int C4, int which);
 /* Fused data-gradient backward of the IntegrationNetwork (integ.hip), same geometries as dist_op_integration_fwd:

@@ -340,9 +340,9 @@ def test_vit_layernorm_fold_survives_the_optimizer_step(gpu_lib):
 
 def test_inference_mode_gives_the_same_logits_and_refuses_backward(gpu_lib):
     """dist_set_inference (the reference's torch.no_grad() evaluation loops): the forward writes nothing that only a backward pass reads.
-    The two QuickGELUs of the IntegrationNetwork then act on the fp32 accumulators instead of on the stored bf16 pre-activations (one
-    rounding less), so the logits agree with the training-mode forward to bf16 rounding (measured 0.005 on a +-6 range), not bit for bit;
-    backward refuses, and a training-mode forward afterwards reproduces the first one."""
+    With the fused IntegrationNetwork kernel both modes run the same arithmetic (the logits are bit-identical on this geometry: gap 0.0; the
+    unfused GEMM path applied the two QuickGELUs to the fp32 accumulators in inference mode: 0.005 on a +-6 range), so the gate only bounds
+    the gap; backward refuses, and a training-mode forward afterwards reproduces the first one."""
     from dist_amd import lib as L
     g, eng, sd, video, text, tgt = build("b16_8+16f", 2, torch.bfloat16)
     loss, logits = eng.forward_backward(video, text, tgt)
@@ -351,7 +351,7 @@ def test_inference_mode_gives_the_same_logits_and_refuses_backward(gpu_lib):
     eng.vit_forward(video)
     lg_inf, vid_inf = eng.branch_forward(text)
     gap = record("inference_vs_training.logits_maxabs", (lg_inf - logits).abs().max())
-    assert 0 < gap < 0.02 and torch.equal(lg_inf.argmax(1), logits.argmax(1))
+    assert 0 <= gap < 0.02 and torch.equal(lg_inf.argmax(1), logits.argmax(1))
     _, dl = eng.loss(tgt)
     with pytest.raises(L.DistError, match="inference"):
         eng.backward(dl)

@@ -257,3 +257,38 @@ def test_fused_integration_backward_vs_fp64_autograd(gpu_lib, clips, t, Ltok):
     torch.cuda.synchronize()
     for k in out:
         assert torch.equal(out[k], again[k]), k
+
+
+@pytest.mark.parametrize("clips,t,Ltok", [(1, 8, 17), (2, 8, 197), (1, 16, 40), (1, 4, 50)])
+def test_fused_integration_with_t2i_in_front(gpu_lib, clips, t, Ltok):
+    """M' = M + [cls_token_f ; conv_strided(X') + b] (dist.py:68-86) formed inside the kernel: the same M' (bf16, one ulp) as torch on the same
+    operands, and from there on the outputs of the kernel fed with that M'"""
+    from dist_amd import ops
+    w, M = make(clips, t, Ltok, seed=9 + Ltok)
+    g = torch.Generator().manual_seed(21)
+    N = Ltok - 1
+    Xp = (torch.randn(clips * 2 * t * N, C4, generator=g) * 0.8).to(torch.bfloat16)
+    Wt = torch.randn(CI, C4, 2, 1, 1, generator=g) * (2 * C4) ** -0.5
+    bt = 0.1 * torch.randn(CI, generator=g)
+    cls = 0.5 * torch.randn(t, CI, generator=g)
+    wc = {k: v.cuda() for k, v in w.items()}
+    pk = ops.integration_pack(wc, t2i_w=Wt.cuda())
+    out = ops.integration_fwd(M.cuda(), pk, clips, t, Ltok, xhat=True, t2i=(Xp.cuda(), bt.cuda(), cls.cuda()))
+    torch.cuda.synchronize()
+    # reference M' in fp64 from the bf16 operands (weights as the kernel sees them: bf16)
+    Md = M.double().reshape(clips, t, Ltok, CI).clone()
+    Xd = Xp.double().reshape(clips, t, 2, N, C4)
+    Wb = Wt.to(torch.bfloat16).double().reshape(CI, C4, 2)
+    conv = torch.einsum("bjanc,oca->bjno", Xd, Wb) + bt.double()
+    Md[:, :, 1:] += conv
+    Md[:, :, 0] += cls.double()
+    Md = Md.reshape(-1, CI)
+    got = out["Mp"].double().cpu()
+    assert float((got - Md).abs().max()) <= 2 ** -7 * float(Md.abs().max()) + 1e-6          # one bf16 rounding of the sum
+    ref = ops.integration_fwd(out["Mp"], pk, clips, t, Ltok, xhat=True)
+    torch.cuda.synchronize()
+    assert rel(out["mean"], ref["mean"].double().cpu()) < 1e-5 and rel(out["rstd"], ref["rstd"].double().cpu()) < 1e-4
+    for k in ("Xhat", "R", "zf_h2", "hf_g2", "h1"):
+        d = (out[k].float() - ref[k].float()).abs()
+        assert float(d.max()) <= 2 ** -6 * max(1.0, float(ref[k].float().abs().max())), k      # (one-pass against two-pass statistics: last-bit differences in xhat)
+        assert float((d > 0).float().mean()) < 0.02, (k, float((d > 0).float().mean()))

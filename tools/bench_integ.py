@@ -24,3 +24,21 @@ for train in (True, False):
     tt = timeit_rot(fns)
     fl = 2.0 * rows * (CI * (CI + C4) + 3 * C4 * C4 + (CI + C4) * CI)
     print(f"integration_fwd train={train}: {tt*1e6:8.1f} us  {fl/tt/1e12:7.1f} TF", flush=True)
+if "--t2i" in sys.argv:
+    N = Ltok - 1
+    Wt = (torch.randn(CI, C4, 2, 1, 1, device="cuda") * 0.07)
+    bt = torch.randn(CI, device="cuda") * 0.1; cls = torch.randn(t, CI, device="cuda") * 0.5
+    pk2 = ops.integration_pack(wc, t2i_w=Wt)
+    Xps = [(torch.randn(clips * 2 * t * N, C4, device="cuda") * 0.8).to(torch.bfloat16) for _ in range(NSET)]
+    outs = [ops.integration_fwd(x, pk2, clips, t, Ltok, xhat=True, t2i=(xp, bt, cls)) for x, xp in zip(xs, Xps)]
+    fns = [(lambda x=x, xp=xp, o=o: ops.integration_fwd(x, pk2, clips, t, Ltok, xhat=True, t2i=(xp, bt, cls), out=o)) for x, xp, o in zip(xs, Xps, outs)]
+    print(f"integration_fwd with T2I in front (xhat form): {timeit_rot(fns)*1e6:8.1f} us", flush=True)
+    outs = [ops.integration_fwd(x, pk2, clips, t, Ltok, xhat=True) for x in xs]
+    fns = [(lambda x=x, o=o: ops.integration_fwd(x, pk2, clips, t, Ltok, xhat=True, out=o)) for x, o in zip(xs, outs)]
+    print(f"integration_fwd (xhat form): {timeit_rot(fns)*1e6:8.1f} us", flush=True)
+    Wf = Wt.reshape(CI, C4, 2).permute(0, 2, 1).reshape(CI, 2 * C4).to(torch.bfloat16).contiguous()
+    Mps = [torch.empty_like(x) for x in xs]
+    def t2i(x, xp, mp):
+        ops.gemm_nt(xp, Wf, clips * t * N, CI, C4, taps=2, bias=bt, res=x, amap=ops.rowmap(L.RM_STRIDED, 2, N), omap=ops.outmap(L.OM_INSERTCLS, N), C_out=mp)
+    fns = [(lambda x=x, xp=xp, mp=mp: t2i(x, xp, mp)) for x, xp, mp in zip(xs, Xps, Mps)]
+    print(f"T2I GEMM alone: {timeit_rot(fns)*1e6:8.1f} us", flush=True)
