@@ -766,8 +766,11 @@ static int ensure_streams(dist_handle* h) {
     const int prio = (pe && atoi(pe) == 0) ? 0 : least;
     bool ok = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio) == hipSuccess &&
               hipStreamCreateWithPriority(&h->side2, hipStreamNonBlocking, prio) == hipSuccess &&
-              hipStreamCreateWithPriority(&h->pf, hipStreamNonBlocking, least) == hipSuccess &&
-              hipStreamCreateWithPriority(&h->chain2, hipStreamNonBlocking, 0) == hipSuccess;        // (default priority, like the caller's stream: it is half of the critical chain)
+              hipStreamCreateWithPriority(&h->pf, hipStreamNonBlocking, least) == hipSuccess;
+    // the optional second data-gradient chain of the backward (DIST_AMD_BWD_TCHAIN=1, a measurement): created only when asked for - an extra
+    // stream that merely EXISTS beside the gradient reducer's cost 4.7 ms per step (tests/test_rccl_gpu.py: 23.2 vs 18.5 ms)
+    if (getenv("DIST_AMD_BWD_TCHAIN") && atoi(getenv("DIST_AMD_BWD_TCHAIN")) == 1)
+        ok = ok && hipStreamCreateWithPriority(&h->chain2, hipStreamNonBlocking, 0) == hipSuccess;
     auto mk = [&](hipEvent_t& e) { ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
     h->ev_a.resize(10 * c.layers + 4); h->ev_b_dr.resize(c.layers); h->ev_b_done.resize(c.layers);
     for (auto& e : h->ev_a) mk(e);
@@ -1436,7 +1439,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
     // Measured: 18.78 -> 20.23 ms with the fifth stream (any fifth ACTIVE stream costs that much on this system, profiles/r01_streams_and_queues.md),
     // so the default is one chain.  DIST_AMD_BWD_TCHAIN=1: own stream; 2: the second weight-gradient stream carries the temporal chain instead.
     static const int tchain_env = getenv("DIST_AMD_BWD_TCHAIN") ? atoi(getenv("DIST_AMD_BWD_TCHAIN")) : 0;
-    const bool tchain = tchain_env > 0 && !(h->serial & 2) && h->chain2;
+    const bool tchain = tchain_env > 0 && !(h->serial & 2) && (h->chain2 || tchain_env == 2);
     hipStream_t Tc = tchain ? (tchain_env == 2 ? h->side2 : h->chain2) : A;
     if (tchain && tchain_env == 2) { B2 = B; xb2.s = B; }
     Ctx xt{h, Tc, c.dtype};
