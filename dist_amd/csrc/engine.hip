@@ -144,7 +144,7 @@ struct dist_handle {
     float *y_mean, *y_rstd, *logits, *dlogits, *loss;
     // backward scratch
     // layer-loop scratch, double-buffered by layer parity (the weight-gradient stream lags the data-gradient chain)
-    struct BwdSet { void *dMp, *dM, *dXp, *dp, *dXo, *dz, *dU, *dY, *dh2, *dh1, *dzf, *dNa, *dNb; } bs[2];
+    struct BwdSet { void *dMp, *dM, *dXp, *dp, *dXo, *dz, *dU, *dY, *dh2, *dh1, *dzf, *dNa, *dNb, *dcat; } bs[2];   // dcat: [dzf | dh1 | dh2] rows of Ci + 2 C4 (fused IntegrationNetwork backward)
     void *dR, *dkv, *dkn;
     float* ln_partial = nullptr; long ln_partial_elems = 0;     // per-block parameter-gradient sums of the LayerNorm backward (two-phase, no atomics)
     float* tnb_scratch = nullptr; long tnb_scratch_elems = 0;   // parameter-gradient partial rows of the fused TemporalNet backward
@@ -342,9 +342,17 @@ void build_tables(dist_handle* h) {
         l.tn_fc2 = make_lin(h, 0, p + "temporal_net.c_fc2.", Ct, Ct, 9, 1, true, {Ct, Ct, 1, 3, 3});
         l.tn_ln = make_ln(h, 0, p + "ln.", Ct);
         p = fmt("dist_net.integration_nets.%d.", i);
-        l.ffn_fc = make_lin(h, 0, p + "ffn.c_fc.", Ci, Ci, 1, 0, true, {Ci, Ci});
+        // ffn.c_fc and temporal_ffn.c_fc1 read the same (normalised) rows: their weights, and their biases, sit side by side in the flat buffers so that ONE
+        // weight-gradient GEMM over [dzf | dh1] writes both gradients as a [Ci + C4][Ci] matrix (fused IntegrationNetwork backward)
+        l.ffn_fc.N = Ci; l.ffn_fc.K = Ci; l.ffn_fc.taps = 1;
+        l.tf_fc1.N = C4; l.tf_fc1.K = Ci; l.tf_fc1.taps = 1;
+        l.ffn_fc.w = add_param(h, 0, p + "ffn.c_fc.weight", {Ci, Ci});
+        l.tf_fc1.w = add_param(h, 0, p + "temporal_ffn.c_fc1.weight", {C4, Ci, 1, 1, 1});
+        l.ffn_fc.bias = add_param(h, 0, p + "ffn.c_fc.bias", {Ci});
+        l.tf_fc1.bias = add_param(h, 0, p + "temporal_ffn.c_fc1.bias", {C4});
+        add_pack(h, l.ffn_fc, 0, 0, true);
+        add_pack(h, l.tf_fc1, 0, 0, true);
         l.ffn_proj = make_lin(h, 0, p + "ffn.c_proj.", Ci, Ci, 1, 0, true, {Ci, Ci});
-        l.tf_fc1 = make_lin(h, 0, p + "temporal_ffn.c_fc1.", C4, Ci, 1, 0, true, {C4, Ci, 1, 1, 1});
         l.tf_fc2 = make_lin(h, 0, p + "temporal_ffn.c_fc2.", C4, C4, c.temporal_kernel, 1, true, {C4, C4, c.temporal_kernel, 1, 1});
         l.tf_proj = make_lin(h, 0, p + "temporal_ffn.c_proj.", Ci, C4, 1, 0, true, {Ci, C4, 1, 1, 1});
         {   // R = [gelu(zf) | gelu(h2)] [W_ffn | W_tf]^T: the two projections are ONE GEMM over activations stored side by side
@@ -510,6 +518,7 @@ size_t layout_ws(dist_handle* h, char* base) {
         q.dzf = T_(rowsS, Ci + C4);                      // [dzf | dh2], same side-by-side rows
         q.dh2 = q.dzf ? static_cast<char*>(q.dzf) + (size_t)Ci * es : nullptr;
         q.dNa = T_(rowsS, Ci); q.dNb = T_(rowsS, Ci);
+        q.dcat = T_(rowsS, Ci + 2 * C4);
     }
     h->dv = T_(b, c.embed_dim); h->dzp = T_(b, Ci); h->dy = T_(b, Ci); h->du = T_(b, Ci); h->ds = T_(bt, Ci); h->dc = T_(bt, Ci);
     h->dzu = T_(bt, 4 * Ci); h->dun = T_(bt, Ci); h->do2 = T_(b, Ci); h->dq2 = T_(b, Ci); h->dkv2 = T_(bt, 2 * Ci); h->dqn2 = T_(b, Ci);
@@ -1490,13 +1499,26 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
             dist_integ_bwd_args ba;
             memset(&ba, 0, sizeof(ba));
             ba.dR = dR; ba.zf_h2 = w.zf; ba.Xhat = w.Na; ba.rstd = w.in_rstd; ba.B1 = l.ig_B1; ba.B2 = l.ig_B2; ba.B3 = l.ig_B3;
-            ba.dzf_dh2 = q.dzf; ba.dh1 = q.dh1; ba.dMp = q.dMp; ba.dM_copy = last ? nullptr : q.dM; ba.add_dR = last ? 1 : 0;
+            // the three gradients leave in ONE buffer, rows [dzf | dh1 | dh2] of Ci + 2 C4: the weight gradients of ffn.c_fc and temporal_ffn.c_fc1 (both
+            // against xhat, their parameters side by side in the flat buffers) are one GEMM over its first Ci + C4 columns
+            const int Cd = Ci + 2 * C4;
+            char* dcat = static_cast<char*>(q.dcat);
+            void* d_h1 = dcat + (size_t)Ci * es; void* d_h2 = dcat + (size_t)(Ci + C4) * es;
+            ba.dzf_dh2 = q.dcat; ba.ld_dzf = Cd; ba.dh2 = d_h2; ba.ld_dh2 = Cd; ba.dh1 = d_h1; ba.ld_dh1 = Cd;
+            ba.dMp = q.dMp; ba.dM_copy = last ? nullptr : q.dM; ba.add_dR = last ? 1 : 0;
             ba.clips = (int)b; ba.t = t; ba.L = L; ba.Ci = Ci; ba.C4 = C4; ba.tk = l.tf_fc2.taps; ba.dtype = c.dtype;
             RUN(dist_op_integration_bwd(&ba, x.s));
             RUN(fork());
-            RUN(wgrad(xb, l.ffn_fc, q.dzf, Cc, w.Na, Ci, rowsS, RM(), RM(), 0, true));
-            RUN(wgrad(xb2, l.tf_fc2, q.dh2, Cc, w.h1, C4, rowsS, RM(), RM(DIST_RM_SHIFT, t * L, L, 1), 1, true));
-            RUN(wgrad(xb2, l.tf_fc1, q.dh1, C4, w.Na, Ci, rowsS, RM(), RM(), 0, true));
+            Lin both = l.ffn_fc;                              // [Ci + C4][Ci]: ffn.c_fc.weight followed by temporal_ffn.c_fc1.weight (and the two biases)
+            both.N = Ci + C4;
+            static const bool merge_env = !(getenv("DIST_AMD_INTEG_WG_MERGE") && atoi(getenv("DIST_AMD_INTEG_WG_MERGE")) == 0);   // measurement knob
+            if (merge_env && l.tf_fc1.w == l.ffn_fc.w + (long)Ci * Ci && l.tf_fc1.bias == l.ffn_fc.bias + Ci) {
+                RUN(wgrad(xb, both, q.dcat, Cd, w.Na, Ci, rowsS, RM(), RM(), 0, true));
+            } else {
+                RUN(wgrad(xb, l.ffn_fc, q.dcat, Cd, w.Na, Ci, rowsS, RM(), RM(), 0, true));
+                RUN(wgrad(xb2, l.tf_fc1, d_h1, Cd, w.Na, Ci, rowsS, RM(), RM(), 0, true));
+            }
+            RUN(wgrad(xb2, l.tf_fc2, d_h2, Cd, w.h1, C4, rowsS, RM(), RM(DIST_RM_SHIFT, t * L, L, 1), 1, true));
         } else {
         // [dzf | dh2] = (dR [Wp ; W3]) * g'([zf | h2]): one data-gradient GEMM for the two projections
         RUN(gemm(x, dR, Ci, x.pk(l.pk_proj_b), rowsS, Cc, Ci, 1, q.dzf, Cc, nullptr, nullptr, w.zf, nullptr));

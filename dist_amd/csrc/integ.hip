@@ -490,7 +490,8 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_fwd_kernel(con
 struct IgBwdArgs {
     const bf16_t *dR, *zfh2, *Xh; const float* rstd;
     const bf16_t *W1, *W2, *W3;
-    bf16_t *dzfh2, *dh1, *dMp, *dM;
+    bf16_t *dzfh2, *dh2, *dh1, *dMp, *dM;
+    int ldz, ld2, ld1;       // row pitches of dzf, dh2 (a pointer to ITS first column), dh1
     int add_dR;
     int clips, t, L, groups, tokshift;
 };
@@ -596,7 +597,10 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_bwd_kernel(con
                 }
                 if (pr < NP3) *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((pr * 4 + lg) ^ li) << 4)) = dv;
                 else *reinterpret_cast<bf16x8*>(regB + r * (C4 * 2) + (ig_pchunk(r, (pr - NP3) * 4 + lg) << 4)) = dv;
-                if (grow[rb] >= 0) IG_ST(dv, p.dzfh2 + (long)grow[rb] * CC + n0);
+                if (grow[rb] >= 0) {
+                    if (pr < NP3) IG_ST(dv, p.dzfh2 + (long)grow[rb] * p.ldz + n0);
+                    else IG_ST(dv, p.dh2 + (long)grow[rb] * p.ld2 + (n0 - CI));
+                }
             }
         }
     }
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_bwd_kernel(con
 #pragma unroll
             for (int e = 0; e < 4; ++e) { hb[e] = (bf16_t)a2[0][rbh][e]; hb[4 + e] = (bf16_t)a2[1][rbh][e]; }
             *reinterpret_cast<bf16x8*>(regC + r * (C4 * 2) + (ig_pchunk(r, p2 * 4 + lg) << 4)) = hb;
-            if (gr >= 0) IG_ST(hb, p.dh1 + (long)gr * C4 + n0);
+            if (gr >= 0) IG_ST(hb, p.dh1 + (long)gr * p.ld1 + n0);
         }
     }
 
@@ -989,7 +993,13 @@ extern "C" int dist_op_integration_bwd(const dist_integ_bwd_args* a, void* strea
     IgBwdArgs k;
     k.dR = static_cast<const bf16_t*>(a->dR); k.zfh2 = static_cast<const bf16_t*>(a->zf_h2); k.Xh = static_cast<const bf16_t*>(a->Xhat); k.rstd = a->rstd;
     k.W1 = static_cast<const bf16_t*>(a->B1); k.W2 = static_cast<const bf16_t*>(a->B2); k.W3 = static_cast<const bf16_t*>(a->B3);
-    k.dzfh2 = static_cast<bf16_t*>(a->dzf_dh2); k.dh1 = static_cast<bf16_t*>(a->dh1); k.dMp = static_cast<bf16_t*>(a->dMp); k.dM = static_cast<bf16_t*>(a->dM_copy);
+    k.dzfh2 = static_cast<bf16_t*>(a->dzf_dh2); k.dh1 = static_cast<bf16_t*>(a->dh1);
+    k.ldz = a->ld_dzf > 0 ? a->ld_dzf : a->Ci + a->C4;
+    k.dh2 = a->dh2 ? static_cast<bf16_t*>(a->dh2) : k.dzfh2 + a->Ci;
+    k.ld2 = a->dh2 ? (a->ld_dh2 > 0 ? a->ld_dh2 : a->C4) : k.ldz;
+    k.ld1 = a->ld_dh1 > 0 ? a->ld_dh1 : a->C4;
+    if (k.ldz % 8 || k.ld2 % 8 || k.ld1 % 8) return DIST_ERR_ARG;
+    k.dMp = static_cast<bf16_t*>(a->dMp); k.dM = static_cast<bf16_t*>(a->dM_copy);
     k.add_dR = a->add_dR ? 1 : 0;
     k.clips = a->clips; k.t = a->t; k.L = a->L;
     const int TOK = BM / a->t;

@@ -290,6 +290,9 @@ typedef struct dist_integ_bwd_args {
     void* dzf_dh2; void* dh1; void* dMp; void* dM_copy;
     int add_dR;
     int clips, t, L, Ci, C4, tk; int dtype;
+    /* optional layout of the three gradient outputs (0 / NULL = the defaults above): row pitch of dzf_dh2, a separate place and pitch for its dh2 columns,
+     * row pitch of dh1 - e.g. one buffer with rows [dzf | dh1 | dh2] so that ONE weight-gradient GEMM over [dzf | dh1] serves both Linears that read xhat */
+    int ld_dzf; void* dh2; int ld_dh2; int ld_dh1;
 } dist_integ_bwd_args;
 int dist_op_integration_bwd(const dist_integ_bwd_args* a, void* stream);
 /* backward side of the LayerNorm fold.  On entry d_ffn_fc_w / d_tf_fc1_w hold G' = dz^T xhat (dist_op_gemm_tn with B = Xhat) and d_*_b the bias

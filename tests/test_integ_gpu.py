@@ -292,3 +292,35 @@ def test_fused_integration_with_t2i_in_front(gpu_lib, clips, t, Ltok):
         d = (out[k].float() - ref[k].float()).abs()
         assert float(d.max()) <= 2 ** -6 * max(1.0, float(ref[k].float().abs().max())), k      # (one-pass against two-pass statistics: last-bit differences in xhat)
         assert float((d > 0).float().mean()) < 0.02, (k, float((d > 0).float().mean()))
+
+
+def test_fused_integration_backward_custom_output_layout(gpu_lib):
+    """the three gradient outputs in ONE buffer with rows [dzf | dh1 | dh2] (what the engine passes: one weight-gradient GEMM over [dzf | dh1]):
+    the same values as the default layout, bit for bit"""
+    import ctypes as C
+    from dist_amd import ops, lib as L
+    clips, t, Ltok = 2, 8, 37
+    w, Mp = make(clips, t, Ltok, seed=12)
+    dR = (torch.randn(Mp.shape, generator=torch.Generator().manual_seed(5)) * 0.5).to(torch.bfloat16).cuda()
+    wc = {k: v.cuda() for k, v in w.items()}
+    pk = ops.integration_pack(wc, bwd=True)
+    saved = ops.integration_fwd(Mp.cuda(), pk, clips, t, Ltok, xhat=True)
+    ref = ops.integration_bwd(dR, saved, pk, clips, t, Ltok)
+    rows = Mp.shape[0]
+    cat = torch.zeros(rows, CI + 2 * C4, dtype=torch.bfloat16, device="cuda")
+    dMp = torch.empty_like(dR)
+    a = L.IntegBwdArgs()
+    p_ = lambda x: x.data_ptr()
+    a.dR, a.zf_h2, a.Xhat, a.rstd = p_(dR), p_(saved["zf_h2"]), p_(saved["Xhat"]), p_(saved["rstd"])
+    a.B1, a.B2, a.B3 = p_(pk["B1"]), p_(pk["B2"]), p_(pk["B3"])
+    a.dzf_dh2, a.ld_dzf = p_(cat), CI + 2 * C4
+    a.dh1, a.ld_dh1 = p_(cat) + CI * 2, CI + 2 * C4
+    a.dh2, a.ld_dh2 = p_(cat) + (CI + C4) * 2, CI + 2 * C4
+    a.dMp = p_(dMp)
+    a.add_dR, a.clips, a.t, a.L, a.Ci, a.C4, a.tk, a.dtype = 0, clips, t, Ltok, CI, C4, 3, L.BF16
+    L.check(L.load().dist_op_integration_bwd(C.byref(a), ops._stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(cat[:, :CI], ref["dzf_dh2"][:, :CI])
+    assert torch.equal(cat[:, CI:CI + C4], ref["dh1"])
+    assert torch.equal(cat[:, CI + C4:], ref["dzf_dh2"][:, CI:])
+    assert torch.equal(dMp, ref["dMp"])
