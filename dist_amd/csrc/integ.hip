@@ -498,7 +498,11 @@ struct IgBwdArgs {
 
 template <int CI, int C4, int BM>
 __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_bwd_kernel(const IgBwdArgs p) {
+#ifdef DIST_INTEG_BWD_DBG
+    constexpr int DBG = DIST_INTEG_BWD_DBG;      // timing-only ablation (tools/integ_ablate.sh), same bits as the forward kernel
+#else
     constexpr int DBG = 0;
+#endif
     constexpr int CC = CI + C4;
     constexpr int CPR = CI / 8, LCH = CPR / 8, RPW = BM / 8, NPASS = RPW / 8;
     constexpr int RB = BM / 16, RBH = RB / 2;

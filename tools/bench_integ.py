@@ -42,3 +42,20 @@ if "--t2i" in sys.argv:
         ops.gemm_nt(xp, Wf, clips * t * N, CI, C4, taps=2, bias=bt, res=x, amap=ops.rowmap(L.RM_STRIDED, 2, N), omap=ops.outmap(L.OM_INSERTCLS, N), C_out=mp)
     fns = [(lambda x=x, xp=xp, mp=mp: t2i(x, xp, mp)) for x, xp, mp in zip(xs, Xps, Mps)]
     print(f"T2I GEMM alone: {timeit_rot(fns)*1e6:8.1f} us", flush=True)
+if "--bwd" in sys.argv:
+    pkb = ops.integration_pack(wc, bwd=True)
+    saved = [ops.integration_fwd(x, pkb, clips, t, Ltok, xhat=True) for x in xs]
+    dRs = [(torch.randn(rows, CI, device="cuda") * 0.5).to(torch.bfloat16) for _ in range(NSET)]
+    from dist_amd import lib as LL
+    import ctypes as C
+    outs = [ops.integration_bwd(d, sv, pkb, clips, t, Ltok, copy=True) for d, sv in zip(dRs, saved)]
+    def call(d, sv, o):
+        a = LL.IntegBwdArgs()
+        p_ = lambda x: x.data_ptr()
+        a.dR, a.zf_h2, a.Xhat, a.rstd = p_(d), p_(sv["zf_h2"]), p_(sv["Xhat"]), p_(sv["rstd"])
+        a.B1, a.B2, a.B3 = p_(pkb["B1"]), p_(pkb["B2"]), p_(pkb["B3"])
+        a.dzf_dh2, a.dh1, a.dMp, a.dM_copy = p_(o["dzf_dh2"]), p_(o["dh1"]), p_(o["dMp"]), p_(o["dM"])
+        a.add_dR, a.clips, a.t, a.L, a.Ci, a.C4, a.tk, a.dtype = 0, clips, t, Ltok, CI, C4, 3, LL.BF16
+        LL.check(LL.load().dist_op_integration_bwd(C.byref(a), ops._stream()))
+    fns = [(lambda d=d, sv=sv, o=o: call(d, sv, o)) for d, sv, o in zip(dRs, saved, outs)]
+    print(f"integration_bwd: {timeit_rot(fns)*1e6:8.1f} us", flush=True)
