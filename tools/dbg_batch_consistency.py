@@ -1,5 +1,6 @@
 """Which intermediate tensor of the b=32 run first departs from the b=2 run (rows of clips 0-1)?"""
 import sys, os
+os.environ.setdefault("DIST_AMD_KEEP_MID", "1")   # M' of every layer stays readable ("mid.i"): the fused IntegrationNetwork forward forms it on chip otherwise
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
