@@ -9,8 +9,11 @@
 // Work decomposition: one workgroup (8 waves) per (clip, group of TOK = BM / t tokens): its BM rows are ALL t frames of those tokens, so
 // the temporal taps of temporal_ffn.c_fc2 (rows +-L apart in memory) are rows +-TOK of the same tile.
 //
+//   stage -1 (template T2I; dist.py:68-86) M' = M + [cls_token ; X' Wt^T + bt] formed here instead of read: the X' rows of the tile's tokens in regions B / C,
+//            M' on the accumulators, LayerNorm statistics from row sums across lanes and waves, xhat straight into region A - replaces stage 0
 //   stage 0  rows -> registers (8 lanes per row) -> statistics -> xhat = (x - mean) rstd as bf16 in LDS (region A, [BM][Ci]);
-//            training: the two affine outputs Na / Nb (what the weight-gradient GEMMs of backward read) and mean / rstd go to HBM
+//            training: xhat itself (MODE 2: the weight gradients are taken against it and unfolded, dist_op_integration_unfold) or the two affine
+//            outputs Na / Nb (MODE 1), and mean / rstd go to HBM
 //   stage 1  [zf | h1] = xhat [Wa diag(ga) ; Wb diag(gb)]^T + [ba + Wa beta_a ; bb + Wb beta_b]      (LayerNorm folded into the weights,
 //            dist_op_integration_pack) - N = Ci + C4 columns split over the waves by PAIRS of 16-column blocks
 //            hf = g(zf) replaces xhat in region A, h1 goes to region B
