@@ -324,3 +324,40 @@ def test_fused_integration_backward_custom_output_layout(gpu_lib):
     assert torch.equal(cat[:, CI:CI + C4], ref["dh1"])
     assert torch.equal(cat[:, CI + C4:], ref["dzf_dh2"][:, CI:])
     assert torch.equal(dMp, ref["dMp"])
+
+
+def test_fused_integration_refuses_what_it_cannot_take(gpu_lib):
+    """geometries outside Ci = 384 / C4 = 96 / t in {4, 8, 16, 32}, half-given training outputs and half-given T2I operands are errors, not silent fallbacks"""
+    import ctypes as C
+    from dist_amd import ops, lib as L
+    w, Mp = make(1, 8, 16, seed=2)
+    wc = {k: v.cuda() for k, v in w.items()}
+    pk = ops.integration_pack(wc, bwd=True)
+    x = Mp.cuda()
+    with pytest.raises(L.DistError):
+        ops.integration_fwd(x[:12 * 16].contiguous(), pk, 1, 12, 16, xhat=True)                    # t = 12 does not divide the 128-row tile
+    lib = L.load()
+
+    def args(**kw):
+        a = L.IntegArgs()
+        a.Mp, a.W1, a.W2, a.W3, a.b1, a.b2, a.b3 = (v.data_ptr() for v in (x, pk["W1"], pk["W2"], pk["W3"], pk["b1"], pk["b2"], pk["b3"]))
+        R = torch.empty_like(x)
+        a.R = R.data_ptr()
+        a.clips, a.t, a.L, a.Ci, a.C4, a.tk, a.dtype, a.eps = 1, 8, 16, CI, C4, 3, L.BF16, 1e-5
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a, R
+    a, keep = args(Ci=512)
+    assert lib.dist_op_integration_fwd(C.byref(a), None) == -1                                       # DIST_ERR_ARG
+    a, keep = args(tk=5)
+    assert lib.dist_op_integration_fwd(C.byref(a), None) == -1
+    a, keep = args(dtype=L.F32)
+    assert lib.dist_op_integration_fwd(C.byref(a), None) == -1
+    buf = torch.empty_like(x)
+    a, keep = args(Xhat=buf.data_ptr())                                                                # the tensors for backward: all or none
+    assert lib.dist_op_integration_fwd(C.byref(a), None) == -1
+    a, keep = args(t2i_Xp=buf.data_ptr())                                                              # T2I in front needs M, the packed weight, bias, cls tokens
+    assert lib.dist_op_integration_fwd(C.byref(a), None) == -1
+    b = L.IntegBwdArgs()
+    assert lib.dist_op_integration_bwd(C.byref(b), None) == -1                                       # nothing bound
+    assert lib.dist_op_integration_fwd(None, None) == -1
