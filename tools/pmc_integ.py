@@ -9,7 +9,9 @@ clips, t, Ltok = 32, 8, 197
 rows = clips * t * Ltok
 w, _ = make(1, 8, 16, seed=1)
 wc = {k: v.cuda() for k, v in w.items()}
-pk = ops.integration_pack(wc, bwd=True)
+Wt = torch.randn(CI, C4, 2, 1, 1, device="cuda") * 0.07
+bt2 = torch.randn(CI, device="cuda") * 0.1; cls = torch.randn(t, CI, device="cuda") * 0.5
+pk = ops.integration_pack(wc, bwd=True, t2i_w=Wt)
 bf = lambda v: v.to(torch.bfloat16).contiguous()
 def cold():
     big = torch.empty(96 << 20, device="cuda"); big.zero_(); del big                      # push the operands out of the Infinity Cache
@@ -20,6 +22,9 @@ for rep in range(3):
     saved = ops.integration_fwd(x, pk, clips, t, Ltok, xhat=True)
     cold()
     ops.integration_fwd(x, pk, clips, t, Ltok, train=False)
+    cold()
+    Xp = (torch.randn(clips * 2 * t * (Ltok - 1), C4, device="cuda") * 0.8).to(torch.bfloat16)
+    ops.integration_fwd(x, pk, clips, t, Ltok, xhat=True, t2i=(Xp, bt2, cls))        # T2I in front (what the engine launches; M' is also written here)
     cold()
     ops.integration_bwd(dR, saved, pk, clips, t, Ltok, copy=True)
     cold()
