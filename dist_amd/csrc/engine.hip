@@ -1505,7 +1505,8 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
             char* dcat = static_cast<char*>(q.dcat);
             void* d_h1 = dcat + (size_t)Ci * es; void* d_h2 = dcat + (size_t)(Ci + C4) * es;
             ba.dzf_dh2 = q.dcat; ba.ld_dzf = Cd; ba.dh2 = d_h2; ba.ld_dh2 = Cd; ba.dh1 = d_h1; ba.ld_dh1 = Cd;
-            ba.dMp = q.dMp; ba.dM_copy = last ? nullptr : q.dM; ba.add_dR = last ? 1 : 0;
+            // (dM = dM' + I2T term: the I2T data-gradient GEMM below reads dM' as its residual and writes every patch row of dM; only the cls rows come from here)
+            ba.dMp = q.dMp; ba.dM_copy = last ? nullptr : q.dM; ba.dM_cls_only = 1; ba.add_dR = last ? 1 : 0;
             ba.clips = (int)b; ba.t = t; ba.L = L; ba.Ci = Ci; ba.C4 = C4; ba.tk = l.tf_fc2.taps; ba.dtype = c.dtype;
             RUN(dist_op_integration_bwd(&ba, x.s));
             RUN(fork());
@@ -1552,7 +1553,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         if (!last) {
             if (tchain) HIP_CHECK_RET(hipStreamWaitEvent(A, h->ev_dx[i + 1], 0));       // dX_{i+1} comes from the temporal chain
             RUN(dist_k_pair_sum(dXn, q.dY, bt, N * Ct, al, c.dtype, A));
-            RUN(gemm(x, q.dY, Ct, x.pk(l.i2t.pk.b), rowsQ, Ci, Ct, 1, q.dM, Ci, nullptr, q.dM, nullptr, nullptr, RM(), OM(DIST_OM_INSERTCLS, N)));
+            RUN(gemm(x, q.dY, Ct, x.pk(l.i2t.pk.b), rowsQ, Ci, Ct, 1, q.dM, Ci, nullptr, h->ig_bwd ? q.dMp : q.dM, nullptr, nullptr, RM(), OM(DIST_OM_INSERTCLS, N)));
             dM = q.dM;
         }
         RUN(fork());

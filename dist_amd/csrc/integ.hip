@@ -495,7 +495,7 @@ struct IgBwdArgs {
     const bf16_t *W1, *W2, *W3;
     bf16_t *dzfh2, *dh2, *dh1, *dMp, *dM;
     int ldz, ld2, ld1;       // row pitches of dzf, dh2 (a pointer to ITS first column), dh1
-    int add_dR;
+    int add_dR, dm_cls;      // dm_cls: the second copy of dM' only receives the cls rows (token 0)
     int clips, t, L, groups, tokshift;
 };
 
@@ -758,7 +758,8 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_bwd_kernel(con
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
             IG_ST(o, p.dMp + (long)gr * CI + pF * 32 + lg * 8);
-            if (p.dM) IG_ST(o, p.dM + (long)gr * CI + pF * 32 + lg * 8);
+            const bool to_dm = p.dM && (!p.dm_cls || ((grp << tsh) + (r & tokmask)) == 0);
+            if (to_dm) IG_ST(o, p.dM + (long)gr * CI + pF * 32 + lg * 8);
             if (rr < RBH) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_bwd_kernel(con
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
                 IG_ST(o, p.dMp + (long)gr * CI + pH * 32 + lg * 8);
-                if (p.dM) IG_ST(o, p.dM + (long)gr * CI + pH * 32 + lg * 8);
+                if (to_dm) IG_ST(o, p.dM + (long)gr * CI + pH * 32 + lg * 8);
             }
         }
     }
@@ -1008,6 +1009,7 @@ extern "C" int dist_op_integration_bwd(const dist_integ_bwd_args* a, void* strea
     if (k.ldz % 8 || k.ld2 % 8 || k.ld1 % 8) return DIST_ERR_ARG;
     k.dMp = static_cast<bf16_t*>(a->dMp); k.dM = static_cast<bf16_t*>(a->dM_copy);
     k.add_dR = a->add_dR ? 1 : 0;
+    k.dm_cls = a->dM_cls_only ? 1 : 0;
     k.clips = a->clips; k.t = a->t; k.L = a->L;
     const int TOK = BM / a->t;
     int sh = 0;

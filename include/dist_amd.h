@@ -293,6 +293,7 @@ typedef struct dist_integ_bwd_args {
     /* optional layout of the three gradient outputs (0 / NULL = the defaults above): row pitch of dzf_dh2, a separate place and pitch for its dh2 columns,
      * row pitch of dh1 - e.g. one buffer with rows [dzf | dh1 | dh2] so that ONE weight-gradient GEMM over [dzf | dh1] serves both Linears that read xhat */
     int ld_dzf; void* dh2; int ld_dh2; int ld_dh1;
+    int dM_cls_only;         /* dM_copy only receives the cls rows (token 0 of every frame): for a caller whose next GEMM writes the other rows of that tensor anyway */
 } dist_integ_bwd_args;
 int dist_op_integration_bwd(const dist_integ_bwd_args* a, void* stream);
 /* backward side of the LayerNorm fold.  On entry d_ffn_fc_w / d_tf_fc1_w hold G' = dz^T xhat (dist_op_gemm_tn with B = Xhat) and d_*_b the bias
