@@ -1,0 +1,22 @@
+"""Every fused kernel of the engine has a knob that turns it off (the path the other geometries and the fp32 parity mode take, and the A/B reference of
+tools/ab_step.sh).  The knobs are read once per process, so each variant runs the bf16 ViT-B/16 engine tests against the reference golden in a child process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KNOBS = ["DIST_AMD_INTEG_FUSED", "DIST_AMD_INTEG_XHAT", "DIST_AMD_INTEG_BWD_FUSED", "DIST_AMD_INTEG_T2I", "DIST_AMD_INTEG_WG_MERGE", "DIST_AMD_TNET_FUSED",
+         "DIST_AMD_TNET_BWD_FUSED", "DIST_AMD_ATTN_FULLROW"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knob", KNOBS)
+def test_engine_parity_with_a_fused_kernel_switched_off(knob):
+    env = dict(os.environ, **{knob: "0"})
+    cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_engine_gpu.py"), "-q", "-x", "-k",
+           "b16_bf16_vs_reference_golden or full_size_batch or inference_mode or grad_ready_hook"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (knob, r.stdout[-1500:], r.stderr[-500:])
+    assert "passed" in r.stdout and "failed" not in r.stdout
