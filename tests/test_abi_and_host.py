@@ -90,6 +90,13 @@ def test_engine_tables_without_gpu():
             end += int(np.prod(shape))
             seen.add(name)
         assert seen == set(shapes)
+        # the two Linears of an IntegrationNetwork that read the same normalised rows keep their weights, and their biases, side by side: the fused
+        # backward takes both weight gradients as ONE [Ci + C4][Ci] GEMM (engine.hip; the engine falls back to two GEMMs if this ever stops holding)
+        off = {l.dist_param_name(h, 0, i).decode(): l.dist_param_offset(h, 0, i) for i in range(n)}
+        for i in range(g.layers):
+            p = f"dist_net.integration_nets.{i}."
+            assert off[p + "temporal_ffn.c_fc1.weight"] == off[p + "ffn.c_fc.weight"] + g.Ci * g.Ci
+            assert off[p + "temporal_ffn.c_fc1.bias"] == off[p + "ffn.c_fc.bias"] + g.Ci
         vs = synth.visual_shapes(g)
         assert {l.dist_param_name(h, 1, i).decode() for i in range(l.dist_param_count(h, 1))} == set(vs)
         assert l.dist_param_total(h, 1) == sum(int(np.prod(s)) for s in vs.values()) == 86192640
