@@ -233,6 +233,19 @@ long add_param(dist_handle* h, int kind, const std::string& name, std::initializ
     return p.offset;
 }
 
+// which fused IntegrationNetwork kernels this handle uses (geometry + measurement knobs): decided BEFORE the tables are built, because the packed GEMM
+// operands of the launches they replace are then neither allocated nor re-packed every step
+void set_fused_flags(dist_handle* h) {
+    const dist_config& c = h->cfg;
+    const int Ci = c.integration_dim, Ct = c.temporal_dim, C4 = h->C4;
+    h->ig_on = dist_k_integ_eligible(c.dtype, Ci, C4, h->t, c.temporal_kernel) && !(getenv("DIST_AMD_INTEG_FUSED") && atoi(getenv("DIST_AMD_INTEG_FUSED")) == 0);
+    h->ig_xhat = h->ig_on && !(getenv("DIST_AMD_INTEG_XHAT") && atoi(getenv("DIST_AMD_INTEG_XHAT")) == 0);
+    h->ig_bwd = h->ig_xhat && !(getenv("DIST_AMD_INTEG_BWD_FUSED") && atoi(getenv("DIST_AMD_INTEG_BWD_FUSED")) == 0);
+    // T2I (dist.py:68-86) formed in front of the fused forward instead of a GEMM + a cls-row kernel + a round trip of M' (alpha = 2, temporal width = C4)
+    h->ig_t2i = h->ig_xhat && c.alpha == 2 && Ct == C4 && !(getenv("DIST_AMD_INTEG_T2I") && atoi(getenv("DIST_AMD_INTEG_T2I")) == 0);
+    h->keep_mid = getenv("DIST_AMD_KEEP_MID") && atoi(getenv("DIST_AMD_KEEP_MID"));     // debugging: M' of every layer stays readable (dist_debug_tensor "mid.i")
+}
+
 long pk_alloc(dist_handle* h, long elems) {
     h->packed_elems = (h->packed_elems + 127) & ~127L;
     const long o = h->packed_elems;
@@ -243,7 +256,7 @@ long pk_alloc(dist_handle* h, long elems) {
 // registers the pack descriptors of one GEMM weight.  `style`: 0 linear [N][K]; 1 conv [Co][Ci][taps] with
 // shift/spatial taps (data-gradient = per-tap transposes); 2 strided conv (data-gradient = plain transpose);
 // 3 patch conv [Co][3][tp][P][P] (forward only, K padded to Kp); 4 [K][N] projection matrix used as x @ W.
-void add_pack(dist_handle* h, Lin& l, int kind, int style, bool need_bwd) {
+void add_pack(dist_handle* h, Lin& l, int kind, int style, bool need_bwd, bool need_fwd = true) {
     PackDesc d;
     memset(&d, 0, sizeof(d));
     d.src_off = l.w; d.src_kind = kind; d.co = l.N; d.kin = l.K; d.kpad = l.K; d.inner = 1;
@@ -251,10 +264,12 @@ void add_pack(dist_handle* h, Lin& l, int kind, int style, bool need_bwd) {
     else if (style == 1 || style == 2) { d.s_co = (long)l.K * l.taps; d.s_tap = 1; d.s_outer = l.taps; }
     else if (style == 3) { d.kin = h->PP3; d.kpad = h->Kp; d.inner = h->PP3 / 3; d.s_co = (long)h->PP3 * l.taps; d.s_tap = h->PP3 / 3; d.s_outer = (long)(h->PP3 / 3) * l.taps; }
     else { d.s_co = 1; d.s_tap = 0; d.s_outer = l.N; }
-    // forward layout [N][taps*kpad]
-    d.layout = PACK_F; d.rows = l.N; d.cols = l.taps * d.kpad;
-    l.pk.f = d.dst_off = pk_alloc(h, (long)d.rows * d.cols);
-    h->descs.push_back(d);
+    // forward layout [N][taps*kpad]  (need_fwd / need_bwd false: a fused kernel with its own operand order replaces the GEMM that read this copy)
+    if (need_fwd) {
+        d.layout = PACK_F; d.rows = l.N; d.cols = l.taps * d.kpad;
+        l.pk.f = d.dst_off = pk_alloc(h, (long)d.rows * d.cols);
+        h->descs.push_back(d);
+    }
     if (!need_bwd) return;
     if (style == 1) { d.layout = PACK_B; d.rows = l.K; d.cols = l.taps * l.N; }
     else { d.layout = PACK_FT; d.rows = l.taps * d.kpad; d.cols = l.N; }
@@ -336,7 +351,10 @@ void build_tables(dist_handle* h) {
         l.in_lin = make_lin(h, 0, fmt("dist_net.input_linears.%d.", i), Ci, d, 1, 0, false, {Ci, d});
         l.i2t = make_lin(h, 0, fmt("dist_net.integration2temporal_nets.%d.linear_fuse.", i), Ct, Ci, 1, 0, true, {Ct, Ci});
         l.cls_token = add_param(h, 0, fmt("dist_net.temporal2integration_nets.%d.cls_token", i), {1, 1, t, Ci});
-        l.t2i = make_lin(h, 0, fmt("dist_net.temporal2integration_nets.%d.linear_fuse.", i), Ci, Ct, c.alpha, 2, true, {Ci, Ct, c.alpha, 1, 1});
+        l.t2i.N = Ci; l.t2i.K = Ct; l.t2i.taps = c.alpha;
+        l.t2i.w = add_param(h, 0, fmt("dist_net.temporal2integration_nets.%d.linear_fuse.weight", i), {Ci, Ct, c.alpha, 1, 1});
+        l.t2i.bias = add_param(h, 0, fmt("dist_net.temporal2integration_nets.%d.linear_fuse.bias", i), {Ci});
+        add_pack(h, l.t2i, 0, 2, true, !h->ig_t2i);
         std::string p = fmt("dist_net.temporal_nets.%d.", i);
         l.tn_fc1 = make_lin(h, 0, p + "temporal_net.c_fc1.", Ct, Ct, c.temporal_kernel, 1, true, {Ct, Ct, c.temporal_kernel, 1, 1});
         l.tn_fc2 = make_lin(h, 0, p + "temporal_net.c_fc2.", Ct, Ct, 9, 1, true, {Ct, Ct, 1, 3, 3});
@@ -350,11 +368,16 @@ void build_tables(dist_handle* h) {
         l.tf_fc1.w = add_param(h, 0, p + "temporal_ffn.c_fc1.weight", {C4, Ci, 1, 1, 1});
         l.ffn_fc.bias = add_param(h, 0, p + "ffn.c_fc.bias", {Ci});
         l.tf_fc1.bias = add_param(h, 0, p + "temporal_ffn.c_fc1.bias", {C4});
-        add_pack(h, l.ffn_fc, 0, 0, true);
-        add_pack(h, l.tf_fc1, 0, 0, true);
-        l.ffn_proj = make_lin(h, 0, p + "ffn.c_proj.", Ci, Ci, 1, 0, true, {Ci, Ci});
-        l.tf_fc2 = make_lin(h, 0, p + "temporal_ffn.c_fc2.", C4, C4, c.temporal_kernel, 1, true, {C4, C4, c.temporal_kernel, 1, 1});
-        l.tf_proj = make_lin(h, 0, p + "temporal_ffn.c_proj.", Ci, C4, 1, 0, true, {Ci, C4, 1, 1, 1});
+        add_pack(h, l.ffn_fc, 0, 0, !h->ig_bwd, !h->ig_on);
+        add_pack(h, l.tf_fc1, 0, 0, !h->ig_bwd, !h->ig_on);
+        // (ffn.c_proj / temporal_ffn.c_proj are only ever multiplied as the side-by-side pair packed below: no copies of their own)
+        l.ffn_proj.N = Ci; l.ffn_proj.K = Ci; l.ffn_proj.taps = 1;
+        l.ffn_proj.w = add_param(h, 0, p + "ffn.c_proj.weight", {Ci, Ci}); l.ffn_proj.bias = add_param(h, 0, p + "ffn.c_proj.bias", {Ci});
+        l.tf_fc2.N = C4; l.tf_fc2.K = C4; l.tf_fc2.taps = c.temporal_kernel;
+        l.tf_fc2.w = add_param(h, 0, p + "temporal_ffn.c_fc2.weight", {C4, C4, c.temporal_kernel, 1, 1}); l.tf_fc2.bias = add_param(h, 0, p + "temporal_ffn.c_fc2.bias", {C4});
+        add_pack(h, l.tf_fc2, 0, 1, !h->ig_bwd, !h->ig_on);
+        l.tf_proj.N = Ci; l.tf_proj.K = C4; l.tf_proj.taps = 1;
+        l.tf_proj.w = add_param(h, 0, p + "temporal_ffn.c_proj.weight", {Ci, C4, 1, 1, 1}); l.tf_proj.bias = add_param(h, 0, p + "temporal_ffn.c_proj.bias", {Ci});
         {   // R = [gelu(zf) | gelu(h2)] [W_ffn | W_tf]^T: the two projections are ONE GEMM over activations stored side by side
             // (forward), one data-gradient GEMM and one weight-gradient GEMM (backward)
             const int Cc = Ci + C4;
@@ -365,12 +388,16 @@ void build_tables(dist_handle* h) {
                 d.s_co = lin.K; d.s_tap = 0; d.s_outer = 1; d.layout = layout;
                 if (layout == PACK_F) { d.rows = lin.N; d.cols = lin.K; } else { d.rows = lin.K; d.cols = lin.N; }
             };
-            l.pk_proj_f = pk_alloc(h, (long)Ci * Cc);
-            desc_of(l.ffn_proj, PACK_F); d.dst_off = l.pk_proj_f; d.dpitch = Cc; h->descs.push_back(d);
-            desc_of(l.tf_proj, PACK_F); d.dst_off = l.pk_proj_f + Ci; d.dpitch = Cc; h->descs.push_back(d);
-            l.pk_proj_b = pk_alloc(h, (long)Cc * Ci);
-            desc_of(l.ffn_proj, PACK_FT); d.dst_off = l.pk_proj_b; h->descs.push_back(d);
-            desc_of(l.tf_proj, PACK_FT); d.dst_off = l.pk_proj_b + (long)Ci * Ci; h->descs.push_back(d);
+            if (!h->ig_on) {
+                l.pk_proj_f = pk_alloc(h, (long)Ci * Cc);
+                desc_of(l.ffn_proj, PACK_F); d.dst_off = l.pk_proj_f; d.dpitch = Cc; h->descs.push_back(d);
+                desc_of(l.tf_proj, PACK_F); d.dst_off = l.pk_proj_f + Ci; d.dpitch = Cc; h->descs.push_back(d);
+            }
+            if (!h->ig_bwd) {
+                l.pk_proj_b = pk_alloc(h, (long)Cc * Ci);
+                desc_of(l.ffn_proj, PACK_FT); d.dst_off = l.pk_proj_b; h->descs.push_back(d);
+                desc_of(l.tf_proj, PACK_FT); d.dst_off = l.pk_proj_b + (long)Ci * Ci; h->descs.push_back(d);
+            }
         }
         l.in_ln = make_ln(h, 0, p + "ln.", Ci);
         l.in_ln_t = make_ln(h, 0, p + "ln_temporal.", Ci);
@@ -489,12 +516,6 @@ size_t layout_ws(dist_handle* h, char* base) {
     h->ln_partial = F_(h->ln_partial_elems);
     h->tnb_scratch_elems = dist_op_temporal_net_bwd_scratch((int)b, c.frames, Ct);
     h->tnb_scratch = F_(h->tnb_scratch_elems * c.layers);        // one partial table per layer
-    h->ig_on = dist_k_integ_eligible(c.dtype, Ci, C4, h->t, c.temporal_kernel) && !(getenv("DIST_AMD_INTEG_FUSED") && atoi(getenv("DIST_AMD_INTEG_FUSED")) == 0);
-    h->ig_xhat = h->ig_on && !(getenv("DIST_AMD_INTEG_XHAT") && atoi(getenv("DIST_AMD_INTEG_XHAT")) == 0);
-    h->ig_bwd = h->ig_xhat && !(getenv("DIST_AMD_INTEG_BWD_FUSED") && atoi(getenv("DIST_AMD_INTEG_BWD_FUSED")) == 0);
-    // T2I (dist.py:68-86) formed in front of the fused forward instead of a GEMM + a cls-row kernel + a round trip of M' (alpha = 2, temporal width = C4)
-    h->ig_t2i = h->ig_xhat && c.alpha == 2 && Ct == C4 && !(getenv("DIST_AMD_INTEG_T2I") && atoi(getenv("DIST_AMD_INTEG_T2I")) == 0);
-    h->keep_mid = getenv("DIST_AMD_KEEP_MID") && atoi(getenv("DIST_AMD_KEEP_MID"));     // debugging: M' of every layer stays readable (dist_debug_tensor "mid.i")
     if (h->ig_on) {
         for (int i = 0; i < c.layers; ++i) {
             DistLayer& l = h->dl[i];
@@ -753,6 +774,7 @@ extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
     h->G = c.resolution / c.patch; h->N = h->G * h->G; h->L = h->N + 1; h->t = c.frames / c.alpha;
     h->heads = c.width / 64; h->iheads = c.integration_dim / 64; h->C4 = c.integration_dim / c.int_temporal_div;
     h->PP3 = 3 * c.patch * c.patch; h->Kp = (h->PP3 + 7) / 8 * 8;
+    set_fused_flags(h);
     build_tables(h);
     h->ws_bytes = layout_ws(h, nullptr);
     if (const char* e = getenv("DIST_AMD_SERIAL")) h->serial = atoi(e);
@@ -1231,7 +1253,7 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
         }
         // T2I (dist.py:68-86,232): strided temporal conv into the patch rows of M', learnable cls row
         HIP_CHECK_RET(hipStreamWaitEvent(x.s, ev_xp(i), 0));
-        const bool t2i_in_front = h->ig_t2i && !(h->skip & 8);
+        const bool t2i_in_front = h->ig_t2i;                // (with DIST_AMD_SKIP & 8 nothing forms M': the knob's results are wrong by design)
         if (!t2i_in_front) {
         RUN(gemm(x, w.Xp, Ct, x.pk(l.t2i.pk.f), rowsQ, Ci, Ct, al, w.Mp, Ci, x.th(l.t2i.bias), w.M, nullptr, nullptr,
                  RM(DIST_RM_STRIDED, al, N), OM(DIST_OM_INSERTCLS, N)));
