@@ -62,6 +62,7 @@ struct DistLayer {
     void *ig_W1 = nullptr, *ig_W2 = nullptr, *ig_W3 = nullptr; float *ig_b1 = nullptr, *ig_b2 = nullptr, *ig_b3 = nullptr;
     void *ig_B1 = nullptr, *ig_B2 = nullptr, *ig_B3 = nullptr;      // ... and the data-gradient side (fused backward)
     void* ig_Wt = nullptr;                                          // ... and the T2I weight (T2I formed in front of the fused forward)
+    void* ig_Wi = nullptr;                                          // ... and the I2T weight (I2T behind it)
 };
 struct XAttn { LNp ln1; Lin q, kv, out; };   // CrossAttentionBlockGenral (in_proj split into q / kv rows)
 struct AdaLayer { long pos = -1; XAttn sp, tm; LNp ln_sp, ln_tm; Lin sp_fc, sp_proj, tm_fc, tm_proj; };
@@ -148,7 +149,7 @@ struct dist_handle {
     void *dR, *dkv, *dkn;
     float* ln_partial = nullptr; long ln_partial_elems = 0;     // per-block parameter-gradient sums of the LayerNorm backward (two-phase, no atomics)
     float* tnb_scratch = nullptr; long tnb_scratch_elems = 0;   // parameter-gradient partial rows of the fused TemporalNet backward
-    bool ig_on = false, ig_xhat = false, ig_bwd = false, ig_t2i = false, keep_mid = false; void* ig_descs = nullptr;   // ig_xhat: the forward keeps xhat (in the Na buffer) instead of Na / Nb; the weight gradients of the two folded Linears are unfolded afterwards
+    bool ig_on = false, ig_xhat = false, ig_bwd = false, ig_t2i = false, ig_i2t = false, keep_mid = false; void* ig_descs = nullptr;   // ig_xhat: the forward keeps xhat (in the Na buffer) instead of Na / Nb; the weight gradients of the two folded Linears are unfolded afterwards
                   // fused IntegrationNetwork forward: taken for this geometry; its pack descriptors (device)
     float* tn_partial[3] = {nullptr, nullptr, nullptr};   // two-phase dW reduction scratch, one per stream that launches dW GEMMs
     long tn_partial_elems = 0;
@@ -243,6 +244,8 @@ void set_fused_flags(dist_handle* h) {
     h->ig_bwd = h->ig_xhat && !(getenv("DIST_AMD_INTEG_BWD_FUSED") && atoi(getenv("DIST_AMD_INTEG_BWD_FUSED")) == 0);
     // T2I (dist.py:68-86) formed in front of the fused forward instead of a GEMM + a cls-row kernel + a round trip of M' (alpha = 2, temporal width = C4)
     h->ig_t2i = h->ig_xhat && c.alpha == 2 && Ct == C4 && !(getenv("DIST_AMD_INTEG_T2I") && atoi(getenv("DIST_AMD_INTEG_T2I")) == 0);
+    // ... and I2T (dist.py:90-105) behind it: the next layer's temporal map leaves the same launch (the I2T GEMM and its second pass over M are gone)
+    h->ig_i2t = h->ig_t2i && !(getenv("DIST_AMD_INTEG_I2T") && atoi(getenv("DIST_AMD_INTEG_I2T")) == 0);
     h->keep_mid = getenv("DIST_AMD_KEEP_MID") && atoi(getenv("DIST_AMD_KEEP_MID"));     // debugging: M' of every layer stays readable (dist_debug_tensor "mid.i")
 }
 
@@ -522,6 +525,7 @@ size_t layout_ws(dist_handle* h, char* base) {
             l.ig_W1 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 0) * 2); l.ig_W2 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 1) * 2);
             l.ig_W3 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 2) * 2);
             if (h->ig_t2i) l.ig_Wt = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 6) * 2);
+            if (h->ig_i2t) l.ig_Wi = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 7) * 2);
             if (h->ig_bwd) {
                 l.ig_B1 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 0) * 2); l.ig_B2 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 1) * 2);
                 l.ig_B3 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 2) * 2);
@@ -887,6 +891,7 @@ extern "C" int dist_bind(dist_handle* h, float* theta, float* grads, const float
             a.W1 = l.ig_W1; a.W2 = l.ig_W2; a.W3 = l.ig_W3; a.b1 = l.ig_b1; a.b2 = l.ig_b2; a.b3 = l.ig_b3;
             a.B1 = l.ig_B1; a.B2 = l.ig_B2; a.B3 = l.ig_B3;
             if (h->ig_t2i) { a.t2i_w = theta + l.t2i.w; a.Wt = l.ig_Wt; }
+            if (h->ig_i2t) { a.i2t_w = theta + l.i2t.w; a.Wi = l.ig_Wi; }
             a.Ci = h->cfg.integration_dim; a.C4 = h->C4;
             dist_k_integ_pack_desc(&a, host.data() + i * db);
         }
@@ -1243,10 +1248,11 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
         // ---- integration chain: mid_feat = input_linear(F_i) + res_feat (dist.py:229)
         HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_feat[i], 0));
         RUN(gemm(x, h->feat[i], d, x.pk(l.in_lin.pk.f), rowsS, Ci, d, 1, w.M, Ci, x.th(l.in_lin.bias), i ? h->lw[i - 1].R : nullptr, nullptr, nullptr));
-        HIP_CHECK_RET(hipEventRecord(ev_m(i), x.s));
-        // I2T (dist.py:90-105,231) on the temporal chain: Linear on the non-cls rows, nearest-upsampled x alpha in T, + x_temporal.
-        // (the last layer's result is discarded by the reference, dist.py:235 -> skipped)
-        if (i + 1 < nl) {
+        // I2T (dist.py:90-105,231): Linear on the non-cls rows, nearest-upsampled x alpha in T, + x_temporal - inside the fused IntegrationNetwork launch below
+        // (behind its T2I stage), or as a GEMM on the temporal chain.  (the last layer's result is discarded by the reference, dist.py:235 -> skipped)
+        const bool i2t_fused = h->ig_i2t && i + 1 < nl && !(h->skip & 8);
+        if (!i2t_fused) HIP_CHECK_RET(hipEventRecord(ev_m(i), x.s));
+        if (i + 1 < nl && !i2t_fused) {
             HIP_CHECK_RET(hipStreamWaitEvent(xt.s, ev_m(i), 0));
             RUN(gemm(xt, w.M, Ci, x.pk(l.i2t.pk.f), rowsQ, Ct, Ci, 1, Xnext, Ct, x.th(l.i2t.bias), w.Xp, nullptr, nullptr,
                      RM(DIST_RM_SKIPCLS, N), OM(DIST_OM_DUP, al, N)));
@@ -1267,6 +1273,7 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
                 if (t2i_in_front) {       // M' is formed in the kernel; it is written out only where something else reads it (the last layer's residual, the unfused backward)
                     ia.t2i_M = w.M; ia.t2i_Xp = w.Xp; ia.t2i_W = l.ig_Wt; ia.t2i_bias = x.th(l.t2i.bias); ia.t2i_cls = x.th(l.cls_token);
                     if (i == nl - 1 || !h->ig_bwd || h->keep_mid) ia.Mp_out = w.Mp;
+                    if (i2t_fused) { ia.i2t_W = l.ig_Wi; ia.i2t_bias = x.th(l.i2t.bias); ia.i2t_Xnext = Xnext; }
                 } else ia.Mp = w.Mp;
                 ia.W1 = l.ig_W1; ia.W2 = l.ig_W2; ia.W3 = l.ig_W3; ia.b1 = l.ig_b1; ia.b2 = l.ig_b2; ia.b3 = l.ig_b3;
                 ia.R = w.R;
@@ -1280,6 +1287,10 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
                 }
                 ia.clips = (int)b; ia.t = t; ia.L = L; ia.Ci = Ci; ia.C4 = C4; ia.tk = l.tf_fc2.taps; ia.dtype = c.dtype; ia.eps = 1e-5f;
                 RUN(dist_op_integration_fwd(&ia, x.s));
+                if (i2t_fused) {                                                // X of the next layer is written by this launch: the temporal chain continues behind it
+                    HIP_CHECK_RET(hipEventRecord(ev_m(i), x.s));
+                    HIP_CHECK_RET(hipStreamWaitEvent(xt.s, ev_m(i), 0));
+                }
             }
         } else {
         RUN(ln_fwd(x, h->theta, l.in_ln, w.Mp, w.Na, rowsS, w.in_mean, w.in_rstd, &l.in_ln_t, w.Nb));

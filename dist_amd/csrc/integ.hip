@@ -49,6 +49,8 @@ struct IgArgs {
     float eps;
     // T2I in front (template T2I): M' = M + [cls_token ; conv_strided(X')] is formed here instead of being read
     const bf16_t *M, *Xp, *Wt; const float *bt, *cls; bf16_t* Mpo;
+    // ... and I2T behind it (dist.py:90-105): X_next[frames 2f, 2f+1; position j-1] = X' + (M[f, j] Wi^T + bi), when Xn is given
+    const bf16_t* Wi; const float* bi; bf16_t* Xn;
 };
 
 DEV int ig_pchunk(const int row, const int c) { return (c & ~3) | ((c & 3) ^ (((row >> 2) & 1) << 1)); }
@@ -141,7 +143,59 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_fwd_kernel(con
             mF[rr] = *reinterpret_cast<const bf16x8*>(p.M + base + pF * 32 + lg * 8);
             if (rr < RBH) mH[rr] = *reinterpret_cast<const bf16x8*>(p.M + base + pH * 32 + lg * 8);
         }
+        const bool i2t = p.Xn != nullptr;                  // (kernel argument: the same for every workgroup)
+        if (i2t) {                                         // M also goes to region A row-major: the A operand of the I2T product below
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr) {
+                const int r = (((rr + odd * RBH) & (RB - 1)) * 16) + li;
+                *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((pF * 4 + lg) ^ li) << 4)) = mF[rr];
+                if (rr < RBH) *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((pH * 4 + lg) ^ li) << 4)) = mH[rr];
+            }
+        }
         __syncthreads();
+        if (i2t && wid < NP2 * 2) {
+            // ---------------- I2T (dist.py:90-105): Linear on the patch rows of M (C4 columns: item = (column pair, half of the row blocks) as in stage 2), the
+            // result added to BOTH frames 2f, 2f+1 of X' (nearest upsampling in time) -> X of the next layer.  Reads region A (M) and regions B / C (X').
+            const int pi = wid % NP2, hi = wid / NP2;
+            f32x4 ai[2][RBH];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int rb = 0; rb < RBH; ++rb) ai[q][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bf16x8 wi[2][2];
+            wi[0][0] = IG_LDW(p.Wi, ((long)pi * KS1) * 2); wi[0][1] = IG_LDW(p.Wi, ((long)pi * KS1) * 2 + 1);
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                if (ks + 1 < KS1) { wi[(ks + 1) & 1][0] = IG_LDW(p.Wi, ((long)pi * KS1 + ks + 1) * 2); wi[(ks + 1) & 1][1] = IG_LDW(p.Wi, ((long)pi * KS1 + ks + 1) * 2 + 1); }
+#pragma unroll
+                for (int rbh = 0; rbh < RBH; ++rbh) {
+                    const int r = (hi * RBH + rbh) * 16 + li;
+                    const bf16x8 a = IG_LDS(regA + r * (CI * 2) + (((ks * 4 + lg) ^ li) << 4));
+                    ai[0][rbh] = IG_MMA(wi[ks & 1][0], a, ai[0][rbh]);
+                    ai[1][rbh] = IG_MMA(wi[ks & 1][1], a, ai[1][rbh]);
+                }
+            }
+            const int n0 = pi * 32 + lg * 8;
+            float bv[8];
+            ig_load8(p.bi + n0, bv);
+#pragma unroll
+            for (int rbh = 0; rbh < RBH; ++rbh) {
+                const int r = (hi * RBH + rbh) * 16 + li;
+                const int f = r >> tsh, j = (grp << tsh) + (r & tokmask);
+                if (j < 1 || j >= L) continue;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = ai[0][rbh][e] + bv[e]; v[4 + e] = ai[1][rbh][e] + bv[4 + e]; }     // (one rounding, of the sum with X')
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const bf16x8 xp = *reinterpret_cast<const bf16x8*>((a ? regC : regB) + r * (C4 * 2) + (ig_pchunk(r, pi * 4 + lg) << 4));
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(v[e] + (float)xp[e]);
+                    IG_ST(o, p.Xn + ((long)(clip * T + 2 * f + a) * N + (j - 1)) * C4 + n0);
+                }
+            }
+        }
         f32x4 aF[2][RB], aH[2][RBH];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -791,6 +845,7 @@ struct IgPack {
     bf16_t *W1o, *W2o, *W3o; float *b1o, *b2o, *b3o;
     bf16_t *B1o, *B2o, *B3o;                 // optional: the data-gradient operands of integ_bwd_kernel (same shapes, transposed weights)
     const float* Wt2i; bf16_t* Wto;          // optional: temporal2integration linear_fuse [Ci][C4][2] -> [Ci][2 C4] in fragment order (T2I in front of the forward)
+    const float* Wi2t; bf16_t* Wio;          // optional: integration2temporal linear_fuse [C4][Ci] in fragment order (I2T behind it)
 };
 
 template <int CI, int C4>
@@ -833,20 +888,23 @@ __global__ __launch_bounds__(256) void integ_pack_kernel(const IgPack* __restric
         *reinterpret_cast<bf16x8*>(dst + (long)piece * 8) = o;
         return;
     }
-    constexpr int KST = 2 * C4 / 32, FT = NP3 * KST * 2, TBLK = (FT * 64 + 255) / 256;
-    if ((int)blockIdx.x < 2 * PBLK + TBLK) {               // T2I weight: Wt[n][a C4 + c] = W[n][c][a]
-        if (!d.Wto) return;
-        const int piece = ((int)blockIdx.x - 2 * PBLK) * 256 + tid;
-        if (piece >= FT * 64) return;
-        const int l = piece & 63, frag = piece >> 6, q = frag & 1, pk = frag >> 1, ks = pk % KST, pr = pk / KST;
+    constexpr int KST = 2 * C4 / 32, FT = NP3 * KST * 2, FI = NP2 * KS1 * 2, TBLK = ((FT + FI) * 64 + 255) / 256;
+    if ((int)blockIdx.x < 2 * PBLK + TBLK) {               // T2I weight: Wt[n][a C4 + c] = W[n][c][a]; behind it the I2T weight [C4][Ci] as it is
+        int piece = ((int)blockIdx.x - 2 * PBLK) * 256 + tid;
+        if (piece >= (FT + FI) * 64) return;
+        const bool second = piece >= FT * 64;
+        if (second) piece -= FT * 64;
+        if (second ? !d.Wio : !d.Wto) return;
+        const int KS = second ? KS1 : KST;
+        const int l = piece & 63, frag = piece >> 6, q = frag & 1, pk = frag >> 1, ks = pk % KS, pr = pk / KS;
         const int n = 32 * pr + 8 * ((l & 15) >> 2) + 4 * q + (l & 3), k0 = 32 * ks + 8 * (l >> 4);
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = k0 + e, a = k / C4, c = k - a * C4;
-            o[e] = (bf16_t)d.Wt2i[((long)n * C4 + c) * 2 + a];
+            o[e] = (bf16_t)(second ? d.Wi2t[(long)n * CI + k] : d.Wt2i[((long)n * C4 + c) * 2 + a]);
         }
-        *reinterpret_cast<bf16x8*>(d.Wto + (long)piece * 8) = o;
+        *reinterpret_cast<bf16x8*>((second ? d.Wio : d.Wto) + (long)piece * 8) = o;
         return;
     }
     // biases: b1 = [ba + Wa beta_a ; bb + Wb beta_b] (the LayerNorm shift through the weights), b2, b3 = bp + bt
@@ -951,6 +1009,7 @@ extern "C" int64_t dist_op_integration_pack_elems(int Ci, int C4, int which) {
         case 4: return C4;                      // b2
         case 5: return Ci;                      // b3
         case 6: return (int64_t)Ci * 2 * C4;    // Wt (bf16 elements): the T2I weight in front of the forward
+        case 7: return (int64_t)C4 * Ci;        // Wi: the I2T weight behind it
         default: return -1;
     }
 }
@@ -965,6 +1024,7 @@ static IgPack ig_pack_of(const dist_integ_pack_args& a) {
     d.b1o = a.b1; d.b2o = a.b2; d.b3o = a.b3;
     d.B1o = static_cast<bf16_t*>(a.B1); d.B2o = static_cast<bf16_t*>(a.B2); d.B3o = static_cast<bf16_t*>(a.B3);
     d.Wt2i = a.t2i_w; d.Wto = static_cast<bf16_t*>(a.Wt);
+    d.Wi2t = a.i2t_w; d.Wio = static_cast<bf16_t*>(a.Wi);
     return d;
 }
 
@@ -976,7 +1036,7 @@ int dist_k_integ_pack(const void* descs_dev, const dist_integ_pack_args* one, in
     if (Ci != 384 || C4 != 96 || n <= 0) return DIST_ERR_ARG;
     constexpr int CI = 384, C4c = 96, CC = CI + C4c;
     constexpr int PIECES = ((CC / 32) * (CI / 32) * 2 + (C4c / 32) * (3 * C4c / 32) * 2 + (CI / 32) * (CC / 32) * 2) * 64;
-    const int pblk = (PIECES + 255) / 256, bblk = (CC + C4c + CI + 3) / 4, tblk = ((CI / 32) * (2 * C4c / 32) * 2 * 64 + 255) / 256;
+    const int pblk = (PIECES + 255) / 256, bblk = (CC + C4c + CI + 3) / 4, tblk = (((CI / 32) * (2 * C4c / 32) * 2 + (C4c / 32) * (CI / 32) * 2) * 64 + 255) / 256;
     IgPack d{};
     if (!descs_dev) { if (!one || n != 1) return DIST_ERR_ARG; d = ig_pack_of(*one); }
     hipLaunchKernelGGL((integ_pack_kernel<CI, C4c>), dim3((unsigned)(2 * pblk + tblk + bblk), (unsigned)n), dim3(256), 0, s, static_cast<const IgPack*>(descs_dev), d);
@@ -1062,6 +1122,8 @@ extern "C" int dist_op_integration_fwd(const dist_integ_args* a, void* stream) {
     k.clips = a->clips; k.t = a->t; k.L = a->L;
     k.M = static_cast<const bf16_t*>(a->t2i_M); k.Xp = static_cast<const bf16_t*>(a->t2i_Xp); k.Wt = static_cast<const bf16_t*>(a->t2i_W);
     k.bt = a->t2i_bias; k.cls = a->t2i_cls; k.Mpo = static_cast<bf16_t*>(a->Mp_out);
+    k.Wi = static_cast<const bf16_t*>(a->i2t_W); k.bi = a->i2t_bias; k.Xn = static_cast<bf16_t*>(a->i2t_Xnext);
+    if (k.Xn && !(t2i && k.Wi && k.bi)) return DIST_ERR_ARG;           // I2T behind needs T2I in front (its X' tile) and its own operands
     if (t2i && (BM != 128 || a->Na)) return DIST_ERR_ARG;
     const int TOK = BM / a->t;
     int sh = 0;

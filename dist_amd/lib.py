@@ -72,7 +72,7 @@ class IntegArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("Mp", "W1", "W2", "W3", "b1", "b2", "b3", "ln_w", "ln_b", "ln_t_w", "ln_t_b", "R", "Na", "Nb", "mean", "rstd",
                                           "zf_h2", "hf_g2", "h1")] + \
                [(n, C.c_int) for n in ("clips", "t", "L", "Ci", "C4", "tk", "dtype")] + [("eps", C.c_float)] + \
-               [(n, C.c_void_p) for n in ("t2i_M", "t2i_Xp", "t2i_W", "t2i_bias", "t2i_cls", "Mp_out", "Xhat")]
+               [(n, C.c_void_p) for n in ("t2i_M", "t2i_Xp", "t2i_W", "t2i_bias", "t2i_cls", "Mp_out", "i2t_W", "i2t_bias", "i2t_Xnext", "Xhat")]
 
 
 class IntegUnfoldArgs(C.Structure):
@@ -83,7 +83,7 @@ class IntegUnfoldArgs(C.Structure):
 class IntegPackArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ffn_fc_w", "ffn_fc_b", "ln_w", "ln_b", "tf_fc1_w", "tf_fc1_b", "ln_t_w", "ln_t_b", "tf_fc2_w", "tf_fc2_b",
                                           "ffn_proj_w", "ffn_proj_b", "tf_proj_w", "tf_proj_b", "W1", "W2", "W3", "b1", "b2", "b3")] + \
-               [("Ci", C.c_int), ("C4", C.c_int)] + [(n, C.c_void_p) for n in ("B1", "B2", "B3", "t2i_w", "Wt")]
+               [("Ci", C.c_int), ("C4", C.c_int)] + [(n, C.c_void_p) for n in ("B1", "B2", "B3", "t2i_w", "Wt", "i2t_w", "Wi")]
 
 
 class IntegBwdArgs(C.Structure):

@@ -140,7 +140,7 @@ def temporal_net_bwd_reduce(scratch, layers, clips, T, Ct, dgammas, dbetas):
     L.check(lib.dist_op_temporal_net_bwd_reduce(_p(scratch), n, layers, clips, T, Ct, dg, db, _stream()))
 
 
-def integration_pack(w, bwd=False, t2i_w=None):
+def integration_pack(w, bwd=False, t2i_w=None, i2t_w=None):
     """fp32 master weights of one IntegrationNetwork (dict with the reference's parameter names below `integration_nets.i.`) -> the operands
     of integration_fwd (dist_op_integration_pack): dict(W1, W2, W3 bf16; b1, b2, b3 fp32 [; B1, B2, B3 bf16 for integration_bwd])."""
     lib = L.load()
@@ -166,12 +166,16 @@ def integration_pack(w, bwd=False, t2i_w=None):
         keep.append(t2i_w.float().contiguous())
         out["Wt"] = torch.empty(lib.dist_op_integration_pack_elems(Ci, C4, 6), dtype=torch.bfloat16, device=dev)
         a.t2i_w, a.Wt = _p(keep[-1]), _p(out["Wt"])
+    if i2t_w is not None:                               # integration2temporal linear_fuse.weight [C4][Ci] -> the I2T operand behind it
+        keep.append(i2t_w.float().contiguous())
+        out["Wi"] = torch.empty(lib.dist_op_integration_pack_elems(Ci, C4, 7), dtype=torch.bfloat16, device=dev)
+        a.i2t_w, a.Wi = _p(keep[-1]), _p(out["Wi"])
     L.check(lib.dist_op_integration_pack(C.byref(a), _stream()))
     torch.cuda.current_stream().synchronize()          # (the fp32 copies in `keep` must outlive the launch)
     return out
 
 
-def integration_fwd(Mp, pk, clips, t, Ltok, *, ln=None, train=True, tk=3, eps=1e-5, out=None, xhat=False, t2i=None):
+def integration_fwd(Mp, pk, clips, t, Ltok, *, ln=None, train=True, tk=3, eps=1e-5, out=None, xhat=False, t2i=None, i2t_bias=None):
     """Fused IntegrationNetwork forward (dist_op_integration_fwd) on Mp [clips*t*Ltok, Ci] (bf16).  `pk` from integration_pack; `ln` =
     (ln.weight, ln.bias, ln_temporal.weight, ln_temporal.bias) fp32, needed when train (the tensors backward reads are written) unless
     xhat=True (the normalised rows themselves are kept instead of the two affine outputs).
@@ -203,6 +207,10 @@ def integration_fwd(Mp, pk, clips, t, Ltok, *, ln=None, train=True, tk=3, eps=1e
             out["Mp"] = torch.empty_like(Mp)
         a.Mp = None
         a.t2i_M, a.t2i_Xp, a.t2i_W, a.t2i_bias, a.t2i_cls, a.Mp_out = _p(Mp), _p(Xp), _p(pk["Wt"]), _p(tb), _p(cls), _p(out["Mp"])
+        if i2t_bias is not None:                        # I2T behind it: X of the next layer = Xp + upsample_t(M[:, 1:] Wi^T + bias) (returned as "Xnext")
+            if "Xnext" not in out:
+                out["Xnext"] = torch.zeros_like(Xp)
+            a.i2t_W, a.i2t_bias, a.i2t_Xnext = _p(pk["Wi"]), _p(i2t_bias), _p(out["Xnext"])
     a.clips, a.t, a.L, a.Ci, a.C4, a.tk, a.dtype, a.eps = clips, t, Ltok, Ci, C4, tk, L.BF16, eps
     L.check(lib.dist_op_integration_fwd(C.byref(a), _stream()))
     return out

@@ -263,6 +263,9 @@ typedef struct dist_integ_args {
      * instead of reading Mp - M [rows][Ci], X' [clips*2t*(L-1)][C4], t2i_W from dist_op_integration_pack (Wt), bias [Ci], cls tokens [t][Ci] (fp32);
      * Mp_out (optional) receives M'.  Xhat / inference forms only. */
     const void* t2i_M; const void* t2i_Xp; const void* t2i_W; const float* t2i_bias; const float* t2i_cls; void* Mp_out;
+    /* ... and I2T behind it (dist.py:90-105; needs the T2I operands): i2t_Xnext [clips*2t*(L-1)][C4] = X' + upsample_t(M[:, 1:] i2t_W^T + i2t_bias), the temporal
+     * map of the NEXT layer; i2t_W from dist_op_integration_pack (Wi) */
+    const void* i2t_W; const float* i2t_bias; void* i2t_Xnext;
     void* Xhat;              /* instead of Na / Nb: the normalised rows (x - mean) rstd themselves, ONE tensor - for a backward pass whose weight-gradient
                               * GEMMs read xhat and whose results dist_op_integration_unfold turns into the gradients of W, gamma and beta */
 } dist_integ_args;
@@ -278,6 +281,7 @@ typedef struct dist_integ_pack_args {
     int Ci, C4;
     void* B1; void* B2; void* B3;   /* optional (all or none): the operands of dist_op_integration_bwd, sized like W1 / W2 / W3 */
     const float* t2i_w; void* Wt;   /* optional: temporal2integration_nets.i.linear_fuse.weight [Ci][C4][2][1][1] -> the t2i_W operand (which = 6 elements) */
+    const float* i2t_w; void* Wi;   /* optional: integration2temporal_nets.i.linear_fuse.weight [C4][Ci] -> the i2t_W operand (which = 7) */
 } dist_integ_pack_args;
 int64_t dist_op_integration_pack_elems(int Ci, int C4, int which);
 /* Fused data-gradient backward of the IntegrationNetwork (integ.hip), same geometries as dist_op_integration_fwd:

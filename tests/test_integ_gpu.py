@@ -272,9 +272,20 @@ def test_fused_integration_with_t2i_in_front(gpu_lib, clips, t, Ltok):
     bt = 0.1 * torch.randn(CI, generator=g)
     cls = 0.5 * torch.randn(t, CI, generator=g)
     wc = {k: v.cuda() for k, v in w.items()}
-    pk = ops.integration_pack(wc, t2i_w=Wt.cuda())
-    out = ops.integration_fwd(M.cuda(), pk, clips, t, Ltok, xhat=True, t2i=(Xp.cuda(), bt.cuda(), cls.cuda()))
+    Wi = torch.randn(C4, CI, generator=g) * CI ** -0.5
+    bi = 0.1 * torch.randn(C4, generator=g)
+    pk = ops.integration_pack(wc, t2i_w=Wt.cuda(), i2t_w=Wi.cuda())
+    out = ops.integration_fwd(M.cuda(), pk, clips, t, Ltok, xhat=True, t2i=(Xp.cuda(), bt.cuda(), cls.cuda()), i2t_bias=bi.cuda())
     torch.cuda.synchronize()
+    # I2T behind it (dist.py:90-105): X_next = X' + upsample_t(M[:, 1:] Wi^T + bi), one bf16 rounding of the sum
+    Y = M.double().reshape(clips, t, Ltok, CI)[:, :, 1:] @ Wi.to(torch.bfloat16).double().t() + bi.double()
+    Xn = (Xp.double().reshape(clips, t, 2, N, C4) + Y[:, :, None]).reshape(-1, C4)
+    gotn = out["Xnext"].double().cpu()
+    assert float((gotn - Xn).abs().max()) <= 2 ** -7 * float(Xn.abs().max()) + 1e-6
+    plain = ops.integration_fwd(M.cuda(), pk, clips, t, Ltok, xhat=True, t2i=(Xp.cuda(), bt.cuda(), cls.cuda()))       # without I2T: everything else unchanged
+    torch.cuda.synchronize()
+    for k in ("Mp", "R", "Xhat"):
+        assert torch.equal(plain[k], out[k]), k
     # reference M' in fp64 from the bf16 operands (weights as the kernel sees them: bf16)
     Md = M.double().reshape(clips, t, Ltok, CI).clone()
     Xd = Xp.double().reshape(clips, t, 2, N, C4)
