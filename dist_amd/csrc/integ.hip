@@ -550,6 +550,9 @@ struct IgBwdArgs {
     bf16_t *dzfh2, *dh2, *dh1, *dMp, *dM;
     int ldz, ld2, ld1;       // row pitches of dzf, dh2 (a pointer to ITS first column), dh1
     int add_dR, dm_cls;      // dm_cls: the second copy of dM' only receives the cls rows (token 0)
+    // I2T backward behind the LayerNorm backward (dist.py:100-105 through autograd): dY = dX_next[2f] + dX_next[2f+1] (written out: the I2T weight gradient reads it),
+    // dM = dM' + dY Wi on the patch rows - dM then holds the WHOLE gradient w.r.t. M, not a copy of dM'
+    const bf16_t *dXn, *W4; bf16_t* dY;
     int clips, t, L, groups, tokshift;
 };
 
@@ -749,6 +752,27 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_bwd_kernel(con
             if (ks + 2 < KS3) ldw(w, ks + 2);
             __builtin_amdgcn_sched_barrier(0);
         }
+        const bool i2tb = p.dXn != nullptr;                // (kernel argument: the same for every workgroup)
+        if (i2tb) {
+            // dY rows of this tile -> region B (free since the barrier inside the K loop: stage 2 was its last reader) and to memory; visible after the
+            // two barriers of the LayerNorm backward below
+            const int lq4 = lane & 3, lrow = lane >> 2;
+            const int r = wid * 16 + lrow, f = r >> tsh, j = (grp << tsh) + (r & tokmask);
+            const bool ok = j >= 1 && j < L;
+            const int N = L - 1, T = 2 * t;
+            const bf16_t* s0 = p.dXn + ((long)(clip * T + 2 * f) * N + (ok ? j - 1 : 0)) * C4;
+            const bf16_t* s1 = s0 + (long)N * C4;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const int c = lq4 + 4 * m;
+                const bf16x8 u = *reinterpret_cast<const bf16x8*>(s0 + c * 8), v = *reinterpret_cast<const bf16x8*>(s1 + c * 8);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = ok ? (bf16_t)((float)u[e] + (float)v[e]) : (bf16_t)0.f;
+                *reinterpret_cast<bf16x8*>(regB + r * (C4 * 2) + (ig_pchunk(r, c) << 4)) = o;
+                if (ok) IG_ST(o, p.dY + ((long)(clip * t + f) * N + (j - 1)) * C4 + c * 8);
+            }
+        }
         // xhat at this lane's (row, 8 columns) positions; partial row sums S1 = sum dxhat, S2 = sum dxhat xhat
         int gro[RB];
         bf16x8 xF[RB], xH[RBH];
@@ -812,8 +836,10 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_bwd_kernel(con
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
             IG_ST(o, p.dMp + (long)gr * CI + pF * 32 + lg * 8);
-            const bool to_dm = p.dM && (!p.dm_cls || ((grp << tsh) + (r & tokmask)) == 0);
+            const bool to_dm = p.dM && !i2tb && (!p.dm_cls || ((grp << tsh) + (r & tokmask)) == 0);
             if (to_dm) IG_ST(o, p.dM + (long)gr * CI + pF * 32 + lg * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { aF[0][rr][e] = (float)o[e]; aF[1][rr][e] = (float)o[4 + e]; }       // (the I2T term below accumulates on the stored dM')
             if (rr < RBH) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -829,6 +855,39 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_bwd_kernel(con
                 for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
                 IG_ST(o, p.dMp + (long)gr * CI + pH * 32 + lg * 8);
                 if (to_dm) IG_ST(o, p.dM + (long)gr * CI + pH * 32 + lg * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { aH[0][rr][e] = (float)o[e]; aH[1][rr][e] = (float)o[4 + e]; }
+            }
+        }
+        if (i2tb) {
+            // dM = dM' + dY W4^T (K = C4): the accumulators hold dM' as stored; cls rows and slots beyond L have all-zero dY rows
+            constexpr int KS4 = C4 / 32;
+#pragma unroll
+            for (int ks = 0; ks < KS4; ++ks) {
+                const bf16x8 w0 = IG_LDW(p.W4, ((long)pF * KS4 + ks) * 2), w1 = IG_LDW(p.W4, ((long)pF * KS4 + ks) * 2 + 1);
+                const bf16x8 w2 = IG_LDW(p.W4, ((long)pH * KS4 + ks) * 2), w3 = IG_LDW(p.W4, ((long)pH * KS4 + ks) * 2 + 1);
+#pragma unroll
+                for (int rr = 0; rr < RB; ++rr) {
+                    const int r = (((rr + odd * RBH) & (RB - 1)) * 16) + li;
+                    const bf16x8 a = IG_LDS(regB + r * (C4 * 2) + (ig_pchunk(r, ks * 4 + lg) << 4));
+                    aF[0][rr] = IG_MMA(w0, a, aF[0][rr]);
+                    aF[1][rr] = IG_MMA(w1, a, aF[1][rr]);
+                    if (rr < RBH) { aH[0][rr] = IG_MMA(w2, a, aH[0][rr]); aH[1][rr] = IG_MMA(w3, a, aH[1][rr]); }
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr) {
+                const int gr = gro[rr];
+                if (gr < 0) continue;
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)aF[0][rr][e]; o[4 + e] = (bf16_t)aF[1][rr][e]; }
+                IG_ST(o, p.dM + (long)gr * CI + pF * 32 + lg * 8);
+                if (rr < RBH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)aH[0][rr][e]; o[4 + e] = (bf16_t)aH[1][rr][e]; }
+                    IG_ST(o, p.dM + (long)gr * CI + pH * 32 + lg * 8);
+                }
             }
         }
     }
@@ -846,6 +905,7 @@ struct IgPack {
     bf16_t *B1o, *B2o, *B3o;                 // optional: the data-gradient operands of integ_bwd_kernel (same shapes, transposed weights)
     const float* Wt2i; bf16_t* Wto;          // optional: temporal2integration linear_fuse [Ci][C4][2] -> [Ci][2 C4] in fragment order (T2I in front of the forward)
     const float* Wi2t; bf16_t* Wio;          // optional: integration2temporal linear_fuse [C4][Ci] in fragment order (I2T behind it)
+    bf16_t* W4o;                             // optional: its transpose [Ci][C4] (I2T backward behind the fused backward)
 };
 
 template <int CI, int C4>
@@ -888,23 +948,24 @@ __global__ __launch_bounds__(256) void integ_pack_kernel(const IgPack* __restric
         *reinterpret_cast<bf16x8*>(dst + (long)piece * 8) = o;
         return;
     }
-    constexpr int KST = 2 * C4 / 32, FT = NP3 * KST * 2, FI = NP2 * KS1 * 2, TBLK = ((FT + FI) * 64 + 255) / 256;
-    if ((int)blockIdx.x < 2 * PBLK + TBLK) {               // T2I weight: Wt[n][a C4 + c] = W[n][c][a]; behind it the I2T weight [C4][Ci] as it is
+    constexpr int KST = 2 * C4 / 32, KS4 = C4 / 32, FT = NP3 * KST * 2, FI = NP2 * KS1 * 2, F4 = NP3 * KS4 * 2, TBLK = ((FT + FI + F4) * 64 + 255) / 256;
+    if ((int)blockIdx.x < 2 * PBLK + TBLK) {               // T2I weight: Wt[n][a C4 + c] = W[n][c][a]; the I2T weight [C4][Ci] as it is; its transpose [Ci][C4]
         int piece = ((int)blockIdx.x - 2 * PBLK) * 256 + tid;
-        if (piece >= (FT + FI) * 64) return;
-        const bool second = piece >= FT * 64;
-        if (second) piece -= FT * 64;
-        if (second ? !d.Wio : !d.Wto) return;
-        const int KS = second ? KS1 : KST;
+        if (piece >= (FT + FI + F4) * 64) return;
+        int which = 0;
+        if (piece >= FT * 64) { piece -= FT * 64; which = 1; if (piece >= FI * 64) { piece -= FI * 64; which = 2; } }
+        bf16_t* dst = which == 0 ? d.Wto : (which == 1 ? d.Wio : d.W4o);
+        if (!dst) return;
+        const int KS = which == 0 ? KST : (which == 1 ? KS1 : KS4);
         const int l = piece & 63, frag = piece >> 6, q = frag & 1, pk = frag >> 1, ks = pk % KS, pr = pk / KS;
         const int n = 32 * pr + 8 * ((l & 15) >> 2) + 4 * q + (l & 3), k0 = 32 * ks + 8 * (l >> 4);
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = k0 + e, a = k / C4, c = k - a * C4;
-            o[e] = (bf16_t)(second ? d.Wi2t[(long)n * CI + k] : d.Wt2i[((long)n * C4 + c) * 2 + a]);
+            o[e] = (bf16_t)(which == 0 ? d.Wt2i[((long)n * C4 + c) * 2 + a] : (which == 1 ? d.Wi2t[(long)n * CI + k] : d.Wi2t[(long)k * CI + n]));
         }
-        *reinterpret_cast<bf16x8*>((second ? d.Wio : d.Wto) + (long)piece * 8) = o;
+        *reinterpret_cast<bf16x8*>(dst + (long)piece * 8) = o;
         return;
     }
     // biases: b1 = [ba + Wa beta_a ; bb + Wb beta_b] (the LayerNorm shift through the weights), b2, b3 = bp + bt
@@ -1010,6 +1071,7 @@ extern "C" int64_t dist_op_integration_pack_elems(int Ci, int C4, int which) {
         case 5: return Ci;                      // b3
         case 6: return (int64_t)Ci * 2 * C4;    // Wt (bf16 elements): the T2I weight in front of the forward
         case 7: return (int64_t)C4 * Ci;        // Wi: the I2T weight behind it
+        case 8: return (int64_t)Ci * C4;        // W4: its transpose, the I2T backward behind the fused backward
         default: return -1;
     }
 }
@@ -1024,7 +1086,7 @@ static IgPack ig_pack_of(const dist_integ_pack_args& a) {
     d.b1o = a.b1; d.b2o = a.b2; d.b3o = a.b3;
     d.B1o = static_cast<bf16_t*>(a.B1); d.B2o = static_cast<bf16_t*>(a.B2); d.B3o = static_cast<bf16_t*>(a.B3);
     d.Wt2i = a.t2i_w; d.Wto = static_cast<bf16_t*>(a.Wt);
-    d.Wi2t = a.i2t_w; d.Wio = static_cast<bf16_t*>(a.Wi);
+    d.Wi2t = a.i2t_w; d.Wio = static_cast<bf16_t*>(a.Wi); d.W4o = static_cast<bf16_t*>(a.W4);
     return d;
 }
 
@@ -1036,7 +1098,7 @@ int dist_k_integ_pack(const void* descs_dev, const dist_integ_pack_args* one, in
     if (Ci != 384 || C4 != 96 || n <= 0) return DIST_ERR_ARG;
     constexpr int CI = 384, C4c = 96, CC = CI + C4c;
     constexpr int PIECES = ((CC / 32) * (CI / 32) * 2 + (C4c / 32) * (3 * C4c / 32) * 2 + (CI / 32) * (CC / 32) * 2) * 64;
-    const int pblk = (PIECES + 255) / 256, bblk = (CC + C4c + CI + 3) / 4, tblk = (((CI / 32) * (2 * C4c / 32) * 2 + (C4c / 32) * (CI / 32) * 2) * 64 + 255) / 256;
+    const int pblk = (PIECES + 255) / 256, bblk = (CC + C4c + CI + 3) / 4, tblk = (((CI / 32) * (2 * C4c / 32) * 2 + (C4c / 32) * (CI / 32) * 2 + (CI / 32) * (C4c / 32) * 2) * 64 + 255) / 256;
     IgPack d{};
     if (!descs_dev) { if (!one || n != 1) return DIST_ERR_ARG; d = ig_pack_of(*one); }
     hipLaunchKernelGGL((integ_pack_kernel<CI, C4c>), dim3((unsigned)(2 * pblk + tblk + bblk), (unsigned)n), dim3(256), 0, s, static_cast<const IgPack*>(descs_dev), d);
@@ -1070,6 +1132,8 @@ extern "C" int dist_op_integration_bwd(const dist_integ_bwd_args* a, void* strea
     k.dMp = static_cast<bf16_t*>(a->dMp); k.dM = static_cast<bf16_t*>(a->dM_copy);
     k.add_dR = a->add_dR ? 1 : 0;
     k.dm_cls = a->dM_cls_only ? 1 : 0;
+    k.dXn = static_cast<const bf16_t*>(a->i2t_dXnext); k.W4 = static_cast<const bf16_t*>(a->i2t_B); k.dY = static_cast<bf16_t*>(a->i2t_dY);
+    if (k.dXn && !(k.W4 && k.dY && k.dM)) return DIST_ERR_ARG;          // the I2T term needs its operand, the dY output and dM_copy (which then receives dM, not a copy)
     k.clips = a->clips; k.t = a->t; k.L = a->L;
     const int TOK = BM / a->t;
     int sh = 0;

@@ -170,6 +170,9 @@ def integration_pack(w, bwd=False, t2i_w=None, i2t_w=None):
         keep.append(i2t_w.float().contiguous())
         out["Wi"] = torch.empty(lib.dist_op_integration_pack_elems(Ci, C4, 7), dtype=torch.bfloat16, device=dev)
         a.i2t_w, a.Wi = _p(keep[-1]), _p(out["Wi"])
+        if bwd:
+            out["W4"] = torch.empty(lib.dist_op_integration_pack_elems(Ci, C4, 8), dtype=torch.bfloat16, device=dev)
+            a.W4 = _p(out["W4"])
     L.check(lib.dist_op_integration_pack(C.byref(a), _stream()))
     torch.cuda.current_stream().synchronize()          # (the fp32 copies in `keep` must outlive the launch)
     return out
@@ -216,7 +219,7 @@ def integration_fwd(Mp, pk, clips, t, Ltok, *, ln=None, train=True, tk=3, eps=1e
     return out
 
 
-def integration_bwd(dR, saved, pk, clips, t, Ltok, *, add_dR=False, copy=False, tk=3):
+def integration_bwd(dR, saved, pk, clips, t, Ltok, *, add_dR=False, copy=False, tk=3, i2t_dXnext=None):
     """Fused IntegrationNetwork data-gradient backward (dist_op_integration_bwd).  `saved`: what integration_fwd(..., xhat=True) returned;
     `pk` from integration_pack(w, bwd=True).  Returns dict(dzf_dh2, dh1, dMp [, dM])."""
     rows, Ci = dR.shape
@@ -229,6 +232,10 @@ def integration_bwd(dR, saved, pk, clips, t, Ltok, *, add_dR=False, copy=False, 
     a.dR, a.zf_h2, a.Xhat, a.rstd = _p(dR), _p(saved["zf_h2"]), _p(saved["Xhat"]), _p(saved["rstd"])
     a.B1, a.B2, a.B3 = _p(pk["B1"]), _p(pk["B2"]), _p(pk["B3"])
     a.dzf_dh2, a.dh1, a.dMp, a.dM_copy = _p(out["dzf_dh2"]), _p(out["dh1"]), _p(out["dMp"]), _p(out.get("dM"))
+    if i2t_dXnext is not None:                          # I2T backward behind it: "dM" = dM' + [0 ; dY Wi], "dY" = the frame-pair sums of dX_next
+        out["dM"] = torch.empty_like(dR)
+        out["dY"] = torch.zeros(clips * t * (Ltok - 1), C4, dtype=dR.dtype, device=dR.device)
+        a.dM_copy, a.i2t_dXnext, a.i2t_B, a.i2t_dY = _p(out["dM"]), _p(i2t_dXnext), _p(pk["W4"]), _p(out["dY"])
     a.add_dR, a.clips, a.t, a.L, a.Ci, a.C4, a.tk, a.dtype = int(add_dR), clips, t, Ltok, Ci, C4, tk, L.BF16
     L.check(L.load().dist_op_integration_bwd(C.byref(a), _stream()))
     return out

@@ -282,6 +282,7 @@ typedef struct dist_integ_pack_args {
     void* B1; void* B2; void* B3;   /* optional (all or none): the operands of dist_op_integration_bwd, sized like W1 / W2 / W3 */
     const float* t2i_w; void* Wt;   /* optional: temporal2integration_nets.i.linear_fuse.weight [Ci][C4][2][1][1] -> the t2i_W operand (which = 6 elements) */
     const float* i2t_w; void* Wi;   /* optional: integration2temporal_nets.i.linear_fuse.weight [C4][Ci] -> the i2t_W operand (which = 7) */
+    void* W4;                       /* optional (with i2t_w): its transpose, the i2t_B operand of dist_op_integration_bwd (which = 8) */
 } dist_integ_pack_args;
 int64_t dist_op_integration_pack_elems(int Ci, int C4, int which);
 /* Fused data-gradient backward of the IntegrationNetwork (integ.hip), same geometries as dist_op_integration_fwd:
@@ -297,6 +298,10 @@ typedef struct dist_integ_bwd_args {
     /* optional layout of the three gradient outputs (0 / NULL = the defaults above): row pitch of dzf_dh2, a separate place and pitch for its dh2 columns,
      * row pitch of dh1 - e.g. one buffer with rows [dzf | dh1 | dh2] so that ONE weight-gradient GEMM over [dzf | dh1] serves both Linears that read xhat */
     int ld_dzf; void* dh2; int ld_dh2; int ld_dh1;
+    /* I2T backward behind it (dist.py:100-105 through autograd; alpha = 2, temporal width = C4): with i2t_dXnext [clips*2t*(L-1)][C4] (the gradient w.r.t. the NEXT
+     * layer's temporal map) the kernel forms dY = dX_next[2f] + dX_next[2f+1] (written to i2t_dY [clips*t*(L-1)][C4]: the I2T weight gradient reads it) and
+     * dM_copy = dM' + [0 ; dY i2t_B^T] - the whole gradient w.r.t. M.  i2t_B from dist_op_integration_pack (W4). */
+    const void* i2t_dXnext; const void* i2t_B; void* i2t_dY;
     int dM_cls_only;         /* dM_copy only receives the cls rows (token 0 of every frame): for a caller whose next GEMM writes the other rows of that tensor anyway */
 } dist_integ_bwd_args;
 int dist_op_integration_bwd(const dist_integ_bwd_args* a, void* stream);

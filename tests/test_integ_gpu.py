@@ -372,3 +372,33 @@ def test_fused_integration_refuses_what_it_cannot_take(gpu_lib):
     b = L.IntegBwdArgs()
     assert lib.dist_op_integration_bwd(C.byref(b), None) == -1                                       # nothing bound
     assert lib.dist_op_integration_fwd(None, None) == -1
+
+
+@pytest.mark.parametrize("clips,t,Ltok", [(1, 8, 17), (2, 8, 197), (1, 16, 40)])
+def test_fused_integration_backward_with_i2t_behind(gpu_lib, clips, t, Ltok):
+    """dM = dM' + [0 ; (dX_next[2f] + dX_next[2f+1]) Wi] (dist.py:100-105 through autograd) inside the backward kernel: dY bit for bit what the pair-sum
+    kernel gives, dM one bf16 rounding from dM' (as stored) + the fp64 product"""
+    from dist_amd import ops
+    w, Mp = make(clips, t, Ltok, seed=3 + Ltok)
+    g = torch.Generator().manual_seed(17)
+    N = Ltok - 1
+    dR = (torch.randn(Mp.shape, generator=g) * 0.5).to(torch.bfloat16)
+    dXn = (torch.randn(clips * 2 * t * N, C4, generator=g) * 0.3).to(torch.bfloat16)
+    Wi = torch.randn(C4, CI, generator=g) * CI ** -0.5
+    wc = {k: v.cuda() for k, v in w.items()}
+    pk = ops.integration_pack(wc, bwd=True, i2t_w=Wi.cuda())
+    saved = ops.integration_fwd(Mp.cuda(), pk, clips, t, Ltok, xhat=True)
+    plain = ops.integration_bwd(dR.cuda(), saved, pk, clips, t, Ltok)
+    out = ops.integration_bwd(dR.cuda(), saved, pk, clips, t, Ltok, i2t_dXnext=dXn.cuda())
+    torch.cuda.synchronize()
+    for k in ("dzf_dh2", "dh1", "dMp"):
+        assert torch.equal(out[k], plain[k]), k
+    dY = (dXn.float().reshape(clips, t, 2, N, C4).sum(2)).to(torch.bfloat16).reshape(-1, C4)
+    assert torch.equal(out["dY"].cpu(), dY)
+    term = dY.double().reshape(clips, t, N, C4) @ Wi.to(torch.bfloat16).double()
+    want = plain["dMp"].double().cpu().reshape(clips, t, Ltok, CI).clone()
+    want[:, :, 1:] += term
+    want = want.reshape(-1, CI)
+    got = out["dM"].double().cpu()
+    assert float((got - want).abs().max()) <= 2 ** -7 * float(want.abs().max()) + 1e-6
+    assert torch.equal(out["dM"].reshape(clips, t, Ltok, CI)[:, :, 0], plain["dMp"].reshape(clips, t, Ltok, CI)[:, :, 0])     # cls rows: no I2T path
