@@ -553,6 +553,8 @@ struct IgBwdArgs {
     // I2T backward behind the LayerNorm backward (dist.py:100-105 through autograd): dY = dX_next[2f] + dX_next[2f+1] (written out: the I2T weight gradient reads it),
     // dM = dM' + dY Wi on the patch rows - dM then holds the WHOLE gradient w.r.t. M, not a copy of dM'
     const bf16_t *dXn, *W4; bf16_t* dY;
+    // T2I backward behind that (dist.py:81-86 through autograd, and through X' = g(p)): dp[2f+a][j-1] = (dX_next[2f+a][j-1] + dM'[f][j] W5_a^T) g'(p[2f+a][j-1])
+    const bf16_t *W5, *pact; bf16_t* dp;
     int clips, t, L, groups, tokshift;
 };
 
@@ -752,7 +754,7 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_bwd_kernel(con
             if (ks + 2 < KS3) ldw(w, ks + 2);
             __builtin_amdgcn_sched_barrier(0);
         }
-        const bool i2tb = p.dXn != nullptr;                // (kernel argument: the same for every workgroup)
+        const bool i2tb = p.dY != nullptr, t2ib = p.dp != nullptr;      // (kernel arguments: the same for every workgroup)
         if (i2tb) {
             // dY rows of this tile -> region B (free since the barrier inside the K loop: stage 2 was its last reader) and to memory; visible after the
             // two barriers of the LayerNorm backward below
@@ -838,6 +840,7 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_bwd_kernel(con
             IG_ST(o, p.dMp + (long)gr * CI + pF * 32 + lg * 8);
             const bool to_dm = p.dM && !i2tb && (!p.dm_cls || ((grp << tsh) + (r & tokmask)) == 0);
             if (to_dm) IG_ST(o, p.dM + (long)gr * CI + pF * 32 + lg * 8);
+            if (t2ib) *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((pF * 4 + lg) ^ li) << 4)) = o;     // dM' tile: the A operand of the T2I product at the end
 #pragma unroll
             for (int e = 0; e < 4; ++e) { aF[0][rr][e] = (float)o[e]; aF[1][rr][e] = (float)o[4 + e]; }       // (the I2T term below accumulates on the stored dM')
             if (rr < RBH) {
@@ -855,6 +858,7 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_bwd_kernel(con
                 for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
                 IG_ST(o, p.dMp + (long)gr * CI + pH * 32 + lg * 8);
                 if (to_dm) IG_ST(o, p.dM + (long)gr * CI + pH * 32 + lg * 8);
+                if (t2ib) *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((pH * 4 + lg) ^ li) << 4)) = o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { aH[0][rr][e] = (float)o[e]; aH[1][rr][e] = (float)o[4 + e]; }
             }
@@ -890,6 +894,56 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_bwd_kernel(con
                 }
             }
         }
+        if (t2ib) {
+            // ---------------- T2I backward: dp = (dX_next + dM' W5^T) g'(p) on the two temporal frames of every patch row of the tile.  N = 2 C4 columns = 6 pairs,
+            // 24 items (pair, quarter of the 16-row blocks), three per wave; A = the dM' tile in region A.
+            __syncthreads();
+            constexpr int NP5 = 2 * C4 / 32, RBQ = RB / 4;
+            const int N = L - 1, T = 2 * t;
+#pragma unroll 1
+            for (int it = 0; it < 3; ++it) {
+                const int id = wid * 3 + it, p5 = id >> 2, qr = id & 3;
+                f32x4 a5[2][RBQ];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int rb = 0; rb < RBQ; ++rb) a5[q][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                bf16x8 w5[2][2];
+                w5[0][0] = IG_LDW(p.W5, ((long)p5 * KS1) * 2); w5[0][1] = IG_LDW(p.W5, ((long)p5 * KS1) * 2 + 1);
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) {
+                    if (ks + 1 < KS1) { w5[(ks + 1) & 1][0] = IG_LDW(p.W5, ((long)p5 * KS1 + ks + 1) * 2); w5[(ks + 1) & 1][1] = IG_LDW(p.W5, ((long)p5 * KS1 + ks + 1) * 2 + 1); }
+#pragma unroll
+                    for (int rb = 0; rb < RBQ; ++rb) {
+                        const int r = (qr * RBQ + rb) * 16 + li;
+                        const bf16x8 a = IG_LDS(regA + r * (CI * 2) + (((ks * 4 + lg) ^ li) << 4));
+                        a5[0][rb] = IG_MMA(w5[ks & 1][0], a, a5[0][rb]);
+                        a5[1][rb] = IG_MMA(w5[ks & 1][1], a, a5[1][rb]);
+                    }
+                }
+                const int fa = p5 / (NP5 / 2), c0 = (p5 % (NP5 / 2)) * 32 + lg * 8;       // temporal frame 2f + fa, columns c0 .. c0 + 7
+#pragma unroll
+                for (int rb = 0; rb < RBQ; ++rb) {
+                    const int r = (qr * RBQ + rb) * 16 + li;
+                    const int f = r >> tsh, j = (grp << tsh) + (r & tokmask);
+                    if (j < 1 || j >= L) continue;
+                    const long row = ((long)(clip * T + 2 * f + fa) * N + (j - 1)) * C4 + c0;
+                    const bf16x8 pv = *reinterpret_cast<const bf16x8*>(p.pact + row);
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = a5[0][rb][e]; v[4 + e] = a5[1][rb][e]; }
+                    if (p.dXn) {
+                        const bf16x8 dx = *reinterpret_cast<const bf16x8*>(p.dXn + row);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)dx[e];
+                    }
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(v[e] * qgelu_grad_t<bf16_t>((float)pv[e]));
+                    IG_ST(o, p.dp + row);
+                }
+            }
+        }
     }
 }
 
@@ -906,6 +960,7 @@ struct IgPack {
     const float* Wt2i; bf16_t* Wto;          // optional: temporal2integration linear_fuse [Ci][C4][2] -> [Ci][2 C4] in fragment order (T2I in front of the forward)
     const float* Wi2t; bf16_t* Wio;          // optional: integration2temporal linear_fuse [C4][Ci] in fragment order (I2T behind it)
     bf16_t* W4o;                             // optional: its transpose [Ci][C4] (I2T backward behind the fused backward)
+    bf16_t* W5o;                             // optional: the T2I weight as [2 C4][Ci] (row a C4 + c = W[:, c, a]): T2I backward behind that
 };
 
 template <int CI, int C4>
@@ -948,22 +1003,27 @@ __global__ __launch_bounds__(256) void integ_pack_kernel(const IgPack* __restric
         *reinterpret_cast<bf16x8*>(dst + (long)piece * 8) = o;
         return;
     }
-    constexpr int KST = 2 * C4 / 32, KS4 = C4 / 32, FT = NP3 * KST * 2, FI = NP2 * KS1 * 2, F4 = NP3 * KS4 * 2, TBLK = ((FT + FI + F4) * 64 + 255) / 256;
+    constexpr int KST = 2 * C4 / 32, KS4 = C4 / 32, FT = NP3 * KST * 2, FI = NP2 * KS1 * 2, F4 = NP3 * KS4 * 2, F5 = (2 * C4 / 32) * KS1 * 2, TBLK = ((FT + FI + F4 + F5) * 64 + 255) / 256;
     if ((int)blockIdx.x < 2 * PBLK + TBLK) {               // T2I weight: Wt[n][a C4 + c] = W[n][c][a]; the I2T weight [C4][Ci] as it is; its transpose [Ci][C4]
         int piece = ((int)blockIdx.x - 2 * PBLK) * 256 + tid;
-        if (piece >= (FT + FI + F4) * 64) return;
+        if (piece >= (FT + FI + F4 + F5) * 64) return;
         int which = 0;
-        if (piece >= FT * 64) { piece -= FT * 64; which = 1; if (piece >= FI * 64) { piece -= FI * 64; which = 2; } }
-        bf16_t* dst = which == 0 ? d.Wto : (which == 1 ? d.Wio : d.W4o);
+        if (piece >= FT * 64) { piece -= FT * 64; which = 1; if (piece >= FI * 64) { piece -= FI * 64; which = 2; if (piece >= F4 * 64) { piece -= F4 * 64; which = 3; } } }
+        bf16_t* dst = which == 0 ? d.Wto : (which == 1 ? d.Wio : (which == 2 ? d.W4o : d.W5o));
         if (!dst) return;
-        const int KS = which == 0 ? KST : (which == 1 ? KS1 : KS4);
+        const int KS = which == 0 ? KST : (which == 2 ? KS4 : KS1);
         const int l = piece & 63, frag = piece >> 6, q = frag & 1, pk = frag >> 1, ks = pk % KS, pr = pk / KS;
         const int n = 32 * pr + 8 * ((l & 15) >> 2) + 4 * q + (l & 3), k0 = 32 * ks + 8 * (l >> 4);
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = k0 + e, a = k / C4, c = k - a * C4;
-            o[e] = (bf16_t)(which == 0 ? d.Wt2i[((long)n * C4 + c) * 2 + a] : (which == 1 ? d.Wi2t[(long)n * CI + k] : d.Wi2t[(long)k * CI + n]));
+            float v;
+            if (which == 0) v = d.Wt2i[((long)n * C4 + c) * 2 + a];
+            else if (which == 1) v = d.Wi2t[(long)n * CI + k];
+            else if (which == 2) v = d.Wi2t[(long)k * CI + n];
+            else v = d.Wt2i[((long)k * C4 + (n % C4)) * 2 + n / C4];          // W5[a C4 + c][k] = W[k][c][a]
+            o[e] = (bf16_t)v;
         }
         *reinterpret_cast<bf16x8*>(dst + (long)piece * 8) = o;
         return;
@@ -1072,6 +1132,7 @@ extern "C" int64_t dist_op_integration_pack_elems(int Ci, int C4, int which) {
         case 6: return (int64_t)Ci * 2 * C4;    // Wt (bf16 elements): the T2I weight in front of the forward
         case 7: return (int64_t)C4 * Ci;        // Wi: the I2T weight behind it
         case 8: return (int64_t)Ci * C4;        // W4: its transpose, the I2T backward behind the fused backward
+        case 9: return (int64_t)2 * C4 * Ci;    // W5: the T2I weight transposed, the T2I backward behind that
         default: return -1;
     }
 }
@@ -1086,7 +1147,7 @@ static IgPack ig_pack_of(const dist_integ_pack_args& a) {
     d.b1o = a.b1; d.b2o = a.b2; d.b3o = a.b3;
     d.B1o = static_cast<bf16_t*>(a.B1); d.B2o = static_cast<bf16_t*>(a.B2); d.B3o = static_cast<bf16_t*>(a.B3);
     d.Wt2i = a.t2i_w; d.Wto = static_cast<bf16_t*>(a.Wt);
-    d.Wi2t = a.i2t_w; d.Wio = static_cast<bf16_t*>(a.Wi); d.W4o = static_cast<bf16_t*>(a.W4);
+    d.Wi2t = a.i2t_w; d.Wio = static_cast<bf16_t*>(a.Wi); d.W4o = static_cast<bf16_t*>(a.W4); d.W5o = static_cast<bf16_t*>(a.W5);
     return d;
 }
 
@@ -1098,7 +1159,7 @@ int dist_k_integ_pack(const void* descs_dev, const dist_integ_pack_args* one, in
     if (Ci != 384 || C4 != 96 || n <= 0) return DIST_ERR_ARG;
     constexpr int CI = 384, C4c = 96, CC = CI + C4c;
     constexpr int PIECES = ((CC / 32) * (CI / 32) * 2 + (C4c / 32) * (3 * C4c / 32) * 2 + (CI / 32) * (CC / 32) * 2) * 64;
-    const int pblk = (PIECES + 255) / 256, bblk = (CC + C4c + CI + 3) / 4, tblk = (((CI / 32) * (2 * C4c / 32) * 2 + (C4c / 32) * (CI / 32) * 2 + (CI / 32) * (C4c / 32) * 2) * 64 + 255) / 256;
+    const int pblk = (PIECES + 255) / 256, bblk = (CC + C4c + CI + 3) / 4, tblk = (((CI / 32) * (2 * C4c / 32) * 2 + (C4c / 32) * (CI / 32) * 2 + (CI / 32) * (C4c / 32) * 2 + (2 * C4c / 32) * (CI / 32) * 2) * 64 + 255) / 256;
     IgPack d{};
     if (!descs_dev) { if (!one || n != 1) return DIST_ERR_ARG; d = ig_pack_of(*one); }
     hipLaunchKernelGGL((integ_pack_kernel<CI, C4c>), dim3((unsigned)(2 * pblk + tblk + bblk), (unsigned)n), dim3(256), 0, s, static_cast<const IgPack*>(descs_dev), d);
@@ -1133,7 +1194,9 @@ extern "C" int dist_op_integration_bwd(const dist_integ_bwd_args* a, void* strea
     k.add_dR = a->add_dR ? 1 : 0;
     k.dm_cls = a->dM_cls_only ? 1 : 0;
     k.dXn = static_cast<const bf16_t*>(a->i2t_dXnext); k.W4 = static_cast<const bf16_t*>(a->i2t_B); k.dY = static_cast<bf16_t*>(a->i2t_dY);
-    if (k.dXn && !(k.W4 && k.dY && k.dM)) return DIST_ERR_ARG;          // the I2T term needs its operand, the dY output and dM_copy (which then receives dM, not a copy)
+    if ((k.dY != nullptr) != (k.dXn != nullptr && k.W4 != nullptr) || (k.dY && !k.dM)) return DIST_ERR_ARG;   // the I2T term: dX_next, its operand, the dY output and dM_copy (which then receives dM) - all or none
+    k.W5 = static_cast<const bf16_t*>(a->t2i_B); k.pact = static_cast<const bf16_t*>(a->t2i_p); k.dp = static_cast<bf16_t*>(a->t2i_dp);
+    if (k.dp && !(k.W5 && k.pact)) return DIST_ERR_ARG;
     k.clips = a->clips; k.t = a->t; k.L = a->L;
     const int TOK = BM / a->t;
     int sh = 0;

@@ -83,14 +83,14 @@ class IntegUnfoldArgs(C.Structure):
 class IntegPackArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ffn_fc_w", "ffn_fc_b", "ln_w", "ln_b", "tf_fc1_w", "tf_fc1_b", "ln_t_w", "ln_t_b", "tf_fc2_w", "tf_fc2_b",
                                           "ffn_proj_w", "ffn_proj_b", "tf_proj_w", "tf_proj_b", "W1", "W2", "W3", "b1", "b2", "b3")] + \
-               [("Ci", C.c_int), ("C4", C.c_int)] + [(n, C.c_void_p) for n in ("B1", "B2", "B3", "t2i_w", "Wt", "i2t_w", "Wi", "W4")]
+               [("Ci", C.c_int), ("C4", C.c_int)] + [(n, C.c_void_p) for n in ("B1", "B2", "B3", "t2i_w", "Wt", "i2t_w", "Wi", "W4", "W5")]
 
 
 class IntegBwdArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dR", "zf_h2", "Xhat", "rstd", "B1", "B2", "B3", "dzf_dh2", "dh1", "dMp", "dM_copy")] + \
                [(n, C.c_int) for n in ("add_dR", "clips", "t", "L", "Ci", "C4", "tk", "dtype")] + \
                [("ld_dzf", C.c_int), ("dh2", C.c_void_p), ("ld_dh2", C.c_int), ("ld_dh1", C.c_int)] + \
-               [(n, C.c_void_p) for n in ("i2t_dXnext", "i2t_B", "i2t_dY")] + [("dM_cls_only", C.c_int)]
+               [(n, C.c_void_p) for n in ("i2t_dXnext", "i2t_B", "i2t_dY", "t2i_B", "t2i_p", "t2i_dp")] + [("dM_cls_only", C.c_int)]
 
 
 class AdamwSeg(C.Structure):

@@ -166,6 +166,9 @@ def integration_pack(w, bwd=False, t2i_w=None, i2t_w=None):
         keep.append(t2i_w.float().contiguous())
         out["Wt"] = torch.empty(lib.dist_op_integration_pack_elems(Ci, C4, 6), dtype=torch.bfloat16, device=dev)
         a.t2i_w, a.Wt = _p(keep[-1]), _p(out["Wt"])
+        if bwd:
+            out["W5"] = torch.empty(lib.dist_op_integration_pack_elems(Ci, C4, 9), dtype=torch.bfloat16, device=dev)
+            a.W5 = _p(out["W5"])
     if i2t_w is not None:                               # integration2temporal linear_fuse.weight [C4][Ci] -> the I2T operand behind it
         keep.append(i2t_w.float().contiguous())
         out["Wi"] = torch.empty(lib.dist_op_integration_pack_elems(Ci, C4, 7), dtype=torch.bfloat16, device=dev)
@@ -219,7 +222,7 @@ def integration_fwd(Mp, pk, clips, t, Ltok, *, ln=None, train=True, tk=3, eps=1e
     return out
 
 
-def integration_bwd(dR, saved, pk, clips, t, Ltok, *, add_dR=False, copy=False, tk=3, i2t_dXnext=None):
+def integration_bwd(dR, saved, pk, clips, t, Ltok, *, add_dR=False, copy=False, tk=3, i2t_dXnext=None, t2i_p=None, t2i_dXnext=None):
     """Fused IntegrationNetwork data-gradient backward (dist_op_integration_bwd).  `saved`: what integration_fwd(..., xhat=True) returned;
     `pk` from integration_pack(w, bwd=True).  Returns dict(dzf_dh2, dh1, dMp [, dM])."""
     rows, Ci = dR.shape
@@ -236,6 +239,11 @@ def integration_bwd(dR, saved, pk, clips, t, Ltok, *, add_dR=False, copy=False, 
         out["dM"] = torch.empty_like(dR)
         out["dY"] = torch.zeros(clips * t * (Ltok - 1), C4, dtype=dR.dtype, device=dR.device)
         a.dM_copy, a.i2t_dXnext, a.i2t_B, a.i2t_dY = _p(out["dM"]), _p(i2t_dXnext), _p(pk["W4"]), _p(out["dY"])
+    if t2i_p is not None:                               # T2I backward behind that: "dp" = (dX_next + conv^T(dM'[:, 1:])) * g'(p); t2i_dXnext None = the last layer
+        out["dp"] = torch.zeros_like(t2i_p)
+        a.t2i_B, a.t2i_p, a.t2i_dp = _p(pk["W5"]), _p(t2i_p), _p(out["dp"])
+        if i2t_dXnext is None and t2i_dXnext is not None:
+            a.i2t_dXnext = _p(t2i_dXnext)
     a.add_dR, a.clips, a.t, a.L, a.Ci, a.C4, a.tk, a.dtype = int(add_dR), clips, t, Ltok, Ci, C4, tk, L.BF16
     L.check(L.load().dist_op_integration_bwd(C.byref(a), _stream()))
     return out

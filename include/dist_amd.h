@@ -283,6 +283,7 @@ typedef struct dist_integ_pack_args {
     const float* t2i_w; void* Wt;   /* optional: temporal2integration_nets.i.linear_fuse.weight [Ci][C4][2][1][1] -> the t2i_W operand (which = 6 elements) */
     const float* i2t_w; void* Wi;   /* optional: integration2temporal_nets.i.linear_fuse.weight [C4][Ci] -> the i2t_W operand (which = 7) */
     void* W4;                       /* optional (with i2t_w): its transpose, the i2t_B operand of dist_op_integration_bwd (which = 8) */
+    void* W5;                       /* optional (with t2i_w): the T2I weight as [2 C4][Ci], the t2i_B operand of dist_op_integration_bwd (which = 9) */
 } dist_integ_pack_args;
 int64_t dist_op_integration_pack_elems(int Ci, int C4, int which);
 /* Fused data-gradient backward of the IntegrationNetwork (integ.hip), same geometries as dist_op_integration_fwd:
@@ -302,6 +303,9 @@ typedef struct dist_integ_bwd_args {
      * layer's temporal map) the kernel forms dY = dX_next[2f] + dX_next[2f+1] (written to i2t_dY [clips*t*(L-1)][C4]: the I2T weight gradient reads it) and
      * dM_copy = dM' + [0 ; dY i2t_B^T] - the whole gradient w.r.t. M.  i2t_B from dist_op_integration_pack (W4). */
     const void* i2t_dXnext; const void* i2t_B; void* i2t_dY;
+    /* T2I backward behind that (dist.py:81-86 and the activation X' = g(p) through autograd): t2i_dp [clips*2t*(L-1)][C4] = (dX_next + conv_strided^T(dM'[:, 1:])) * g'(t2i_p)
+     * with t2i_p the TemporalNet pre-activation of this layer; dX_next = i2t_dXnext (NULL for the last layer: no such term); t2i_B from dist_op_integration_pack (W5). */
+    const void* t2i_B; const void* t2i_p; void* t2i_dp;
     int dM_cls_only;         /* dM_copy only receives the cls rows (token 0 of every frame): for a caller whose next GEMM writes the other rows of that tensor anyway */
 } dist_integ_bwd_args;
 int dist_op_integration_bwd(const dist_integ_bwd_args* a, void* stream);

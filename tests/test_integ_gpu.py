@@ -402,3 +402,41 @@ def test_fused_integration_backward_with_i2t_behind(gpu_lib, clips, t, Ltok):
     got = out["dM"].double().cpu()
     assert float((got - want).abs().max()) <= 2 ** -7 * float(want.abs().max()) + 1e-6
     assert torch.equal(out["dM"].reshape(clips, t, Ltok, CI)[:, :, 0], plain["dMp"].reshape(clips, t, Ltok, CI)[:, :, 0])     # cls rows: no I2T path
+
+
+def qgelu_grad(x):
+    s = torch.sigmoid(1.702 * x)
+    return s * (1 + 1.702 * x * (1 - s))
+
+
+@pytest.mark.parametrize("clips,t,Ltok,with_next", [(1, 8, 17, True), (2, 8, 197, True), (1, 16, 40, True), (1, 8, 33, False)])
+def test_fused_integration_backward_with_t2i_behind(gpu_lib, clips, t, Ltok, with_next):
+    """dp = (dX_next + conv_strided^T(dM'[:, 1:])) * g'(p) (dist.py:81-86 and X' = g(p) through autograd) inside the backward kernel, with and without the
+    dX_next term (the last layer has none); everything else the kernel writes is unchanged"""
+    from dist_amd import ops
+    w, Mp = make(clips, t, Ltok, seed=5 + Ltok)
+    g = torch.Generator().manual_seed(23)
+    N = Ltok - 1
+    dR = (torch.randn(Mp.shape, generator=g) * 0.5).to(torch.bfloat16)
+    dXn = (torch.randn(clips * 2 * t * N, C4, generator=g) * 0.3).to(torch.bfloat16)
+    pact = (torch.randn(clips * 2 * t * N, C4, generator=g) * 1.2).to(torch.bfloat16)
+    Wt = torch.randn(CI, C4, 2, 1, 1, generator=g) * (2 * C4) ** -0.5
+    Wi = torch.randn(C4, CI, generator=g) * CI ** -0.5
+    wc = {k: v.cuda() for k, v in w.items()}
+    pk = ops.integration_pack(wc, bwd=True, t2i_w=Wt.cuda(), i2t_w=Wi.cuda())
+    saved = ops.integration_fwd(Mp.cuda(), pk, clips, t, Ltok, xhat=True)
+    plain = ops.integration_bwd(dR.cuda(), saved, pk, clips, t, Ltok)
+    kw = dict(i2t_dXnext=dXn.cuda()) if with_next else {}
+    out = ops.integration_bwd(dR.cuda(), saved, pk, clips, t, Ltok, t2i_p=pact.cuda(), **kw)
+    torch.cuda.synchronize()
+    for k in ("dzf_dh2", "dh1", "dMp"):
+        assert torch.equal(out[k], plain[k]), k
+    dMp = plain["dMp"].double().cpu().reshape(clips, t, Ltok, CI)[:, :, 1:]                       # [b, t, N, Ci]
+    Wb = Wt.to(torch.bfloat16).double().reshape(CI, C4, 2)
+    conv = torch.einsum("bjnk,kca->bjanc", dMp, Wb).reshape(-1, C4)                              # rows ((b, j, a), n)
+    pre = conv + (dXn.double() if with_next else 0.0)
+    want = pre * qgelu_grad(pact.double())
+    got = out["dp"].double().cpu()
+    err = float((got - want).abs().max() / want.abs().max())
+    record(f"integ.bwd.t2i.{clips}x{t}x{Ltok}", err)
+    assert err < 6e-3, err                                                                        # one bf16 rounding of the product (and the v_rcp QuickGELU derivative)
