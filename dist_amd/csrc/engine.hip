@@ -64,6 +64,7 @@ struct DistLayer {
     void* ig_Wt = nullptr;                                          // ... and the T2I weight (T2I formed in front of the fused forward)
     void* ig_Wi = nullptr;                                          // ... and the I2T weight (I2T behind it)
     void* ig_W4 = nullptr;                                          // ... and its transpose (I2T backward behind the fused backward)
+    void* ig_W5 = nullptr;                                          // ... and the T2I weight transposed (T2I backward behind that)
 };
 struct XAttn { LNp ln1; Lin q, kv, out; };   // CrossAttentionBlockGenral (in_proj split into q / kv rows)
 struct AdaLayer { long pos = -1; XAttn sp, tm; LNp ln_sp, ln_tm; Lin sp_fc, sp_proj, tm_fc, tm_proj; };
@@ -150,7 +151,7 @@ struct dist_handle {
     void *dR, *dkv, *dkn;
     float* ln_partial = nullptr; long ln_partial_elems = 0;     // per-block parameter-gradient sums of the LayerNorm backward (two-phase, no atomics)
     float* tnb_scratch = nullptr; long tnb_scratch_elems = 0;   // parameter-gradient partial rows of the fused TemporalNet backward
-    bool ig_on = false, ig_xhat = false, ig_bwd = false, ig_t2i = false, ig_i2t = false, ig_i2tb = false, keep_mid = false; void* ig_descs = nullptr;   // ig_xhat: the forward keeps xhat (in the Na buffer) instead of Na / Nb; the weight gradients of the two folded Linears are unfolded afterwards
+    bool ig_on = false, ig_xhat = false, ig_bwd = false, ig_t2i = false, ig_i2t = false, ig_i2tb = false, ig_t2ib = false, keep_mid = false; void* ig_descs = nullptr;   // ig_xhat: the forward keeps xhat (in the Na buffer) instead of Na / Nb; the weight gradients of the two folded Linears are unfolded afterwards
                   // fused IntegrationNetwork forward: taken for this geometry; its pack descriptors (device)
     float* tn_partial[3] = {nullptr, nullptr, nullptr};   // two-phase dW reduction scratch, one per stream that launches dW GEMMs
     long tn_partial_elems = 0;
@@ -249,6 +250,8 @@ void set_fused_flags(dist_handle* h) {
     h->ig_i2t = h->ig_t2i && !(getenv("DIST_AMD_INTEG_I2T") && atoi(getenv("DIST_AMD_INTEG_I2T")) == 0);
     // ... and the I2T backward (pair sums of dX_next, dM = dM' + dY Wi) behind the fused backward: the pair-sum kernel and the I2T data-gradient GEMM are gone
     h->ig_i2tb = h->ig_bwd && c.alpha == 2 && Ct == C4 && !(getenv("DIST_AMD_INTEG_I2T_BWD") && atoi(getenv("DIST_AMD_INTEG_I2T_BWD")) == 0);
+    // ... and the T2I backward (dp = (dX_next + conv^T(dM')) g'(p)) behind that: the T2I data-gradient GEMM leaves the chain as well
+    h->ig_t2ib = h->ig_bwd && c.alpha == 2 && Ct == C4 && !(getenv("DIST_AMD_INTEG_T2I_BWD") && atoi(getenv("DIST_AMD_INTEG_T2I_BWD")) == 0);
     h->keep_mid = getenv("DIST_AMD_KEEP_MID") && atoi(getenv("DIST_AMD_KEEP_MID"));     // debugging: M' of every layer stays readable (dist_debug_tensor "mid.i")
 }
 
@@ -530,6 +533,7 @@ size_t layout_ws(dist_handle* h, char* base) {
             if (h->ig_t2i) l.ig_Wt = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 6) * 2);
             if (h->ig_i2t) l.ig_Wi = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 7) * 2);
             if (h->ig_i2tb) l.ig_W4 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 8) * 2);
+            if (h->ig_t2ib) l.ig_W5 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 9) * 2);
             if (h->ig_bwd) {
                 l.ig_B1 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 0) * 2); l.ig_B2 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 1) * 2);
                 l.ig_B3 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 2) * 2);
@@ -894,7 +898,7 @@ extern "C" int dist_bind(dist_handle* h, float* theta, float* grads, const float
             a.ffn_proj_w = theta + l.ffn_proj.w; a.ffn_proj_b = theta + l.ffn_proj.bias; a.tf_proj_w = theta + l.tf_proj.w; a.tf_proj_b = theta + l.tf_proj.bias;
             a.W1 = l.ig_W1; a.W2 = l.ig_W2; a.W3 = l.ig_W3; a.b1 = l.ig_b1; a.b2 = l.ig_b2; a.b3 = l.ig_b3;
             a.B1 = l.ig_B1; a.B2 = l.ig_B2; a.B3 = l.ig_B3;
-            if (h->ig_t2i) { a.t2i_w = theta + l.t2i.w; a.Wt = l.ig_Wt; }
+            if (h->ig_t2i || h->ig_t2ib) { a.t2i_w = theta + l.t2i.w; a.Wt = l.ig_Wt; a.W5 = l.ig_W5; }
             if (h->ig_i2t || h->ig_i2tb) { a.i2t_w = theta + l.i2t.w; a.Wi = l.ig_Wi; a.W4 = l.ig_W4; }
             a.Ci = h->cfg.integration_dim; a.C4 = h->C4;
             dist_k_integ_pack_desc(&a, host.data() + i * db);
@@ -1547,6 +1551,10 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
             if (h->ig_i2tb && !last && !tchain) {             // I2T backward in the same launch: dY (for the I2T weight gradient) and dM = dM' + [0 ; dY Wi] leave it
                 ba.i2t_dXnext = dXn; ba.i2t_B = l.ig_W4; ba.i2t_dY = q.dY; ba.dM_cls_only = 0;
             }
+            if (h->ig_t2ib && !tchain) {                      // ... and the T2I backward: dp = (dX_next + conv^T(dM')) g'(p), what the TemporalNet backward starts from
+                ba.t2i_B = l.ig_W5; ba.t2i_p = w.p; ba.t2i_dp = q.dp;
+                if (!last) ba.i2t_dXnext = dXn;
+            }
             ba.clips = (int)b; ba.t = t; ba.L = L; ba.Ci = Ci; ba.C4 = C4; ba.tk = l.tf_fc2.taps; ba.dtype = c.dtype;
             RUN(dist_op_integration_bwd(&ba, x.s));
             RUN(fork());
@@ -1586,6 +1594,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
             HIP_CHECK_RET(hipEventRecord(h->ev_dmp[i], A));
             HIP_CHECK_RET(hipStreamWaitEvent(Tc, h->ev_dmp[i], 0));
         }
+        if (!(h->ig_bwd && h->ig_t2ib && !tchain))
         RUN(gemm(xt, q.dMp, Ci, x.pk(l.t2i.pk.b), rowsQ, al * Ct, Ci, 1, q.dp, Ct, nullptr, last ? nullptr : dXn, w.p, nullptr,
                  RM(DIST_RM_SKIPCLS, N), OM(DIST_OM_SPLITCOLS, al, N, Ct), DIST_EPI_MULG_POST));
         // ---- I2T backward (dist.py:100-105): X_next = X' + upsample(Linear(M[1:])) ----

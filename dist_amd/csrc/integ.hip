@@ -775,35 +775,36 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_bwd_kernel(con
                 if (ok) IG_ST(o, p.dY + ((long)(clip * t + f) * N + (j - 1)) * C4 + c * 8);
             }
         }
-        // xhat at this lane's (row, 8 columns) positions; partial row sums S1 = sum dxhat, S2 = sum dxhat xhat
+        // xhat at this lane's (row, 8 columns) positions; partial row sums S1 = sum dxhat, S2 = sum dxhat xhat.  The xhat values are needed again behind
+        // the two barriers of the row sums: they wait in region A (dead once every wave has left the K loop - hence the barrier here), each lane's in the
+        // slot its dM' piece of the same (row, pair) will take, instead of in 48 registers (the kernel spilled 76 bytes per lane with them live)
+        __syncthreads();
         int gro[RB];
-        bf16x8 xF[RB], xH[RBH];
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) {
             gro[rr] = grow_of((((rr + odd * RBH) & (RB - 1)) * 16) + li);
-            const long base = (long)max(gro[rr], 0) * CI;
-            xF[rr] = *reinterpret_cast<const bf16x8*>(p.Xh + base + pF * 32 + lg * 8);
-            if (rr < RBH) xH[rr] = *reinterpret_cast<const bf16x8*>(p.Xh + base + pH * 32 + lg * 8);
-        }
-#pragma unroll
-        for (int rr = 0; rr < RB; ++rr) {
             float s1 = 0.f, s2v = 0.f;
+            const long base = (long)max(gro[rr], 0) * CI;
+            const int r = (((rr + odd * RBH) & (RB - 1)) * 16) + li;
+            const bf16x8 xF1 = *reinterpret_cast<const bf16x8*>(p.Xh + base + pF * 32 + lg * 8);
+            *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((pF * 4 + lg) ^ li) << 4)) = xF1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 s1 += aF[0][rr][e] + aF[1][rr][e];
-                s2v += aF[0][rr][e] * (float)xF[rr][e] + aF[1][rr][e] * (float)xF[rr][4 + e];
+                s2v += aF[0][rr][e] * (float)xF1[e] + aF[1][rr][e] * (float)xF1[4 + e];
             }
             if (rr < RBH) {
+                const bf16x8 xH1 = *reinterpret_cast<const bf16x8*>(p.Xh + base + pH * 32 + lg * 8);
+                *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((pH * 4 + lg) ^ li) << 4)) = xH1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     s1 += aH[0][rr][e] + aH[1][rr][e];
-                    s2v += aH[0][rr][e] * (float)xH[rr][e] + aH[1][rr][e] * (float)xH[rr][4 + e];
+                    s2v += aH[0][rr][e] * (float)xH1[e] + aH[1][rr][e] * (float)xH1[4 + e];
                 }
             }
             s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
             s2v += __shfl_xor(s2v, 16, 64); s2v += __shfl_xor(s2v, 32, 64);
             if (lg == 0) {
-                const int r = (((rr + odd * RBH) & (RB - 1)) * 16) + li;
                 reinterpret_cast<float2*>(red)[wid * BM + r] = make_float2(s1, s2v);
             }
         }
@@ -825,10 +826,11 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_bwd_kernel(con
             const float rs = p.rstd[gr], m1 = cs.x * invC, m2 = cs.y * invC;
             bf16x8 o;
             float v[8];
+            const bf16x8 xFr = *reinterpret_cast<const bf16x8*>(regA + r * (CI * 2) + (((pF * 4 + lg) ^ li) << 4));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                v[e] = rs * (aF[0][rr][e] - m1 - (float)xF[rr][e] * m2);
-                v[4 + e] = rs * (aF[1][rr][e] - m1 - (float)xF[rr][4 + e] * m2);
+                v[e] = rs * (aF[0][rr][e] - m1 - (float)xFr[e] * m2);
+                v[4 + e] = rs * (aF[1][rr][e] - m1 - (float)xFr[4 + e] * m2);
             }
             if (p.add_dR) {
                 const bf16x8 d = *reinterpret_cast<const bf16x8*>(p.dR + (long)gr * CI + pF * 32 + lg * 8);
@@ -844,10 +846,11 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_bwd_kernel(con
 #pragma unroll
             for (int e = 0; e < 4; ++e) { aF[0][rr][e] = (float)o[e]; aF[1][rr][e] = (float)o[4 + e]; }       // (the I2T term below accumulates on the stored dM')
             if (rr < RBH) {
+                const bf16x8 xHr = *reinterpret_cast<const bf16x8*>(regA + r * (CI * 2) + (((pH * 4 + lg) ^ li) << 4));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = rs * (aH[0][rr][e] - m1 - (float)xH[rr][e] * m2);
-                    v[4 + e] = rs * (aH[1][rr][e] - m1 - (float)xH[rr][4 + e] * m2);
+                    v[e] = rs * (aH[0][rr][e] - m1 - (float)xHr[e] * m2);
+                    v[4 + e] = rs * (aH[1][rr][e] - m1 - (float)xHr[4 + e] * m2);
                 }
                 if (p.add_dR) {
                     const bf16x8 d = *reinterpret_cast<const bf16x8*>(p.dR + (long)gr * CI + pH * 32 + lg * 8);

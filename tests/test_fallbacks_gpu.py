@@ -7,7 +7,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KNOBS = ["DIST_AMD_INTEG_FUSED", "DIST_AMD_INTEG_XHAT", "DIST_AMD_INTEG_BWD_FUSED", "DIST_AMD_INTEG_T2I", "DIST_AMD_INTEG_I2T", "DIST_AMD_INTEG_I2T_BWD", "DIST_AMD_INTEG_WG_MERGE", "DIST_AMD_TNET_FUSED",
+KNOBS = ["DIST_AMD_INTEG_FUSED", "DIST_AMD_INTEG_XHAT", "DIST_AMD_INTEG_BWD_FUSED", "DIST_AMD_INTEG_T2I", "DIST_AMD_INTEG_I2T", "DIST_AMD_INTEG_I2T_BWD", "DIST_AMD_INTEG_T2I_BWD", "DIST_AMD_INTEG_WG_MERGE", "DIST_AMD_TNET_FUSED",
          "DIST_AMD_TNET_BWD_FUSED", "DIST_AMD_ATTN_FULLROW"]
 
 
