@@ -132,26 +132,30 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_fwd_kernel(con
         const int m3 = wid >> 1, odd = wid & 1;
         const int pF = 3 * m3 + (odd ? 2 : 0), pH = 3 * m3 + 1;
         // M at this lane's (row, 8 columns) positions (rows beyond L are clamped: finite numbers, never stored)
-        bf16x8 mF[RB], mH[RBH];
+        // ... straight into region A, row-major: the A operand of the I2T product below, and where each lane finds its pieces again (M, then M', then xhat
+        // share one slot per (row, pair): 48 registers less across the products and barriers - the kernel spilled with them live)
+        auto slotF = [&](const int r) __attribute__((always_inline)) { return reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((pF * 4 + lg) ^ li) << 4)); };
+        auto slotH = [&](const int r) __attribute__((always_inline)) { return reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((pH * 4 + lg) ^ li) << 4)); };
         int gro[RB];
-#pragma unroll
-        for (int rr = 0; rr < RB; ++rr) {
-            const int r = (((rr + odd * RBH) & (RB - 1)) * 16) + li;
-            const int f = r >> tsh, j = (grp << tsh) + (r & tokmask);
-            gro[rr] = j < L ? (clip * t + f) * L + j : -1;
-            const long base = (long)((clip * t + f) * L + min(j, L - 1)) * CI;
-            mF[rr] = *reinterpret_cast<const bf16x8*>(p.M + base + pF * 32 + lg * 8);
-            if (rr < RBH) mH[rr] = *reinterpret_cast<const bf16x8*>(p.M + base + pH * 32 + lg * 8);
-        }
-        const bool i2t = p.Xn != nullptr;                  // (kernel argument: the same for every workgroup)
-        if (i2t) {                                         // M also goes to region A row-major: the A operand of the I2T product below
+        {
+            bf16x8 mF[RB], mH[RBH];
 #pragma unroll
             for (int rr = 0; rr < RB; ++rr) {
                 const int r = (((rr + odd * RBH) & (RB - 1)) * 16) + li;
-                *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((pF * 4 + lg) ^ li) << 4)) = mF[rr];
-                if (rr < RBH) *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((pH * 4 + lg) ^ li) << 4)) = mH[rr];
+                const int f = r >> tsh, j = (grp << tsh) + (r & tokmask);
+                gro[rr] = j < L ? (clip * t + f) * L + j : -1;
+                const long base = (long)((clip * t + f) * L + min(j, L - 1)) * CI;
+                mF[rr] = *reinterpret_cast<const bf16x8*>(p.M + base + pF * 32 + lg * 8);
+                if (rr < RBH) mH[rr] = *reinterpret_cast<const bf16x8*>(p.M + base + pH * 32 + lg * 8);
+            }
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr) {
+                const int r = (((rr + odd * RBH) & (RB - 1)) * 16) + li;
+                *slotF(r) = mF[rr];
+                if (rr < RBH) *slotH(r) = mH[rr];
             }
         }
+        const bool i2t = p.Xn != nullptr;                  // (kernel argument: the same for every workgroup)
         __syncthreads();
         if (i2t && wid < NP2 * 2) {
             // ---------------- I2T (dist.py:90-105): Linear on the patch rows of M (C4 columns: item = (column pair, half of the row blocks) as in stage 2), the
@@ -228,6 +232,7 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_fwd_kernel(con
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        __syncthreads();                                   // every wave has read M for the I2T product: the slots may change
         float bF[8], bH[8];
         ig_load8(p.bt + pF * 32 + lg * 8, bF);
         ig_load8(p.bt + pH * 32 + lg * 8, bH);
@@ -241,24 +246,28 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_fwd_kernel(con
             {
                 float cl[8];
                 if (is_cls) ig_load8(p.cls + (long)f * CI + pF * 32 + lg * 8, cl);
+                bf16x8 mv = *slotF(r);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float add = is_cls ? cl[e] : (e < 4 ? aF[0][rr][e] : aF[1][rr][e - 4]) + bF[e];
-                    const bf16_t v = (bf16_t)((float)mF[rr][e] + add);
-                    mF[rr][e] = v;
+                    const bf16_t v = (bf16_t)((float)mv[e] + add);
+                    mv[e] = v;
                     s1 += (float)v; s2 += (float)v * (float)v;
                 }
+                *slotF(r) = mv;
             }
             if (rr < RBH) {
                 float cl[8];
                 if (is_cls) ig_load8(p.cls + (long)f * CI + pH * 32 + lg * 8, cl);
+                bf16x8 mv = *slotH(r);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float add = is_cls ? cl[e] : (e < 4 ? aH[0][rr][e] : aH[1][rr][e - 4]) + bH[e];
-                    const bf16_t v = (bf16_t)((float)mH[rr][e] + add);
-                    mH[rr][e] = v;
+                    const bf16_t v = (bf16_t)((float)mv[e] + add);
+                    mv[e] = v;
                     s1 += (float)v; s2 += (float)v * (float)v;
                 }
+                *slotH(r) = mv;
             }
             s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
@@ -282,20 +291,22 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_fwd_kernel(con
             const int r = (((rr + odd * RBH) & (RB - 1)) * 16) + li;
             const float2 st = reinterpret_cast<const float2*>(tot)[r];
             bf16x8 o;
+            const bf16x8 mpF = *slotF(r);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(((float)mF[rr][e] - st.x) * st.y);
-            *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((pF * 4 + lg) ^ li) << 4)) = o;
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(((float)mpF[e] - st.x) * st.y);
+            *slotF(r) = o;
             if (gro[rr] >= 0) {
                 if (MODE == 2) IG_ST(o, p.Xh + (long)gro[rr] * CI + pF * 32 + lg * 8);
-                if (p.Mpo) IG_ST(mF[rr], p.Mpo + (long)gro[rr] * CI + pF * 32 + lg * 8);
+                if (p.Mpo) IG_ST(mpF, p.Mpo + (long)gro[rr] * CI + pF * 32 + lg * 8);
             }
             if (rr < RBH) {
+                const bf16x8 mpH = *slotH(r);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(((float)mH[rr][e] - st.x) * st.y);
-                *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((pH * 4 + lg) ^ li) << 4)) = o;
+                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(((float)mpH[e] - st.x) * st.y);
+                *slotH(r) = o;
                 if (gro[rr] >= 0) {
                     if (MODE == 2) IG_ST(o, p.Xh + (long)gro[rr] * CI + pH * 32 + lg * 8);
-                    if (p.Mpo) IG_ST(mH[rr], p.Mpo + (long)gro[rr] * CI + pH * 32 + lg * 8);
+                    if (p.Mpo) IG_ST(mpH, p.Mpo + (long)gro[rr] * CI + pH * 32 + lg * 8);
                 }
             }
         }
