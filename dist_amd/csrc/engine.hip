@@ -1548,6 +1548,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
             ba.dzf_dh2 = q.dcat; ba.ld_dzf = Cd; ba.dh2 = d_h2; ba.ld_dh2 = Cd; ba.dh1 = d_h1; ba.ld_dh1 = Cd;
             // (dM = dM' + I2T term: the I2T data-gradient GEMM below reads dM' as its residual and writes every patch row of dM; only the cls rows come from here)
             ba.dMp = q.dMp; ba.dM_copy = last ? nullptr : q.dM; ba.dM_cls_only = 1; ba.add_dR = last ? 1 : 0;
+            ba.t2i_dcls = x.gr(l.cls_token);
             if (h->ig_i2tb && !last && !tchain) {             // I2T backward in the same launch: dY (for the I2T weight gradient) and dM = dM' + [0 ; dY Wi] leave it
                 ba.i2t_dXnext = dXn; ba.i2t_B = l.ig_W4; ba.i2t_dY = q.dY; ba.dM_cls_only = 0;
             }
@@ -1585,7 +1586,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         }
         // ---- T2I backward (dist.py:81-86): M' = M + [cls_token ; conv_strided(X')] ----
         RUN(fork());
-        RUN(dist_k_cls_rows_bwd(q.dMp, x.gr(l.cls_token), (int)bt, L, Ci, t, c.dtype, B));
+        if (!h->ig_bwd) RUN(dist_k_cls_rows_bwd(q.dMp, x.gr(l.cls_token), (int)bt, L, Ci, t, c.dtype, B));      // (the fused backward adds the cls rows of dM' itself)
         RUN(wgrad(xb2, l.t2i, q.dMp, Ci, w.Xp, Ct, rowsQ, RM(DIST_RM_SKIPCLS, N), RM(DIST_RM_STRIDED, al, N), 2, true));
         // dX' = dX_next (identity, absent for the last layer) + conv^T(dQ): column block a of row (bj,n) -> frame bj*alpha+a
         // ... and straight through X' = g(p): dp = (dX_next + conv^T(dQ)) * g'(p) in the same epilogue (no dX' tensor, no

@@ -566,6 +566,7 @@ struct IgBwdArgs {
     const bf16_t *dXn, *W4; bf16_t* dY;
     // T2I backward behind that (dist.py:81-86 through autograd, and through X' = g(p)): dp[2f+a][j-1] = (dX_next[2f+a][j-1] + dM'[f][j] W5_a^T) g'(p[2f+a][j-1])
     const bf16_t *W5, *pact; bf16_t* dp;
+    float* dcls;             // optional: the T2I cls-token gradient [t][Ci] += dM' of the cls rows (token 0 of every frame), fp32 atomics
     int clips, t, L, groups, tokshift;
 };
 
@@ -854,6 +855,11 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_bwd_kernel(con
             const bool to_dm = p.dM && !i2tb && (!p.dm_cls || ((grp << tsh) + (r & tokmask)) == 0);
             if (to_dm) IG_ST(o, p.dM + (long)gr * CI + pF * 32 + lg * 8);
             if (t2ib) *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((pF * 4 + lg) ^ li) << 4)) = o;     // dM' tile: the A operand of the T2I product at the end
+            const bool cls_row = p.dcls && grp == 0 && (r & tokmask) == 0;
+            if (cls_row) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) atomicAdd(p.dcls + (long)(r >> tsh) * CI + pF * 32 + lg * 8 + e, (float)o[e]);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) { aF[0][rr][e] = (float)o[e]; aF[1][rr][e] = (float)o[4 + e]; }       // (the I2T term below accumulates on the stored dM')
             if (rr < RBH) {
@@ -873,6 +879,10 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_bwd_kernel(con
                 IG_ST(o, p.dMp + (long)gr * CI + pH * 32 + lg * 8);
                 if (to_dm) IG_ST(o, p.dM + (long)gr * CI + pH * 32 + lg * 8);
                 if (t2ib) *reinterpret_cast<bf16x8*>(regA + r * (CI * 2) + (((pH * 4 + lg) ^ li) << 4)) = o;
+                if (cls_row) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) atomicAdd(p.dcls + (long)(r >> tsh) * CI + pH * 32 + lg * 8 + e, (float)o[e]);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { aH[0][rr][e] = (float)o[e]; aH[1][rr][e] = (float)o[4 + e]; }
             }
@@ -1209,6 +1219,7 @@ extern "C" int dist_op_integration_bwd(const dist_integ_bwd_args* a, void* strea
     k.dm_cls = a->dM_cls_only ? 1 : 0;
     k.dXn = static_cast<const bf16_t*>(a->i2t_dXnext); k.W4 = static_cast<const bf16_t*>(a->i2t_B); k.dY = static_cast<bf16_t*>(a->i2t_dY);
     if ((k.dY != nullptr) != (k.dXn != nullptr && k.W4 != nullptr) || (k.dY && !k.dM)) return DIST_ERR_ARG;   // the I2T term: dX_next, its operand, the dY output and dM_copy (which then receives dM) - all or none
+    k.dcls = a->t2i_dcls;
     k.W5 = static_cast<const bf16_t*>(a->t2i_B); k.pact = static_cast<const bf16_t*>(a->t2i_p); k.dp = static_cast<bf16_t*>(a->t2i_dp);
     if (k.dp && !(k.W5 && k.pact)) return DIST_ERR_ARG;
     k.clips = a->clips; k.t = a->t; k.L = a->L;

@@ -90,7 +90,7 @@ class IntegBwdArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dR", "zf_h2", "Xhat", "rstd", "B1", "B2", "B3", "dzf_dh2", "dh1", "dMp", "dM_copy")] + \
                [(n, C.c_int) for n in ("add_dR", "clips", "t", "L", "Ci", "C4", "tk", "dtype")] + \
                [("ld_dzf", C.c_int), ("dh2", C.c_void_p), ("ld_dh2", C.c_int), ("ld_dh1", C.c_int)] + \
-               [(n, C.c_void_p) for n in ("i2t_dXnext", "i2t_B", "i2t_dY", "t2i_B", "t2i_p", "t2i_dp")] + [("dM_cls_only", C.c_int)]
+               [(n, C.c_void_p) for n in ("i2t_dXnext", "i2t_B", "i2t_dY", "t2i_B", "t2i_p", "t2i_dp", "t2i_dcls")] + [("dM_cls_only", C.c_int)]
 
 
 class AdamwSeg(C.Structure):

@@ -306,6 +306,7 @@ typedef struct dist_integ_bwd_args {
     /* T2I backward behind that (dist.py:81-86 and the activation X' = g(p) through autograd): t2i_dp [clips*2t*(L-1)][C4] = (dX_next + conv_strided^T(dM'[:, 1:])) * g'(t2i_p)
      * with t2i_p the TemporalNet pre-activation of this layer; dX_next = i2t_dXnext (NULL for the last layer: no such term); t2i_B from dist_op_integration_pack (W5). */
     const void* t2i_B; const void* t2i_p; void* t2i_dp;
+    float* t2i_dcls;         /* optional: gradient of the T2I cls tokens [t][Ci] (fp32) += dM' of the cls rows, summed over the clips (atomics) */
     int dM_cls_only;         /* dM_copy only receives the cls rows (token 0 of every frame): for a caller whose next GEMM writes the other rows of that tensor anyway */
 } dist_integ_bwd_args;
 int dist_op_integration_bwd(const dist_integ_bwd_args* a, void* stream);
