@@ -513,36 +513,27 @@ int launch_attn(const void* qkv, void* out, int frames, int L, int heads, int hm
                                        : ((size_t)Lp * (HD + KPAD) + (size_t)HD * (Lp + KPAD)) * sizeof(T);
     if (smem > 160 * 1024) return DIST_ERR_ARG;
     const int nq = (L + 15) / 16;
-    static const int dbg_env = getenv("DIST_AMD_ATTN_DBG") ? atoi(getenv("DIST_AMD_ATTN_DBG")) : 0;
-    static const int nt_env = getenv("DIST_AMD_ATTN_NT") ? atoi(getenv("DIST_AMD_ATTN_NT")) : 0;      // measurement knob: 448 / 576
+    static const int dbg_env = dist_measure_knob("DIST_AMD_ATTN_DBG", 0);
+    static const int nt_env = dist_knob("DIST_AMD_ATTN_NT", 0);      // measurement knob: 448 / 576
     // nine waves only where two 7-wave workgroups do not fit a CU's LDS anyway (L = 257: 234 us with nine waves and one workgroup per CU,
     // 190 us with seven waves and two - tools/bench_attn.py)
     const bool nine = nt_env ? nt_env == NT9 : (nq > 14 && nq <= 18 && smem > 80 * 1024);
     if (nine) {
-        static size_t attr9 = 0;
-        if (smem > attr9) {
-            HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<T, NT9, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr9 = smem;
-        }
+        static DistSmemOnce attr9;
+        RUN_(dist_max_smem(attr9, reinterpret_cast<const void*>(attn_kernel<T, NT9, 0>), smem));
         hipLaunchKernelGGL((attn_kernel<T, NT9, 0>), dim3(frames * heads), dim3(NT9), smem, s, static_cast<const T*>(qkv), static_cast<T*>(out), L, heads, Lp, hm,
                            out8, out8_scale, out8_amax, qkv8, in_scale, dbg_env);
     } else {
         // whole-row softmax where the scores of a query tile fit the register budget of two workgroups per CU (Lp = 224: L = 193 .. 224, the ViT-B/16 plane + cls)
-        static const int full_env = getenv("DIST_AMD_ATTN_FULLROW") ? atoi(getenv("DIST_AMD_ATTN_FULLROW")) : 1;      // measurement knob: 0 = online softmax
+        static const int full_env = dist_knob("DIST_AMD_ATTN_FULLROW", 1);      // measurement knob: 0 = online softmax
         const bool full7 = sizeof(T) == 2 && Lp == 224 && full_env;
-        static size_t attr7 = 0, attr7f = 0;
+        static DistSmemOnce attr7, attr7f;
         if (full7) {
-            if (smem > attr7f) {
-                HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<T, NT7, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                attr7f = smem;
-            }
+            RUN_(dist_max_smem(attr7f, reinterpret_cast<const void*>(attn_kernel<T, NT7, 7>), smem));
             hipLaunchKernelGGL((attn_kernel<T, NT7, 7>), dim3(frames * heads), dim3(NT7), smem, s, static_cast<const T*>(qkv), static_cast<T*>(out), L, heads, Lp, hm,
                                out8, out8_scale, out8_amax, qkv8, in_scale, dbg_env);
         } else {
-            if (smem > attr7) {
-                HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<T, NT7, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                attr7 = smem;
-            }
+            RUN_(dist_max_smem(attr7, reinterpret_cast<const void*>(attn_kernel<T, NT7, 0>), smem));
             hipLaunchKernelGGL((attn_kernel<T, NT7, 0>), dim3(frames * heads), dim3(NT7), smem, s, static_cast<const T*>(qkv), static_cast<T*>(out), L, heads, Lp, hm,
                                out8, out8_scale, out8_amax, qkv8, in_scale, dbg_env);
         }

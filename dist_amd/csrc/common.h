@@ -220,4 +220,37 @@ DEV RowPrep rowmap_step(const dist_rowmap& rm, RowPrep q, int delta) {      // =
     }
 }
 
+// Environment knobs of the library, read once per process at their call sites.
+//   dist_knob():         algorithm selectors - every value computes the SAME results through another kernel sequence (a fused kernel off, a tile
+//                        shape, a stream layout); tests/test_fallbacks_gpu.py runs the engine tests under the ones that switch a kernel off,
+//                        bench.py reports every DIST_AMD_* variable that was set ("knobs").
+//   dist_measure_knob(): timing-only switches whose results are WRONG (kernels skipped, dummy work, debug phases).  They exist only in a
+//                        -DDIST_AMD_MEASURE build (DIST_AMD_BUILD_DEFS=-DDIST_AMD_MEASURE python -m dist_amd.build --force, what tools/skip_step.sh
+//                        and the ablation scripts do; dist_measure_build() reports it): the shipped library cannot be driven wrong by the environment.
+#include <stdlib.h>
+inline int dist_knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#ifdef DIST_AMD_MEASURE
+inline int dist_measure_knob(const char* name, int dflt) { return dist_knob(name, dflt); }
+#else
+inline int dist_measure_knob(const char*, int dflt) { return dflt; }
+#endif
+
+#define HIP_CHECK_RET_(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return -(int)e_ - 1000; } while (0)
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE attribute of a kernel: raise it once per (kernel, device) - `st` is the call
+// site's static state - and again whenever a launch needs more than was set.  (A process-wide `static bool` left the second device of a process
+// with the 64 KB default; two threads racing here both set the same value.)
+#include <atomic>
+struct DistSmemOnce { std::atomic<size_t> bytes[32]; };
+inline int dist_max_smem(DistSmemOnce& st, const void* kernel, size_t smem) {
+    int dev = 0;
+    HIP_CHECK_RET_(hipGetDevice(&dev));
+    const bool tracked = dev >= 0 && dev < 32;
+    if (!tracked || st.bytes[dev].load(std::memory_order_relaxed) < smem) {
+        HIP_CHECK_RET_(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        if (tracked) st.bytes[dev].store(smem, std::memory_order_relaxed);
+    }
+    return 0;
+}
+
+#define RUN_(x) do { const int rc_ = (x); if (rc_ != 0) return rc_; } while (0)
 #define HIP_CHECK_RET(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return -(int)e_ - 1000; } while (0)

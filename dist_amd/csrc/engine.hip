@@ -155,6 +155,9 @@ struct dist_handle {
                   // fused IntegrationNetwork forward: taken for this geometry; its pack descriptors (device)
     float* tn_partial[3] = {nullptr, nullptr, nullptr};   // two-phase dW reduction scratch, one per stream that launches dW GEMMs
     long tn_partial_elems = 0;
+    float* ig_gscratch = nullptr;              // [layers][(Ci + C4) * Ci + (Ci + C4)]: G' = dz^T xhat and db of the two folded Linears when dist_branch_backward ACCUMULATES (zero_grads = 0)
+    long ig_gscratch_elems = 0;                // per layer
+    bool bwd_accumulate = false;               // the running dist_branch_backward was called with zero_grads = 0
     // weight-gradient side stream (created once per handle; host-side objects only)
     hipStream_t side = nullptr, side2 = nullptr, pf = nullptr;   // pf: the handle's own ViT prefetch stream
     hipStream_t chain2 = nullptr;                                // backward: the temporal data-gradient chain (T2I data gradient + TemporalNet backward), beside the integration chain
@@ -241,18 +244,18 @@ long add_param(dist_handle* h, int kind, const std::string& name, std::initializ
 void set_fused_flags(dist_handle* h) {
     const dist_config& c = h->cfg;
     const int Ci = c.integration_dim, Ct = c.temporal_dim, C4 = h->C4;
-    h->ig_on = dist_k_integ_eligible(c.dtype, Ci, C4, h->t, c.temporal_kernel) && !(getenv("DIST_AMD_INTEG_FUSED") && atoi(getenv("DIST_AMD_INTEG_FUSED")) == 0);
-    h->ig_xhat = h->ig_on && !(getenv("DIST_AMD_INTEG_XHAT") && atoi(getenv("DIST_AMD_INTEG_XHAT")) == 0);
-    h->ig_bwd = h->ig_xhat && !(getenv("DIST_AMD_INTEG_BWD_FUSED") && atoi(getenv("DIST_AMD_INTEG_BWD_FUSED")) == 0);
+    h->ig_on = dist_k_integ_eligible(c.dtype, Ci, C4, h->t, c.temporal_kernel) && (dist_knob("DIST_AMD_INTEG_FUSED", 1) != 0);
+    h->ig_xhat = h->ig_on && (dist_knob("DIST_AMD_INTEG_XHAT", 1) != 0);
+    h->ig_bwd = h->ig_xhat && (dist_knob("DIST_AMD_INTEG_BWD_FUSED", 1) != 0);
     // T2I (dist.py:68-86) formed in front of the fused forward instead of a GEMM + a cls-row kernel + a round trip of M' (alpha = 2, temporal width = C4)
-    h->ig_t2i = h->ig_xhat && c.alpha == 2 && Ct == C4 && !(getenv("DIST_AMD_INTEG_T2I") && atoi(getenv("DIST_AMD_INTEG_T2I")) == 0);
+    h->ig_t2i = h->ig_xhat && c.alpha == 2 && Ct == C4 && (dist_knob("DIST_AMD_INTEG_T2I", 1) != 0);
     // ... and I2T (dist.py:90-105) behind it: the next layer's temporal map leaves the same launch (the I2T GEMM and its second pass over M are gone)
-    h->ig_i2t = h->ig_t2i && !(getenv("DIST_AMD_INTEG_I2T") && atoi(getenv("DIST_AMD_INTEG_I2T")) == 0);
+    h->ig_i2t = h->ig_t2i && (dist_knob("DIST_AMD_INTEG_I2T", 1) != 0);
     // ... and the I2T backward (pair sums of dX_next, dM = dM' + dY Wi) behind the fused backward: the pair-sum kernel and the I2T data-gradient GEMM are gone
-    h->ig_i2tb = h->ig_bwd && c.alpha == 2 && Ct == C4 && !(getenv("DIST_AMD_INTEG_I2T_BWD") && atoi(getenv("DIST_AMD_INTEG_I2T_BWD")) == 0);
+    h->ig_i2tb = h->ig_bwd && c.alpha == 2 && Ct == C4 && (dist_knob("DIST_AMD_INTEG_I2T_BWD", 1) != 0);
     // ... and the T2I backward (dp = (dX_next + conv^T(dM')) g'(p)) behind that: the T2I data-gradient GEMM leaves the chain as well
-    h->ig_t2ib = h->ig_bwd && c.alpha == 2 && Ct == C4 && !(getenv("DIST_AMD_INTEG_T2I_BWD") && atoi(getenv("DIST_AMD_INTEG_T2I_BWD")) == 0);
-    h->keep_mid = getenv("DIST_AMD_KEEP_MID") && atoi(getenv("DIST_AMD_KEEP_MID"));     // debugging: M' of every layer stays readable (dist_debug_tensor "mid.i")
+    h->ig_t2ib = h->ig_bwd && c.alpha == 2 && Ct == C4 && (dist_knob("DIST_AMD_INTEG_T2I_BWD", 1) != 0);
+    h->keep_mid = (dist_knob("DIST_AMD_KEEP_MID", 0) != 0);     // debugging: M' of every layer stays readable (dist_debug_tensor "mid.i")
 }
 
 long pk_alloc(dist_handle* h, long elems) {
@@ -544,6 +547,7 @@ size_t layout_ws(dist_handle* h, char* base) {
     }
     h->tn_partial_elems = 16l << 20;                         // 64 MB each: 256 partial tiles of 192 x 256 (the LDS-DMA weight-gradient kernel) + slack
     for (int k = 0; k < 3; ++k) h->tn_partial[k] = F_(h->tn_partial_elems);
+    if (h->ig_xhat) { h->ig_gscratch_elems = (long)(Ci + C4) * Ci + (Ci + C4); h->ig_gscratch = F_(h->ig_gscratch_elems * c.layers); }
     for (int k = 0; k < 2; ++k) {
         dist_handle::BwdSet& q = h->bs[k];
         q.dMp = T_(rowsS, Ci); q.dM = T_(rowsS, Ci); q.dXp = T_(rowsX, Ct); q.dp = T_(rowsX, Ct); q.dXo = T_(rowsX, Ct);
@@ -672,7 +676,7 @@ bool rowstats_ok(const Ctx& c, long M, int N, int K) {
     return N % 64 == 0 && dist_k_gemm_fast_eligible(&g);
 }
 int wgrad(const Ctx& c, const Lin& l, const void* dY, int ld_dy, const void* X, int ldx, long M,
-          dist_rowmap am = RM(), dist_rowmap bm = RM(), int style = 0, bool with_bias = false) {
+          dist_rowmap am = RM(), dist_rowmap bm = RM(), int style = 0, bool with_bias = false, float* out_w = nullptr, float* out_b = nullptr) {
     dist_gemm_tn_args g;
     memset(&g, 0, sizeof(g));
     g.A = dY; g.B = X; g.out = c.gr(l.w);
@@ -685,6 +689,7 @@ int wgrad(const Ctx& c, const Lin& l, const void* dY, int ld_dy, const void* X, 
     if (c.h->skip & 1) return DIST_OK;
     if ((c.h->skip & 16) && l.N >= 384 && l.K >= 384) return DIST_OK;
     g.colsum = (with_bias && l.bias >= 0) ? c.gr(l.bias) : nullptr;       // db fused into the same pass over dY
+    if (out_w) { g.out = out_w; if (g.colsum) g.colsum = out_b; }         // (the accumulating backward: G' of a folded Linear goes to scratch)
     {   // two-phase reduction scratch of the stream this launch goes to
         dist_handle* h = c.h;
         const int k = c.s == h->side ? 1 : (c.s == h->side2 ? 2 : 0);
@@ -734,7 +739,7 @@ int ln_bwd(const Ctx& c, const LNp& l, const void* x, const float* mean, const f
     // Two-phase parameter gradients (dist_ln_bwd_args.partial): measured in the step and NOT the default - 20.03 -> 20.20 ms with the same grid
     // caps, 20.2 with 512 blocks (three alternations): the second launch sits on the data-gradient chain and costs more than the same-line
     // atomics it removes.  DIST_AMD_LN_TWO_PHASE=1 turns it on (the data-gradient chain owns the scratch: its launches are serial).
-    static const bool two_phase = getenv("DIST_AMD_LN_TWO_PHASE") && atoi(getenv("DIST_AMD_LN_TWO_PHASE")) == 1;
+    static const bool two_phase = dist_knob("DIST_AMD_LN_TWO_PHASE", 0) == 1;
     if (two_phase && c.s != c.h->side && c.s != c.h->side2) { a.partial = c.h->ln_partial; a.partial_elems = c.h->ln_partial_elems; }
     return dist_op_layernorm_bwd(&a, c.s);
 }
@@ -756,7 +761,14 @@ extern "C" const char* dist_strerror(int code) {
 // 7: dist_config.vit_fp8 and dist_gemm_args.C8 / ldc8 / out8_scale / out8_amax (both structs grew after 6 without a bump), vit_fp8 range-checked.
 // Rule: EVERY change of a public struct's layout bumps this number (dist_amd/lib.py and tests/test_abi_and_host.py pin it).
 // 8: dist_ln_bwd_args.partial / partial_elems (two-phase LayerNorm parameter gradients), dist_tnet_args / dist_tnet_bwd_args, dist_set_inference.
-extern "C" int dist_abi_version(void) { return 8; }
+extern "C" int dist_abi_version(void) { return DIST_ABI_VERSION; }
+extern "C" int dist_measure_build(void) {
+#ifdef DIST_AMD_MEASURE
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" int dist_abi_sizeof(const char* n) {
     if (!n) return -1;
 #define DIST_SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T)
@@ -789,10 +801,10 @@ extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
     set_fused_flags(h);
     build_tables(h);
     h->ws_bytes = layout_ws(h, nullptr);
-    if (const char* e = getenv("DIST_AMD_SERIAL")) h->serial = atoi(e);
-    if (const char* e = getenv("DIST_AMD_SKIP")) h->skip = atoi(e);
-    if (const char* e = getenv("DIST_AMD_DUMMY")) h->dummy = atoi(e);
-    if (const char* e = getenv("DIST_AMD_DUMMY_REPS")) h->dummy_reps = atoi(e);
+    h->serial = dist_knob("DIST_AMD_SERIAL", h->serial);
+    h->skip = dist_measure_knob("DIST_AMD_SKIP", h->skip);
+    h->dummy = dist_measure_knob("DIST_AMD_DUMMY", h->dummy);
+    h->dummy_reps = dist_measure_knob("DIST_AMD_DUMMY_REPS", h->dummy_reps);
     *out = h;
     return DIST_OK;
 }
@@ -805,14 +817,13 @@ static int ensure_streams(dist_handle* h) {
     // data-gradient chain): lowest priority, so the caller's stream gets freed CUs first (DIST_AMD_SIDE_PRIO=0: default priority)
     int least = 0, greatest = 0;
     hipDeviceGetStreamPriorityRange(&least, &greatest);
-    const char* pe = getenv("DIST_AMD_SIDE_PRIO");
-    const int prio = (pe && atoi(pe) == 0) ? 0 : least;
+    const int prio = dist_knob("DIST_AMD_SIDE_PRIO", 1) == 0 ? 0 : least;
     bool ok = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio) == hipSuccess &&
               hipStreamCreateWithPriority(&h->side2, hipStreamNonBlocking, prio) == hipSuccess &&
               hipStreamCreateWithPriority(&h->pf, hipStreamNonBlocking, least) == hipSuccess;
     // the optional second data-gradient chain of the backward (DIST_AMD_BWD_TCHAIN=1, a measurement): created only when asked for - an extra
     // stream that merely EXISTS beside the gradient reducer's cost 4.7 ms per step (tests/test_rccl_gpu.py: 23.2 vs 18.5 ms)
-    if (getenv("DIST_AMD_BWD_TCHAIN") && atoi(getenv("DIST_AMD_BWD_TCHAIN")) == 1)
+    if (dist_knob("DIST_AMD_BWD_TCHAIN", 0) == 1)
         ok = ok && hipStreamCreateWithPriority(&h->chain2, hipStreamNonBlocking, 0) == hipSuccess;
     auto mk = [&](hipEvent_t& e) { ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
     h->ev_a.resize(10 * c.layers + 4); h->ev_b_dr.resize(c.layers); h->ev_b_done.resize(c.layers);
@@ -929,7 +940,7 @@ extern "C" int dist_pack_weights(dist_handle* h, int what, void* stream) {
     RUN(dist_k_pack(descs, blk_desc, blk_first, first, count, h->theta, h->visual, dst, h->cfg.dtype, s));
     if ((what & 2) && h->ig_on) RUN(dist_k_integ_pack(h->ig_descs, nullptr, h->cfg.layers, h->cfg.integration_dim, h->C4, s));
     // frozen ViT: ln_1 -> attn.in_proj and ln_2 -> mlp.c_fc folded (W diag(gamma), column sums, folded biases); DIST_AMD_LNFOLD=0: off
-    static const bool fold_on = !(getenv("DIST_AMD_LNFOLD") && atoi(getenv("DIST_AMD_LNFOLD")) == 0);
+    static const bool fold_on = (dist_knob("DIST_AMD_LNFOLD", 1) != 0);
     // (only a pack of the frozen weights touches the fold: the per-step re-pack of the trainable weights, what = 2, used to reset
     // vit_fold and every ViT pass after the first optimizer step ran the unfolded LayerNorm + GEMM)
     if (what & 1) h->vit_fold = false;
@@ -998,7 +1009,7 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
     // need, `proj` those of the next block's ln_1 / in_proj; dist_op_ln_stats_from_partials (5 MB in, 0.4 MB out) replaces the
     // statistics pass over the 77 MB tensor (23 of 24 per ViT pass).  The first block of a call still runs the statistics pass (its input comes from ln_pre, or from an
     // earlier partial pass).  DIST_AMD_ROWSTATS=0: off (measurement knob).
-    static const bool rs_env = !(getenv("DIST_AMD_ROWSTATS") && atoi(getenv("DIST_AMD_ROWSTATS")) == 0);
+    static const bool rs_env = (dist_knob("DIST_AMD_ROWSTATS", 1) != 0);
     const bool rs = rs_env && h->vit_fold && rowstats_ok(x, rowsS, d, d) && rowstats_ok(x, rowsS, d, 4 * d);
     bool part_of_xin = false;                          // lnpart holds the partials of `xin`
     // dist_config.vit_fp8 (BASELINE config 5): which of the four GEMMs of a block run on e4m3 operands - bit 0 in_proj, 1 out_proj, 2 c_fc,
@@ -1441,6 +1452,10 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         HIP_CHECK_RET(hipMemsetAsync(h->grads, 0, (size_t)h->total[0] * sizeof(float), x.s));
         HIP_CHECK_RET(hipMemsetAsync(h->dlogit_scale, 0, sizeof(float), x.s));
     }
+    // Accumulating backward with the LayerNorm fold: the weight-gradient GEMMs of ffn.c_fc / temporal_ffn.c_fc1 leave G' = dz^T xhat, which the
+    // unfold turns into dW - in place only when the slots were zero.  With earlier gradients in them G' goes to per-layer scratch and the unfold adds.
+    h->bwd_accumulate = !zero_grads && h->ig_xhat;
+    if (h->bwd_accumulate) HIP_CHECK_RET(hipMemsetAsync(h->ig_gscratch, 0, (size_t)h->ig_gscratch_elems * nl * sizeof(float), x.s));
     // logits -> v (cosine normalisation backward, clip.py:511-517); logit_scale gets its (never applied) gradient
     RUN(dist_k_logits_loss(h->v, h->text, h->logit_scale, nullptr, nullptr, nullptr, nullptr, h->dv, h->dlogit_scale, dlogits, nullptr,
                            b, c.embed_dim, c.num_classes, c.dtype, stream));
@@ -1488,7 +1503,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
     // and dX_{i+1}, the integration chain of layer i-1 needs dM_i = dM'_i + I2T^T(dX_{i+1}) - not dX_i.  DIST_AMD_BWD_TCHAIN=0: one chain.
     // Measured: 18.78 -> 20.23 ms with the fifth stream (any fifth ACTIVE stream costs that much on this system, profiles/r01_streams_and_queues.md),
     // so the default is one chain.  DIST_AMD_BWD_TCHAIN=1: own stream; 2: the second weight-gradient stream carries the temporal chain instead.
-    static const int tchain_env = getenv("DIST_AMD_BWD_TCHAIN") ? atoi(getenv("DIST_AMD_BWD_TCHAIN")) : 0;
+    static const int tchain_env = dist_knob("DIST_AMD_BWD_TCHAIN", 0);
     const bool tchain = tchain_env > 0 && !(h->serial & 2) && (h->chain2 || tchain_env == 2);
     hipStream_t Tc = tchain ? (tchain_env == 2 ? h->side2 : h->chain2) : A;
     if (tchain && tchain_env == 2) { B2 = B; xb2.s = B; }
@@ -1561,24 +1576,30 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
             RUN(fork());
             Lin both = l.ffn_fc;                              // [Ci + C4][Ci]: ffn.c_fc.weight followed by temporal_ffn.c_fc1.weight (and the two biases)
             both.N = Ci + C4;
-            static const bool merge_env = !(getenv("DIST_AMD_INTEG_WG_MERGE") && atoi(getenv("DIST_AMD_INTEG_WG_MERGE")) == 0);   // measurement knob
+            static const bool merge_env = (dist_knob("DIST_AMD_INTEG_WG_MERGE", 1) != 0);   // measurement knob
+            // (accumulating backward: G' and db of the two folded Linears go to this layer's scratch, [Ci + C4][Ci] then [Ci + C4])
+            float* gs_w = h->bwd_accumulate ? h->ig_gscratch + (long)i * h->ig_gscratch_elems : nullptr;
+            float* gs_b = gs_w ? gs_w + (long)(Ci + C4) * Ci : nullptr;
             if (merge_env && l.tf_fc1.w == l.ffn_fc.w + (long)Ci * Ci && l.tf_fc1.bias == l.ffn_fc.bias + Ci) {
-                RUN(wgrad(xb, both, q.dcat, Cd, w.Na, Ci, rowsS, RM(), RM(), 0, true));
+                RUN(wgrad(xb, both, q.dcat, Cd, w.Na, Ci, rowsS, RM(), RM(), 0, true, gs_w, gs_b));
             } else {
-                RUN(wgrad(xb, l.ffn_fc, q.dcat, Cd, w.Na, Ci, rowsS, RM(), RM(), 0, true));
-                RUN(wgrad(xb2, l.tf_fc1, d_h1, Cd, w.Na, Ci, rowsS, RM(), RM(), 0, true));
+                RUN(wgrad(xb, l.ffn_fc, q.dcat, Cd, w.Na, Ci, rowsS, RM(), RM(), 0, true, gs_w, gs_b));
+                RUN(wgrad(xb2, l.tf_fc1, d_h1, Cd, w.Na, Ci, rowsS, RM(), RM(), 0, true, gs_w ? gs_w + (long)Ci * Ci : nullptr, gs_b ? gs_b + Ci : nullptr));
             }
             RUN(wgrad(xb2, l.tf_fc2, d_h2, Cd, w.h1, C4, rowsS, RM(), RM(DIST_RM_SHIFT, t * L, L, 1), 1, true));
         } else {
         // [dzf | dh2] = (dR [Wp ; W3]) * g'([zf | h2]): one data-gradient GEMM for the two projections
         RUN(gemm(x, dR, Ci, x.pk(l.pk_proj_b), rowsS, Cc, Ci, 1, q.dzf, Cc, nullptr, nullptr, w.zf, nullptr));
         RUN(fork());
-        RUN(wgrad(xb, l.ffn_fc, q.dzf, Cc, w.Na, Ci, rowsS, RM(), RM(), 0, true));
+        float* gs_w = h->bwd_accumulate ? h->ig_gscratch + (long)i * h->ig_gscratch_elems : nullptr;
+        float* gs_b = gs_w ? gs_w + (long)(Ci + C4) * Ci : nullptr;
+        RUN(wgrad(xb, l.ffn_fc, q.dzf, Cc, w.Na, Ci, rowsS, RM(), RM(), 0, true, gs_w, gs_b));
         RUN(wgrad(xb2, l.tf_fc2, q.dh2, Cc, w.h1, C4, rowsS, RM(), RM(DIST_RM_SHIFT, t * L, L, 1), 1, true));
         RUN(gemm(x, q.dh2, Cc, x.pk(l.tf_fc2.pk.b), rowsS, C4, C4, l.tf_fc2.taps, q.dh1, C4, nullptr, nullptr, nullptr, nullptr,
                  RM(DIST_RM_SHIFT, t * L, L, -1)));
         RUN(fork());
-        RUN(wgrad(xb2, l.tf_fc1, q.dh1, C4, h->ig_xhat ? w.Na : w.Nb, Ci, rowsS, RM(), RM(), 0, true));     // (ig_xhat: w.Na holds xhat, see the unfold below)
+        RUN(wgrad(xb2, l.tf_fc1, q.dh1, C4, h->ig_xhat ? w.Na : w.Nb, Ci, rowsS, RM(), RM(), 0, true,     // (ig_xhat: w.Na holds xhat, see the unfold below)
+                  gs_w ? gs_w + (long)Ci * Ci : nullptr, gs_b ? gs_b + Ci : nullptr));
         RUN(lin_dx(h, x, l.ffn_fc, q.dzf, rowsS, q.dNa, nullptr, nullptr, Cc));
         RUN(lin_dx(h, x, l.tf_fc1, q.dh1, rowsS, q.dNb));
         // dM' = LN'(dNa, dNb) (+ dFz for the last layer); a second copy becomes dM (updated in place by the I2T term)
@@ -1616,7 +1637,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         // bf16: two fused launches (tnet.hip): dz = conv3x3^T(dp) * g'(z); dX = dp + LN'(conv_t^T(dz)) with the LayerNorm parameter
         // gradients as per-workgroup partial rows (no atomics); otherwise two row-mapped GEMMs + the LayerNorm backward kernel
         const bool tn_fused = dist_k_tnet_fwd_eligible(c.dtype, Ct, h->G, l.tn_fc1.taps) &&
-                              !(getenv("DIST_AMD_TNET_BWD_FUSED") && atoi(getenv("DIST_AMD_TNET_BWD_FUSED")) == 0);   // measurement knob
+                              (dist_knob("DIST_AMD_TNET_BWD_FUSED", 1) != 0);   // measurement knob
         if (h->skip & 2) {
         } else if (tn_fused) {
             dist_tnet_bwd_args ta;
@@ -1638,6 +1659,11 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         RUN(merge_b2());
         if (h->ig_xhat && !(h->skip & 1)) {   // the weight gradients of ffn.c_fc / temporal_ffn.c_fc1 were taken against xhat: unfold them (+ the two LayerNorms' gradients)
             dist_integ_unfold_args ua;
+            memset(&ua, 0, sizeof(ua));
+            if (h->bwd_accumulate) {
+                const float* gs_w = h->ig_gscratch + (long)i * h->ig_gscratch_elems; const float* gs_b = gs_w + (long)(Ci + C4) * Ci;
+                ua.g_ffn_fc_w = gs_w; ua.g_ffn_fc_b = gs_b; ua.g_tf_fc1_w = gs_w + (long)Ci * Ci; ua.g_tf_fc1_b = gs_b + Ci;
+            }
             ua.ffn_fc_w = x.th(l.ffn_fc.w); ua.ln_w = x.th(l.in_ln.w); ua.ln_b = x.th(l.in_ln.b);
             ua.d_ffn_fc_w = x.gr(l.ffn_fc.w); ua.d_ffn_fc_b = x.gr(l.ffn_fc.bias); ua.d_ln_w = x.gr(l.in_ln.w); ua.d_ln_b = x.gr(l.in_ln.b);
             ua.tf_fc1_w = x.th(l.tf_fc1.w); ua.ln_t_w = x.th(l.in_ln_t.w); ua.ln_t_b = x.th(l.in_ln_t.b);
@@ -1659,7 +1685,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
             ta.phase = 2;
             // measurement knob: leave the LayerNorm parameter gradients unsummed (phase 3).  The step does not change (19.64 vs 19.70 ms),
             // so one multi-layer dist_op_temporal_net_bwd_reduce at the end of backward would buy nothing: the per-layer sum stays here
-            static const bool no_reduce = getenv("DIST_AMD_TNET_BWD_NOREDUCE") && atoi(getenv("DIST_AMD_TNET_BWD_NOREDUCE"));
+            static const bool no_reduce = (dist_measure_knob("DIST_AMD_TNET_BWD_NOREDUCE", 0) != 0);
             if (no_reduce) ta.phase = 3;
             RUN(dist_op_temporal_net_bwd(&ta, xt.s));
         }

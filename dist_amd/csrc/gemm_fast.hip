@@ -712,9 +712,9 @@ static bool fast_common_ok(const dist_gemm_args* a) {
 // 0 = not eligible, 4 / 8 = waves of the variant that takes the shape
 static int fast_variant(const dist_gemm_args* a) {
     if (!fast_common_ok(a)) return 0;
-    static const int forced = [] { const char* e = getenv("DIST_AMD_FAST_NW"); return e ? atoi(e) : 0; }();   // measurement knob
+    static const int forced = dist_knob("DIST_AMD_FAST_NW", 0);   // measurement knob
     // (a half-empty last column tile only pays with a deep K loop - bf16 has the branch-GEMM kernels for the rest; fp8 has no other kernel)
-    static const int kmin = [] { const char* e = getenv("DIST_AMD_FAST_KMIN"); return e ? atoi(e) : 768; }();                 // measurement knob
+    static const int kmin = dist_knob("DIST_AMD_FAST_KMIN", 768);                 // measurement knob
     const bool ok8 = a->N >= 256 && !(a->N % 256 > 0 && (a->N % 256 < 128 || (a->K < kmin && !(a->flags & DIST_EPI_FP8))));
     const bool ok4 = a->N >= 128 && a->N % 128 == 0;
     // measured (tools/bench_fastk.py, profiles/r01_fast_gemm_shapes.md): the two-block shape hides ~40 % of the fixed
@@ -731,14 +731,11 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
     using S = Shape<NW>;
     constexpr size_t smem = (size_t)S::STAGES * S::STAGE_BYTES;
     static_assert(NW * EPI_BYTES <= S::STAGES * S::STAGE_BYTES, "epilogue staging fits in the operand ring");
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_done = true;
-    }
+    static DistSmemOnce attr;
+    RUN_(dist_max_smem(attr, reinterpret_cast<const void*>(gemm_fast_kernel<NW>), smem));
     const long tiles = ((a->M + BM - 1) / BM) * ((a->N + S::BN - 1) / S::BN);
     // column-tile groups: as few groups as keep one group's weight rows under ~2.5 MB (DIST_AMD_FAST_NG forces a count; 1 = off)
-    static const int forced_ng = [] { const char* e = getenv("DIST_AMD_FAST_NG"); return e ? atoi(e) : 0; }();
+    static const int forced_ng = dist_knob("DIST_AMD_FAST_NG", 0);
     const int tiles_n = (a->N + S::BN - 1) / S::BN;
     int ng = forced_ng > 0 ? forced_ng : 1;
     if (forced_ng == 0) {
@@ -758,26 +755,20 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
     if (ng < 1) ng = 1;
     // two-group 256x256x64 main loop (gemm_fast8p_kernel) when K is a multiple of 64; DIST_AMD_FAST_8P=0 keeps the
     // lock-step 256x256x32 loop (measurement knob, and the A/B reference of tools/bench_fast8p.py)
-    static const bool use_8p = !(getenv("DIST_AMD_FAST_8P") && atoi(getenv("DIST_AMD_FAST_8P")) == 0);
+    static const bool use_8p = (dist_knob("DIST_AMD_FAST_8P", 1) != 0);
     constexpr size_t smem8 = (size_t)P8_LDS;
     static_assert(8 * EPI_BYTES <= P8_LDS, "epilogue staging fits in the operand buffers");
     if (a->flags & DIST_EPI_FP8) {                        // fast_common_ok checked the shape; only the two-group loop has the fp8 MFMAs
         if (NW != 8) return DIST_ERR_ARG;
-        static bool attr8f_done = false;
-        if (!attr8f_done) {
-            HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast8p_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8));
-            attr8f_done = true;
-        }
+        static DistSmemOnce attr8f;
+        RUN_(dist_max_smem(attr8f, reinterpret_cast<const void*>(gemm_fast8p_kernel<true>), smem8));
         hipLaunchKernelGGL(gemm_fast8p_kernel<true>, dim3((unsigned)tiles), dim3(512), smem8, s, *a, ng);
         HIP_CHECK_RET(hipGetLastError());
         return 1;
     }
     if (NW == 8 && use_8p && a->K % P8_BK == 0 && a->K >= 2 * P8_BK && a->amap.mode == DIST_RM_PLAIN) {
-        static bool attr8_done = false;
-        if (!attr8_done) {
-            HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast8p_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8));
-            attr8_done = true;
-        }
+        static DistSmemOnce attr8;
+        RUN_(dist_max_smem(attr8, reinterpret_cast<const void*>(gemm_fast8p_kernel<false>), smem8));
         hipLaunchKernelGGL(gemm_fast8p_kernel<false>, dim3((unsigned)tiles), dim3(512), smem8, s, *a, ng);
         HIP_CHECK_RET(hipGetLastError());
         return 1;

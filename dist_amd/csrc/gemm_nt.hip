@@ -520,14 +520,11 @@ int launch_dma(const dist_gemm_args& a, hipStream_t s) {
     constexpr size_t ring = (size_t)3 * (BM + 128) * 64;
     constexpr size_t stag = (size_t)WM * WN * (BM / WM) * ((BN / WN) * 2 + 16);
     constexpr size_t smem = ring > stag ? ring : stag;
-    static bool attr_done = false;
+    static DistSmemOnce attr;
     auto kern = gemm_nt_dma_kernel<BM, BN, WM, WN, GENERIC, MINW, OGEN>;
-    if (!attr_done) {
-        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_done = true;
-    }
+    RUN_(dist_max_smem(attr, reinterpret_cast<const void*>(kern), smem));
     const long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    static const int rotate = getenv("DIST_AMD_NT_ROTATE") ? atoi(getenv("DIST_AMD_NT_ROTATE")) : 0;   // measurement knob: 1 = rotated K order, 2 = no tile prefetch
+    static const int rotate = dist_knob("DIST_AMD_NT_ROTATE", 0);   // measurement knob: 1 = rotated K order, 2 = no tile prefetch
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), smem, s, a, rotate);
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
@@ -540,12 +537,9 @@ int launch(const dist_gemm_args& a, hipStream_t s) {
     constexpr size_t opnd = (size_t)2 * (BM + BN) * ld * sizeof(T);
     constexpr size_t stag = (size_t)WM * WN * (BM / WM) * ((BN / WN) * sizeof(T) + 16);
     constexpr size_t smem = opnd > stag ? opnd : stag;
-    static bool attr_done = false;
+    static DistSmemOnce attr;
     auto kern = gemm_nt_kernel<T, BM, BN, BK, WM, WN, GENERIC, MINW>;
-    if (!attr_done) {
-        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_done = true;
-    }
+    RUN_(dist_max_smem(attr, reinterpret_cast<const void*>(kern), smem));
     const long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(WM * WN * 64), smem, s, a);
     HIP_CHECK_RET(hipGetLastError());
@@ -560,16 +554,16 @@ int dispatch(const dist_gemm_args& a, hipStream_t s) {
     // 8-wave blocks (16 waves) share a CU where the 4-wave shapes had 2-3 blocks of 4 (conv3x3 69.6 -> 59.3 us, 384x384 Linear
     // 48.6 -> 44.8 us, 384->96 Linear 18.3 -> 16.7 us alone; profiles/r01_nt_8wave.md).  DIST_AMD_NT_W8=0 restores the 4-wave shapes
     // (measurement knob: bit 0 = N % 96 shapes, bit 1 = plain K % 64, bit 2 = generic).
-    static const int w8 = getenv("DIST_AMD_NT_W8") ? atoi(getenv("DIST_AMD_NT_W8")) : 7;
+    static const int w8 = dist_knob("DIST_AMD_NT_W8", 7);
     // DIST_AMD_NT_OCC=0 (measurement knob): the N % 96 shape compiled for 4 instead of 6 waves per SIMD (two 8-wave blocks per CU
     // instead of three).  Measured (profiles/r02_nt_occupancy.md): conv3x3 59.6 -> 55.8 us, step -0.15 ms with three blocks; the
     // generic 128x128x32 shape needs spills at 80 registers and gains nothing, so only N % 96 has the variant.
-    static const int occ = getenv("DIST_AMD_NT_OCC") ? atoi(getenv("DIST_AMD_NT_OCC")) : 1;
+    static const int occ = dist_knob("DIST_AMD_NT_OCC", 1);
     if constexpr (std::is_same<T, bf16_t>::value) {
         // LDS-DMA loader (three stages in flight, no staging registers).  DIST_AMD_NT_DMA=0: the register-staged loader.
-        static const int dma = getenv("DIST_AMD_NT_DMA") ? atoi(getenv("DIST_AMD_NT_DMA")) : 1;
+        static const int dma = dist_knob("DIST_AMD_NT_DMA", 1);
         if (dma && a.K % 32 == 0) {
-            static const bool oplain_on = !(getenv("DIST_AMD_NT_OPLAIN") && atoi(getenv("DIST_AMD_NT_OPLAIN")) == 0);   // measurement knob
+            static const bool oplain_on = (dist_knob("DIST_AMD_NT_OPLAIN", 1) != 0);   // measurement knob
             const bool op = oplain_on && a.omap.mode == DIST_OM_PLAIN;
             if (n96 && a.N == 96 && a.M > 768l * 128)                                                      // 392 blocks: one round of 2 per CU
                 return op ? launch_dma<256, 96, 8, 1, true, 4, false>(a, s) : launch_dma<256, 96, 8, 1, true, 4>(a, s);
@@ -579,7 +573,7 @@ int dispatch(const dist_gemm_args& a, hipStream_t s) {
         // A block is a serial chain of latency-bound K-tile steps, so a launch takes (rounds of resident blocks) x (one block's
         // time): 100 352 rows as 128-row tiles are 784 blocks on 768 resident slots (256 CUs x 3) - TWO rounds for 16 blocks.
         // 256-row tiles (8 x 1 waves, 32 x 96 per wave) make the same work 392 blocks = one round.  DIST_AMD_NT_BM256=0: off.
-        static const int bm256 = getenv("DIST_AMD_NT_BM256") ? atoi(getenv("DIST_AMD_NT_BM256")) : 1;
+        static const int bm256 = dist_knob("DIST_AMD_NT_BM256", 1);
         if (n96 && a.N == 96 && bm256 && a.M > 768l * 128) return launch<T, 256, 96, 32, 8, 1, true, 4>(a, s);
         if (n96 && (occ & 1)) return launch<T, 128, 96, 32, 4, 2, true, 6>(a, s);
     }

@@ -361,182 +361,12 @@ __global__ __launch_bounds__(NT) void tn_reduce_kernel(const dist_gemm_tn_args p
     atomicAdd(tn_dst(p, ii, c, tap), (a0 + a1) + (a2 + a3));
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The large plain gradients (input_linear 384 x 768, the c_proj pair 384 x 480, ffn.c_fc 384 x 384: 63 of the 103 GF of weight
-// gradients per layer) with an LDS-DMA operand ring and 192 x 256 / 192 x 192 output tiles (round 3).
-//
-// The register-staged kernel above is a serial chain per 64-row step (8 ds_write_b128, barrier, 24 transpose reads, 16 MFMAs per
-// wave; two register sets = 64 KB in flight per CU): 38 % of its wave cycles are parked, 36 % issue-stalled, MFMA 20 %
-// (profiles/r03_tn_big_tiles.md), and larger tiles spill on the staging registers.  Here:
-//   * rows travel L2 / HBM -> LDS by `buffer_load ... lds` (no staging registers, no ds_write pass) into a ring of FOUR 32-row stages
-//     (three in flight); a stage is [32][BI + 16] + [32][BJ + 16] bf16 = 30 KB for 192 x 256 - exactly 30 one-KB pieces; every wave
-//     issues four pieces per stage (the two waves that would have three re-request the last piece: same bytes, same place), so the
-//     counted wait is the same immediate for everyone;
-//   * per-lane SOURCE offsets place the row-major image with its 16-element padding (the padding lanes and the columns beyond K read
-//     zero through an out-of-range offset); the row advance is a scalar offset; rows beyond M read zero through the descriptor's bound;
-//   * fragments by ds_read_b64_tr_b16 exactly as above; per 32-row step a wave issues 4 DMA pieces and 20 (18) transpose reads for
-//     24 (18) MFMAs - the 128 x 128 tile: 12 reads + 4 register loads + 4 LDS stores per 8;
-//   * the bias gradient rides the same fragments: one more MFMA per A fragment against an all-ones B fragment;
-//   * the partial tile leaves straight from the accumulators (its fp32 image does not fit the LDS beside the ring).
-typedef __attribute__((address_space(3))) void* tn_lds_ptr;
-
-template <int BI, int BJ>
-__global__ __launch_bounds__(512) void gemm_tn_dma_kernel(const dist_gemm_tn_args p, int chunk, int tiles_i, int tiles_c) {
-    using T = bf16_t;
-    constexpr int WI = 2, WJ = 4, BRD = 32, STAGES = 4;
-    constexpr int LDI = BI + PADT, LDJ = BJ + PADT;
-    constexpr int A_BYTES = BRD * LDI * 2, B_BYTES = BRD * LDJ * 2, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int PA = A_BYTES / 1024, PB = B_BYTES / 1024, NP = PA + PB;
-    static_assert(A_BYTES % 1024 == 0 && B_BYTES % 1024 == 0 && NP > 24 && NP <= 32, "whole 1 KB pieces, four per wave");
-    constexpr int WTI = BI / WI, WTJ = BJ / WJ, FI = WTI / 16, FJ = WTJ / 16;
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wi = wid / WJ, wj = wid % WJ;
-    const int li = lane & 15, lg = lane >> 4;
-    const int tiles_ij = tiles_i * tiles_c;
-    int bid = blockIdx.x;
-    {
-        const int nblk = gridDim.x;
-        const int q = nblk / 8, r = nblk % 8, x = bid % 8, y = bid / 8;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
-    }
-    const int ms = bid / tiles_ij;
-    const int t = bid % tiles_ij;
-    const int ti = t % tiles_i, tc = t / tiles_i;
-    const int i0 = ti * BI, c0 = tc * BJ;
-    const int M = (int)p.M;
-    const int mbeg = ms * chunk, mend = min(M, mbeg + chunk);
-    if (mbeg >= mend) return;
-    const int nsteps = (mend - mbeg + BRD - 1) / BRD;
-
-    constexpr unsigned OOB = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)((long)M * p.lda * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)((long)M * p.ldb * 2), 0x00020000);
-    // this wave's four pieces: index q in [0, NP) -> operand, LDS position, per-lane source offset (bytes from the tile's first row / column)
-    unsigned voff[4]; int pidx[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int q = min(wid + 8 * k, NP - 1);                        // (the re-request of the last piece for waves without a fourth one)
-        pidx[k] = q;
-        const bool isA = q < PA;
-        const int byte = (isA ? q : q - PA) * 1024 + lane * 16;
-        const int rowb = isA ? LDI * 2 : LDJ * 2;
-        const int row = byte / rowb, cb = byte - row * rowb, col = cb >> 1;
-        const bool ok = isA ? (col < BI && i0 + col < p.NI) : (col < BJ && c0 + col < p.K);
-        voff[k] = ok ? (unsigned)((row * (isA ? p.lda : p.ldb) + col) * 2) : OOB;
-    }
-    // a row-chunk boundary is a multiple of 32 rows (the launcher rounds it), so a stage never straddles two splits; rows >= M read zero
-    auto stage = [&](const int s) __attribute__((always_inline)) {
-        char* sb = smem + (s % STAGES) * STAGE_BYTES;
-        const int m = mbeg + s * BRD;
-        const unsigned sa = (unsigned)(((long)m * p.lda + i0) * 2), sbb = (unsigned)(((long)m * p.ldb + c0) * 2);
-        const bool live = m < mend;                                    // stages behind the chunk are requested (constant wait counts) but read zeros
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int q = pidx[k];
-            const unsigned vo = live ? voff[k] : OOB;
-            if (q < PA) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (tn_lds_ptr)(sb + q * 1024), 16, vo, sa, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (tn_lds_ptr)(sb + A_BYTES + (q - PA) * 1024), 16, vo, sbb, 0, 0);
-        }
-    };
-
-    f32x4 acc[FI][FJ], accb[FI];
-#pragma unroll
-    for (int i = 0; i < FI; ++i) {
-        accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const bool do_colsum = p.colsum != nullptr && tc == 0 && wj == 0;
-    Frag<T> ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones.v[e] = (bf16_t)1.0f;
-
-    stage(0); stage(1); stage(2);
-    for (int s = 0; s < nsteps; ++s) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");               // this wave's pieces of stage s (s+1, s+2 may be in flight)
-        __builtin_amdgcn_s_barrier();                                   // ... everyone's; nobody reads slot (s + 3) % 4 any more
-        stage(s + 3);
-        __builtin_amdgcn_sched_barrier(0);
-        const T* ys = reinterpret_cast<const T*>(smem + (s % STAGES) * STAGE_BYTES);
-        const T* xs = reinterpret_cast<const T*>(smem + (s % STAGES) * STAGE_BYTES + A_BYTES);
-        Frag<T> fa[FI], fb[FJ];
-#pragma unroll
-        for (int i = 0; i < FI; ++i) gather_frag<T, true>(fa[i], ys, LDI, wi * WTI + i * 16, li, lg);
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) gather_frag<T, true>(fb[j], xs, LDJ, wj * WTJ + j * 16, li, lg);
-#pragma unroll
-        for (int i = 0; i < FI; ++i)
-#pragma unroll
-            for (int j = 0; j < FJ; ++j) mma16(fa[i], fb[j], acc[i][j]);
-        if (do_colsum) {
-#pragma unroll
-            for (int i = 0; i < FI; ++i) mma16(fa[i], ones, accb[i]);   // every column of D holds sum_m A[m][i]
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // (the requests behind the chunk)
-
-    // ---- partial tile + bias-gradient partial, straight from the accumulators (plain stores; tn_reduce_kernel sums the splits)
-    float* pt = p.partial + ((long)ms * tiles_ij + t) * (BI * BJ);
-#pragma unroll
-    for (int i = 0; i < FI; ++i)
-#pragma unroll
-        for (int j = 0; j < FJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pt[(wi * WTI + i * 16 + lg * 4 + r) * BJ + wj * WTJ + j * 16 + li] = acc[i][j][r];
-    if (do_colsum && li == 0) {
-        float* cp = p.partial + (long)gridDim.x * (BI * BJ) + ((long)ms * tiles_i + ti) * BI;
-#pragma unroll
-        for (int i = 0; i < FI; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cp[wi * WTI + i * 16 + lg * 4 + r] = accb[i][r];
-    }
-}
-
-template <int BI, int BJ>
-int launch_tn_dma(const dist_gemm_tn_args& a, hipStream_t s) {
-    constexpr size_t smem = (size_t)4 * 32 * (BI + BJ + 2 * PADT) * 2;
-    static bool attr_done = false;
-    auto kern = gemm_tn_dma_kernel<BI, BJ>;
-    if (!attr_done) {
-        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_done = true;
-    }
-    const int tiles_i = a.NI / BI, tiles_c = (a.K + BJ - 1) / BJ;
-    const long tiles = (long)tiles_i * tiles_c;
-    long msplit = 256 / tiles;
-    const long max_split = (a.M + 511) / 512;
-    if (msplit > max_split) msplit = max_split;
-    if (msplit < 1) msplit = 1;
-    int chunk = (int)((a.M + msplit - 1) / msplit);
-    chunk = (chunk + 31) / 32 * 32;
-    msplit = (a.M + chunk - 1) / chunk;
-    if (!a.partial || tiles * msplit * (long)(BI * BJ) + msplit * (long)tiles_i * BI > a.partial_elems) return 0;   // not taken: the register-staged kernel
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * msplit)), dim3(512), smem, s, a, chunk, tiles_i, tiles_c);
-    HIP_CHECK_RET(hipGetLastError());
-    const long total = tiles * (long)(BI * BJ);
-    const long gx = (total + (a.colsum ? (long)tiles_i * BI : 0) + NT - 1) / NT;
-    long groups = (1024 + gx - 1) / gx;
-    if (groups > msplit / 4) groups = msplit / 4;
-    if (groups < 1) groups = 1;
-    const int per = (int)((msplit + groups - 1) / groups);
-    groups = (msplit + per - 1) / per;
-    hipLaunchKernelGGL((tn_reduce_kernel<BI, BJ>), dim3((unsigned)gx, (unsigned)groups), dim3(NT), 0, s, a, (int)msplit, tiles_i, tiles_c, per);
-    HIP_CHECK_RET(hipGetLastError());
-    return 1;
-}
-
 template <typename T, int BI, int BJ, int WI, int WJ, bool TR, int MODES>
 int launch(const dist_gemm_tn_args& a, hipStream_t s) {
     constexpr size_t smem = (size_t)2 * BR * (BI + BJ + 2 * PADT) * sizeof(T);
-    static bool attr_done = false;
+    static DistSmemOnce attr;
     auto kern = gemm_tn_kernel<T, BI, BJ, WI, WJ, TR, MODES>;
-    if (!attr_done) {
-        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_done = true;
-    }
+    RUN_(dist_max_smem(attr, reinterpret_cast<const void*>(kern), smem));
     const int tiles_i = (a.NI + BI - 1) / BI, tiles_c = (a.K + BJ - 1) / BJ;
     const long tiles = (long)tiles_i * tiles_c * a.taps;
     // split the reduction so that at most 256 blocks exist (one per CU); at least 512 rows per block (every block ends with a
@@ -544,13 +374,13 @@ int launch(const dist_gemm_tn_args& a, hipStream_t s) {
     // partial tile that is written and read again (33 MB each way for the 384x768 gradient at 28 splits, against 116 MB of
     // operands): in the step, where the other streams fill the CUs anyway, 256 blocks are 0.25 ms faster (22.77 / 22.79 ->
     // 22.52 / 22.53 ms; 384: 22.69, 128: 22.85).
-    static const int max_blocks = getenv("DIST_AMD_TN_BLOCKS") ? atoi(getenv("DIST_AMD_TN_BLOCKS")) : 256;   // measurement knob
+    static const int max_blocks = dist_knob("DIST_AMD_TN_BLOCKS", 256);   // measurement knob
     long msplit = max_blocks / tiles;
     const long max_split = (a.M + 511) / 512;
     if (msplit > max_split) msplit = max_split;
     if (msplit < 1) msplit = 1;
     int chunk = (int)((a.M + msplit - 1) / msplit);
-    static const bool pairs = !(getenv("DIST_AMD_TN_PAIRS") && atoi(getenv("DIST_AMD_TN_PAIRS")) == 0);   // measurement knob: 0 = no fast path
+    static const bool pairs = (dist_knob("DIST_AMD_TN_PAIRS", 1) != 0);   // measurement knob: 0 = no fast path
     const int CH = (MODES == 0 && pairs) ? 2 * BR : BR;   // plain maps: whole step pairs per block (the kernel's all-valid fast path)
     chunk = (chunk + CH - 1) / CH * CH;
     msplit = (a.M + chunk - 1) / chunk;
@@ -559,7 +389,7 @@ int launch(const dist_gemm_tn_args& a, hipStream_t s) {
     if (!two_phase) b.partial = nullptr;
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * msplit)), dim3(WI * WJ * 64), smem, s, b, chunk, tiles_i, tiles_c);
     HIP_CHECK_RET(hipGetLastError());
-    static const bool skip_reduce = getenv("DIST_AMD_TN_SKIP_REDUCE") && atoi(getenv("DIST_AMD_TN_SKIP_REDUCE"));   // measurement knob (results WRONG): what the second phase holds of the step
+    static const bool skip_reduce = (dist_measure_knob("DIST_AMD_TN_SKIP_REDUCE", 0) != 0);   // measurement knob (results WRONG): what the second phase holds of the step
     if (two_phase && !skip_reduce) {
         const long total = tiles * (long)(BI * BJ);
         const long gx = (total + (a.colsum ? (long)tiles_i * BI : 0) + NT - 1) / NT;
@@ -582,27 +412,9 @@ int dispatch2(const dist_gemm_tn_args& a, hipStream_t s) {
     // (216-280 registers: 1-2 blocks of 4 waves per CU; now 119-152: 8 waves per CU in one block).  10-20 % faster per launch
     // alone (conv3x3 dW 95.5 -> 77.4 us, 384x768 dW 71.9 -> 62.0 us); capping the registers at 128 for two 8-wave blocks spills
     // and loses (92 us).  DIST_AMD_TN_W8=0: the 4-wave shapes (measurement knob; they exist for plain and runtime modes only).
-    static const int w8 = getenv("DIST_AMD_TN_W8") ? atoi(getenv("DIST_AMD_TN_W8")) : 1;
-    // Large plain gradients (input_linear 384 x 768, the c_proj pair 384 x 480, ffn.c_fc 384 x 384: 63 of the 103 GF of weight gradients
-    // per layer): 192 x 256 / 192 x 192 tiles.  A block's time follows the bytes it moves through registers and LDS per MFMA - the 128 x 128
-    // tile loads 32 KB and does 12 LDS transpose reads per 16 MFMAs per wave; 192 x 256 loads 56 KB and 10 reads per 24 MFMAs per wave:
-    // 1.7x fewer bytes in every path (profiles/r03_tn_big_tiles.md).  DIST_AMD_TN_BIG=0: off (measurement knob).
-    if constexpr (MODES == 0 && std::is_same<T, bf16_t>::value && TR) {
-        // MEASURED AND NOT KEPT (profiles/r03_tn_big_tiles.md): correct on every parity case, but 75 / 56 / 50 us against 64 / 52 / 38 us for the
-        // register-staged 128 x 128 kernel on the three shapes.  DIST_AMD_TN_DMA=1 (192 x 256 where it wastes less) / 3 (192 x 192) runs it.
-        static const int dma = getenv("DIST_AMD_TN_DMA") ? atoi(getenv("DIST_AMD_TN_DMA")) : 0;
-        if (dma && a.NI % 192 == 0 && a.K >= 192 && a.K % 8 == 0 && a.M >= 16384 && a.taps == 1 && (long)a.M * a.lda < (1l << 30) && (long)a.M * a.ldb < (1l << 30)) {
-            const int waste256 = (a.K + 255) / 256 * 256 - a.K, waste192 = (a.K + 191) / 192 * 192 - a.K;
-            const int rc = (waste192 * 256 < waste256 * 192 || (dma & 2)) ? launch_tn_dma<192, 192>(a, s) : launch_tn_dma<192, 256>(a, s);
-            if (rc != 0) return rc < 0 ? rc : DIST_OK;
-        }
-        static const int big = getenv("DIST_AMD_TN_BIG") ? atoi(getenv("DIST_AMD_TN_BIG")) : 0;
-        if (big && a.NI % 192 == 0 && a.K >= 384 && a.M >= 16384) {
-            const int waste256 = (a.K + 255) / 256 * 256 - a.K, waste192 = (a.K + 191) / 192 * 192 - a.K;
-            if (waste192 * 256 < waste256 * 192 || (big & 2)) return launch<T, 192, 192, 2, 4, TR, MODES>(a, s);
-            return launch<T, 192, 256, 2, 4, TR, MODES>(a, s);
-        }
-    }
+    static const int w8 = dist_knob("DIST_AMD_TN_W8", 1);
+    // (the large plain gradients - both extents >= 192, >= 8192 rows - run on gemm_tn8p_kernel, gemm_tn8p.hip: dist_op_gemm_tn tries it first;
+    //  192 x 256 / 192 x 192 register-staged tiles and an LDS-DMA ring in THIS kernel's lock-step schedule were measured and lost, profiles/r03_tn_big_tiles.md)
     if (w8 || MODES > 0) {
         if (i96 && j96) return launch<T, 96, 96, 3, 2, TR, MODES>(a, s);
         if (i96) return launch<T, 96, 128, 2, 4, TR, MODES>(a, s);
@@ -623,8 +435,8 @@ int dispatch(const dist_gemm_tn_args& a, hipStream_t s) {
     if (a.amap.mode == DIST_RM_PLAIN && a.bmap.mode == DIST_RM_PLAIN && a.taps == 1) return dispatch2<T, TR, 0>(a, s);
     // the combinations the engine uses (conv_t / temporal-ffn / stem, conv3x3, I2T, T2I weight gradients) with constant modes
     if constexpr (std::is_same<T, bf16_t>::value && TR) {
-        static const int w8 = getenv("DIST_AMD_TN_W8") ? atoi(getenv("DIST_AMD_TN_W8")) : 1;
-        static const int spec = getenv("DIST_AMD_TN_MODES") ? atoi(getenv("DIST_AMD_TN_MODES")) : 1;   // 0: runtime modes (measurement knob)
+        static const int w8 = dist_knob("DIST_AMD_TN_W8", 1);
+        static const int spec = dist_knob("DIST_AMD_TN_MODES", 1);   // 0: runtime modes (measurement knob)
         const int modes = a.amap.mode * 8 + a.bmap.mode;
         auto steppable = [](const dist_rowmap& rm) {       // rowmap_inc_ok for a step of BR rows
             switch (rm.mode) {
@@ -655,6 +467,10 @@ extern "C" int dist_op_gemm_tn(const dist_gemm_tn_args* a, void* stream) {
     if (a->out2 && (a->taps != 1 || a->inner != 1 || a->so_outer != 1 || a->split_c <= 0 || a->split_c >= a->K)) return DIST_ERR_ARG;
     if (a->colsum2 && !a->colsum) return DIST_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    {   // the large plain gradients: two-group LDS-DMA kernel (gemm_tn8p.hip)
+        const int rc = dist_k_gemm_tn8p(a, s);
+        if (rc != 0) return rc < 0 ? rc : DIST_OK;
+    }
     if (a->dtype == DIST_BF16) return a->use_tr ? dispatch<bf16_t, true>(*a, s) : dispatch<bf16_t, false>(*a, s);
     return dispatch<float, false>(*a, s);
 }

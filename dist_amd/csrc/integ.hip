@@ -1077,28 +1077,35 @@ __global__ __launch_bounds__(256) void integ_pack_kernel(const IgPack* __restric
 // In place:  dW = G' diag(gamma) + db beta^T,  and  dgamma[k] += sum_n W[n][k] G'[n][k],  dbeta[k] += sum_n W[n][k] db[n].
 // One block per 64 columns k (the lanes of a wave walk consecutive k: coalesced), its 16 waves split the rows n and keep 8 rows of loads in
 // flight (12 blocks of 4 waves walking 96 dependent rows each took 69 us on the weight-gradient stream); fixed summation order.
-struct IgUnfold { const float *W, *gamma, *beta; float *G; const float* db; float *dgamma, *dbeta; int N, K; };
+struct IgUnfold { const float *W, *gamma, *beta; float *G; float* db; float *dgamma, *dbeta; int N, K; const float *Gs, *dbs; };
 __global__ __launch_bounds__(1024) void integ_unfold_kernel(const IgUnfold a, const IgUnfold b) {
     const int nba = a.K / 64;
     const IgUnfold& d = (int)blockIdx.x < nba ? a : b;
     const int kl = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int k = ((int)blockIdx.x < nba ? blockIdx.x : blockIdx.x - nba) * 64 + kl;
+    const int kb = (int)blockIdx.x < nba ? blockIdx.x : blockIdx.x - nba;
+    const int k = kb * 64 + kl;
     __shared__ float red[2][16][64];
     const float g = d.gamma[k], be = d.beta[k];
     float sg = 0.f, sb = 0.f;
     const int per = (d.N + 15) / 16, n0 = wv * per, n1 = min(n0 + per, d.N);
+    // accumulating form: this pass's G' / db come from scratch (Gs / dbs), the slots d.G / d.db hold earlier passes' gradients and are added to
+    const bool acc = d.Gs != nullptr;
+    const float* __restrict__ Gin = acc ? d.Gs : d.G;
+    const float* __restrict__ dbin = acc ? d.dbs : d.db;
     for (int n = n0; n < n1; n += 8) {
-        float w[8], gp[8], dbn[8];
+        float w[8], gp[8], dbn[8], old[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int nn = min(n + u, n1 - 1);
-            w[u] = d.W[(long)nn * d.K + k]; gp[u] = d.G[(long)nn * d.K + k]; dbn[u] = d.db[nn];
+            w[u] = d.W[(long)nn * d.K + k]; gp[u] = Gin[(long)nn * d.K + k]; dbn[u] = dbin[nn];
+            old[u] = acc ? d.G[(long)nn * d.K + k] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (n + u < n1) {
                 sg += w[u] * gp[u]; sb += w[u] * dbn[u];
-                d.G[(long)(n + u) * d.K + k] = gp[u] * g + dbn[u] * be;
+                d.G[(long)(n + u) * d.K + k] = old[u] + (gp[u] * g + dbn[u] * be);
+                if (acc && kb == 0 && kl == 0) d.db[n + u] += dbn[u];
             }
         }
     }
@@ -1116,8 +1123,8 @@ __global__ __launch_bounds__(1024) void integ_unfold_kernel(const IgUnfold a, co
 template <int CI, int C4, int BM, int MODE, int DBG, bool T2I = false>
 int launch_integ_v(const IgArgs& a, hipStream_t s) {
     const int smem = BM * CI * 2 + 2 * BM * C4 * 2 + (T2I ? 9 * BM * 2 * 4 : 0);
-    static bool attr = false;
-    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)integ_fwd_kernel<CI, C4, BM, MODE, DBG, T2I>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr = true; }
+    static DistSmemOnce attr;
+    RUN_(dist_max_smem(attr, (const void*)integ_fwd_kernel<CI, C4, BM, MODE, DBG, T2I>, (size_t)smem));
     hipLaunchKernelGGL((integ_fwd_kernel<CI, C4, BM, MODE, DBG, T2I>), dim3((unsigned)(a.clips * a.groups)), dim3(512), smem, s, a);
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
@@ -1125,7 +1132,7 @@ int launch_integ_v(const IgArgs& a, hipStream_t s) {
 template <int CI, int C4, int BM>
 int launch_integ(const IgArgs& a, const int mode, hipStream_t s) {
 #ifdef DIST_INTEG_ABLATE
-    static const int dbg = getenv("DIST_AMD_INTEG_DBG") ? atoi(getenv("DIST_AMD_INTEG_DBG")) : 0;
+    static const int dbg = dist_measure_knob("DIST_AMD_INTEG_DBG", 0);
 #define IG_VARIANT(D) if (dbg == D) return mode ? launch_integ_v<CI, C4, BM, 1, D>(a, s) : launch_integ_v<CI, C4, BM, 0, D>(a, s);
     IG_VARIANT(1) IG_VARIANT(2) IG_VARIANT(4) IG_VARIANT(8) IG_VARIANT(16) IG_VARIANT(32) IG_VARIANT(3) IG_VARIANT(19) IG_VARIANT(23) IG_VARIANT(63) IG_VARIANT(59)
 #undef IG_VARIANT
@@ -1229,8 +1236,8 @@ extern "C" int dist_op_integration_bwd(const dist_integ_bwd_args* a, void* strea
     k.tokshift = sh;
     k.groups = (a->L + TOK - 1) / TOK;
     const int smem = BM * 384 * 2 + 2 * BM * 96 * 2 + 9 * BM * 2 * 4;
-    static bool attr = false;
-    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)integ_bwd_kernel<384, 96, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr = true; }
+    static DistSmemOnce attr;
+    RUN_(dist_max_smem(attr, (const void*)integ_bwd_kernel<384, 96, BM>, (size_t)smem));
     hipLaunchKernelGGL((integ_bwd_kernel<384, 96, BM>), dim3((unsigned)(k.clips * k.groups)), dim3(512), smem, static_cast<hipStream_t>(stream), k);
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
@@ -1240,8 +1247,10 @@ extern "C" int dist_op_integration_unfold(const dist_integ_unfold_args* a, void*
     if (!a || !a->ffn_fc_w || !a->ln_w || !a->ln_b || !a->d_ffn_fc_w || !a->d_ffn_fc_b || !a->d_ln_w || !a->d_ln_b || !a->tf_fc1_w || !a->ln_t_w ||
         !a->ln_t_b || !a->d_tf_fc1_w || !a->d_tf_fc1_b || !a->d_ln_t_w || !a->d_ln_t_b) return DIST_ERR_ARG;
     if (a->Ci <= 0 || a->Ci % 64 || a->C4 <= 0) return DIST_ERR_ARG;
-    IgUnfold x{a->ffn_fc_w, a->ln_w, a->ln_b, a->d_ffn_fc_w, a->d_ffn_fc_b, a->d_ln_w, a->d_ln_b, a->Ci, a->Ci};
-    IgUnfold y{a->tf_fc1_w, a->ln_t_w, a->ln_t_b, a->d_tf_fc1_w, a->d_tf_fc1_b, a->d_ln_t_w, a->d_ln_t_b, a->C4, a->Ci};
+    const int ng = (a->g_ffn_fc_w != nullptr) + (a->g_ffn_fc_b != nullptr) + (a->g_tf_fc1_w != nullptr) + (a->g_tf_fc1_b != nullptr);
+    if (ng != 0 && ng != 4) return DIST_ERR_ARG;
+    IgUnfold x{a->ffn_fc_w, a->ln_w, a->ln_b, a->d_ffn_fc_w, a->d_ffn_fc_b, a->d_ln_w, a->d_ln_b, a->Ci, a->Ci, a->g_ffn_fc_w, a->g_ffn_fc_b};
+    IgUnfold y{a->tf_fc1_w, a->ln_t_w, a->ln_t_b, a->d_tf_fc1_w, a->d_tf_fc1_b, a->d_ln_t_w, a->d_ln_t_b, a->C4, a->Ci, a->g_tf_fc1_w, a->g_tf_fc1_b};
     hipLaunchKernelGGL(integ_unfold_kernel, dim3((unsigned)(2 * a->Ci / 64)), dim3(1024), 0, static_cast<hipStream_t>(stream), x, y);
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
@@ -1260,7 +1269,7 @@ extern "C" int dist_op_integration_fwd(const dist_integ_args* a, void* stream) {
         if (a->Xhat) { if (a->Na || a->Nb) return DIST_ERR_ARG; mode = 2; }
         else { if (!(a->Na && a->Nb && a->ln_w && a->ln_b && a->ln_t_w && a->ln_t_b)) return DIST_ERR_ARG; mode = 1; }
     }
-    static const int bm_env = getenv("DIST_AMD_INTEG_BM") ? atoi(getenv("DIST_AMD_INTEG_BM")) : 0;     // measurement knob: 64 / 128
+    static const int bm_env = dist_knob("DIST_AMD_INTEG_BM", 0);     // measurement knob: 64 / 128
     int BM = bm_env == 64 || bm_env == 128 ? bm_env : 128;
     if (BM / a->t < 1 || (BM % a->t)) return DIST_ERR_ARG;
     IgArgs k;

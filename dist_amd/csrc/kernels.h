@@ -36,6 +36,8 @@ int dist_k_logits_loss(const void* v, const float* text, const float* logit_scal
 bool dist_k_gemm_fast_eligible(const dist_gemm_args* a);
 int dist_k_gemm_fast(const dist_gemm_args* a, hipStream_t s);
 int dist_k_gemm_small(const dist_gemm_args* a, hipStream_t s);       // M < 1024 (gemm_small.hip)
+// two-group LDS-DMA weight-gradient GEMM for the large plain gradients (gemm_tn8p.hip): 1 = launched, 0 = not its shape, <0 = error
+int dist_k_gemm_tn8p(const dist_gemm_tn_args* a, hipStream_t s);
 // fused TemporalNet (tnet.hip): does dist_op_temporal_net_fwd take this geometry?
 bool dist_k_tnet_fwd_eligible(int dtype, int Ct, int G, int tk);
 // fused IntegrationNetwork forward (integ.hip): eligibility, and the all-layers form of dist_op_integration_pack (`descs_dev`: n descriptors

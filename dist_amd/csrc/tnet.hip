@@ -333,11 +333,8 @@ int launch_tnet_fwd2(const TnArgs& a, hipStream_t s) {
     const int act_bytes = ((a.N + 1) * CT * 2 + 1023) & ~1023;
     const size_t smem = (size_t)act_bytes + 2 * (CT / 32) * CT * 64 + 4 * CT * sizeof(float);
     if (smem > 160 * 1024) return DIST_ERR_ARG;
-    static size_t attr_done = 0;
-    if (attr_done < smem) {
-        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(tnet_fwd_kernel<CT, SAVE_UV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_done = smem;
-    }
+    static DistSmemOnce attr;
+    RUN_(dist_max_smem(attr, reinterpret_cast<const void*>(tnet_fwd_kernel<CT, SAVE_UV>), smem));
     const int groups = (a.clips + 7) / 8;
     hipLaunchKernelGGL((tnet_fwd_kernel<CT, SAVE_UV>), dim3((unsigned)(groups * 8 * a.T)), dim3(512), smem, s, a);
     HIP_CHECK_RET(hipGetLastError());
@@ -687,12 +684,9 @@ int launch_tnet_bwd(const TnBwdArgs& aa, float* dgamma, float* dbeta, int phase,
     const int act_bytes = ((aa.N + 1) * CT * 2 + 1023) & ~1023;
     const size_t smem = (size_t)act_bytes + 2 * (CT / 32) * CT * 64 + 3 * CT * sizeof(float);
     if (smem > 160 * 1024) return DIST_ERR_ARG;
-    static size_t attr_done = 0;
-    if (attr_done < smem) {
-        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(tnet_bwd_spatial_kernel<CT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(tnet_bwd_temporal_kernel<CT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_done = smem;
-    }
+    static DistSmemOnce attr_s, attr_t;
+    RUN_(dist_max_smem(attr_s, reinterpret_cast<const void*>(tnet_bwd_spatial_kernel<CT>), smem));
+    RUN_(dist_max_smem(attr_t, reinterpret_cast<const void*>(tnet_bwd_temporal_kernel<CT>), smem));
     const int groups = (aa.clips + 7) / 8, nwg = groups * 8 * aa.T;
     TnBwdArgs a = aa;
     a.nwg = nwg;
@@ -708,7 +702,7 @@ int launch_tnet_bwd(const TnBwdArgs& aa, float* dgamma, float* dbeta, int phase,
 }  // namespace
 
 bool dist_k_tnet_fwd_eligible(int dtype, int Ct, int G, int tk) {
-    static const bool on = !(getenv("DIST_AMD_TNET_FUSED") && atoi(getenv("DIST_AMD_TNET_FUSED")) == 0);   // measurement knob: 0 = LayerNorm + two GEMMs
+    static const bool on = (dist_knob("DIST_AMD_TNET_FUSED", 1) != 0);   // measurement knob: 0 = LayerNorm + two GEMMs
     return on && dtype == DIST_BF16 && (Ct == 32 || Ct == 64 || Ct == 96) && G >= 1 && G * G <= 256 && tk % 2 == 1 && tk <= 5;
 }
 
@@ -724,8 +718,8 @@ extern "C" int dist_op_temporal_net_fwd(const dist_tnet_args* a, void* stream) {
     k.z = static_cast<bf16_t*>(a->z); k.p = static_cast<bf16_t*>(a->p); k.Xp = static_cast<bf16_t*>(a->Xp);
     k.U = static_cast<bf16_t*>(a->U); k.V = static_cast<bf16_t*>(a->V);
     k.mean = a->mean; k.rstd = a->rstd;
-    static const int dbg = getenv("DIST_AMD_TNET_DBG") ? atoi(getenv("DIST_AMD_TNET_DBG")) : 0;
-    static const int stagger = getenv("DIST_AMD_TNET_STAGGER") ? atoi(getenv("DIST_AMD_TNET_STAGGER")) : 0;
+    static const int dbg = dist_measure_knob("DIST_AMD_TNET_DBG", 0);
+    static const int stagger = dist_knob("DIST_AMD_TNET_STAGGER", 0);
     k.dbg = dbg; k.stagger = stagger;
     k.clips = a->clips; k.T = a->T; k.G = a->G; k.N = a->G * a->G; k.tk = a->tk; k.eps = a->eps;
     hipStream_t s = static_cast<hipStream_t>(stream);

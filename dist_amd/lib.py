@@ -77,7 +77,8 @@ class IntegArgs(C.Structure):
 
 class IntegUnfoldArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ffn_fc_w", "ln_w", "ln_b", "d_ffn_fc_w", "d_ffn_fc_b", "d_ln_w", "d_ln_b",
-                                          "tf_fc1_w", "ln_t_w", "ln_t_b", "d_tf_fc1_w", "d_tf_fc1_b", "d_ln_t_w", "d_ln_t_b")] + [("Ci", C.c_int), ("C4", C.c_int)]
+                                          "tf_fc1_w", "ln_t_w", "ln_t_b", "d_tf_fc1_w", "d_tf_fc1_b", "d_ln_t_w", "d_ln_t_b")] + [("Ci", C.c_int), ("C4", C.c_int)] + \
+               [(n, C.c_void_p) for n in ("g_ffn_fc_w", "g_ffn_fc_b", "g_tf_fc1_w", "g_tf_fc1_b")]
 
 
 class IntegPackArgs(C.Structure):
@@ -106,7 +107,7 @@ class Config(C.Structure):
 
 GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
 
-ABI_VERSION = 8    # include/dist_amd.h DIST_ABI_VERSION: bumped on every struct-layout change
+ABI_VERSION = 9    # include/dist_amd.h DIST_ABI_VERSION: bumped on every struct-layout change
 ABI_MIRRORS = (("dist_gemm_args", GemmArgs), ("dist_gemm_tn_args", GemmTnArgs), ("dist_ln_args", LnArgs), ("dist_ln_bwd_args", LnBwdArgs),
                ("dist_adamw_seg", AdamwSeg), ("dist_config", Config), ("dist_rowmap", RowMap), ("dist_outmap", OutMap), ("dist_tnet_args", TnetArgs), ("dist_tnet_bwd_args", TnetBwdArgs),
                ("dist_integ_args", IntegArgs), ("dist_integ_pack_args", IntegPackArgs), ("dist_integ_unfold_args", IntegUnfoldArgs), ("dist_integ_bwd_args", IntegBwdArgs))
@@ -150,6 +151,7 @@ def load():
     for cname, mirror in ABI_MIRRORS:
         if lib.dist_abi_sizeof(cname.encode()) != C.sizeof(mirror):
             raise DistError(f"{LIB_PATH}: sizeof({cname}) = {lib.dist_abi_sizeof(cname.encode())}, the ctypes mirror has {C.sizeof(mirror)}")
+    _sig(lib, "dist_measure_build", argtypes=[])
     _sig(lib, "dist_strerror", restype=C.c_char_p)
     _sig(lib, "dist_strerror", argtypes=[C.c_int])
     _sig(lib, "dist_abi_sizeof", argtypes=[C.c_char_p])

@@ -249,10 +249,14 @@ def integration_bwd(dR, saved, pk, clips, t, Ltok, *, add_dR=False, copy=False, 
     return out
 
 
-def integration_unfold(w, g):
+def integration_unfold(w, g, gs=None):
     """backward side of the LayerNorm fold (dist_op_integration_unfold), in place on the fp32 gradient dict `g` (same keys as the weights `w`):
-    g["ffn.c_fc.weight"] / g["temporal_ffn.c_fc1.weight"] hold dz^T xhat on entry."""
+    g["ffn.c_fc.weight"] / g["temporal_ffn.c_fc1.weight"] hold dz^T xhat on entry.  `gs` (accumulating form): this pass's dz^T xhat and bias
+    gradients of the two Linears (same four keys); `g` then holds EARLIER passes' gradients and is added to."""
     a = L.IntegUnfoldArgs()
+    if gs is not None:
+        a.g_ffn_fc_w, a.g_ffn_fc_b = _p(gs["ffn.c_fc.weight"]), _p(gs["ffn.c_fc.bias"])
+        a.g_tf_fc1_w, a.g_tf_fc1_b = _p(gs["temporal_ffn.c_fc1.weight"]), _p(gs["temporal_ffn.c_fc1.bias"])
     a.ffn_fc_w, a.ln_w, a.ln_b = _p(w["ffn.c_fc.weight"]), _p(w["ln.weight"]), _p(w["ln.bias"])
     a.d_ffn_fc_w, a.d_ffn_fc_b, a.d_ln_w, a.d_ln_b = _p(g["ffn.c_fc.weight"]), _p(g["ffn.c_fc.bias"]), _p(g["ln.weight"]), _p(g["ln.bias"])
     a.tf_fc1_w, a.ln_t_w, a.ln_t_b = _p(w["temporal_ffn.c_fc1.weight"]), _p(w["ln_temporal.weight"]), _p(w["ln_temporal.bias"])
@@ -273,7 +277,8 @@ def ln_fold(W, bias, gamma, beta):
     return Wp, colsum, bout
 
 
-def gemm_tn(A, B, out, M, NI, K, *, taps=1, amap=None, bmap=None, so_i=None, so_tap=None, so_outer=1, inner=1, use_tr=1, colsum=None, partial=None):
+def gemm_tn(A, B, out, M, NI, K, *, taps=1, amap=None, bmap=None, so_i=None, so_tap=None, so_outer=1, inner=1, use_tr=1, colsum=None, partial=None,
+            out2=None, split_c=0, so_i2=0, colsum2=None):
     lib = L.load()
     a = L.GemmTnArgs()
     a.A, a.B, a.out = _p(A), _p(B), _p(out)
@@ -288,6 +293,8 @@ def gemm_tn(A, B, out, M, NI, K, *, taps=1, amap=None, bmap=None, so_i=None, so_
     a.colsum = _p(colsum)
     a.partial = _p(partial)
     a.partial_elems = partial.numel() if partial is not None else 0
+    if out2 is not None:      # columns >= split_c go to a second tensor (two weights that share dY)
+        a.out2, a.split_c, a.so_i2, a.colsum2 = _p(out2), split_c, so_i2, _p(colsum2)
     L.check(lib.dist_op_gemm_tn(C.byref(a), _stream()))
 
 

@@ -38,10 +38,14 @@ enum {
 };
 
 const char* dist_strerror(int code);
-/* 8 for this header (8: dist_ln_bwd_args.partial / partial_elems).  Bumped on EVERY layout change of a struct below; a binding compares it, and dist_abi_sizeof() of each
+/* 9 for this header (8: dist_ln_bwd_args.partial / partial_elems; 9: the dist_integ_args / dist_integ_bwd_args fields of the fused T2I / I2T stages, which round 3
+ * added under 8, and dist_measure_build).  Bumped on EVERY layout change of a struct below; a binding compares it, and dist_abi_sizeof() of each
  * struct it mirrors, before the first dist_create (dist_amd/lib.py does). */
-#define DIST_ABI_VERSION 8
+#define DIST_ABI_VERSION 9
 int dist_abi_version(void);
+/* 1 when the library was compiled with -DDIST_AMD_MEASURE: only then do the timing-only environment knobs whose results are wrong
+ * (DIST_AMD_SKIP, DIST_AMD_DUMMY*, DIST_AMD_TN_SKIP_REDUCE, DIST_AMD_*_DBG, DIST_AMD_TNET_BWD_NOREDUCE) exist.  The shipped build returns 0. */
+int dist_measure_build(void);
 /* sizeof() of an argument struct of this header by name ("dist_gemm_args", "dist_gemm_tn_args", "dist_ln_args",
  * "dist_ln_bwd_args", "dist_adamw_seg", "dist_config", "dist_rowmap", "dist_outmap", "dist_tnet_args", "dist_tnet_bwd_args", "dist_integ_args", "dist_integ_pack_args", "dist_integ_unfold_args", "dist_integ_bwd_args"); -1 for an unknown name.
  * Lets a foreign-language binding verify its mirror of the layout without a GPU. */
@@ -314,9 +318,12 @@ int dist_op_integration_bwd(const dist_integ_bwd_args* a, void* stream);
  * gradients; on exit they hold the gradients of the unfolded weights, dW = G' diag(gamma) + db beta^T, and
  * d_ln_w[k] += sum_n W[n][k] G'[n][k], d_ln_b[k] += sum_n W[n][k] db[n] (likewise ln_temporal through temporal_ffn.c_fc1).  fp32, fixed order. */
 typedef struct dist_integ_unfold_args {
-    const float* ffn_fc_w; const float* ln_w; const float* ln_b; float* d_ffn_fc_w; const float* d_ffn_fc_b; float* d_ln_w; float* d_ln_b;
-    const float* tf_fc1_w; const float* ln_t_w; const float* ln_t_b; float* d_tf_fc1_w; const float* d_tf_fc1_b; float* d_ln_t_w; float* d_ln_t_b;
+    const float* ffn_fc_w; const float* ln_w; const float* ln_b; float* d_ffn_fc_w; float* d_ffn_fc_b; float* d_ln_w; float* d_ln_b;
+    const float* tf_fc1_w; const float* ln_t_w; const float* ln_t_b; float* d_tf_fc1_w; float* d_tf_fc1_b; float* d_ln_t_w; float* d_ln_t_b;
     int Ci, C4;
+    /* ACCUMULATING form (ABI 9; all four or none): G' and the bias gradients of THIS backward pass were written to scratch instead of the gradient
+     * slots (which already hold earlier passes' unfolded gradients): d_*_w += G' diag(gamma) + db beta^T, d_*_b += db, d_ln_* += ... as above. */
+    const float* g_ffn_fc_w; const float* g_ffn_fc_b; const float* g_tf_fc1_w; const float* g_tf_fc1_b;
 } dist_integ_unfold_args;
 int dist_op_integration_unfold(const dist_integ_unfold_args* a, void* stream);
 int dist_op_integration_pack(const dist_integ_pack_args* a, void* stream);

@@ -22,9 +22,9 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert len(syms) >= 30
     for s in syms:
         assert hasattr(l, s), s
-    assert l.dist_abi_version() == lib.ABI_VERSION == 8
+    assert l.dist_abi_version() == lib.ABI_VERSION == 9
     hdr = open(os.path.join(ROOT, "include", "dist_amd.h")).read()
-    assert "#define DIST_ABI_VERSION 8" in hdr
+    assert "#define DIST_ABI_VERSION 9" in hdr
     # the ctypes mirrors of the argument structs have the library's layout size (checked without a GPU)
     for cname, mirror in (("dist_gemm_args", lib.GemmArgs), ("dist_gemm_tn_args", lib.GemmTnArgs), ("dist_ln_args", lib.LnArgs),
                           ("dist_ln_bwd_args", lib.LnBwdArgs), ("dist_adamw_seg", lib.AdamwSeg), ("dist_config", lib.Config),
@@ -53,7 +53,7 @@ def test_integration_md_stub_matches_the_library():
     nargs = len(re.findall(r"-?\d+", init_src.split("(", 1)[1]))
     assert nargs == len(stub._fields_), "the example initializer must fill every field"
     cfg = eval(init_src, ns)
-    assert "dist_abi_version() == 8" in block and 'dist_abi_sizeof(b"dist_config")' in block
+    assert "dist_abi_version() == 9" in block and 'dist_abi_sizeof(b"dist_config")' in block
     h = ctypes.c_void_p()
     pcfg = ctypes.cast(ctypes.pointer(cfg), ctypes.POINTER(lib.Config))    # the stub's own struct type, handed over as the bytes it is
     assert l.dist_create(pcfg, ctypes.byref(h)) == 0
