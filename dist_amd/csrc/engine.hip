@@ -1146,6 +1146,31 @@ extern "C" int dist_vit_forward(dist_handle* h, const float* video, int b, void*
     return DIST_OK;
 }
 
+// The caller's own frozen-ViT features instead of a dist_vit_forward pass (reference DiSTNetwork.forward reads input['mid_feat']['img'][layer_id]
+// and input['images'], dist.py:222-247): copied into the current feature slot, converted to the engine's storage type and token-major rows.
+extern "C" int dist_features_import(dist_handle* h, const void* const* mid_feat, int src_dtype, const float* video, int b, void* stream) {
+    RUN(vit_args_ok(h, video, b, "dist_features_import"));
+    if (!mid_feat || (src_dtype != DIST_F32 && src_dtype != DIST_BF16)) return fail(h, DIST_ERR_ARG, "dist_features_import: mid_feat / src_dtype");
+    const dist_config& c = h->cfg;
+    for (int i = 0; i < c.layers; ++i)
+        if (!mid_feat[i]) return fail(h, DIST_ERR_ARG, "dist_features_import: mid_feat[%d] is NULL (every selected layer is needed)", i);
+    dist_handle::FeatSlot& S = h->slot[h->cur];
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    S.prefetched = false;
+    if (h->vit_ran) HIP_CHECK_RET(hipStreamWaitEvent(s, h->ev_vit_done, 0));      // a ViT pass still in flight may be writing this slot
+    HIP_CHECK_RET(hipEventRecord(S.ev_pre, s));
+    RUN(dist_op_patchify(video, S.patches, b, c.frames, c.resolution, c.resolution, c.patch, c.dtype, stream));
+    HIP_CHECK_RET(hipEventRecord(S.ev_feat[c.layers], s));
+    for (int i = 0; i < c.layers; ++i) {
+        RUN(dist_k_import_feat(mid_feat[i], src_dtype, S.feat[i], c.dtype, b * h->t, h->L, c.width, s));
+        HIP_CHECK_RET(hipEventRecord(S.ev_feat[i], s));
+    }
+    S.next_layer = c.layers; S.pending_b = b; S.b = b;
+    h->fwd_b = b;
+    h->branch_b = 0;
+    return DIST_OK;
+}
+
 // Software pipelining over batches: the ViT is frozen, so its forward for batch n+1 does not depend on the optimizer step of
 // batch n.  dist_vit_prefetch runs it into the spare feature slot on its own (low-priority) stream while the branch
 // forward / backward / AdamW of batch n run on the caller's stream; dist_vit_adopt makes that slot the current one.
@@ -1781,7 +1806,13 @@ extern "C" int dist_debug_tensor(dist_handle* h, const char* name, const void** 
     if (key == "tn_out" && layer_ok()) { *ptr = h->lw[i].Xp; *rows = rowsX; *cols = c.temporal_dim; return DIST_OK; }
     if (key == "int_out" && layer_ok()) { *ptr = h->lw[i].R; *rows = rowsS; *cols = c.integration_dim; return DIST_OK; }
     if (key == "x_temporal" && layer_ok()) { *ptr = (i + 1 < c.layers) ? h->lw[i + 1].X : h->Xlast; *rows = rowsX; *cols = c.temporal_dim; return DIST_OK; }
-    if (key == "mid" && layer_ok()) { *ptr = h->lw[i].Mp; *rows = rowsS; *cols = c.integration_dim; return DIST_OK; }
+    if (key == "mid" && layer_ok()) {
+        // with T2I formed inside the fused forward and the fused backward reading xhat, M' is only written for the last layer (DIST_AMD_KEEP_MID=1 keeps all)
+        if (h->ig_t2i && h->ig_bwd && !h->keep_mid && i != c.layers - 1)
+            return fail(h, DIST_ERR_STATE, "mid.%d is not materialised by the fused IntegrationNetwork kernels (set DIST_AMD_KEEP_MID=1)", i);
+        if (h->branch_infer || h->inference) return fail(h, DIST_ERR_STATE, "mid.%d is not written in inference mode", i);
+        *ptr = h->lw[i].Mp; *rows = rowsS; *cols = c.integration_dim; return DIST_OK;
+    }
     if (key == "patches") { *ptr = h->patches; *rows = rowsX; *cols = h->Kp; return DIST_OK; }
     if (key == "vit_ln_out") { *ptr = h->hbuf; *rows = rowsS; *cols = c.width; return DIST_OK; }   // LayerNorm output scratch of the ViT (unused when folded)
     return fail(h, DIST_ERR_ARG, "unknown debug tensor %s", name);

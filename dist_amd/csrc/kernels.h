@@ -27,6 +27,7 @@ int dist_k_cls_rows_bwd(const void* d, float* dtable, int nbj, int L, int C, int
 int dist_k_add_table(const void* x, const float* table, void* out, long rows, int C, int period, int dtype, hipStream_t s);
 int dist_k_pair_sum(const void* x, void* out, long nbj, int rowlen, int alpha, int dtype, hipStream_t s);
 int dist_k_mean_cls(const void* feat, void* out, int b, int t, int L, int C, int dtype, hipStream_t s);
+int dist_k_import_feat(const void* src, int src_dtype, void* dst, int dst_dtype, int bt, int L, int C, hipStream_t s);   // [L][bt][C] -> [(bt)*L][C]
 int dist_k_bcast_rows(const float* table, void* out, long rows, int C, int dtype, hipStream_t s);
 int dist_k_logits_loss(const void* v, const float* text, const float* logit_scale, const float* soft_target,
                        float* logits, float* vid_norm, float* loss, void* dv, float* dlogit_scale,

@@ -446,6 +446,32 @@ extern "C" int dist_op_patchify(const float* video, void* patches, int b, int T,
     return DIST_OK;
 }
 
+// frozen-ViT features handed over by the caller in the reference's layout [L][b*t][C] (sequence first, clip.py:282-300) -> the engine's token rows
+// [(b*t)*L][C] in its storage type: one wave per destination row, 8 elements per lane and step.
+namespace {
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void import_feat_kernel(const TI* __restrict__ src, TO* __restrict__ dst, const int bt, const int L, const int C) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)bt * L) return;
+    const int bj = (int)(row / L), l = (int)(row - (long)bj * L);
+    const TI* s = src + ((long)l * bt + bj) * C;
+    TO* d = dst + row * C;
+    for (int c = (threadIdx.x & 63) * 8; c < C; c += 512) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (c + e < C) d[c + e] = from_f<TO>(to_f(s[c + e]));
+    }
+}
+}  // namespace
+int dist_k_import_feat(const void* src, int src_dtype, void* dst, int dst_dtype, int bt, int L, int C, hipStream_t s) {
+    const dim3 grid((unsigned)(((long)bt * L + 3) / 4));
+    if (src_dtype == DIST_F32 && dst_dtype == DIST_F32) hipLaunchKernelGGL((import_feat_kernel<float, float>), grid, dim3(256), 0, s, (const float*)src, (float*)dst, bt, L, C);
+    else if (src_dtype == DIST_F32) hipLaunchKernelGGL((import_feat_kernel<float, bf16_t>), grid, dim3(256), 0, s, (const float*)src, (bf16_t*)dst, bt, L, C);
+    else if (dst_dtype == DIST_F32) hipLaunchKernelGGL((import_feat_kernel<bf16_t, float>), grid, dim3(256), 0, s, (const bf16_t*)src, (float*)dst, bt, L, C);
+    else hipLaunchKernelGGL((import_feat_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, bt, L, C);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+
 extern "C" int dist_op_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream) {
     if (!a || !b || !out || n <= 0 || n % 8) return DIST_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -63,6 +63,7 @@ class Engine:
         self._segs_key = None
         self._text = None
         self._pf_video = None
+        self._feat_stamp = 0                 # bumped whenever the current feature slot receives another pass
         self._cur_video = None
         self._cur_ver = self._pf_ver = -1
         self.b = 0
@@ -144,6 +145,31 @@ class Engine:
         self.b = video.shape[0]
         L.check(self.lib.dist_vit_forward(self.h, video.data_ptr(), self.b, ops._stream()), self.h)
         self._cur_video, self._cur_ver = video, video._version
+        self._feat_stamp = getattr(self, "_feat_stamp", 0) + 1      # (which pass the current feature slot holds: CLIP's lazy img_logits checks it)
+
+    def import_features(self, mid_feat, video):
+        """The caller's own frozen-ViT features instead of a ViT pass (dist_features_import): `mid_feat` = one tensor per ViT block in the
+        reference's layout [L, b*t, width] (fp32 or bf16, CUDA, contiguous), `video` [b,3,T,H,W] fp32.  What the reference's
+        DiSTNetwork.forward reads from input['mid_feat']['img'] / input['images'] (dist.py:222-247)."""
+        assert video.dtype == torch.float32 and video.is_contiguous() and video.is_cuda
+        nl = self.cfg.layers
+        if len(mid_feat) != nl:
+            raise L.DistError(f"import_features needs {nl} layer tensors, got {len(mid_feat)}")
+        dt = mid_feat[0].dtype
+        if dt not in (torch.float32, torch.bfloat16):
+            raise L.DistError(f"mid_feat dtype {dt}: float32 or bfloat16")
+        b = video.shape[0]
+        t_, Lt = self.cfg.frames // self.cfg.alpha, (self.cfg.resolution // self.cfg.patch) ** 2 + 1
+        keep = []
+        for i, m in enumerate(mid_feat):
+            if tuple(m.shape) != (Lt, b * t_, self.cfg.width) or m.dtype != dt or not m.is_cuda:
+                raise L.DistError(f"mid_feat[{i}]: expected a CUDA {dt} tensor of shape {(Lt, b * t_, self.cfg.width)}, got {m.dtype} {tuple(m.shape)}")
+            keep.append(m.contiguous())
+        ptrs = (C.c_void_p * nl)(*[C.c_void_p(m.data_ptr()) for m in keep])
+        self.b = b
+        L.check(self.lib.dist_features_import(self.h, ptrs, L.F32 if dt == torch.float32 else L.BF16, video.data_ptr(), b, ops._stream()), self.h)
+        self._cur_video, self._cur_ver = None, -1          # the slot no longer holds the pass of a known clip tensor
+        self._feat_stamp = getattr(self, "_feat_stamp", 0) + 1
 
     def has_features_for(self, video):
         """True when the current feature slot already holds the frozen-ViT pass of exactly this tensor (same object,
@@ -168,6 +194,7 @@ class Engine:
         L.check(self.lib.dist_vit_adopt(self.h), self.h)
         self.b = self._pf_video.shape[0]
         self._cur_video, self._cur_ver, self._pf_video = self._pf_video, self._pf_ver, None
+        self._feat_stamp = getattr(self, "_feat_stamp", 0) + 1
 
     def set_inference(self, on=True):
         """forward passes keep nothing for a backward pass (dist_set_inference); `backward` then raises until a training-mode forward ran"""

@@ -180,6 +180,7 @@ def load():
     _sig(lib, "dist_vit_prefetch", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_vit_prefetch_layers", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_vit_adopt", argtypes=[C.c_void_p])
+    _sig(lib, "dist_features_import", argtypes=[C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_void_p])
     _sig(lib, "dist_branch_forward", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_branch_backward", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p])
     _sig(lib, "dist_loss", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])

@@ -168,6 +168,33 @@ class _DistFunction(torch.autograd.Function):
         return (None, None, None, eng.dlogit_scale.view(()).clone()) + grads
 
 
+class _OutputDict(dict):
+    """The reference's output dictionary (clip.py:532) with `img_logits` computed on first access."""
+    _lazy_img = None
+
+    def _img(self):
+        clip, stamp = self._lazy_img
+        if clip.engine._feat_stamp != stamp:
+            raise L.DistError("img_logits was requested after the engine's feature slot moved on to another batch; read it before the next forward / adopt")
+        v = clip.image_logits()
+        dict.__setitem__(self, "img_logits", v)
+        return v
+
+    def __getitem__(self, k):
+        if k == "img_logits" and not dict.__contains__(self, k) and self._lazy_img is not None:
+            return self._img()
+        return dict.__getitem__(self, k)
+
+    def __contains__(self, k):
+        return k == "img_logits" or dict.__contains__(self, k)
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def keys(self):
+        return list(dict.keys(self)) + ([] if dict.__contains__(self, "img_logits") else ["img_logits"])
+
+
 class CLIP(nn.Module):
     def __init__(self, cfg, embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size,
                  context_length, vocab_size, transformer_width, transformer_heads, transformer_layers):
@@ -265,7 +292,12 @@ class CLIP(nn.Module):
             self.engine.set_inference(infer)
             self._infer = infer
         logits, vid = _DistFunction.apply(self.engine, video, text_features, self.logit_scale, *self._dist_params)
-        return {"logits_per_image": logits, "logits_per_text": logits.t(), "img_logits": self.image_logits(), "vid_logits": vid[:, None, :]}
+        # `img_logits` (the frozen ViT's own frame embeddings) is read by no DiST configuration (zero_shot_test / prediction fusion are off): it is
+        # computed on first access, from the feature slot this forward left (a gather, a LayerNorm, a GEMM and a copy less per train step)
+        out = _OutputDict({"logits_per_image": logits, "logits_per_text": logits.t(), "vid_logits": vid[:, None, :]})
+        out._lazy_img = (self, self.engine._feat_stamp)
+        dict.__setitem__(out, "_dist_engine", self.engine)      # for models/utils/losses.py: the loss of these logits is dist_loss
+        return out
 
     @torch.no_grad()
     def image_logits(self):

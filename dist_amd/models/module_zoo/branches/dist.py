@@ -15,7 +15,7 @@ from ...base.clip import DiSTParams
 def engine_config(cfg, width, layers, patch, resolution, embed_dim, batch, dtype):
     d = cfg.VIDEO.BACKBONE.DIST
     sel = list(d.SELECTED_LAYERS)
-    if sel != list(range(layers)):
+    if sel != list(range(layers)):      # (a restriction the reference does not have - dist.py:170-190 takes any subset; every released yaml selects all: INTEGRATION.md A)
         raise L.DistError(f"SELECTED_LAYERS must be 0..{layers - 1} (every DiST yaml selects all layers), got {sel}")
     if int(d.S_PATCH_SIZE) != int(patch):
         raise L.DistError(f"DIST.S_PATCH_SIZE {d.S_PATCH_SIZE} must equal the ViT patch {patch} "
@@ -68,9 +68,21 @@ class DiSTNetwork(DiSTParams):
         eng.pack(2)
 
     def forward(self, input):
-        """reference signature `forward(input: dict) -> (cls_x [b,E], input)`; needs the frozen ViT features of the
-        same batch in the engine (CLIP.forward runs dist_vit_forward first)."""
+        """reference signature `forward(input: dict) -> (cls_x [b,E], input)` (dist.py:222-247).  The reference reads
+        input['mid_feat']['img'][layer_id] ([L, b*t, width], one per selected layer) and input['images'] ([b*T,3,H,W] or [b,3,T,H,W]): when the
+        caller supplies them they are copied into the engine's feature slot (dist_features_import) and the branch runs on THEM; without
+        them the branch runs on the features of the engine's own frozen-ViT pass of the same batch (CLIP.forward runs dist_vit_forward
+        first).  input['text_features'] as in the reference (clip.py:507)."""
         eng = self._engine[0]
+        mid = input.get("mid_feat", {}).get("img") if isinstance(input.get("mid_feat"), dict) else None
+        if mid is not None and all(i in mid for i in self.selected_layers):
+            if "images" not in input:
+                raise L.DistError("DiSTNetwork.forward: input['mid_feat'] needs input['images'] beside it (the temporal stem reads the frames, dist.py:225)")
+            img = input["images"]
+            if img.dim() == 4:                               # [b*T,3,H,W] as the reference backbone passes it
+                bt, c, h, w = img.shape
+                img = img.view(bt // self.num_frames, self.num_frames, c, h, w).permute(0, 2, 1, 3, 4)
+            eng.import_features([mid[i] for i in self.selected_layers], img.contiguous().float())
         tf = input["text_features"].float().contiguous()
         logits, vid = eng.branch_forward(tf)
         input["logits_per_image"] = logits

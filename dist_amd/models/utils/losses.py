@@ -4,10 +4,32 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
-class SoftTargetCrossEntropy(nn.Module):
-    """mean_b sum_k -target * log_softmax(x) (reference losses.py:20-31, timm's SoftTargetCrossEntropy)."""
+class _EngineSoftTargetCE(torch.autograd.Function):
+    """Soft-target CE of the engine's own logits through dist_loss (logits_loss_kernel: loss and dlogits in one launch) - the call
+    bench.py times, so the shipped train loop and the benchmarked step are one kernel sequence.  `preds` only carries the graph: the
+    kernel reads the video embedding the branch forward left in the engine."""
 
-    def forward(self, x, target):
+    @staticmethod
+    def forward(ctx, preds, target, engine):
+        loss, dlogits = engine.loss(target.contiguous().float())
+        ctx.save_for_backward(dlogits)
+        ctx.shape = preds.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return (g * dlogits).view(ctx.shape), None, None
+
+
+class SoftTargetCrossEntropy(nn.Module):
+    """mean_b sum_k -target * log_softmax(x) (reference losses.py:20-31, timm's SoftTargetCrossEntropy).  `engine`: the logits are the ones
+    that engine's branch forward just produced -> dist_loss (HIP); tensors of any other origin (unit tests on the host) take the
+    torch expression."""
+
+    def forward(self, x, target, engine=None):
+        if engine is not None and x.is_cuda and x.dim() == 2 and x.shape[0] == engine.b:
+            return _EngineSoftTargetCE.apply(x, target, engine)
         return torch.sum(-target * F.log_softmax(x, dim=-1), dim=-1).mean()
 
 
@@ -16,7 +38,9 @@ def calculate_loss(cfg, preds, logits, labels, cur_epoch):
     produced soft labels, plain CE otherwise.  Returns (loss, {name: loss}, weight)."""
     target = labels["supervised"] if isinstance(labels, dict) else labels
     if target.dtype in (torch.float32, torch.float16, torch.bfloat16) and target.dim() == 2:
-        loss = SoftTargetCrossEntropy()(preds, target)
+        # `logits` is the backbone's output dictionary (models.py:forward -> head returns (preds, x)); CLIP.forward_video leaves its engine in it
+        engine = logits.get("_dist_engine") if isinstance(logits, dict) and torch.is_grad_enabled() else None
+        loss = SoftTargetCrossEntropy()(preds, target, engine)
         name = "soft_target"
     else:
         loss = F.cross_entropy(preds, target)

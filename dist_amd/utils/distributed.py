@@ -124,6 +124,7 @@ def all_gather(tensors):
 
 
 class GradReducer:
+    # (see exposed_ms below)
     """Sum all-reduce of the flat dist_net gradient buffer, overlapped with backward.
 
     The engine reports each gradient slice as soon as the kernels producing it are enqueued (ada-pooling + head,
@@ -132,8 +133,12 @@ class GradReducer:
     the remaining layers' backward kernels execute.  The 1/world average is folded into AdamW (`grad_scale`);
     the 1-element logit_scale gradient stays local (it is never optimised)."""
 
-    def __init__(self, engine, world, bucket_bytes=16 << 20, overlap=True):
+    def __init__(self, engine, world, bucket_bytes=16 << 20, overlap=True, grad_dtype=None):
         self.eng = engine
+        # exchange precision (SURVEY 8(e): "fp32 (76.0 / 158.3 MB) or bf16"): fp32 by default; torch.bfloat16 halves the bytes on xGMI - the
+        # bucket is rounded into a staging buffer on the communication stream, summed there and added back as fp32
+        self.grad_dtype = grad_dtype or (torch.bfloat16 if os.environ.get("DIST_AMD_REDUCER_DTYPE", "") == "bf16" else torch.float32)
+        self._timing = []             # (backward enqueued on the compute stream, last bucket reduced on the communication stream) per step
         self.world = world
         self.grad_scale = 1.0 / world
         self.bucket_elems = bucket_bytes // 4
@@ -159,7 +164,13 @@ class GradReducer:
         self.comm.wait_event(ev)
         with torch.cuda.stream(self.comm):
             if self.mode != "noop":
-                dist.all_reduce(self.eng.grads[begin:end])
+                g = self.eng.grads[begin:end]
+                if self.grad_dtype == torch.float32:
+                    dist.all_reduce(g)
+                else:
+                    st = g.to(self.grad_dtype)
+                    dist.all_reduce(st)
+                    g.copy_(st)
         self.n_collectives += 1
         self._sent.append((begin, end))
 
@@ -175,6 +186,14 @@ class GradReducer:
             self._send(*self._pending)
             self._pending = None
 
+    def exposed_ms(self):
+        """Mean time per step the optimizer waited for the exchange AFTER the backward pass had finished on the compute stream (0 when the
+        last bucket's all-reduce ends first): the un-hidden part of the RCCL leg.  Synchronises; call it outside the timed region."""
+        if not self._timing:
+            return None
+        torch.cuda.synchronize()
+        return sum(max(0.0, a.elapsed_time(b)) for a, b in self._timing) / len(self._timing)
+
     def backward_and_reduce(self, dlogits):
         self.n_collectives = 0
         self._sent = []
@@ -188,9 +207,16 @@ class GradReducer:
         if self._pending is not None:
             self._send(*self._pending)
             self._pending = None
-        done = torch.cuda.Event()
+        # what AdamW waits for: `exposed_ms` = the part of the exchange that is NOT hidden behind the backward pass (two timed events:
+        # backward fully enqueued on the compute stream -> last bucket reduced on the communication stream)
+        bwd_done = torch.cuda.Event(enable_timing=True)
+        bwd_done.record(torch.cuda.current_stream())
+        done = torch.cuda.Event(enable_timing=True)
         done.record(self.comm)
         torch.cuda.current_stream().wait_event(done)      # AdamW waits for the last bucket
+        self._timing.append((bwd_done, done))
+        if len(self._timing) > 64:
+            self._timing.pop(0)
         covered = sum(e - b for b, e in self._sent)
         if covered != self.eng.grads.numel():              # must never happen: every element is reduced exactly once
             raise RuntimeError(f"gradient buckets cover {covered} of {self.eng.grads.numel()} elements")

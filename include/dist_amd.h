@@ -465,6 +465,12 @@ int dist_vit_prefetch(dist_handle* h, const float* video, int b, void* stream, v
  * adoptable once layer_end == cfg.layers was reached. */
 int dist_vit_prefetch_layers(dist_handle* h, const float* video, int b, int layer_end, void* stream, void* after);
 int dist_vit_adopt(dist_handle* h);
+/* The CALLER's frozen-ViT features instead of a dist_vit_forward pass - what the reference's DiSTNetwork.forward consumes
+ * (models/module_zoo/branches/dist.py:222-247: input['mid_feat']['img'][layer_id] and input['images']): mid_feat[i], i < layers, is the device
+ * pointer of block i's output in the reference's layout [L][b*t][width] (sequence first, clip.py:282-300; src_dtype DIST_F32 or DIST_BF16), video the
+ * frames [b][3][T][H][W] fp32 (the temporal stem's input).  Copied into the current feature slot (converted, token-major); dist_branch_forward(b)
+ * follows as after dist_vit_forward. */
+int dist_features_import(dist_handle* h, const void* const* mid_feat, int src_dtype, const float* video, int b, void* stream);
 /* DiSTNetwork.forward + cosine logits (dist.py:222-247, clip.py:509-518): -> logits [b,K] fp32,
  * vid_logits [b,E] fp32 (L2-normalised video embedding) */
 int dist_branch_forward(dist_handle* h, const float* text_features, int b, float* logits, float* vid_logits, void* stream);

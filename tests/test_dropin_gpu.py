@@ -183,3 +183,105 @@ def test_train_loop_pipelines_the_frozen_vit_without_changing_results(gpu_lib):
     for x, y in zip(a, b):
         assert abs(x["loss"] - y["loss"]) < 1e-4 * max(1.0, abs(x["loss"])), (x, y)
         assert x["top1_err"] == y["top1_err"] and x["lr"] == y["lr"]
+
+
+def _tiny_model(*extra):
+    from dist_amd import synth
+    from dist_amd.models.base.builder import build_model
+    from dist_amd.utils.checkpoint import normalize_state_dict
+    cfg = tiny_cfg("TRAIN.FP32_PARITY", "true", "TRAIN.BATCH_SIZE", "2", *extra)
+    model, _ = build_model(cfg)
+    g = synth.geometry("tiny")
+    sd = {"backbone.base_encoder." + k: torch.from_numpy(v) for k, v in synth.state_dict(g).items()}
+    model.backbone.base_encoder.load_state_dict(normalize_state_dict({"model_state": sd}), strict=False)
+    clip = model.backbone.base_encoder
+    clip.text_features = torch.from_numpy(synth.text_features(g)).cuda()
+    clip.text_logits = clip.text_features
+    return cfg, model, clip, g
+
+
+def test_distnetwork_forward_consumes_the_callers_mid_feat(gpu_lib):
+    """reference dist.py:222-247: DiSTNetwork.forward(input) reads input['mid_feat']['img'][layer_id] ([L, b*t, C]) and input['images'].
+    Round 3 ignored them and used the engine's own slot.  Proof that the CALLER's tensors are consumed: the features of clip B (taken from a
+    pass over B, in the reference's layout) handed over while the engine's slot holds the pass over clip A must give B's embedding."""
+    from dist_amd import synth
+    cfg, model, clip, g = _tiny_model()
+    eng = clip.engine
+    L_, bt = g.N + 1, 2 * g.t
+    vA = torch.from_numpy(synth.video(g, 2, seed=1)).cuda()
+    vB = torch.from_numpy(synth.video(g, 2, seed=7)).cuda()
+    texts = torch.zeros(g.K, 77, dtype=torch.long, device="cuda")
+    model.eval()
+    with torch.no_grad():
+        outB = clip.forward_video(vB, texts)
+        want_logits, want_vid = outB["logits_per_image"].clone(), outB["vid_logits"][:, 0].clone()
+        # block outputs of the pass over B in the reference's layout [L, b*t, width] (clip.py:282-300: sequence first)
+        midB = {i: eng.debug(f"feat.{i}").view(bt, L_, g.d).permute(1, 0, 2).contiguous().float().clone() for i in range(g.layers)}
+        outA = clip.forward_video(vA, texts)                                   # the slot now holds clip A
+        assert float((outA["logits_per_image"] - want_logits).abs().max()) > 1e-3
+        inp = {"mid_feat": {"img": midB}, "images": vB.permute(0, 2, 1, 3, 4).reshape(2 * g.T, 3, g.res, g.res).contiguous(),
+               "text_features": clip.text_features}
+        vid, inp2 = clip.dist_net(inp)
+    assert inp2 is inp
+    torch.testing.assert_close(vid, want_vid, rtol=0, atol=0)                  # fp32 mode: the copies are exact, the kernels the same
+    torch.testing.assert_close(inp["logits_per_image"], want_logits, rtol=0, atol=0)
+    # without mid_feat the engine's own pass is used (what CLIP.forward does)
+    with torch.no_grad():
+        vid_own, _ = clip.dist_net({"text_features": clip.text_features})
+    torch.testing.assert_close(vid_own, want_vid, rtol=0, atol=0)               # (the slot still holds B's imported features)
+    # bf16 tensors and wrong shapes
+    with pytest.raises(Exception):
+        clip.dist_net({"mid_feat": {"img": {i: midB[i][:, :1] for i in midB}}, "images": vB, "text_features": clip.text_features})
+    with pytest.raises(Exception):
+        clip.dist_net({"mid_feat": {"img": midB}, "text_features": clip.text_features})      # frames missing
+
+
+def test_train_loop_loss_is_the_engines_dist_loss(gpu_lib):
+    """runs/train.py computes the loss through models/utils/losses.calculate_loss: with the engine's logits that is dist_loss (the launch bench.py
+    times), not a torch expression - same value and the same gradients as the torch form."""
+    from dist_amd import synth
+    from dist_amd.models.utils import losses
+    cfg, model, clip, g = _tiny_model()
+    video = torch.from_numpy(synth.video(g, 2)).cuda()
+    tgt = torch.from_numpy(synth.soft_target(g, 2)[0]).cuda()
+    texts = torch.zeros(g.K, 77, dtype=torch.long, device="cuda")
+    model.train()
+    pd = dict(model.named_parameters())
+    grads = []
+    for use_engine in (True, False):
+        for p in pd.values():
+            p.grad = None
+        preds, out = model({"video": video, "texts": texts})
+        assert out["_dist_engine"] is clip.engine
+        if use_engine:
+            calls = []
+            orig = clip.engine.loss
+            clip.engine.loss = lambda t: (calls.append(1), orig(t))[1]
+            loss, _, _ = losses.calculate_loss(cfg, preds, out, {"supervised": tgt}, 0)
+            clip.engine.loss = orig
+            assert calls == [1]                                                # went through dist_loss
+        else:
+            loss = losses.SoftTargetCrossEntropy()(preds, tgt)                 # the torch expression
+        loss.backward()
+        grads.append((float(loss), {n: p.grad.clone() for n, p in pd.items() if p.grad is not None}))
+    assert abs(grads[0][0] - grads[1][0]) < 1e-5
+    assert grads[0][1].keys() == grads[1][1].keys() and len(grads[0][1]) > 100
+    for n in grads[0][1]:
+        a, b = grads[0][1][n].double(), grads[1][1][n].double()
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-9, n
+
+
+def test_img_logits_is_lazy_and_guarded(gpu_lib):
+    from dist_amd import synth
+    cfg, model, clip, g = _tiny_model()
+    video = torch.from_numpy(synth.video(g, 2)).cuda()
+    texts = torch.zeros(g.K, 77, dtype=torch.long, device="cuda")
+    with torch.no_grad():
+        out = clip.forward_video(video, texts)
+        assert "img_logits" in out and not dict.__contains__(out, "img_logits")      # not computed yet
+        v = out["img_logits"]
+        assert v.shape == (2 * g.t, g.E) and dict.__contains__(out, "img_logits")
+        out2 = clip.forward_video(video.clone(), texts)
+        clip.forward_video(video, texts)                                               # the slot moves on
+        with pytest.raises(Exception):
+            out2["img_logits"]

@@ -360,3 +360,29 @@ def test_inference_mode_gives_the_same_logits_and_refuses_backward(gpu_lib):
     assert torch.equal(logits2, logits)
     rel = float((eng.grads - grads).abs().max() / grads.abs().max())
     assert rel < 1e-4, rel
+
+
+def test_backward_accumulates_with_the_layernorm_fold(gpu_lib):
+    """dist_branch_backward(zero_grads=0) ADDS to the bound gradient buffer (include/dist_amd.h).  On ViT-B/16 the weight-gradient GEMMs of the two
+    folded Linears leave G' = dz^T xhat and the unfold used to rewrite the slot in place - rescaling what an earlier pass had left there.
+    Two accumulated backward passes of the same batch must give twice the gradient of one."""
+    g, eng, sd, video, text, tgt = build("b16_8+16f", 2, torch.bfloat16)
+    eng.vit_forward(video)
+    eng.branch_forward(text)
+    _, dl = eng.loss(tgt)
+    eng.backward(dl, zero_grads=True)
+    torch.cuda.synchronize()
+    g1 = eng.grads.clone()
+    eng.branch_forward(text)
+    _, dl = eng.loss(tgt)
+    eng.backward(dl, zero_grads=False)
+    torch.cuda.synchronize()
+    g2 = eng.grads.clone()
+    worst = ("", 0.0)
+    for n, (off, shape, _) in eng.tables[0].items():
+        k = int(np.prod(shape)) if shape else 1
+        a, b2 = g1[off:off + k].double(), g2[off:off + k].double()
+        err = float((b2 - 2 * a).abs().max() / (2 * a.abs().max() + 1e-30))
+        if err > worst[1]:
+            worst = (n, err)
+    assert worst[1] < 1e-4, worst          # (fp32 sums in another order; the defect was a factor gamma on two weights and wrong LayerNorm gradients)

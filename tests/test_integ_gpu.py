@@ -186,6 +186,32 @@ def test_layernorm_fold_backward_unfolds_to_the_autograd_gradients(gpu_lib):
         assert err < 2e-5, (k, err)
 
 
+def test_layernorm_fold_unfold_accumulating_form(gpu_lib):
+    """with earlier gradients already in the slots (dist_branch_backward(zero_grads=0)) the in-place unfold rescaled them a second
+    time.  The accumulating form takes this pass's G' / db from scratch and ADDS: slots = earlier + (in-place result on zeroed slots)."""
+    from dist_amd import ops
+    g = torch.Generator().manual_seed(12)
+    w = {"ffn.c_fc.weight": torch.randn(CI, CI, generator=g) * 0.05, "ln.weight": 1 + 0.2 * torch.randn(CI, generator=g), "ln.bias": 0.1 * torch.randn(CI, generator=g),
+         "temporal_ffn.c_fc1.weight": torch.randn(C4, CI, generator=g) * 0.05, "ln_temporal.weight": 1 + 0.2 * torch.randn(CI, generator=g),
+         "ln_temporal.bias": 0.1 * torch.randn(CI, generator=g)}
+    this = {"ffn.c_fc.weight": torch.randn(CI, CI, generator=g), "ffn.c_fc.bias": torch.randn(CI, generator=g),
+            "temporal_ffn.c_fc1.weight": torch.randn(C4, CI, generator=g), "temporal_ffn.c_fc1.bias": torch.randn(C4, generator=g)}
+    keys = list(this) + ["ln.weight", "ln.bias", "ln_temporal.weight", "ln_temporal.bias"]
+    earlier = {k: torch.randn((w[k] if k in w else this[k]).shape, generator=g) for k in keys}
+    wc = {k: v.cuda().contiguous() for k, v in w.items()}
+    # reference: the in-place form on slots that hold only this pass's G' / db (LayerNorm slots zero)
+    ref = {k: (this[k].clone() if k in this else torch.zeros_like(earlier[k])).cuda().contiguous() for k in keys}
+    ops.integration_unfold(wc, ref)
+    # accumulating form
+    acc = {k: earlier[k].clone().cuda().contiguous() for k in keys}
+    ops.integration_unfold(wc, acc, gs={k: v.cuda().contiguous() for k, v in this.items()})
+    torch.cuda.synchronize()
+    for k in keys:
+        want = earlier[k].double() + ref[k].double().cpu()
+        err = float((acc[k].double().cpu() - want).abs().max() / want.abs().max())
+        assert err < 1e-6, (k, err)
+
+
 def test_fused_integration_xhat_form(gpu_lib):
     """Xhat instead of Na / Nb: the same R and pre-activations bit for bit, Xhat = bf16((x - mean) rstd)"""
     from dist_amd import ops
