@@ -23,6 +23,18 @@ tests/golden/; tests/test_oracle_golden.py checks it on every run.
 `rnd` hooks: when `bf16=True` every tensor that the HIP path stores in bf16
 (kernel boundaries) is rounded to bf16 here too, so the bf16 kernels can be
 checked against an oracle with identical rounding points.
+
+`fused=True` (with bf16=True) moves the rounding points to where the FUSED kernels of
+rounds 2-3 have them (the unfused launch sequences keep the `fused=False` points):
+  * LayerNorm folded into the consumer GEMM (frozen ViT ln_1 -> in_proj, ln_2 -> c_fc;
+    csrc/engine.hip gemm_lnfold): the GEMM multiplies the RAW bf16 rows with
+    bf16(W diag(gamma)) and normalises behind it - no rounded LayerNorm output;
+  * IntegrationNetwork (csrc/integ.hip:12-34): xhat = (M' - mean) rstd is the one rounded
+    LayerNorm tensor (statistics of the UNROUNDED M' that the T2I stage leaves on the
+    accumulators), both first Linears use bf16(W diag(gamma)) and b + W beta, the two
+    c_proj products are ONE accumulation (r1 is not rounded);
+  * gradients are rounded to bf16 where the backward kernels store them in bf16
+    (dM, dM', [dzf | dh1 | dh2], dY, dp, dz, dX): `gr` hooks.
 """
 import math
 
@@ -41,7 +53,7 @@ def layer_norm(x, w, b, eps=1e-5):
 
 
 class Oracle:
-    def __init__(self, g, params, dtype=torch.float32, bf16=False, vit_fp8=0):
+    def __init__(self, g, params, dtype=torch.float32, bf16=False, vit_fp8=0, fused=False):
         """g: dist_amd.synth.Geometry; params: name -> tensor (reference state-dict names).
         vit_fp8 (with bf16=True): bit mask of the frozen-ViT GEMMs evaluated on per-row e4m3 operands the way dist_config.vit_fp8 does
         (1 in_proj, 2 out_proj, 4 c_fc, 8 c_proj; oracle/fp8_oracle.py - no counterpart in the reference, parity unpinned)."""
@@ -49,6 +61,7 @@ class Oracle:
         self.dtype = dtype
         self.bf16 = bf16
         self.vit_fp8 = vit_fp8 if bf16 else 0
+        self.fused = bool(fused and bf16)
         self.p = {k: torch.as_tensor(v).to(dtype) for k, v in params.items()}
         self.selected = list(range(g.layers))
 
@@ -57,6 +70,18 @@ class Oracle:
         if not self.bf16:
             return x
         return x.to(torch.bfloat16).to(self.dtype) if not x.requires_grad else _RoundBF16.apply(x)
+
+    def gr(self, x):
+        """identity whose GRADIENT is rounded to bf16 (fused mode: a gradient tensor the backward kernels store in bf16)"""
+        return _RoundGradBF16.apply(x) if (self.fused and x.requires_grad) else x
+
+    def ln_fold_lin(self, x, W, bias, gamma, beta):
+        """LayerNorm folded into the consumer GEMM (csrc/engine.hip gemm_lnfold, dist_op_ln_fold): raw rows x bf16(W diag(gamma)), normalised
+        behind the product: rstd * (x W'^T - mean * rowsum(W')) + (bias + W beta)"""
+        mean = x.mean(dim=-1, keepdim=True)
+        rstd = (x.var(dim=-1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+        Wf = self.rnd(W * gamma[None, :])
+        return rstd * (x @ Wf.t() - mean * Wf.sum(dim=1)) + (bias + W @ beta)
 
     def w(self, name):
         """weight as the kernels see it (bf16-rounded working copy in bf16 mode)."""
@@ -142,6 +167,8 @@ class Oracle:
         if f8 & 1:
             qkv = self.rnd(self._fp8_ln_lin(x, p[pre + "attn.in_proj_weight"], p[pre + "attn.in_proj_bias"], p[pre + "ln_1.weight"], p[pre + "ln_1.bias"],
                                             per_tensor=img and i > 0))
+        elif self.fused:
+            qkv = self.rnd(self.ln_fold_lin(x, p[pre + "attn.in_proj_weight"], p[pre + "attn.in_proj_bias"], p[pre + "ln_1.weight"], p[pre + "ln_1.bias"]))
         else:
             h = self.rnd(layer_norm(x, p[pre + "ln_1.weight"], p[pre + "ln_1.bias"]))
             qkv = self.rnd(h @ self.w(pre + "attn.in_proj_weight").t() + p[pre + "attn.in_proj_bias"])
@@ -157,6 +184,8 @@ class Oracle:
             x = self.rnd(x + o @ self.w(pre + "attn.out_proj.weight").t() + p[pre + "attn.out_proj.bias"])
         if f8 & 4:
             h = self.rnd(qgelu(self._fp8_ln_lin(x, p[pre + "mlp.c_fc.weight"], p[pre + "mlp.c_fc.bias"], p[pre + "ln_2.weight"], p[pre + "ln_2.bias"], per_tensor=img)))
+        elif self.fused:
+            h = self.rnd(qgelu(self.ln_fold_lin(x, p[pre + "mlp.c_fc.weight"], p[pre + "mlp.c_fc.bias"], p[pre + "ln_2.weight"], p[pre + "ln_2.bias"])))
         else:
             h = self.rnd(layer_norm(x, p[pre + "ln_2.weight"], p[pre + "ln_2.bias"]))
             h = self.rnd(qgelu(h @ self.w(pre + "mlp.c_fc.weight").t() + p[pre + "mlp.c_fc.bias"]))
@@ -190,12 +219,15 @@ class Oracle:
         pre = f"dist_net.temporal_nets.{i}."
         b = X.shape[0]
         U = self.rnd(layer_norm(X, p[pre + "ln.weight"], p[pre + "ln.bias"]))
+        keep[f"tn_U.{i}"] = U
         W1 = self.w(pre + "temporal_net.c_fc1.weight")               # [Co,Ct,tk,1,1]
         z = p[pre + "temporal_net.c_fc1.bias"].expand_as(U)
         for dt in range(g.tk):
             z = z + self.shift_t(U, dt - g.tk // 2) @ W1[:, :, dt, 0, 0].t()
-        z = self.rnd(z)
+        zr = self.rnd(z)
+        z = self.gr(zr)                                              # (dz is stored in bf16: tnet_bwd_spatial_kernel)
         V = self.rnd(qgelu(z))
+        keep[f"tn_V.{i}"] = V
         W2 = self.w(pre + "temporal_net.c_fc2.weight")               # [Ct,Co,1,3,3]
         Vg = V.reshape(b, g.T, g.grid, g.grid, g.Ct)
         Vp = F.pad(Vg, (0, 0, 1, 1, 1, 1))
@@ -203,9 +235,11 @@ class Oracle:
         for dy in range(3):
             for dx in range(3):
                 acc = acc + Vp[:, :, dy:dy + g.grid, dx:dx + g.grid] @ W2[:, :, 0, dy, dx].t()
-        pre_act = self.rnd(X + acc.reshape(X.shape))
+        pr = self.rnd(X + acc.reshape(X.shape))
+        pre_act = self.gr(pr)                                        # (dp is stored in bf16: the fused T2I backward / the T2I data-gradient GEMM)
         Xp = self.rnd(qgelu(pre_act))
-        keep[f"tn_z.{i}"] = z
+        keep[f"tn_p.{i}"] = pr
+        keep[f"tn_z.{i}"] = zr
         keep[f"tn_out.{i}"] = Xp
         return Xp
 
@@ -213,9 +247,12 @@ class Oracle:
         """ffn(ln(x)) + temporal_ffn(ln_temporal(x)) (dist.py:16-45)."""
         g, p = self.g, self.p
         pre = f"dist_net.integration_nets.{i}."
+        if self.fused:
+            return self.integration_net_fused(Mp, i, keep)
         na = self.rnd(layer_norm(Mp, p[pre + "ln.weight"], p[pre + "ln.bias"]))
         nb = self.rnd(layer_norm(Mp, p[pre + "ln_temporal.weight"], p[pre + "ln_temporal.bias"]))
-        hf = self.rnd(qgelu(self.rnd(na @ self.w(pre + "ffn.c_fc.weight").t() + p[pre + "ffn.c_fc.bias"])))
+        zf = self.rnd(na @ self.w(pre + "ffn.c_fc.weight").t() + p[pre + "ffn.c_fc.bias"])
+        hf = self.rnd(qgelu(zf))
         h1 = self.rnd(nb @ self.w(pre + "temporal_ffn.c_fc1.weight")[:, :, 0, 0, 0].t() + p[pre + "temporal_ffn.c_fc1.bias"])
         W2 = self.w(pre + "temporal_ffn.c_fc2.weight")               # [C4,C4,tk,1,1]
         h2 = p[pre + "temporal_ffn.c_fc2.bias"].expand_as(h1)
@@ -226,6 +263,36 @@ class Oracle:
         r1 = self.rnd(hf @ self.w(pre + "ffn.c_proj.weight").t() + p[pre + "ffn.c_proj.bias"])
         R = self.rnd(r1 + g2 @ self.w(pre + "temporal_ffn.c_proj.weight")[:, :, 0, 0, 0].t() + p[pre + "temporal_ffn.c_proj.bias"])
         keep[f"int_out.{i}"] = R
+        keep.update({f"int_na.{i}": na, f"int_nb.{i}": nb, f"int_zf.{i}": zf, f"int_hf.{i}": hf, f"int_h1.{i}": h1, f"int_h2.{i}": h2, f"int_g2.{i}": g2})
+        return R
+
+    def integration_net_fused(self, Mp, i, keep):
+        """the same network with the rounding points of integ_fwd_kernel / integ_bwd_kernel (csrc/integ.hip:12-34): `Mp` is the UNROUNDED
+        M' when the T2I stage runs in front of it (it stays on the accumulators)."""
+        g, p = self.g, self.p
+        pre = f"dist_net.integration_nets.{i}."
+        mean = Mp.mean(dim=-1, keepdim=True)
+        rstd = (Mp.var(dim=-1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+        xh = self.rnd((Mp - mean) * rstd)                            # the ONE LayerNorm tensor of the block
+        Wa, Wb = p[pre + "ffn.c_fc.weight"], p[pre + "temporal_ffn.c_fc1.weight"][:, :, 0, 0, 0]
+        Waf = self.rnd(Wa * p[pre + "ln.weight"][None, :])           # W diag(gamma) in bf16, re-derived from the fp32 masters every step
+        Wbf = self.rnd(Wb * p[pre + "ln_temporal.weight"][None, :])
+        zfr = self.rnd(xh @ Waf.t() + (p[pre + "ffn.c_fc.bias"] + Wa @ p[pre + "ln.bias"]))
+        zf = self.gr(zfr)
+        hf = self.rnd(qgelu(zf))
+        h1r = self.rnd(xh @ Wbf.t() + (p[pre + "temporal_ffn.c_fc1.bias"] + Wb @ p[pre + "ln_temporal.bias"]))
+        h1 = self.gr(h1r)
+        W2 = self.w(pre + "temporal_ffn.c_fc2.weight")
+        h2 = p[pre + "temporal_ffn.c_fc2.bias"].expand_as(h1)
+        for dt in range(g.tk):
+            h2 = h2 + self.shift_t(h1, dt - g.tk // 2) @ W2[:, :, dt, 0, 0].t()
+        h2r = self.rnd(h2)
+        h2 = self.gr(h2r)
+        g2 = self.rnd(qgelu(h2))
+        R = self.rnd(hf @ self.w(pre + "ffn.c_proj.weight").t() + p[pre + "ffn.c_proj.bias"]
+                     + g2 @ self.w(pre + "temporal_ffn.c_proj.weight")[:, :, 0, 0, 0].t() + p[pre + "temporal_ffn.c_proj.bias"])
+        keep[f"int_out.{i}"] = R
+        keep.update({f"int_xhat.{i}": xh, f"int_zf.{i}": zfr, f"int_hf.{i}": hf, f"int_h1.{i}": h1r, f"int_h2.{i}": h2r, f"int_g2.{i}": g2})
         return R
 
     def mha_1q(self, pre, q_in, kv_in):
@@ -264,11 +331,11 @@ class Oracle:
             M = feats[lid] @ self.w(f"dist_net.input_linears.{idx}.weight").t() + p[f"dist_net.input_linears.{idx}.bias"]
             if R is not None:
                 M = M + R                                                                  # dist.py:229
-            M = self.rnd(M)
+            M = self.gr(self.rnd(M))                                                       # (dM = dM' + I2T term is stored in bf16)
             # I2T (dist.py:90-105): drop cls row, Linear Ci->Ct, nearest upsample x alpha in T
             pre = f"dist_net.integration2temporal_nets.{idx}.linear_fuse."
-            Y = M[:, :, 1:] @ self.w(pre + "weight").t() + p[pre + "bias"]
-            X_next = self.rnd(Xp + Y.repeat_interleave(g.alpha, dim=1))                    # dist.py:231
+            Y = self.gr(M[:, :, 1:] @ self.w(pre + "weight").t() + p[pre + "bias"])         # (dY, the frame-pair sums of dX_next, is stored in bf16)
+            X_next = self.gr(self.rnd(Xp + Y.repeat_interleave(g.alpha, dim=1)))           # dist.py:231 (dX of the next TemporalNet: bf16)
             # T2I (dist.py:68-86): Conv3d k=s=(alpha,1,1) + learnable per-frame cls row
             pre = f"dist_net.temporal2integration_nets.{idx}."
             Wt = self.w(pre + "linear_fuse.weight")                                        # [Ci,Ct,alpha,1,1]
@@ -277,8 +344,12 @@ class Oracle:
             for a in range(g.alpha):
                 Q = Q + Xr[:, :, a] @ Wt[:, :, a, 0, 0].t()
             cls = p[pre + "cls_token"][0, 0].reshape(1, g.t, 1, g.Ci).expand(b, g.t, 1, g.Ci)
-            Mp = self.rnd(M + torch.cat([cls, Q], dim=2))                                  # dist.py:232
-            R = self.integration_net(Mp, idx, keep)                                        # dist.py:234
+            Mp_raw = self.gr(M + torch.cat([cls, Q], dim=2))                               # dist.py:232 (dM' is stored in bf16)
+            Mp = self.rnd(Mp_raw)
+            # fused: T2I is formed in front of the fused IntegrationNetwork kernel where alpha = 2 and the temporal width equals Ci / 4
+            # (engine.hip set_fused_flags: ig_t2i) - the LayerNorm then sees the unrounded M'
+            t2i_fused = self.fused and g.alpha == 2 and g.Ct * 4 == g.Ci
+            R = self.integration_net(Mp_raw if t2i_fused else Mp, idx, keep)               # dist.py:234
             X = X_next
             keep[f"x_temporal.{idx}"] = X
             keep[f"mid.{idx}"] = Mp
@@ -330,6 +401,18 @@ class Oracle:
         out["loss"] = loss.detach()
         out["grads"] = grads
         return out
+
+
+class _RoundGradBF16(torch.autograd.Function):
+    """identity in forward, bf16 rounding of the gradient in backward"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return gy.to(torch.bfloat16).to(gy.dtype)
 
 
 class _RoundBF16(torch.autograd.Function):

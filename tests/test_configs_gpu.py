@@ -216,8 +216,13 @@ def _rel(a, b):
 
 
 # (measured, gate): relative L2 error of one ViT block on the ENGINE's own block input; of the branch tensors end to end
-#   measured (round 3): vit_block 0.0026, stem 4.9e-5, branch_act 0.0122, logits 0.0119 (range +-6), loss 0.00025, worst gradient 0.0214
-SAME_ROUNDING_GATES = {"vit_block": 6e-3, "stem": 2e-4, "branch_act": 0.025, "logits": 0.025, "loss": 2e-3, "grad": 0.045}
+#   measured (round 4, Oracle(bf16=True, fused=True): the fused kernels' rounding points): vit_block 0.0017, stem 5e-5, branch_act 0.0110,
+#   logits 0.0107 (range +-6), loss 0.0006, worst gradient 0.0216 of its tensor's maximum = dist_net.temporal_stem.weight, then
+#   temporal_nets.0.ln.weight, the T2I cls tokens of the last layers, temporal_nets.0/1 (gpurun_out/same_rounding_grad_worst.json ->
+#   profiles/r04_parity_gaps.json): the tensors at the far END of the backward chain, i.e. twelve layers of bf16-stored gradients, not one
+#   defective tensor; median 0.005.  With the unfused sequence's rounding points (round 3's oracle) the same run reads 0.0125 / 0.0111 / 0.035.
+#   Every gate is 2x its measured value.
+SAME_ROUNDING_GATES = {"vit_block": 3.5e-3, "stem": 1e-4, "branch_act": 0.022, "logits": 0.0215, "loss": 1.3e-3, "grad": 0.043}
 
 
 def test_b16_bf16_fast_path_vs_oracle_with_the_same_rounding_points(gpu_lib):
@@ -227,7 +232,10 @@ def test_b16_bf16_fast_path_vs_oracle_with_the_same_rounding_points(gpu_lib):
     g, eng, sd, video, text, tgt = build("b16_8+16f", 2, torch.bfloat16)
     loss, logits = eng.forward_backward(video, text, tgt)
     feats = [eng.debug(f"feat.{i}").clone().cpu().float() for i in range(g.layers)]
-    o = Oracle(g, sd, dtype=torch.float32, bf16=True)
+    # fused=True: the rounding points of the FUSED kernels (LayerNorm fold in the ViT GEMMs; xhat / bf16(W diag gamma) / one c_proj accumulation in
+    # the IntegrationNetwork; bf16 gradient tensors of the backward chain) - oracle/dist_oracle.py header.  The unfused points are measured beside
+    # it (record only) to show what the flag buys.
+    o = Oracle(g, sd, dtype=torch.float32, bf16=True, fused=True)
     # ---- frozen ViT, block by block on the engine's own input of the block (errors cannot hide in accumulated drift)
     worst = 0.0
     for i in (1, 4, 7, 11):
@@ -244,7 +252,8 @@ def test_b16_bf16_fast_path_vs_oracle_with_the_same_rounding_points(gpu_lib):
     ref = o.forward_backward(synth.video(g, 2), synth.text_features(g), synth.soft_target(g, 2)[0])
     worst_act, which = 0.0, ""
     for i in range(g.layers):
-        for name in (f"tn_out.{i}", f"int_out.{i}", f"x_temporal.{i}", f"mid.{i}"):
+        # (M' of the earlier layers is never materialised by the fused kernels: dist_debug_tensor refuses "mid.i" for them)
+        for name in (f"tn_out.{i}", f"int_out.{i}", f"x_temporal.{i}") + ((f"mid.{i}",) if i == g.layers - 1 else ()):
             e = _rel(eng.debug(name), ref["keep"][name].detach())
             if e > worst_act:
                 worst_act, which = e, name
@@ -265,5 +274,18 @@ def test_b16_bf16_fast_path_vs_oracle_with_the_same_rounding_points(gpu_lib):
     errs.sort(reverse=True)
     record("same_rounding.grad_worst_relmax", errs[0][0])
     record("same_rounding.grad_median_relmax", errs[len(errs) // 2][0])
-    print(f"bf16 fast path: logits gap {lgap:.4f}, loss gap {sgap:.5f}, worst gradient {errs[0]}, median {errs[len(errs) // 2][0]:.4f}")
+    record("same_rounding.grad_worst_rel_l2", max(_rel(eng.view(n, grad=True), ref["grads"][n]) for _, n in errs))
+    import json
+    try:      # which tensors sit behind the worst gaps ("nobody can tell whether that is rounding or a defect in one tensor")
+        json.dump({"worst_relmax": [[n, e] for e, n in errs[:12]]}, open(os.path.join(os.path.dirname(GOLD), "..", "gpurun_out", "same_rounding_grad_worst.json"), "w"), indent=1)
+    except OSError:
+        pass
+    print(f"bf16 fast path: logits gap {lgap:.4f}, loss gap {sgap:.5f}, worst gradients {errs[:5]}, median {errs[len(errs) // 2][0]:.4f}")
     assert errs[0][0] < SAME_ROUNDING_GATES["grad"], errs[:5]
+    # the unfused rounding points on the same engine run, for the record (no gate): what `fused=True` changes
+    o2 = Oracle(g, sd, dtype=torch.float32, bf16=True)
+    ref2 = o2.forward_backward(synth.video(g, 2), synth.text_features(g), synth.soft_target(g, 2)[0])
+    record("same_rounding.unfused_points.logits_maxabs", (logits.cpu().double() - ref2["logits"].detach().double()).abs().max())
+    record("same_rounding.unfused_points.branch_act_worst", max(_rel(eng.debug(nm), ref2["keep"][nm].detach()) for i in range(g.layers) for nm in (f"tn_out.{i}", f"int_out.{i}", f"x_temporal.{i}")))
+    record("same_rounding.unfused_points.grad_worst_relmax", max(float((eng.view(n, grad=True).double().cpu() - gr.double()).abs().max() / (gr.abs().max() + 1e-12))
+                                                                for n, gr in ref2["grads"].items() if gr.abs().max() >= 1e-6))
