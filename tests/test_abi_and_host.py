@@ -195,3 +195,25 @@ def test_grad_reducer_bucketing_logic():
         r._send(*r._pending)
     assert sent == [(700, 1000), (400, 700), (100, 400), (0, 100)]
     assert sorted(sent)[0][0] == 0 and sum(e - b for b, e in sent) == 1000
+
+
+def test_result_changing_knobs_exist_only_in_a_measure_build():
+    """49 getenv knobs lived in the product library, several of which changed RESULTS (DIST_AMD_SKIP, DIST_AMD_DUMMY*,
+    DIST_AMD_TN_SKIP_REDUCE, *_DBG).  Now: one place reads the environment (csrc/common.h), the result-changing names go through
+    dist_measure_knob - a constant unless the library is built with -DDIST_AMD_MEASURE - and the shipped library says which kind it is."""
+    import glob
+    import re
+    from dist_amd import lib
+    l = lib.load()
+    assert l.dist_measure_build() == 0                          # the in-tree library is the product build
+    csrc = os.path.join(ROOT, "dist_amd", "csrc")
+    for f in glob.glob(os.path.join(csrc, "*.hip")):
+        assert "getenv" not in open(f).read(), f                # only common.h's dist_knob touches the environment
+    txt = "".join(open(f).read() for f in glob.glob(os.path.join(csrc, "*.hip")))
+    measure_only = {"DIST_AMD_SKIP", "DIST_AMD_DUMMY", "DIST_AMD_DUMMY_REPS", "DIST_AMD_TN_SKIP_REDUCE", "DIST_AMD_ATTN_DBG", "DIST_AMD_INTEG_DBG",
+                    "DIST_AMD_TNET_DBG", "DIST_AMD_TNET_BWD_NOREDUCE"}
+    sel = set(re.findall(r'dist_knob\("(DIST_AMD_[A-Z0-9_]+)"', txt))
+    mea = set(re.findall(r'dist_measure_knob\("(DIST_AMD_[A-Z0-9_]+)"', txt))
+    assert mea == measure_only and not (sel & measure_only), (mea ^ measure_only, sel & measure_only)
+    common = open(os.path.join(csrc, "common.h")).read()
+    assert "#ifdef DIST_AMD_MEASURE" in common and "inline int dist_measure_knob(const char*, int dflt) { return dflt; }" in common

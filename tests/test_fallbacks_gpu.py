@@ -7,7 +7,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KNOBS = ["DIST_AMD_INTEG_FUSED", "DIST_AMD_INTEG_XHAT", "DIST_AMD_INTEG_BWD_FUSED", "DIST_AMD_INTEG_T2I", "DIST_AMD_INTEG_I2T", "DIST_AMD_INTEG_I2T_BWD", "DIST_AMD_INTEG_T2I_BWD", "DIST_AMD_INTEG_WG_MERGE", "DIST_AMD_TNET_FUSED",
+KNOBS = ["DIST_AMD_TN8P", "DIST_AMD_INTEG_FUSED", "DIST_AMD_INTEG_XHAT", "DIST_AMD_INTEG_BWD_FUSED", "DIST_AMD_INTEG_T2I", "DIST_AMD_INTEG_I2T", "DIST_AMD_INTEG_I2T_BWD", "DIST_AMD_INTEG_T2I_BWD", "DIST_AMD_INTEG_WG_MERGE", "DIST_AMD_TNET_FUSED",
          "DIST_AMD_TNET_BWD_FUSED", "DIST_AMD_ATTN_FULLROW"]
 
 
@@ -19,4 +19,16 @@ def test_engine_parity_with_a_fused_kernel_switched_off(knob):
            "b16_bf16_vs_reference_golden or full_size_batch or inference_mode or grad_ready_hook"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (knob, r.stdout[-1500:], r.stderr[-500:])
+    assert "passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.gpu
+def test_result_changing_knobs_are_inert_in_the_shipped_library():
+    """DIST_AMD_SKIP = 1 (no weight-gradient GEMMs) used to yield wrong gradients through the C ABI with rc 0; in the product build the variable is not
+    read at all: the engine's gradient tests pass with it (and with the other measure-only switches) set."""
+    env = dict(os.environ, DIST_AMD_SKIP="1", DIST_AMD_DUMMY="7", DIST_AMD_TN_SKIP_REDUCE="1", DIST_AMD_TNET_DBG="3", DIST_AMD_ATTN_DBG="1",
+               DIST_AMD_TNET_BWD_NOREDUCE="1")
+    cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_engine_gpu.py"), "-q", "-x", "-k", "b16_bf16_vs_reference_golden"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-500:])
     assert "passed" in r.stdout and "failed" not in r.stdout

@@ -281,6 +281,41 @@ def test_gemm_tn_plain(gpu_lib, dtype, use_tr, M, NI, K):
     torch.testing.assert_close(out2.double(), ref, rtol=1e-4, atol=1e-4 * M ** 0.5)
 
 
+@pytest.mark.parametrize("M,NI,K,lda,ldb,split", [(50432, 384, 768, 384, 768, 0), (9001, 384, 480, 384, 480, 384), (12345, 480, 384, 576, 384, 0),
+                                                    (8262, 192, 256, 192, 256, 0), (20000, 384, 1024, 384, 1024, 0), (10000, 200, 200, 200, 200, 0)])
+def test_gemm_tn_large_plain_two_group_kernel(gpu_lib, M, NI, K, lda, ldb, split):
+    """the large plain weight gradients run on gemm_tn8p.hip (two wave groups, LDS-DMA ring, transpose reads; >= 8192 rows, both extents >= 192):
+    ragged row counts (the descriptor zeroes rows behind a block's range), operands wider than the product (ld > NI / K), the split
+    destination of the c_proj pair, the swapped orientation (480 x 384 runs as 384 x 480), the fused bias gradient - against fp64, and bit-repeatable."""
+    from dist_amd import ops
+    g = torch.Generator(device="cuda"); g.manual_seed(M + NI)
+    A = (torch.randn(M, lda, device="cuda", generator=g) + 0.05).to(torch.bfloat16)
+    B = torch.randn(M, ldb, device="cuda", generator=g).to(torch.bfloat16)
+    part = torch.empty(16 << 20, dtype=torch.float32, device="cuda")
+    ref = A[:, :NI].double().t() @ B[:, :K].double()
+    refb = A[:, :NI].double().sum(0)
+
+    def run():
+        cs = torch.zeros(NI, device="cuda")
+        if split:
+            o1, o2, cs2 = torch.zeros(NI, split, device="cuda"), torch.zeros(NI, K - split, device="cuda"), torch.zeros(NI, device="cuda")
+            ops.gemm_tn(A, B, o1, M, NI, K, so_i=split, so_tap=0, colsum=cs, partial=part, out2=o2, split_c=split, so_i2=K - split, colsum2=cs2)
+            assert torch.equal(cs, cs2)
+            return torch.cat([o1, o2], 1), cs
+        o = torch.zeros(NI, K, device="cuda")
+        ops.gemm_tn(A, B, o, M, NI, K, colsum=cs, partial=part)
+        return o, cs
+    out, cs = run()
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    assert float((cs.double() - refb).abs().max() / refb.abs().max()) < 2e-5
+    out2, cs2 = run()
+    assert torch.equal(out, out2) and torch.equal(cs, cs2)            # the second phase sums the row splits in a fixed order
+    # accumulates INTO the destination
+    o = torch.full((NI, K), 0.5, device="cuda")
+    ops.gemm_tn(A, B, o, M, NI, K, partial=part)
+    assert float((o.double() - 0.5 - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
 @pytest.mark.parametrize("dtype,use_tr", [(torch.float32, 0), (torch.bfloat16, 1)])
 @pytest.mark.parametrize("mode,kw,taps", [("shift", dict(p0=8 * 9, p1=9), 3), ("spatial", dict(p0=4), 9), ("strided", dict(p0=2, p1=9), 2),
                                           ("shift", dict(p0=16 * 49, p1=49), 3), ("spatial", dict(p0=14), 9), ("strided", dict(p0=2, p1=196), 2)])
