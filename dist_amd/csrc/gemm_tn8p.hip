@@ -586,8 +586,10 @@ int dist_k_gemm_tn8p(const dist_gemm_tn_args* a, hipStream_t s) {
     if ((long)a->M * a->lda >= (1l << 30) || (long)a->M * a->ldb >= (1l << 30)) return 0;     // 32-bit byte offsets inside a row range
     static const int mode = dist_knob("DIST_AMD_TN8P", 20);       // 0: gemm_tn_kernel for everything (the A/B reference); 1: two 64-row buffers; 16 / 20: ring slots
     if (!mode) return 0;
-    static const int max_blocks = dist_knob("DIST_AMD_TN8P_BLOCKS", 128);   // partial bytes = blocks x 196 KB, written and read again: 128 blocks (25 MB) leave half the CUs to the
-                                                                           // other streams of the step (17.80-17.86 ms against 17.90-17.98 with 256; alone 256 is faster: profiles/r04_tn8p.md)
+    static const int max_blocks = dist_knob("DIST_AMD_TN8P_BLOCKS", 96);    // partial bytes = blocks x 196 KB, written and read again, and a block holds its CU for the whole
+                                                                           // launch: 96 blocks leave the other CUs to the data-gradient chain the backward pass waits for
+                                                                           // (step 17.90-17.98 ms with 256, 17.80-17.86 with 128, 17.50-17.55 with 96 here and in gemm_tn.hip;
+                                                                           // alone 256 is the fastest: profiles/r04_tn8p.md)
     // the orientation with the smaller padded tile area; swapped: the kernel's A is the caller's B (the destination strides stay the caller's)
     auto pad = [](int x, int q) { return (long)((x + q - 1) / q * q); };
     if (pad(a->NI, 192) * pad(a->K, 256) <= pad(a->K, 192) * pad(a->NI, 256)) return launch_tn8p_kind<false>(mode, *a, s, max_blocks);
