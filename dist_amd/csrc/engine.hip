@@ -157,6 +157,8 @@ struct dist_handle {
     long tn_partial_elems = 0;
     float* ig_gscratch = nullptr;              // [layers][(Ci + C4) * Ci + (Ci + C4)]: G' = dz^T xhat and db of the two folded Linears when dist_branch_backward ACCUMULATES (zero_grads = 0)
     long ig_gscratch_elems = 0;                // per layer
+    int wgrad_blocks = 0;                      // dist_gemm_tn_args.max_blocks of the engine's weight gradients (0 = the library's default, 96; one block per CU for the last
+                                               // layers of the pass - whose gradients finish behind the chain - was measured: 17.85 -> 17.90 ms, not kept)
     bool bwd_accumulate = false;               // the running dist_branch_backward was called with zero_grads = 0
     // weight-gradient side stream (created once per handle; host-side objects only)
     hipStream_t side = nullptr, side2 = nullptr, pf = nullptr;   // pf: the handle's own ViT prefetch stream
@@ -685,7 +687,7 @@ int wgrad(const Ctx& c, const Lin& l, const void* dY, int ld_dy, const void* X, 
     else if (style == 1 || style == 2) { g.so_i = (long)l.K * l.taps; g.so_tap = 1; g.so_outer = l.taps; g.inner = 1; }
     else if (style == 4) { g.NI = l.K; g.K = l.N; g.so_i = l.N; g.so_tap = 0; g.so_outer = 1; g.inner = 1; }   // [K][N] matrix used as x @ W
     else { const int PP3 = c.h->PP3, PP = PP3 / 3; g.K = PP3; g.so_i = (long)PP3 * l.taps; g.so_tap = PP; g.so_outer = (long)PP * l.taps; g.inner = PP; }
-    g.dtype = c.dtype; g.use_tr = c.h->cfg.use_tr;
+    g.dtype = c.dtype; g.use_tr = c.h->cfg.use_tr; g.max_blocks = c.h->wgrad_blocks;
     if (c.h->skip & 1) return DIST_OK;
     if ((c.h->skip & 16) && l.N >= 384 && l.K >= 384) return DIST_OK;
     g.colsum = (with_bias && l.bias >= 0) ? c.gr(l.bias) : nullptr;       // db fused into the same pass over dY
@@ -707,7 +709,7 @@ int wgrad_pair(const Ctx& c, const Lin& l1, const Lin& l2, const void* dY, int l
     g.so_i = l1.K; g.so_tap = 0; g.so_outer = 1; g.inner = 1;
     g.split_c = l1.K; g.out2 = c.gr(l2.w); g.so_i2 = l2.K;
     if (c.h->skip & 17) return DIST_OK;
-    g.dtype = c.dtype; g.use_tr = c.h->cfg.use_tr;
+    g.dtype = c.dtype; g.use_tr = c.h->cfg.use_tr; g.max_blocks = c.h->wgrad_blocks;
     g.colsum = c.gr(l1.bias); g.colsum2 = c.gr(l2.bias);
     dist_handle* h = c.h;
     const int k = c.s == h->side ? 1 : (c.s == h->side2 ? 2 : 0);

@@ -376,7 +376,7 @@ int launch(const dist_gemm_tn_args& a, hipStream_t s) {
     // 22.52 / 22.53 ms; 384: 22.69, 128: 22.85).
     static const int max_blocks = dist_knob("DIST_AMD_TN_BLOCKS", 96);   // (round 4: 96 - the weight-gradient streams only have to keep up with the data-gradient chain,
                                                                        //  and every block they do not hold a CU with is one the chain gets: 17.93 ms with 256, 17.79 with 128, 17.57 with 96, 18.14 with 64)
-    long msplit = max_blocks / tiles;
+    long msplit = (a.max_blocks > 0 ? a.max_blocks : max_blocks) / tiles;
     const long max_split = (a.M + 511) / 512;
     if (msplit > max_split) msplit = max_split;
     if (msplit < 1) msplit = 1;

@@ -592,8 +592,9 @@ int dist_k_gemm_tn8p(const dist_gemm_tn_args* a, hipStream_t s) {
                                                                            // alone 256 is the fastest: profiles/r04_tn8p.md)
     // the orientation with the smaller padded tile area; swapped: the kernel's A is the caller's B (the destination strides stay the caller's)
     auto pad = [](int x, int q) { return (long)((x + q - 1) / q * q); };
-    if (pad(a->NI, 192) * pad(a->K, 256) <= pad(a->K, 192) * pad(a->NI, 256)) return launch_tn8p_kind<false>(mode, *a, s, max_blocks);
+    const int mb = a->max_blocks > 0 ? a->max_blocks : max_blocks;
+    if (pad(a->NI, 192) * pad(a->K, 256) <= pad(a->K, 192) * pad(a->NI, 256)) return launch_tn8p_kind<false>(mode, *a, s, mb);
     dist_gemm_tn_args b = *a;
     b.A = a->B; b.B = a->A; b.lda = a->ldb; b.ldb = a->lda; b.NI = a->K; b.K = a->NI;
-    return launch_tn8p_kind<true>(mode, b, s, max_blocks);
+    return launch_tn8p_kind<true>(mode, b, s, mb);
 }

@@ -38,7 +38,7 @@ class GemmTnArgs(C.Structure):
                 ("lda", C.c_int), ("ldb", C.c_int), ("amap", RowMap), ("bmap", RowMap),
                 ("so_i", C.c_int64), ("so_tap", C.c_int64), ("so_outer", C.c_int64), ("inner", C.c_int),
                 ("dtype", C.c_int), ("use_tr", C.c_int), ("colsum", C.c_void_p), ("partial", C.c_void_p), ("partial_elems", C.c_int64),
-                ("split_c", C.c_int), ("out2", C.c_void_p), ("so_i2", C.c_int64), ("colsum2", C.c_void_p)]
+                ("split_c", C.c_int), ("out2", C.c_void_p), ("so_i2", C.c_int64), ("colsum2", C.c_void_p), ("max_blocks", C.c_int)]
 
 
 class LnArgs(C.Structure):

@@ -278,7 +278,7 @@ def ln_fold(W, bias, gamma, beta):
 
 
 def gemm_tn(A, B, out, M, NI, K, *, taps=1, amap=None, bmap=None, so_i=None, so_tap=None, so_outer=1, inner=1, use_tr=1, colsum=None, partial=None,
-            out2=None, split_c=0, so_i2=0, colsum2=None):
+            out2=None, split_c=0, so_i2=0, colsum2=None, max_blocks=0):
     lib = L.load()
     a = L.GemmTnArgs()
     a.A, a.B, a.out = _p(A), _p(B), _p(out)
@@ -293,6 +293,7 @@ def gemm_tn(A, B, out, M, NI, K, *, taps=1, amap=None, bmap=None, so_i=None, so_
     a.colsum = _p(colsum)
     a.partial = _p(partial)
     a.partial_elems = partial.numel() if partial is not None else 0
+    a.max_blocks = max_blocks          # 0: the library's default (96); 256: one block per CU, the fastest form of a lone launch
     if out2 is not None:      # columns >= split_c go to a second tensor (two weights that share dY)
         a.out2, a.split_c, a.so_i2, a.colsum2 = _p(out2), split_c, so_i2, _p(colsum2)
     L.check(lib.dist_op_gemm_tn(C.byref(a), _stream()))

@@ -152,6 +152,9 @@ typedef struct dist_gemm_tn_args {
      * are stored side by side): columns c >= split_c go to out2[i*so_i2 + (c - split_c)], colsum is also added to colsum2.
      * Plain layouts only (taps == 1, inner == 1, so_outer == 1). */
     int split_c; float* out2; int64_t so_i2; float* colsum2;
+    /* ABI 9: upper bound of the workgroups of the main kernel (0 = the library's default, 96: a launch that runs BESIDE a critical chain should not hold
+     * every CU while it waits for HBM; a caller with nothing else in flight passes 256: one block per CU is the fastest form of a lone launch) */
+    int max_blocks;
 } dist_gemm_tn_args;
 int dist_op_gemm_tn(const dist_gemm_tn_args* a, void* stream);
 

@@ -52,14 +52,15 @@ for (M, NI, K, lda, ldb, split) in CASES:
     assert err < 2e-5 and eb < 2e-5 and eb2 < 2e-5, "MISMATCH"
     del A, B
 
-# ---- timing, cold operands (10 operand sets in rotation)
+# ---- timing, cold operands (10 operand sets in rotation); --blocks N: dist_gemm_tn_args.max_blocks (default 256: the lone launch's best form)
+MB = int(sys.argv[sys.argv.index('--blocks') + 1]) if '--blocks' in sys.argv else 256
 NSET = 10
 M = 50432
 for (NI, K, lda, ldb, tag) in [(384, 768, 384, 768, "in_lin"), (384, 480, 384, 480, "proj pair"), (480, 384, 576, 384, "[fc|fc1]"), (384, 384, 384, 384, "ffn_fc")]:
     As = [torch.randn(M, lda, device="cuda").to(dt) for _ in range(NSET)]
     Bs = [torch.randn(M, ldb, device="cuda").to(dt) for _ in range(NSET)]
     out = torch.zeros(NI, K, device="cuda"); cs = torch.zeros(NI, device="cuda")
-    fns = [(lambda a=a, b=b: ops.gemm_tn(a, b, out, M, NI, K, colsum=cs, partial=part)) for a, b in zip(As, Bs)]
+    fns = [(lambda a=a, b=b: ops.gemm_tn(a, b, out, M, NI, K, colsum=cs, partial=part, max_blocks=MB)) for a, b in zip(As, Bs)]
     t = timeit_rot(fns)
     byts = (M * NI + M * K) * 2
     print(f"gemm_tn {tag:10s} {NI}x{K}: {t*1e6:8.1f} us  {2*M*NI*K/t/1e12:7.1f} TF = {2*M*NI*K/t/2.5e15:.3f} of peak (operands once: {byts/t/1e9:6.0f} GB/s)", flush=True)
