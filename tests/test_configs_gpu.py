@@ -221,7 +221,8 @@ def _rel(a, b):
 #   temporal_nets.0.ln.weight, the T2I cls tokens of the last layers, temporal_nets.0/1 (gpurun_out/same_rounding_grad_worst.json ->
 #   profiles/r04_parity_gaps.json): the tensors at the far END of the backward chain, i.e. twelve layers of bf16-stored gradients, not one
 #   defective tensor; median 0.005.  With the unfused sequence's rounding points (round 3's oracle) the same run reads 0.0125 / 0.0111 / 0.035.
-#   Every gate is 2x its measured value.
+#   Every gate is 2x its measured value.  Noise floor: the oracle in fp32 against ITSELF in fp64 (same rounding points) differs by logits 0.0099,
+#   activations 0.0107, worst gradient 0.027 (tools/oracle_rounding_noise.py -> profiles/r04_oracle_rounding_noise.json): the engine sits on it.
 SAME_ROUNDING_GATES = {"vit_block": 3.5e-3, "stem": 1e-4, "branch_act": 0.022, "logits": 0.0215, "loss": 1.3e-3, "grad": 0.043}
 
 
