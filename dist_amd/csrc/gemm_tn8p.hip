@@ -5,27 +5,34 @@
 // ROW index.  gemm_tn_kernel (gemm_tn.hip) is a serial chain per 64-row step - global loads -> registers -> ds_write_b128 (13 LDS
 // cycles each) -> block barrier -> 24 transpose reads -> 16 MFMAs, every wave of the block in the same stage at the same time: 20 %
 // MFMA busy, 25 % LDS busy, 38 % of the wave cycles parked (profiles/r03_tn_big_tiles.md).  Here
-//   * rows travel L2 / HBM -> LDS by `buffer_load ... lds` (no staging registers, no ds_write pass): a K-tile is 64 reduction rows,
-//     staged as four half-tiles of [64 rows][128 column slots] bf16 (16 KB, rows of 256 B = one pass over the 64 banks);
+//   * rows travel L2 / HBM -> LDS by `buffer_load ... lds` (no staging registers, no ds_write pass) into a RING of S = 20 half-tile slots of
+//     [32 rows][128 column slots] bf16 (8 KB = one 1 KB piece per wave; rows of 256 B = one pass over the 64 banks), in staging order
+//         seq = 4*t + {A-h0: 0, B-h0: 1, B-h1: 2, A-h1: 3}   ->   slot seq mod S,
+//     phase r reads seq r + 2 and stages seq r + S into the slot phase r - 2 read (the WAR rule of gemm_fast.hip); S - 3 = 17 half-tiles = 136 KB
+//     stay in flight behind the counted vmcnt;
 //   * waves 0-3 and 4-7 (the SIMD partners) run ONE barrier apart: in every barrier interval one group is in its load section
-//     (transpose reads for the multiply section AFTER the next, two LDS-DMA pieces, a counted vmcnt) and the other multiplies
-//     (4*FA MFMAs on one quadrant of its (32*FA) x 64 sub-tile) - the phase table of gemm_fast.hip, unchanged;
-//   * fragments by ds_read_b64_tr_b16 (2 LDS cycles per wave instruction): lane (li, lg) addresses 4 consecutive slots of row
-//     4*lg + (li >> 2) (and 16 rows further) and receives column li - k-slot (lg, e) <-> row 4*lg + e / 16 + 4*lg + (e - 4), the same
-//     assignment for both operands;
+//     (transpose reads for the multiply section AFTER the next, one LDS-DMA piece, the counted wait) and the other multiplies
+//     (2*FA MFMAs on one quadrant of its (32*FA) x 64 sub-tile) - the phase table of gemm_fast.hip;
+//   * fragments by ds_read_b64_tr_b16 (2 LDS cycles per wave instruction), issued as INLINE ASSEMBLY: behind the builtin hipcc waits vmcnt(0)
+//     in front of every transpose read (it cannot separate the read from the LDS-DMA pieces in flight), which serialises the ring; the counted
+//     vmcnt + barrier one phase earlier is the ordering.  Lane (li, lg) addresses 4 consecutive slots of row 4*lg + (li >> 2) (and 16 rows
+//     further) and receives column li - k-slot (lg, e) <-> row 4*lg + e / 16 + 4*lg + (e - 4), the same assignment for both operands;
 //   * 32-byte piece c32 of row r lives at piece c32 ^ (r & 7): the eight rows a 32-lane service group touches cover the 64 banks
-//     exactly once; the LDS-DMA image is lane-linear, so the same involution sits on the per-lane SOURCE offset;
-//   * rows behind the block's row range read ZERO through the buffer descriptor (base = first row of the range, size = the range):
-//     no row clamping, no validity flags; column slots beyond NI / K read whatever follows in the row (or zero behind the range) -
-//     output element (i, c) depends on column i of A and column c of B only, and the second phase never stores those outputs;
+//     exactly once (SQ_LDS_BANK_CONFLICT = 0); the LDS-DMA image is lane-linear, so the same involution sits on the per-lane SOURCE offset;
+//   * rows behind the block's row range read ZERO through the buffer descriptor (base = first row of the range, size = the range) and are
+//     requested like any other piece: no row clamping, no validity flags, no tail logic - the loop body is lcm(4, S) phases (x 2: the two B
+//     register sets swap roles every K-tile) with compile-time slots, and the launcher makes a row range a whole number of bodies.  Column slots
+//     beyond NI / K read whatever follows in the row - output element (i, c) depends on column i of A and column c of B only, and the second
+//     phase never stores those outputs;
 //   * the bias gradient (column sums of A) rides along: wave (wr, wc) reads fragment wc of its wave row a second time and sums its
-//     packed pairs with v_dot2_f32_bf16 against (1, 1) - 4 transpose reads and 8 VALU per quadrant and K-tile, no branch
+//     packed pairs with v_dot2_f32_bf16 against (1, 1) - 2 transpose reads and 4 VALU per quadrant and K-tile, no branch
 //     (CSB: the operands are SWAPPED - the kernel's rows are B's columns - and the sums run over fragment wr of the wave column);
 //   * the row-split partial tile leaves the accumulators in FRAGMENT order (one 1 KB piece per wave instruction, 16 bytes per lane);
-//     tn8p_reduce_kernel sums the splits in index order (one thread per 16-byte piece: bit-repeatable) into the parameter layout.
-// Tile = 192 x 256 (FA = 3 fragments per quadrant: 226 registers; FA = 4 spills on the bias-gradient fragment).  Every large gradient of
-// the path has a 384-wide side: that side becomes the tile rows (2 x 192), if necessary by swapping the operands (480 x 384 runs as
-// 384 x 480: 94 % of the MFMAs useful instead of 70 %).
+//     tn8p_reduce_kernel sums the splits in index order (bit-repeatable) into the parameter layout.
+// Tile = 192 x 256 (FA = 3 fragments per quadrant).  Every large gradient of the path has a 384-wide side: that side becomes the tile rows
+// (2 x 192), if necessary by swapping the operands (480 x 384 runs as 384 x 480: 94 % of the MFMAs useful instead of 70 %).
+// Measured (profiles/r04_tn8p.md): main kernel 53 -> 43 us on the input_linear gradient at 3.7-3.9 TB/s whatever the ring depth (S = 16, 20, or two
+// 64-row K-tile buffers: 42.4 / 43.0 / 44.8 us) - the gradients are memory-bound (operands + partial tiles), not schedule-bound.
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
@@ -37,11 +44,6 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef s16x4 __attribute__((address_space(3))) * lds_v4;
 typedef __attribute__((ext_vector_type(2))) __bf16 t8_bf16x2;
 
-constexpr int T8_BK = 64;                                 // reduction rows per K-tile
-constexpr int T8_HALF = T8_BK * 256;                      // 16 KB: 64 rows x 128 column slots
-constexpr int T8_BUF = T8_HALF;                           // second buffer of a half-tile: right behind the first
-constexpr int T8_A0 = 0, T8_A1 = 2 * T8_HALF, T8_B0 = 4 * T8_HALF, T8_B1 = 6 * T8_HALF;
-constexpr int T8_LDS = 8 * T8_HALF;                       // 128 KB
 constexpr int T8_BJ = 256;
 
 DEV float* tn8_dst(const dist_gemm_tn_args& p, int ii, int c) {
@@ -50,20 +52,6 @@ DEV float* tn8_dst(const dist_gemm_tn_args& p, int ii, int c) {
 }
 
 template <int V> using IC = std::integral_constant<int, V>;
-template <int N> DEV void t8_wait_vm() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else static_assert(N < 0, "unsupported count");
-}
-template <int FA> DEV void t8_ready(bf16x8 (&f)[FA][2]) {
-#pragma unroll
-    for (int i = 0; i < FA; ++i) asm volatile("" : "+v"(f[i][0]), "+v"(f[i][1]));
-}
-
 // 8 k-slots of one column for each of 16 columns: two transpose reads 16 rows apart (row pitch 256 B)
 template <int OFF> DEV bf16x8 t8_tr8(const unsigned addr) {
     static_assert(OFF >= 0 && OFF + 16 * 256 < 65536, "16-bit ds offset");
@@ -75,234 +63,6 @@ template <int OFF> DEV bf16x8 t8_tr8(const unsigned addr) {
     return u.v;
 }
 
-template <int FA, bool CSB>
-__global__ __launch_bounds__(512, 1) void gemm_tn8p_kernel(const dist_gemm_tn_args p, const int chunk, const int tiles_i, const int tiles_c) {
-    constexpr int BI = 64 * FA;
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 2, wc = wid & 3;                // 2 x 4 waves; wr is also the wave group
-    const int li = lane & 15, lg = lane >> 4;
-
-    // XCD-aware, bijective remap: the output tiles of ONE row range get consecutive ids on the same XCD, so the range's rows of A and B
-    // come from HBM once and the other tiles re-read them from that XCD's L2
-    const int tiles_ij = tiles_i * tiles_c;
-    int bid = blockIdx.x;
-    {
-        const int nblk = gridDim.x;
-        const int q = nblk / 8, r = nblk % 8, x = bid % 8, y = bid / 8;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
-    }
-    const int ms = bid / tiles_ij, t = bid % tiles_ij;
-    const int ti = t % tiles_i, tc = t / tiles_i;
-    const int i0 = ti * BI, c0 = tc * T8_BJ;
-    const int M = (int)p.M;
-    const int mbeg = ms * chunk, rows = min(M, mbeg + chunk) - mbeg;
-    if (rows <= 0) return;
-    const int nk = max(2, (rows + T8_BK - 1) / T8_BK);    // (a second, all-zero K-tile for a range of <= 64 rows: the loop is built for >= 2)
-
-    // ---- LDS-DMA sources.  Per half-tile this wave moves rows 8*wid + 4*j + (lane >> 4), j = 0, 1 (1 KB each): lane -> 16 bytes =
-    // half of the physical 32-byte piece (lane & 15) >> 1 of its row.
-    const bf16_t* Ab = static_cast<const bf16_t*>(p.A) + ((long)mbeg * p.lda + i0);
-    const bf16_t* Bb = static_cast<const bf16_t*>(p.B) + ((long)mbeg * p.ldb + c0);
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ab), 0, (int)(((long)rows * p.lda - i0) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Bb), 0, (int)(((long)rows * p.ldb - c0) * 2), 0x00020000);
-    constexpr unsigned OOB = 0x80000000u;
-    unsigned ga[2], gb[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = 8 * wid + 4 * j + (lane >> 4);
-        const int pc = lane & 15;
-        const int slot = (((pc >> 1) ^ (r & 7)) << 4) + (pc & 1) * 8;       // logical column slot of this lane's 8 elements
-        // A: slot = wave row * 64 + f*16 + e  ->  column wave row * (BI/2) + [quadrant * 16*FA] + f*16 + e; slots f >= FA are not fetched
-        ga[j] = (slot & 63) < 16 * FA ? (unsigned)(r * p.lda + (slot >> 6) * (BI / 2) + (slot & 63)) * 2u : OOB;
-        // B: slot = wave column * 32 + j*16 + e  ->  column wave column * 64 + [quadrant * 32] + j*16 + e
-        gb[j] = (unsigned)(r * p.ldb + (slot >> 5) * 64 + (slot & 31)) * 2u;
-    }
-    const int atile = T8_BK * p.lda * 2, btile = T8_BK * p.ldb * 2;          // bytes per K-tile
-    auto stage = [&](const int slot, const int kt) __attribute__((always_inline)) {
-        char* sb = smem + (kt & 1) * T8_BUF + slot + wid * 2048;
-        if (slot == T8_A0 || slot == T8_A1) {
-            const int so = kt * atile + (slot == T8_A1 ? 16 * FA * 2 : 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)sb, 16, ga[0], so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sb + 1024), 16, ga[1], so, 0, 0);
-        } else {
-            const int so = kt * btile + (slot == T8_B1 ? 64 : 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)sb, 16, gb[0], so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + 1024), 16, gb[1], so, 0, 0);
-        }
-    };
-
-    // ---- transpose-read offsets inside a half-tile: row 4*lg + (li >> 2) (+ 32*kk, + 16 for the second half of the k-slots),
-    // logical 32-byte piece = wave row * 4 + f (A) / wave column * 2 + j (B), 8 bytes per lane inside it
-    const int rx = 4 * (lg & 1) + (li >> 2);               // (row & 7)
-    const int rbase = (4 * lg + (li >> 2)) * 256 + (li & 3) * 8;
-    int a_rd[FA], b_rd[2];
-#pragma unroll
-    for (int f = 0; f < FA; ++f) a_rd[f] = rbase + (((wr * 4 + f) ^ rx) << 5);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) b_rd[j] = T8_B0 + rbase + (((wc * 2 + j) ^ rx) << 5);
-    // the bias gradient's fragment: number wc of this wave row (CSB: number wr of this wave column)
-    const int c_rd = CSB ? T8_B0 + rbase + (((wc * 2 + wr) ^ rx) << 5) : rbase + (((wr * 4 + wc) ^ rx) << 5);
-
-    // (inline assembly: behind the builtin hipcc waits vmcnt(0) in front of every transpose read - it cannot tell the read from the LDS-DMA
-    //  pieces in flight - which serialises the ring; the counted vmcnt + barrier one phase earlier is the ordering, see gemm_fast.hip)
-    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((lds_ptr)smem);
-    unsigned a_ad[FA], b_ad[2];
-#pragma unroll
-    for (int f = 0; f < FA; ++f) a_ad[f] = lds0 + a_rd[f];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) b_ad[j] = lds0 + b_rd[j];
-    const unsigned c_ad = lds0 + c_rd;
-    bf16x8 fa[2][FA][2], sb_[2][2][2], fc[2];
-    auto read_a = [&](bf16x8 (&f)[FA][2], auto off_c) __attribute__((always_inline)) {
-        constexpr int OFF = decltype(off_c)::value;       // half-tile + buffer
-#pragma unroll
-        for (int i = 0; i < FA; ++i) { f[i][0] = t8_tr8<OFF>(a_ad[i]); f[i][1] = t8_tr8<OFF + 32 * 256>(a_ad[i]); }
-        if constexpr (!CSB) { fc[0] = t8_tr8<OFF>(c_ad); fc[1] = t8_tr8<OFF + 32 * 256>(c_ad); }
-    };
-    auto read_b = [&](bf16x8 (&f)[2][2], auto off_c) __attribute__((always_inline)) {
-        constexpr int OFF = decltype(off_c)::value - T8_B0;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { f[j][0] = t8_tr8<OFF>(b_ad[j]); f[j][1] = t8_tr8<OFF + 32 * 256>(b_ad[j]); }
-        if constexpr (CSB) { fc[0] = t8_tr8<OFF>(c_ad); fc[1] = t8_tr8<OFF + 32 * 256>(c_ad); }
-    };
-
-    f32x4 acc[2 * FA][4];
-#pragma unroll
-    for (int i = 0; i < 2 * FA; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float cs[2] = {0.f, 0.f};
-
-    // multiply section: barrier (this wave's counted DMA wait is behind it), 4*FA MFMAs on fragments read a phase ago, retire the reads
-    // of the load section in front (they have had the MFMAs to complete)
-    auto mmaq = [&](const int qa, const int qb, const bf16x8 (&a)[FA][2], const bf16x8 (&b)[2][2]) __attribute__((always_inline)) {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < FA; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)     // swapped: D rows (4*lg + r) <-> B's columns, D column li <-> A's column: a lane holds 4 consecutive c of one i
-                    acc[qa * FA + i][qb * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][kk], a[i][kk], acc[qa * FA + i][qb * 2 + j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-    // the bias-gradient fragment of the A half-tile read in this phase's load section: sum of this lane's 16 k-slots
-    auto colsum_q = [&](const int q) __attribute__((always_inline)) {
-        asm volatile("" : "+v"(fc[0]), "+v"(fc[1]));
-        const t8_bf16x2 one = {(bf16_t)1.0f, (bf16_t)1.0f};
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const t8_bf16x2 pr = {fc[kk][2 * e], fc[kk][2 * e + 1]};
-                cs[q] = __builtin_amdgcn_fdot2_f32_bf16(pr, one, cs[q], false);
-            }
-    };
-    auto close_phase = [&]() __attribute__((always_inline)) {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    // one K-tile = four phases (gemm_fast.hip: phase table and ordering rules); the tail is selected by wave-uniform scalars
-    auto ktile = [&](auto buf_c, const int kt) __attribute__((always_inline)) {
-        constexpr int BUF = decltype(buf_c)::value, NB = BUF ^ 1;
-        const bool s1 = kt + 1 < nk, s2 = kt + 2 < nk;
-        // phase 0
-        read_b(sb_[NB], IC<T8_B1 + BUF * T8_BUF>{});
-        __builtin_amdgcn_sched_barrier(0);
-        if (s2) { stage(T8_A0, kt + 2); t8_wait_vm<10>(); } else if (s1) t8_wait_vm<8>(); else t8_wait_vm<0>();
-        mmaq(0, 0, fa[0], sb_[BUF]);
-        asm volatile("" : "+v"(sb_[NB][0][0]), "+v"(sb_[NB][0][1]), "+v"(sb_[NB][1][0]), "+v"(sb_[NB][1][1]));
-        if constexpr (CSB) colsum_q(1);
-        close_phase();
-        // phase 1
-        read_a(fa[1], IC<T8_A1 + BUF * T8_BUF>{});
-        __builtin_amdgcn_sched_barrier(0);
-        if (s2) { stage(T8_B0, kt + 2); t8_wait_vm<10>(); } else if (s1) t8_wait_vm<6>();
-        mmaq(0, 1, fa[0], sb_[NB]);
-        t8_ready<FA>(fa[1]);
-        if constexpr (!CSB) colsum_q(1);
-        close_phase();
-        // phase 2
-        if (s1) read_a(fa[0], IC<T8_A0 + NB * T8_BUF>{});
-        __builtin_amdgcn_sched_barrier(0);
-        if (s2) { stage(T8_B1, kt + 2); t8_wait_vm<10>(); } else if (s1) t8_wait_vm<4>();
-        mmaq(1, 1, fa[1], sb_[NB]);
-        t8_ready<FA>(fa[0]);
-        if constexpr (!CSB) { if (s1) colsum_q(0); }
-        close_phase();
-        // phase 3
-        if (s1) read_b(sb_[NB], IC<T8_B0 + NB * T8_BUF>{});
-        __builtin_amdgcn_sched_barrier(0);
-        if (s2) { stage(T8_A1, kt + 2); t8_wait_vm<10>(); } else if (s1) t8_wait_vm<2>();
-        mmaq(1, 0, fa[1], sb_[BUF]);
-        asm volatile("" : "+v"(sb_[NB][0][0]), "+v"(sb_[NB][0][1]), "+v"(sb_[NB][1][0]), "+v"(sb_[NB][1][1]));
-        if constexpr (CSB) { if (s1) colsum_q(0); }
-        close_phase();
-    };
-
-    // prologue: tiles 0 and 1 in the steady-state issue order; A-h0, B-h0, B-h1 of tile 0 must have landed (five half-tiles behind)
-    stage(T8_A0, 0); stage(T8_B0, 0); stage(T8_B1, 0); stage(T8_A1, 0);
-    stage(T8_A0, 1); stage(T8_B0, 1); stage(T8_B1, 1); stage(T8_A1, 1);
-    t8_wait_vm<10>();
-    __builtin_amdgcn_s_barrier();
-    read_a(fa[0], IC<T8_A0>{});
-    read_b(sb_[0], IC<T8_B0>{});
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    t8_ready<FA>(fa[0]);
-    asm volatile("" : "+v"(sb_[0][0][0]), "+v"(sb_[0][0][1]), "+v"(sb_[0][1][0]), "+v"(sb_[0][1][1]));
-    colsum_q(0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (wr == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one barrier interval behind group 0
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-    int kt = 0;
-#pragma unroll 1
-    for (; kt + 1 < nk; kt += 2) {
-        ktile(I0{}, kt);
-        ktile(I1{}, kt + 1);
-    }
-    if (kt < nk) ktile(I0{}, kt);
-    if (wr == 0) __builtin_amdgcn_s_barrier();            // pairs with group 1's extra barrier
-
-    // ---- partial tile in fragment order: piece ((wave * 2*FA + qa*FA + f) * 4 + qb*2 + j) = 64 lanes x 16 bytes
-    float* pt = p.partial + ((long)ms * tiles_ij + t) * (BI * T8_BJ) + (long)wid * (2 * FA * 4 * 256) + lane * 4;
-#pragma unroll
-    for (int i = 0; i < 2 * FA; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(pt + (i * 4 + j) * 256) = acc[i][j];
-    if (p.colsum != nullptr && (CSB ? ti : tc) == 0) {
-        // bias-gradient partial: the lane's k-slot sums -> over the four k-slot groups of the wave; row of the tile = wave row * (BI/2) + q*16*FA
-        // + wc*16 + li (CSB: column of the tile = wave column * 64 + q*32 + wr*16 + li)
-        float* cp = p.partial + (long)gridDim.x * (BI * T8_BJ) + (CSB ? ((long)ms * tiles_c + tc) * T8_BJ : ((long)ms * tiles_i + ti) * BI);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            float v = cs[q];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            if constexpr (CSB) { if (lg == 0) cp[wc * 64 + q * 32 + wr * 16 + li] = v; }
-            else if (lg == 0 && wc < FA) cp[wr * (BI / 2) + q * 16 * FA + wc * 16 + li] = v;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------------
-// The same schedule on a RING of S half-tile slots with 32-row K-tiles (gemm_tn8r_kernel).  What the counters of the kernel above say
-// (profiles/r04_tn8p.md): cold operands, it moves 116 MB in + 50 MB out in 44.5 us = 3.7 TB/s with the MFMA pipe 30 % busy and no LDS bank
-// conflict - the block waits for its LDS-DMA pieces.  Two 64-row K-tile buffers leave five half-tiles = 80 KB in flight per CU, and with a loaded
-// HBM round trip of ~3 us that is ~4 TB/s for the chip (MI355X_MICROARCH.md "ldsdma-fill": 6.4 TB/s needs a 128 KB ring): the bytes in flight are
-// the bound.  Here a half-tile is [32 rows][128 slots] = 8 KB = ONE piece per wave, the slots form a ring in staging order
-//     seq = 4*t + {A-h0: 0, B-h0: 1, B-h1: 2, A-h1: 3}   ->   slot seq mod S,
-// phase r reads seq r + 2 and stages seq r + S into the slot phase r - 2 read (the WAR rule of gemm_fast.hip), S - 3 half-tiles stay in flight
-// behind the counted wait: S = 16 -> 104 KB of 128 KB, S = 20 -> 136 KB of 160 KB.  A phase is 2*FA MFMAs; pieces behind the row range are requested
-// like any other (the descriptor returns zeros without touching memory), so the loop has no tail logic at all: the body is lcm(4, S) phases
-// (x 2 when that is an odd number of K-tiles: the two B register sets swap roles every K-tile) with compile-time slots, and the launcher makes
-// a row range a whole number of bodies.
 template <int G, int N, class F> DEV void t8_unroll(F& f) {
     if constexpr (G < N) { f(IC<G>{}); t8_unroll<G + 1, N>(f); }
 }
@@ -538,13 +298,13 @@ __global__ __launch_bounds__(256) void tn8p_reduce_kernel(const dist_gemm_tn_arg
         if (col + q < p.K) atomicAdd(SWAP ? tn8_dst(p, col + q, row) : tn8_dst(p, row, col + q), v[q]);
 }
 
-// KIND: 1 = two 64-row K-tile buffers (gemm_tn8p_kernel), 16 / 20 = the ring of that many 32-row half-tile slots (gemm_tn8r_kernel)
-template <int KIND, bool SWAP>
+// S = slots of the ring (20: 160 KB of LDS, 136 KB in flight)
+template <int S, bool SWAP>
 int launch_tn8p(const dist_gemm_tn_args& a, hipStream_t s, const int max_blocks) {
     constexpr int FA = 3, BI = 64 * FA, TILE = BI * T8_BJ;
-    constexpr int PER0 = KIND == 1 ? 4 : ((KIND % 4 == 0) ? KIND : 2 * KIND);
-    constexpr int GRAIN = KIND == 1 ? T8_BK : 32 * ((PER0 / 4) % 2 == 0 ? PER0 / 4 : PER0 / 2);     // rows per loop body
-    constexpr size_t LDS = KIND == 1 ? (size_t)T8_LDS : (size_t)KIND * 32 * 256;
+    constexpr int PER0 = (S % 4 == 0) ? S : 2 * S;
+    constexpr int GRAIN = 32 * ((PER0 / 4) % 2 == 0 ? PER0 / 4 : PER0 / 2);     // rows per loop body: a row range is a whole number of them
+    constexpr size_t LDS = (size_t)S * 32 * 256;
     const int tiles_i = (a.NI + BI - 1) / BI, tiles_c = (a.K + T8_BJ - 1) / T8_BJ;
     const long tiles = (long)tiles_i * tiles_c;
     long msplit = max_blocks / tiles;
@@ -557,7 +317,7 @@ int launch_tn8p(const dist_gemm_tn_args& a, hipStream_t s, const int max_blocks)
     const long nblk = tiles * msplit;
     if (nblk * TILE + msplit * (SWAP ? (long)tiles_c * T8_BJ : (long)tiles_i * BI) > a.partial_elems) return 0;      // not taken: gemm_tn_kernel
     static DistSmemOnce attr;
-    auto kern = [] { if constexpr (KIND == 1) return gemm_tn8p_kernel<FA, SWAP>; else return gemm_tn8r_kernel<KIND, SWAP>; }();
+    auto kern = gemm_tn8r_kernel<S, SWAP>;
     RUN_(dist_max_smem(attr, reinterpret_cast<const void*>(kern), LDS));
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), LDS, s, a, chunk, tiles_i, tiles_c);
     HIP_CHECK_RET(hipGetLastError());
@@ -566,12 +326,6 @@ int launch_tn8p(const dist_gemm_tn_args& a, hipStream_t s, const int max_blocks)
     hipLaunchKernelGGL((tn8p_reduce_kernel<FA, SWAP>), dim3((unsigned)blocks), dim3(256), 0, s, a, (int)msplit, tiles_i, tiles_c, (int)nblk);
     HIP_CHECK_RET(hipGetLastError());
     return 1;
-}
-template <bool SWAP>
-int launch_tn8p_kind(const int kind, const dist_gemm_tn_args& a, hipStream_t s, const int max_blocks) {
-    if (kind == 1) return launch_tn8p<1, SWAP>(a, s, max_blocks);
-    if (kind == 16) return launch_tn8p<16, SWAP>(a, s, max_blocks);
-    return launch_tn8p<20, SWAP>(a, s, max_blocks);
 }
 
 }  // namespace
@@ -584,7 +338,7 @@ int dist_k_gemm_tn8p(const dist_gemm_tn_args* a, hipStream_t s) {
     if (a->NI < 192 || a->K < 192 || a->M < 8192) return 0;
     if (a->lda % 8 || a->ldb % 8 || ((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15)) return 0;
     if ((long)a->M * a->lda >= (1l << 30) || (long)a->M * a->ldb >= (1l << 30)) return 0;     // 32-bit byte offsets inside a row range
-    static const int mode = dist_knob("DIST_AMD_TN8P", 20);       // 0: gemm_tn_kernel for everything (the A/B reference); 1: two 64-row buffers; 16 / 20: ring slots
+    static const int mode = dist_knob("DIST_AMD_TN8P", 1);        // 0: gemm_tn_kernel for everything (the A/B reference)
     if (!mode) return 0;
     static const int max_blocks = dist_knob("DIST_AMD_TN8P_BLOCKS", 96);    // partial bytes = blocks x 196 KB, written and read again, and a block holds its CU for the whole
                                                                            // launch: 96 blocks leave the other CUs to the data-gradient chain the backward pass waits for
@@ -593,8 +347,8 @@ int dist_k_gemm_tn8p(const dist_gemm_tn_args* a, hipStream_t s) {
     // the orientation with the smaller padded tile area; swapped: the kernel's A is the caller's B (the destination strides stay the caller's)
     auto pad = [](int x, int q) { return (long)((x + q - 1) / q * q); };
     const int mb = a->max_blocks > 0 ? a->max_blocks : max_blocks;
-    if (pad(a->NI, 192) * pad(a->K, 256) <= pad(a->K, 192) * pad(a->NI, 256)) return launch_tn8p_kind<false>(mode, *a, s, mb);
+    if (pad(a->NI, 192) * pad(a->K, 256) <= pad(a->K, 192) * pad(a->NI, 256)) return launch_tn8p<20, false>(*a, s, mb);
     dist_gemm_tn_args b = *a;
     b.A = a->B; b.B = a->A; b.lda = a->ldb; b.ldb = a->lda; b.NI = a->K; b.K = a->NI;
-    return launch_tn8p_kind<true>(mode, b, s, mb);
+    return launch_tn8p<20, true>(b, s, mb);
 }

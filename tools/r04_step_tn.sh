@@ -7,7 +7,7 @@ for i in 1 2; do
   run DIST_AMD_TN8P=1
   run DIST_AMD_TN8P=16
   run DIST_AMD_TN8P=20
-  run DIST_AMD_TN8P=20 DIST_AMD_TN8P_BLOCKS=128
+  run DIST_AMD_TN8P_BLOCKS=128
   run DIST_AMD_TN8P=20 DIST_AMD_TN8P_BLOCKS=192
   run DIST_AMD_TN8P=1 DIST_AMD_TN8P_BLOCKS=128
 done
