@@ -72,7 +72,11 @@ class DiSTNetwork(DiSTParams):
         input['mid_feat']['img'][layer_id] ([L, b*t, width], one per selected layer) and input['images'] ([b*T,3,H,W] or [b,3,T,H,W]): when the
         caller supplies them they are copied into the engine's feature slot (dist_features_import) and the branch runs on THEM; without
         them the branch runs on the features of the engine's own frozen-ViT pass of the same batch (CLIP.forward runs dist_vit_forward
-        first).  input['text_features'] as in the reference (clip.py:507)."""
+        first).  input['text_features'] as in the reference (clip.py:507).
+        Two documented differences: the returned embedding is already L2-normalised (the reference normalises cls_x in the next statement of its
+        caller, clip.py:511; the engine's head kernel does it in the same launch that forms the logits, which are left in input['logits_per_image']),
+        and this direct call does not record an autograd graph - training goes through CLIP.forward (`_DistFunction`), whose backward is
+        dist_branch_backward."""
         eng = self._engine[0]
         mid = input.get("mid_feat", {}).get("img") if isinstance(input.get("mid_feat"), dict) else None
         if mid is not None and all(i in mid for i in self.selected_layers):
