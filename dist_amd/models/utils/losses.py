@@ -43,6 +43,11 @@ def calculate_loss(cfg, preds, logits, labels, cur_epoch):
         loss = SoftTargetCrossEntropy()(preds, target, engine)
         name = "soft_target"
     else:
-        loss = F.cross_entropy(preds, target)
+        # hard labels (no mixup / label smoothing): the same HIP loss on their one-hot form when the logits are the engine's
+        engine = logits.get("_dist_engine") if isinstance(logits, dict) and torch.is_grad_enabled() else None
+        if engine is not None and preds.is_cuda and preds.dim() == 2 and preds.shape[0] == engine.b and target.dim() == 1:
+            loss = SoftTargetCrossEntropy()(preds, F.one_hot(target.long(), preds.shape[1]).float(), engine)
+        else:
+            loss = F.cross_entropy(preds, target)
         name = "cross_entropy"
     return loss, {name: loss}, None

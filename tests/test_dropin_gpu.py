@@ -265,6 +265,11 @@ def test_train_loop_loss_is_the_engines_dist_loss(gpu_lib):
         loss.backward()
         grads.append((float(loss), {n: p.grad.clone() for n, p in pd.items() if p.grad is not None}))
     assert abs(grads[0][0] - grads[1][0]) < 1e-5
+    # hard labels take the same kernel on their one-hot form
+    preds, out = model({"video": video, "texts": texts})
+    hard = tgt.argmax(1)
+    lh, names, _ = losses.calculate_loss(cfg, preds, out, {"supervised": hard}, 0)
+    assert "cross_entropy" in names and abs(float(lh.detach()) - float(torch.nn.functional.cross_entropy(preds.detach(), hard))) < 1e-5
     assert grads[0][1].keys() == grads[1][1].keys() and len(grads[0][1]) > 100
     for n in grads[0][1]:
         a, b = grads[0][1][n].double(), grads[1][1][n].double()
