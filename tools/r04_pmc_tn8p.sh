@@ -17,7 +17,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   rm -rf gpurun_out/pmc_tn
   timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_tn -o p -- python3 tools/pmc_tn_shape.py $NI $K > gpurun_out/pmc_tn.log 2>&1
   tail -1 gpurun_out/pmc_tn.log >> $out
-  python3 tools/pmc_generic.py gpurun_out/pmc_tn tn8p >> $out 2>&1
+  python3 tools/pmc_generic.py gpurun_out/pmc_tn tn8 >> $out 2>&1
 done
 rm -rf gpurun_out/pmc_tn gpurun_out/kt_tn
 cat $out
