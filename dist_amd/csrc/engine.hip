@@ -157,6 +157,8 @@ struct dist_handle {
     long tn_partial_elems = 0;
     float* ig_gscratch = nullptr;              // [layers][(Ci + C4) * Ci + (Ci + C4)]: G' = dz^T xhat and db of the two folded Linears when dist_branch_backward ACCUMULATES (zero_grads = 0)
     long ig_gscratch_elems = 0;                // per layer
+    std::vector<int> sel;                      // DIST.SELECTED_LAYERS: ViT block of DiST layer i (dist_config.selected_mask)
+    int nsel = 0;                              // number of DiST layers
     int wgrad_blocks = 0;                      // dist_gemm_tn_args.max_blocks of the engine's weight gradients (0 = the library's default, 96; one block per CU for the last
                                                // layers of the pass - whose gradients finish behind the chain - was measured: 17.85 -> 17.90 ms, not kept)
     bool bwd_accumulate = false;               // the running dist_branch_backward was called with zero_grads = 0
@@ -357,9 +359,9 @@ void build_tables(dist_handle* h) {
     h->stem.w = add_param(h, 0, "dist_net.temporal_stem.weight", {Ct, 3, c.temporal_patch, P, P});
     h->stem.bias = add_param(h, 0, "dist_net.temporal_stem.bias", {Ct});
     add_pack(h, h->stem, 0, 3, false);
-    h->dl.resize(c.layers);
-    h->layer_begin.resize(c.layers); h->layer_end.resize(c.layers);
-    for (int i = 0; i < c.layers; ++i) {
+    h->dl.resize(h->nsel);
+    h->layer_begin.resize(h->nsel); h->layer_end.resize(h->nsel);
+    for (int i = 0; i < h->nsel; ++i) {
         DistLayer& l = h->dl[i];
         h->layer_begin[i] = h->total[0];
         l.in_lin = make_lin(h, 0, fmt("dist_net.input_linears.%d.", i), Ci, d, 1, 0, false, {Ci, d});
@@ -497,8 +499,8 @@ size_t layout_ws(dist_handle* h, char* base) {
         for (int i = 0; i < c.layers; ++i) h->slot[k].feat[i] = T_(rowsS, d);
     }
     h->patches = h->slot[h->cur].patches; h->feat = h->slot[h->cur].feat;
-    h->lw.resize(c.layers);
-    for (int i = 0; i < c.layers; ++i) {
+    h->lw.resize(h->nsel);
+    for (int i = 0; i < h->nsel; ++i) {
         DistLayerWs& w = h->lw[i];
         w.X = T_(rowsX, Ct); w.U = T_(rowsX, Ct); w.z = T_(rowsX, Ct); w.V = T_(rowsX, Ct); w.p = T_(rowsX, Ct); w.Xp = T_(rowsX, Ct);
         w.M = T_(rowsS, Ci); w.Mp = T_(rowsS, Ci); w.Na = T_(rowsS, Ci); w.Nb = T_(rowsS, Ci);
@@ -529,9 +531,9 @@ size_t layout_ws(dist_handle* h, char* base) {
     h->ln_partial_elems = dist_op_layernorm_bwd_scratch(rowsS > rowsX ? rowsS : rowsX, Ci > Ct ? Ci : Ct);
     h->ln_partial = F_(h->ln_partial_elems);
     h->tnb_scratch_elems = dist_op_temporal_net_bwd_scratch((int)b, c.frames, Ct);
-    h->tnb_scratch = F_(h->tnb_scratch_elems * c.layers);        // one partial table per layer
+    h->tnb_scratch = F_(h->tnb_scratch_elems * h->nsel);         // one partial table per DiST layer
     if (h->ig_on) {
-        for (int i = 0; i < c.layers; ++i) {
+        for (int i = 0; i < h->nsel; ++i) {
             DistLayer& l = h->dl[i];
             l.ig_W1 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 0) * 2); l.ig_W2 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 1) * 2);
             l.ig_W3 = a.take((size_t)dist_op_integration_pack_elems(Ci, C4, 2) * 2);
@@ -545,11 +547,11 @@ size_t layout_ws(dist_handle* h, char* base) {
             }
             l.ig_b1 = F_(dist_op_integration_pack_elems(Ci, C4, 3)); l.ig_b2 = F_(dist_op_integration_pack_elems(Ci, C4, 4)); l.ig_b3 = F_(dist_op_integration_pack_elems(Ci, C4, 5));
         }
-        h->ig_descs = a.take((size_t)dist_k_integ_pack_desc_bytes() * c.layers);
+        h->ig_descs = a.take((size_t)dist_k_integ_pack_desc_bytes() * h->nsel);
     }
     h->tn_partial_elems = 16l << 20;                         // 64 MB each: 256 partial tiles of 192 x 256 (the LDS-DMA weight-gradient kernel) + slack
     for (int k = 0; k < 3; ++k) h->tn_partial[k] = F_(h->tn_partial_elems);
-    if (h->ig_xhat) { h->ig_gscratch_elems = (long)(Ci + C4) * Ci + (Ci + C4); h->ig_gscratch = F_(h->ig_gscratch_elems * c.layers); }
+    if (h->ig_xhat) { h->ig_gscratch_elems = (long)(Ci + C4) * Ci + (Ci + C4); h->ig_gscratch = F_(h->ig_gscratch_elems * h->nsel); }
     for (int k = 0; k < 2; ++k) {
         dist_handle::BwdSet& q = h->bs[k];
         q.dMp = T_(rowsS, Ci); q.dM = T_(rowsS, Ci); q.dXp = T_(rowsX, Ct); q.dp = T_(rowsX, Ct); q.dXo = T_(rowsX, Ct);
@@ -790,12 +792,15 @@ extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
     if (c.int_temporal_div <= 0 || c.integration_dim % c.int_temporal_div || (c.integration_dim / c.int_temporal_div) % 8) return DIST_ERR_ARG;
     if (c.temporal_kernel % 2 == 0 || c.temporal_patch % 2 == 0 || c.num_classes <= 0 || c.embed_dim % 8 || c.embed_dim > 1024) return DIST_ERR_ARG;
     if (c.width > 1024 || c.integration_dim > 1024) return DIST_ERR_ARG;
+    if (c.layers > 32 || (c.layers < 32 && ((unsigned)c.selected_mask >> c.layers) != 0)) return DIST_ERR_ARG;      // SELECTED_LAYERS beyond the ViT's blocks
     // vit_fp8: bits 1 | 2 | 4 | 8 select GEMMs, 16 needs all four; bf16 engines only (a binding built against the 17-field struct of
     // ABI <= 6 hands over 4 bytes of garbage here: refuse instead of silently switching the frozen ViT to e4m3)
     if ((c.vit_fp8 & ~31) || (c.vit_fp8 && c.dtype != DIST_BF16) || ((c.vit_fp8 & 16) && (c.vit_fp8 & 15) != 15)) return DIST_ERR_ARG;
     dist_handle* h = new (std::nothrow) dist_handle();
     if (!h) return DIST_ERR_ARG;
     h->cfg = c;
+    for (int i = 0; i < c.layers; ++i) if (!c.selected_mask || ((unsigned)c.selected_mask >> i) & 1u) h->sel.push_back(i);
+    h->nsel = (int)h->sel.size();
     h->es = c.dtype == DIST_BF16 ? 2 : 4;
     h->G = c.resolution / c.patch; h->N = h->G * h->G; h->L = h->N + 1; h->t = c.frames / c.alpha;
     h->heads = c.width / 64; h->iheads = c.integration_dim / 64; h->C4 = c.integration_dim / c.int_temporal_div;
@@ -940,7 +945,7 @@ extern "C" int dist_pack_weights(dist_handle* h, int what, void* stream) {
     else if (what == 2) { first = h->nblk_visual; count = nblk - h->nblk_visual; }
     else if (what != 3) return fail(h, DIST_ERR_ARG, "dist_pack_weights: what must be 1, 2 or 3");
     RUN(dist_k_pack(descs, blk_desc, blk_first, first, count, h->theta, h->visual, dst, h->cfg.dtype, s));
-    if ((what & 2) && h->ig_on) RUN(dist_k_integ_pack(h->ig_descs, nullptr, h->cfg.layers, h->cfg.integration_dim, h->C4, s));
+    if ((what & 2) && h->ig_on) RUN(dist_k_integ_pack(h->ig_descs, nullptr, h->nsel, h->cfg.integration_dim, h->C4, s));
     // frozen ViT: ln_1 -> attn.in_proj and ln_2 -> mlp.c_fc folded (W diag(gamma), column sums, folded biases); DIST_AMD_LNFOLD=0: off
     static const bool fold_on = (dist_knob("DIST_AMD_LNFOLD", 1) != 0);
     // (only a pack of the frozen weights touches the fold: the per-step re-pack of the trainable weights, what = 2, used to reset
@@ -1154,8 +1159,8 @@ extern "C" int dist_features_import(dist_handle* h, const void* const* mid_feat,
     RUN(vit_args_ok(h, video, b, "dist_features_import"));
     if (!mid_feat || (src_dtype != DIST_F32 && src_dtype != DIST_BF16)) return fail(h, DIST_ERR_ARG, "dist_features_import: mid_feat / src_dtype");
     const dist_config& c = h->cfg;
-    for (int i = 0; i < c.layers; ++i)
-        if (!mid_feat[i]) return fail(h, DIST_ERR_ARG, "dist_features_import: mid_feat[%d] is NULL (every selected layer is needed)", i);
+    for (int i : h->sel)
+        if (!mid_feat[i]) return fail(h, DIST_ERR_ARG, "dist_features_import: mid_feat[%d] is NULL (every selected block is needed; the others may be NULL)", i);
     dist_handle::FeatSlot& S = h->slot[h->cur];
     hipStream_t s = static_cast<hipStream_t>(stream);
     S.prefetched = false;
@@ -1164,7 +1169,7 @@ extern "C" int dist_features_import(dist_handle* h, const void* const* mid_feat,
     RUN(dist_op_patchify(video, S.patches, b, c.frames, c.resolution, c.resolution, c.patch, c.dtype, stream));
     HIP_CHECK_RET(hipEventRecord(S.ev_feat[c.layers], s));
     for (int i = 0; i < c.layers; ++i) {
-        RUN(dist_k_import_feat(mid_feat[i], src_dtype, S.feat[i], c.dtype, b * h->t, h->L, c.width, s));
+        if (mid_feat[i]) RUN(dist_k_import_feat(mid_feat[i], src_dtype, S.feat[i], c.dtype, b * h->t, h->L, c.width, s));
         HIP_CHECK_RET(hipEventRecord(S.ev_feat[i], s));
     }
     S.next_layer = c.layers; S.pending_b = b; S.b = b;
@@ -1244,10 +1249,10 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
     Ctx x{h, S1, c.dtype};
     const int d = c.width, Ci = c.integration_dim, Ct = c.temporal_dim, C4 = h->C4, N = h->N, L = h->L, T = c.frames, t = h->t, al = c.alpha;
     const long rowsX = (long)b * T * N, rowsS = (long)b * t * L, rowsQ = (long)b * t * N, bt = (long)b * t;
-    const int nl = c.layers;
+    const int nl = h->nsel, nv = c.layers;       // DiST layers (one per SELECTED ViT block, dist.py:226) / ViT blocks
     stream = S1;
     HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_pre, 0));               // what preceded dist_vit_forward on the caller's stream
-    HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_feat[nl], 0));          // patch rows
+    HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_feat[nv], 0));          // patch rows
     const bool pref = h->slot[h->cur].prefetched && !(h->serial & 1);
     if (pref) {                                                         // the features come from another stream: the side streams
         HIP_CHECK_RET(hipEventRecord(h->ev_bpre, A));                   // must also follow the caller's stream (re-pack of the last step)
@@ -1260,7 +1265,7 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
     // not R_i, so it runs underneath IntegrationNetwork_i; the two chains meet at M_i (-> I2T) and X'_i (-> T2I).
     Ctx xt{h, S2, c.dtype};
     HIP_CHECK_RET(hipStreamWaitEvent(xt.s, h->ev_pre, 0));
-    HIP_CHECK_RET(hipStreamWaitEvent(xt.s, h->ev_feat[nl], 0));
+    HIP_CHECK_RET(hipStreamWaitEvent(xt.s, h->ev_feat[nv], 0));
     auto ev_xp = [&](int i) { return h->ev_a[i]; };
     auto ev_m = [&](int i) { return h->ev_a[nl + i]; };
 
@@ -1292,8 +1297,8 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
         }
         HIP_CHECK_RET(hipEventRecord(ev_xp(i), xt.s));
         // ---- integration chain: mid_feat = input_linear(F_i) + res_feat (dist.py:229)
-        HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_feat[i], 0));
-        RUN(gemm(x, h->feat[i], d, x.pk(l.in_lin.pk.f), rowsS, Ci, d, 1, w.M, Ci, x.th(l.in_lin.bias), i ? h->lw[i - 1].R : nullptr, nullptr, nullptr));
+        HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_feat[h->sel[i]], 0));
+        RUN(gemm(x, h->feat[h->sel[i]], d, x.pk(l.in_lin.pk.f), rowsS, Ci, d, 1, w.M, Ci, x.th(l.in_lin.bias), i ? h->lw[i - 1].R : nullptr, nullptr, nullptr));
         // I2T (dist.py:90-105,231): Linear on the non-cls rows, nearest-upsampled x alpha in T, + x_temporal - inside the fused IntegrationNetwork launch below
         // (behind its T2I stage), or as a GEMM on the temporal chain.  (the last layer's result is discarded by the reference, dist.py:235 -> skipped)
         const bool i2t_fused = h->ig_i2t && i + 1 < nl && !(h->skip & 8);
@@ -1383,7 +1388,7 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
         RUN(gemm(x, w.hu, 4 * Ci, x.pk(A.tm_proj.pk.f), b, Ci, 4 * Ci, 1, h->ubuf[a + 1], Ci, x.th(A.tm_proj.bias), w.u1, nullptr, nullptr));
     }
     // x_logits = ln_post(top_cls + proj_spatial_cls_token(mean_t vit_cls)); cls_x = x_logits @ proj (dist.py:242-246)
-    RUN(dist_k_mean_cls(h->feat[nl - 1], h->mean_cls, b, t, L, d, c.dtype, x.s));
+    RUN(dist_k_mean_cls(h->feat[h->sel[nl - 1]], h->mean_cls, b, t, L, d, c.dtype, x.s));
     RUN(gemm(x, h->mean_cls, d, x.pk(h->cls_proj.pk.f), b, Ci, d, 1, h->ysum, Ci, x.th(h->cls_proj.bias), h->ubuf[c.ada_layers], nullptr, nullptr));
     RUN(ln_fwd(x, h->theta, h->ln_post, h->ysum, h->zpost, b, h->y_mean, h->y_rstd));
     RUN(gemm(x, h->zpost, Ci, x.pk(h->proj.pk.f), b, c.embed_dim, Ci, 1, h->v, c.embed_dim, nullptr, nullptr, nullptr, nullptr));
@@ -1471,7 +1476,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
     Ctx x{h, static_cast<hipStream_t>(stream), c.dtype};
     const int d = c.width, Ci = c.integration_dim, Ct = c.temporal_dim, C4 = h->C4, N = h->N, L = h->L, T = c.frames, t = h->t, al = c.alpha;
     const long rowsX = (long)b * T * N, rowsS = (long)b * t * L, rowsQ = (long)b * t * N, bt = (long)b * t;
-    const int nl = c.layers, na = c.ada_layers;
+    const int nl = h->nsel, na = c.ada_layers;
     const size_t es = h->es;
 
     mark(h, DIST_MARK_BWD_BEGIN, x.s);
@@ -1659,7 +1664,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         RUN(fork());
         if (!last) RUN(wgrad(xb2, l.i2t, q.dY, Ct, w.M, Ci, rowsQ, RM(), RM(DIST_RM_SKIPCLS, N), 0, true));
         // ---- mid_feat = input_linear(F_i) + R_{i-1}: no dF_i (frozen ViT) ----
-        RUN(wgrad(xb, l.in_lin, dM, Ci, h->feat[i], d, rowsS, RM(), RM(), 0, true));
+        RUN(wgrad(xb, l.in_lin, dM, Ci, h->feat[h->sel[i]], d, rowsS, RM(), RM(), 0, true));
         // ---- TemporalNet backward (dist.py:63-65): X' = g(p), p = X + conv3x3(V) + b, V = g(z), z = conv_t(U), U = LN(X) ----
         // bf16: two fused launches (tnet.hip): dz = conv3x3^T(dp) * g'(z); dX = dp + LN'(conv_t^T(dz)) with the LayerNorm parameter
         // gradients as per-workgroup partial rows (no atomics); otherwise two row-mapped GEMMs + the LayerNorm backward kernel
@@ -1699,8 +1704,8 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
             RUN(dist_op_integration_unfold(&ua, B));
         }
         HIP_CHECK_RET(hipEventRecord(h->ev_b_done[i], B));
-        if (h->dummy & 2) for (int r = 0; r < h->dummy_reps; ++r) RUN(ln_fwd(x, h->visual, h->vit[0].ln1, h->feat[i], nullptr, rowsS, h->lnstats2, h->lnstats2 + rowsS));
-        if (h->dummy & 4) for (int r = 0; r < h->dummy_reps; ++r) RUN(ln_fwd(xb, h->visual, h->vit[0].ln1, h->feat[i], nullptr, rowsS, h->lnstats3, h->lnstats3 + rowsS));
+        if (h->dummy & 2) for (int r = 0; r < h->dummy_reps; ++r) RUN(ln_fwd(x, h->visual, h->vit[0].ln1, h->feat[h->sel[i]], nullptr, rowsS, h->lnstats2, h->lnstats2 + rowsS));
+        if (h->dummy & 4) for (int r = 0; r < h->dummy_reps; ++r) RUN(ln_fwd(xb, h->visual, h->vit[0].ln1, h->feat[h->sel[i]], nullptr, rowsS, h->lnstats3, h->lnstats3 + rowsS));
         if (!(h->skip & 2) && tn_fused) {
             dist_tnet_bwd_args ta;
             memset(&ta, 0, sizeof(ta));
@@ -1802,15 +1807,16 @@ extern "C" int dist_debug_tensor(dist_handle* h, const char* name, const void** 
     const char* dot = strchr(name, '.');
     if (dot) i = atoi(dot + 1);
     const std::string key(name, dot ? (size_t)(dot - name) : strlen(name));
-    auto layer_ok = [&]() { return i >= 0 && i < c.layers; };
-    if (key == "feat" && layer_ok()) { *ptr = h->feat[i]; *rows = rowsS; *cols = c.width; return DIST_OK; }
+    auto vit_ok = [&]() { return i >= 0 && i < c.layers; };            // "feat.i": ViT block i; every other name: DiST layer i (< number of selected blocks)
+    auto layer_ok = [&]() { return i >= 0 && i < h->nsel; };
+    if (key == "feat" && vit_ok()) { *ptr = h->feat[i]; *rows = rowsS; *cols = c.width; return DIST_OK; }
     if (key == "stem") { *ptr = h->lw[0].X; *rows = rowsX; *cols = c.temporal_dim; return DIST_OK; }
     if (key == "tn_out" && layer_ok()) { *ptr = h->lw[i].Xp; *rows = rowsX; *cols = c.temporal_dim; return DIST_OK; }
     if (key == "int_out" && layer_ok()) { *ptr = h->lw[i].R; *rows = rowsS; *cols = c.integration_dim; return DIST_OK; }
-    if (key == "x_temporal" && layer_ok()) { *ptr = (i + 1 < c.layers) ? h->lw[i + 1].X : h->Xlast; *rows = rowsX; *cols = c.temporal_dim; return DIST_OK; }
+    if (key == "x_temporal" && layer_ok()) { *ptr = (i + 1 < h->nsel) ? h->lw[i + 1].X : h->Xlast; *rows = rowsX; *cols = c.temporal_dim; return DIST_OK; }
     if (key == "mid" && layer_ok()) {
         // with T2I formed inside the fused forward and the fused backward reading xhat, M' is only written for the last layer (DIST_AMD_KEEP_MID=1 keeps all)
-        if (h->ig_t2i && h->ig_bwd && !h->keep_mid && i != c.layers - 1)
+        if (h->ig_t2i && h->ig_bwd && !h->keep_mid && i != h->nsel - 1)
             return fail(h, DIST_ERR_STATE, "mid.%d is not materialised by the fused IntegrationNetwork kernels (set DIST_AMD_KEEP_MID=1)", i);
         if (h->branch_infer || h->inference) return fail(h, DIST_ERR_STATE, "mid.%d is not written in inference mode", i);
         *ptr = h->lw[i].Mp; *rows = rowsS; *cols = c.integration_dim; return DIST_OK;

@@ -28,6 +28,8 @@ def config_from_geometry(g, batch, dtype, use_tr=True, vit_fp8=0):
     c.ada_layers, c.num_classes, c.embed_dim = g.ada, g.K, g.E
     c.use_tr = int(use_tr)
     c.vit_fp8 = int(vit_fp8)
+    sel = tuple(getattr(g, "selected", None) or range(g.layers))           # DIST.SELECTED_LAYERS -> bit mask (0 = every block)
+    c.selected_mask = 0 if sel == tuple(range(g.layers)) else sum(1 << i for i in sel)
     return c
 
 
@@ -37,6 +39,8 @@ class Engine:
             raise L.DistError("dist_amd.Engine needs a GPU: the HIP library is the only implementation")
         self.lib = L.load()
         self.cfg = cfg
+        # DIST.SELECTED_LAYERS: the ViT blocks whose outputs feed the branch (DiST layer k reads block selected[k])
+        self.selected = [i for i in range(cfg.layers) if (not cfg.selected_mask) or (cfg.selected_mask >> i) & 1]
         self.device = torch.device(device)
         self.dtype = torch.bfloat16 if cfg.dtype == L.BF16 else torch.float32
         h = C.c_void_p()
@@ -153,8 +157,14 @@ class Engine:
         DiSTNetwork.forward reads from input['mid_feat']['img'] / input['images'] (dist.py:222-247)."""
         assert video.dtype == torch.float32 and video.is_contiguous() and video.is_cuda
         nl = self.cfg.layers
-        if len(mid_feat) != nl:
-            raise L.DistError(f"import_features needs {nl} layer tensors, got {len(mid_feat)}")
+        sel = self.selected
+        if isinstance(mid_feat, dict):                      # {ViT block: tensor} as the reference's input['mid_feat']['img']
+            missing = [i for i in sel if i not in mid_feat]
+            if missing:
+                raise L.DistError(f"import_features: no tensor for the selected blocks {missing}")
+            mid_feat = [mid_feat[i] for i in sel]
+        if len(mid_feat) != len(sel):
+            raise L.DistError(f"import_features needs one tensor per selected block ({len(sel)}), got {len(mid_feat)}")
         dt = mid_feat[0].dtype
         if dt not in (torch.float32, torch.bfloat16):
             raise L.DistError(f"mid_feat dtype {dt}: float32 or bfloat16")
@@ -165,7 +175,9 @@ class Engine:
             if tuple(m.shape) != (Lt, b * t_, self.cfg.width) or m.dtype != dt or not m.is_cuda:
                 raise L.DistError(f"mid_feat[{i}]: expected a CUDA {dt} tensor of shape {(Lt, b * t_, self.cfg.width)}, got {m.dtype} {tuple(m.shape)}")
             keep.append(m.contiguous())
-        ptrs = (C.c_void_p * nl)(*[C.c_void_p(m.data_ptr()) for m in keep])
+        ptrs = (C.c_void_p * nl)()                           # indexed by ViT block; NULL for blocks that are not selected
+        for blk, m in zip(sel, keep):
+            ptrs[blk] = m.data_ptr()
         self.b = b
         L.check(self.lib.dist_features_import(self.h, ptrs, L.F32 if dt == torch.float32 else L.BF16, video.data_ptr(), b, ops._stream()), self.h)
         self._cur_video, self._cur_ver = None, -1          # the slot no longer holds the pass of a known clip tensor

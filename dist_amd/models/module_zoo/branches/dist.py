@@ -14,9 +14,10 @@ from ...base.clip import DiSTParams
 
 def engine_config(cfg, width, layers, patch, resolution, embed_dim, batch, dtype):
     d = cfg.VIDEO.BACKBONE.DIST
-    sel = list(d.SELECTED_LAYERS)
-    if sel != list(range(layers)):      # (a restriction the reference does not have - dist.py:170-190 takes any subset; every released yaml selects all: INTEGRATION.md A)
-        raise L.DistError(f"SELECTED_LAYERS must be 0..{layers - 1} (every DiST yaml selects all layers), got {sel}")
+    sel = [int(i) for i in d.SELECTED_LAYERS]
+    # any subset of the ViT's blocks in increasing order (reference dist.py:170-190, 226: one DiST layer per selected block; every released yaml selects all)
+    if not sel or sel != sorted(set(sel)) or sel[0] < 0 or sel[-1] >= layers or layers > 32:
+        raise L.DistError(f"SELECTED_LAYERS must be an increasing list of blocks in [0, {layers}), got {sel}")
     if int(d.S_PATCH_SIZE) != int(patch):
         raise L.DistError(f"DIST.S_PATCH_SIZE {d.S_PATCH_SIZE} must equal the ViT patch {patch} "
                           "(the L/14 yamls of the reference carry 16, which fails there as well: SURVEY.md §0)")
@@ -34,6 +35,7 @@ def engine_config(cfg, width, layers, patch, resolution, embed_dim, batch, dtype
     # BASELINE config 5 (fp8 frozen spatial branch): VIDEO.BACKBONE.FP8_SPATIAL = bit mask of the frozen-ViT GEMMs on e4m3 operands
     # (15 = all four; absent / 0 = bf16).  Not a key of the reference's yamls: pass it as a trailing KEY VAL override.
     c.vit_fp8 = int(getattr(cfg.VIDEO.BACKBONE, "FP8_SPATIAL", 0) or 0) if dtype == torch.bfloat16 else 0
+    c.selected_mask = 0 if sel == list(range(layers)) else sum(1 << i for i in sel)
     return c
 
 
@@ -86,7 +88,7 @@ class DiSTNetwork(DiSTParams):
             if img.dim() == 4:                               # [b*T,3,H,W] as the reference backbone passes it
                 bt, c, h, w = img.shape
                 img = img.view(bt // self.num_frames, self.num_frames, c, h, w).permute(0, 2, 1, 3, 4)
-            eng.import_features([mid[i] for i in self.selected_layers], img.contiguous().float())
+            eng.import_features({int(i): mid[i] for i in self.selected_layers}, img.contiguous().float())
         tf = input["text_features"].float().contiguous()
         logits, vid = eng.branch_forward(tf)
         input["logits_per_image"] = logits

@@ -63,6 +63,9 @@ class Geometry(dict):
         g["heads"] = g.d // 64
         g["C4"] = int(g.Ci * g.int_t_ratio)
         g["iheads"] = g.Ci // 64
+        # VIDEO.BACKBONE.DIST.SELECTED_LAYERS (reference dist.py:170-190, 226): the ViT blocks whose outputs feed the branch, one DiST layer each
+        g["selected"] = tuple(g.get("selected") or range(g.layers))
+        g["nsel"] = len(g["selected"])
         return g
 
 
@@ -74,6 +77,9 @@ def geometry(name):
     elif name == "tiny3":
         # odd grid (3x3 patches -> L=10): ragged rows for every tile shape
         g = Geometry(base, name="tiny3", d=128, layers=3, patch=16, res=48, Ci=128, Ct=32, T=4, K=7, E=64)
+    elif name == "tiny3_sel":
+        # a real SUBSET of the ViT blocks: blocks 0 and 2 of three feed two DiST layers (every released yaml selects all; the reference takes any)
+        g = Geometry(base, name="tiny3_sel", d=128, layers=3, patch=16, res=48, Ci=128, Ct=32, T=4, K=7, E=64, selected=(0, 2))
     elif name == "b16_8+16f":
         g = Geometry(base, name="b16_8+16f", d=768, layers=12, patch=16, res=224, Ci=384, Ct=96, T=16, K=174, E=512)
     elif name == "b16_16+32f":
@@ -94,7 +100,7 @@ def dist_net_shapes(g):
     Ct, Ci, d, t, C4 = g.Ct, g.Ci, g.d, g.t, g.C4
     s["dist_net.temporal_stem.weight"] = (Ct, 3, g.tpatch, g.patch, g.patch)
     s["dist_net.temporal_stem.bias"] = (Ct,)
-    for i in range(g.layers):
+    for i in range(len(g.selected)):
         s[f"dist_net.input_linears.{i}.weight"] = (Ci, d)
         s[f"dist_net.input_linears.{i}.bias"] = (Ci,)
         s[f"dist_net.integration2temporal_nets.{i}.linear_fuse.weight"] = (Ct, Ci)

@@ -401,7 +401,7 @@ typedef struct dist_config {
     int resolution;       /* frame H = W */
     int patch;            /* ViT patch = DIST.S_PATCH_SIZE */
     int width;            /* ViT width d */
-    int layers;           /* ViT layers = len(DIST.SELECTED_LAYERS) */
+    int layers;           /* ViT layers (<= 32) */
     int integration_dim;  /* DIST.INTEGRATION_DIM */
     int temporal_dim;     /* DIST.TEMPORAL_DIM */
     int temporal_kernel;  /* DIST.TEMPORAL_KERNEL_SIZE */
@@ -418,6 +418,9 @@ typedef struct dist_config {
                            * power-of-two scales from the previous pass's maxima; the first pass after a pack calibrates with the per-token
                            * quantisers) - the hidden tensor of the MLP, the q | k | v tensor and the attention output then exist as e4m3
                            * only */
+    int selected_mask;    /* ABI 9: DIST.SELECTED_LAYERS as a bit mask - bit i set = the output of ViT block i feeds one DiST layer (reference dist.py:170-190, 226:
+                           * `for idx, layer_id in enumerate(self.selected_layers)`); 0 = every block (what all released yamls select).  The dist_net.* tables then
+                           * hold popcount(mask) layers, numbered 0.. in block order; the frozen ViT always runs all `layers` blocks. */
 } dist_config;
 
 typedef struct dist_handle dist_handle;
@@ -470,7 +473,7 @@ int dist_vit_prefetch_layers(dist_handle* h, const float* video, int b, int laye
 int dist_vit_adopt(dist_handle* h);
 /* The CALLER's frozen-ViT features instead of a dist_vit_forward pass - what the reference's DiSTNetwork.forward consumes
  * (models/module_zoo/branches/dist.py:222-247: input['mid_feat']['img'][layer_id] and input['images']): mid_feat[i], i < layers, is the device
- * pointer of block i's output in the reference's layout [L][b*t][width] (sequence first, clip.py:282-300; src_dtype DIST_F32 or DIST_BF16), video the
+ * pointer of ViT block i's output (NULL allowed for a block that is not in dist_config.selected_mask) in the reference's layout [L][b*t][width] (sequence first, clip.py:282-300; src_dtype DIST_F32 or DIST_BF16), video the
  * frames [b][3][T][H][W] fp32 (the temporal stem's input).  Copied into the current feature slot (converted, token-major); dist_branch_forward(b)
  * follows as after dist_vit_forward. */
 int dist_features_import(dist_handle* h, const void* const* mid_feat, int src_dtype, const float* video, int b, void* stream);

@@ -63,7 +63,7 @@ class Oracle:
         self.vit_fp8 = vit_fp8 if bf16 else 0
         self.fused = bool(fused and bf16)
         self.p = {k: torch.as_tensor(v).to(dtype) for k, v in params.items()}
-        self.selected = list(range(g.layers))
+        self.selected = list(getattr(g, "selected", None) or range(g.layers))       # DIST.SELECTED_LAYERS (reference dist.py:170-190,226)
 
     # ---- rounding points ---------------------------------------------------------------
     def rnd(self, x):

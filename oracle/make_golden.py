@@ -10,7 +10,7 @@ writes ONLY outputs (logits, loss, gradients, intermediate activations or their
 checksums) to tests/golden/*.npz.  No reference source is copied; the inputs are
 regenerated from dist_amd/synth.py wherever the fixtures are consumed.
 
-    python oracle/make_golden.py [name ...]   # writes tests/golden/{tiny,tiny3,b16_b2,l14_t8,b16_t32_b1,l14_t64_b1}.npz
+    python oracle/make_golden.py [name ...]   # writes tests/golden/{tiny,tiny3,tiny3_sel,b16_b2,l14_t8,b16_t32_b1,l14_t64_b1}.npz
 """
 import os
 import sys
@@ -76,7 +76,7 @@ def make_cfg(g):
                         DIST=NS(INTEGRATION_DIM=g.Ci, TEMPORAL_DIM=g.Ct, TEMPORAL_KERNEL_SIZE=g.tk,
                                 TEMPORAL_CONV_MLP_RATIO=1, INTEGRATION_MLP_RATIO=1,
                                 INTEGRATION_TEMPORAL_MLP_RATIO=g.int_t_ratio, ADA_POOLING_LAYERS=g.ada,
-                                SELECTED_LAYERS=list(range(g.layers)), S_PATCH_SIZE=g.patch,
+                                SELECTED_LAYERS=list(g.selected), S_PATCH_SIZE=g.patch,
                                 T_PATCH_SIZE=g.tpatch)),
             HEAD=NS(NUM_CLASSES=g.K)),
     )
@@ -139,9 +139,10 @@ def run(gname, b, full, dtype=torch.float32, with_steps=False):
             inter[name] = out[0] if isinstance(out, tuple) else out
         return f
     hs = []
-    for i in range(g.layers):
+    for i in range(g.nsel):                      # one DiST layer per SELECTED ViT block (dist.py:170-190)
         hs.append(model.dist_net.temporal_nets[i].register_forward_hook(hook(f"tn_out.{i}")))
         hs.append(model.dist_net.integration_nets[i].register_forward_hook(hook(f"int_out.{i}")))
+    for i in range(g.layers):
         hs.append(model.visual.transformer.resblocks[i].register_forward_hook(hook(f"feat.{i}")))
     hs.append(model.dist_net.temporal_stem.register_forward_hook(hook("stem")))
 
@@ -214,6 +215,8 @@ def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     jobs = [("tiny", "tiny", 2, True, True), ("tiny3", "tiny3", 3, False, False),
+            # SELECTED_LAYERS = [0, 2] of three ViT blocks (round 4): the reference takes any subset (dist.py:170-190); full tensors
+            ("tiny3_sel", "tiny3_sel", 3, True, False),
             ("b16_b2", "b16_8+16f", 2, False, False), ("l14_t8", "l14_tiny_t", 1, False, False),
             # BASELINE configs 3 and 4 / 5 at their real frame counts (T = 32, T = 64), one clip: the temporal branch at the sizes the bench
             # configurations run (round 3; the full-batch GPU tests compare rows of a b = 32 / 8 / 16 run with these through batch invariance)

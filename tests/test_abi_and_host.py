@@ -66,6 +66,16 @@ def test_integration_md_stub_matches_the_library():
     cfg.vit_fp8 = 31
     cfg.dtype = 0                                      # fp8 spatial branch on an fp32 engine
     assert l.dist_create(pcfg, ctypes.byref(h)) == -1
+    # DIST.SELECTED_LAYERS as a bit mask: a subset gives that many DiST layers in the parameter table; a block beyond the ViT is refused
+    cfg.vit_fp8, cfg.dtype = 0, 1
+    cfg.selected_mask = 0b101000000101                 # blocks 0, 2, 9, 11 of 12
+    assert l.dist_create(pcfg, ctypes.byref(h)) == 0
+    names = [l.dist_param_name(h, 0, i).decode() for i in range(l.dist_param_count(h, 0))]
+    assert sum(n.startswith("dist_net.input_linears.") and n.endswith(".weight") for n in names) == 4
+    assert "dist_net.integration_nets.3.ln.weight" in names and "dist_net.integration_nets.4.ln.weight" not in names
+    l.dist_destroy(h)
+    cfg.selected_mask = 1 << 12
+    assert l.dist_create(pcfg, ctypes.byref(h)) == -1
 
 
 def test_engine_tables_without_gpu():

@@ -263,7 +263,7 @@ def test_train_loop_loss_is_the_engines_dist_loss(gpu_lib):
         else:
             loss = losses.SoftTargetCrossEntropy()(preds, tgt)                 # the torch expression
         loss.backward()
-        grads.append((float(loss), {n: p.grad.clone() for n, p in pd.items() if p.grad is not None}))
+        grads.append((float(loss.detach()), {n: p.grad.clone() for n, p in pd.items() if p.grad is not None}))
     assert abs(grads[0][0] - grads[1][0]) < 1e-5
     # hard labels take the same kernel on their one-hot form
     preds, out = model({"video": video, "texts": texts})

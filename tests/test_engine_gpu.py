@@ -67,7 +67,7 @@ def test_param_tables_match_reference_names(gpu_lib):
     assert e2.theta.numel() == 19001184
 
 
-@pytest.mark.parametrize("gname,b", [("tiny", 2), ("tiny3", 3)])
+@pytest.mark.parametrize("gname,b", [("tiny", 2), ("tiny3", 3), ("tiny3_sel", 3)])
 def test_fp32_forward_backward_vs_reference_golden(gpu_lib, gname, b):
     g, eng, sd, video, text, tgt = build(gname, b, torch.float32)
     loss, logits = eng.forward_backward(video, text, tgt)
@@ -90,7 +90,7 @@ def test_fp32_forward_backward_vs_reference_golden(gpu_lib, gname, b):
             bad.append((n, err))
     assert not bad, bad[:10]
     # tensors that must NOT receive a gradient (last layer's I2T, SURVEY.md §2.2 B*)
-    last = g.layers - 1
+    last = g.nsel - 1                                   # (DiST layers: one per selected ViT block)
     assert float(eng.view(f"dist_net.integration2temporal_nets.{last}.linear_fuse.weight", grad=True).abs().max()) == 0.0
 
 
@@ -386,3 +386,34 @@ def test_backward_accumulates_with_the_layernorm_fold(gpu_lib):
         if err > worst[1]:
             worst = (n, err)
     assert worst[1] < 1e-4, worst          # (fp32 sums in another order; the defect was a factor gamma on two weights and wrong LayerNorm gradients)
+
+
+def test_selected_layers_subset_intermediates_and_import(gpu_lib):
+    """DIST.SELECTED_LAYERS = [0, 2] (dist_config.selected_mask = 0b101; reference dist.py:170-190, 226): DiST layer k reads ViT block selected[k].
+    Every intermediate against the reference's own tensors (tests/golden/tiny3_sel.npz), the parameter table holds two DiST layers, and
+    dist_features_import takes the two selected blocks only."""
+    g, eng, sd, video, text, tgt = build("tiny3_sel", 3, torch.float32)
+    assert eng.selected == [0, 2] and eng.cfg.selected_mask == 5
+    assert not any(".2." in n and ("temporal_nets" in n or "integration_nets" in n or "input_linears" in n) for n in eng.tables[0])
+    eng.vit_forward(video)
+    logits, vid = eng.branch_forward(text)
+    gold = np.load(os.path.join(GOLD, "tiny3_sel.npz"))
+    torch.testing.assert_close(logits.cpu().double(), torch.from_numpy(gold["logits"]).double(), rtol=1e-3, atol=1e-4)
+    for k in gold.files:
+        if k.startswith("act."):
+            got = eng.debug(k[4:]).cpu().double()
+            assert rel_err(got, torch.from_numpy(gold[k]).double().reshape(got.shape)) < 1e-4, k
+    # the caller's features for the selected blocks only, in the reference's [L, b*t, C] layout
+    bt, L_ = 3 * g.t, g.N + 1
+    mid = {i: eng.debug(f"feat.{i}").view(bt, L_, g.d).permute(1, 0, 2).contiguous().float().clone() for i in (0, 2)}
+    other = torch.from_numpy(__import__("dist_amd.synth", fromlist=["x"]).video(g, 3, seed=9)).cuda()
+    eng.vit_forward(other)                                             # the slot now holds another clip
+    eng.import_features(mid, video)
+    logits2, _ = eng.branch_forward(text)
+    torch.testing.assert_close(logits2, logits, rtol=0, atol=0)
+    with pytest.raises(Exception):
+        eng.import_features({0: mid[0]}, video)                        # block 2 missing
+    # bf16 engine of the same geometry: runs, finite, close
+    g2, e2, _, v2, t2, y2 = build("tiny3_sel", 3, torch.bfloat16)
+    loss, lg = e2.forward_backward(v2, t2, y2)
+    assert torch.isfinite(lg).all() and float((lg.cpu().double() - torch.from_numpy(gold["logits"]).double()).abs().max()) < 0.15
