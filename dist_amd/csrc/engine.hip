@@ -159,6 +159,7 @@ struct dist_handle {
     long ig_gscratch_elems = 0;                // per layer
     std::vector<int> sel;                      // DIST.SELECTED_LAYERS: ViT block of DiST layer i (dist_config.selected_mask)
     int nsel = 0;                              // number of DiST layers
+    int Ch = 0, Cf = 0;                        // hidden widths: TemporalNet (Ct * TEMPORAL_CONV_MLP_RATIO), IntegrationNetwork.ffn (Ci * INTEGRATION_MLP_RATIO)
     int wgrad_blocks = 0;                      // dist_gemm_tn_args.max_blocks of the engine's weight gradients (0 = the library's default, 96; one block per CU for the last
                                                // layers of the pass - whose gradients finish behind the chain - was measured: 17.85 -> 17.90 ms, not kept)
     bool bwd_accumulate = false;               // the running dist_branch_backward was called with zero_grads = 0
@@ -248,7 +249,7 @@ long add_param(dist_handle* h, int kind, const std::string& name, std::initializ
 void set_fused_flags(dist_handle* h) {
     const dist_config& c = h->cfg;
     const int Ci = c.integration_dim, Ct = c.temporal_dim, C4 = h->C4;
-    h->ig_on = dist_k_integ_eligible(c.dtype, Ci, C4, h->t, c.temporal_kernel) && (dist_knob("DIST_AMD_INTEG_FUSED", 1) != 0);
+    h->ig_on = dist_k_integ_eligible(c.dtype, Ci, C4, h->t, c.temporal_kernel) && h->Cf == Ci && (dist_knob("DIST_AMD_INTEG_FUSED", 1) != 0);
     h->ig_xhat = h->ig_on && (dist_knob("DIST_AMD_INTEG_XHAT", 1) != 0);
     h->ig_bwd = h->ig_xhat && (dist_knob("DIST_AMD_INTEG_BWD_FUSED", 1) != 0);
     // T2I (dist.py:68-86) formed in front of the fused forward instead of a GEMM + a cls-row kernel + a round trip of M' (alpha = 2, temporal width = C4)
@@ -326,7 +327,7 @@ XAttn make_xattn(dist_handle* h, const std::string& prefix, int C) {
 
 void build_tables(dist_handle* h) {
     const dist_config& c = h->cfg;
-    const int d = c.width, Ci = c.integration_dim, Ct = c.temporal_dim, P = c.patch, C4 = h->C4, t = h->t;
+    const int d = c.width, Ci = c.integration_dim, Ct = c.temporal_dim, P = c.patch, C4 = h->C4, t = h->t, Ch = h->Ch, Cf = h->Cf;
     // ---- frozen visual.* (kind 1), OpenAI-CLIP names (reference clip.py:218-247) ----
     h->conv1.N = d; h->conv1.K = h->Kp; h->conv1.taps = 1;
     h->conv1.w = add_param(h, 1, "visual.conv1.weight", {d, 3, P, P});
@@ -372,23 +373,23 @@ void build_tables(dist_handle* h) {
         l.t2i.bias = add_param(h, 0, fmt("dist_net.temporal2integration_nets.%d.linear_fuse.bias", i), {Ci});
         add_pack(h, l.t2i, 0, 2, true, !h->ig_t2i);
         std::string p = fmt("dist_net.temporal_nets.%d.", i);
-        l.tn_fc1 = make_lin(h, 0, p + "temporal_net.c_fc1.", Ct, Ct, c.temporal_kernel, 1, true, {Ct, Ct, c.temporal_kernel, 1, 1});
-        l.tn_fc2 = make_lin(h, 0, p + "temporal_net.c_fc2.", Ct, Ct, 9, 1, true, {Ct, Ct, 1, 3, 3});
+        l.tn_fc1 = make_lin(h, 0, p + "temporal_net.c_fc1.", Ch, Ct, c.temporal_kernel, 1, true, {Ch, Ct, c.temporal_kernel, 1, 1});
+        l.tn_fc2 = make_lin(h, 0, p + "temporal_net.c_fc2.", Ct, Ch, 9, 1, true, {Ct, Ch, 1, 3, 3});
         l.tn_ln = make_ln(h, 0, p + "ln.", Ct);
         p = fmt("dist_net.integration_nets.%d.", i);
         // ffn.c_fc and temporal_ffn.c_fc1 read the same (normalised) rows: their weights, and their biases, sit side by side in the flat buffers so that ONE
         // weight-gradient GEMM over [dzf | dh1] writes both gradients as a [Ci + C4][Ci] matrix (fused IntegrationNetwork backward)
-        l.ffn_fc.N = Ci; l.ffn_fc.K = Ci; l.ffn_fc.taps = 1;
+        l.ffn_fc.N = Cf; l.ffn_fc.K = Ci; l.ffn_fc.taps = 1;
         l.tf_fc1.N = C4; l.tf_fc1.K = Ci; l.tf_fc1.taps = 1;
-        l.ffn_fc.w = add_param(h, 0, p + "ffn.c_fc.weight", {Ci, Ci});
+        l.ffn_fc.w = add_param(h, 0, p + "ffn.c_fc.weight", {Cf, Ci});
         l.tf_fc1.w = add_param(h, 0, p + "temporal_ffn.c_fc1.weight", {C4, Ci, 1, 1, 1});
-        l.ffn_fc.bias = add_param(h, 0, p + "ffn.c_fc.bias", {Ci});
+        l.ffn_fc.bias = add_param(h, 0, p + "ffn.c_fc.bias", {Cf});
         l.tf_fc1.bias = add_param(h, 0, p + "temporal_ffn.c_fc1.bias", {C4});
         add_pack(h, l.ffn_fc, 0, 0, !h->ig_bwd, !h->ig_on);
         add_pack(h, l.tf_fc1, 0, 0, !h->ig_bwd, !h->ig_on);
         // (ffn.c_proj / temporal_ffn.c_proj are only ever multiplied as the side-by-side pair packed below: no copies of their own)
-        l.ffn_proj.N = Ci; l.ffn_proj.K = Ci; l.ffn_proj.taps = 1;
-        l.ffn_proj.w = add_param(h, 0, p + "ffn.c_proj.weight", {Ci, Ci}); l.ffn_proj.bias = add_param(h, 0, p + "ffn.c_proj.bias", {Ci});
+        l.ffn_proj.N = Ci; l.ffn_proj.K = Cf; l.ffn_proj.taps = 1;
+        l.ffn_proj.w = add_param(h, 0, p + "ffn.c_proj.weight", {Ci, Cf}); l.ffn_proj.bias = add_param(h, 0, p + "ffn.c_proj.bias", {Ci});
         l.tf_fc2.N = C4; l.tf_fc2.K = C4; l.tf_fc2.taps = c.temporal_kernel;
         l.tf_fc2.w = add_param(h, 0, p + "temporal_ffn.c_fc2.weight", {C4, C4, c.temporal_kernel, 1, 1}); l.tf_fc2.bias = add_param(h, 0, p + "temporal_ffn.c_fc2.bias", {C4});
         add_pack(h, l.tf_fc2, 0, 1, !h->ig_bwd, !h->ig_on);
@@ -396,7 +397,7 @@ void build_tables(dist_handle* h) {
         l.tf_proj.w = add_param(h, 0, p + "temporal_ffn.c_proj.weight", {Ci, C4, 1, 1, 1}); l.tf_proj.bias = add_param(h, 0, p + "temporal_ffn.c_proj.bias", {Ci});
         {   // R = [gelu(zf) | gelu(h2)] [W_ffn | W_tf]^T: the two projections are ONE GEMM over activations stored side by side
             // (forward), one data-gradient GEMM and one weight-gradient GEMM (backward)
-            const int Cc = Ci + C4;
+            const int Cc = Cf + C4;
             PackDesc d;
             auto desc_of = [&](const Lin& lin, int layout) {
                 memset(&d, 0, sizeof(d));
@@ -407,12 +408,12 @@ void build_tables(dist_handle* h) {
             if (!h->ig_on) {
                 l.pk_proj_f = pk_alloc(h, (long)Ci * Cc);
                 desc_of(l.ffn_proj, PACK_F); d.dst_off = l.pk_proj_f; d.dpitch = Cc; h->descs.push_back(d);
-                desc_of(l.tf_proj, PACK_F); d.dst_off = l.pk_proj_f + Ci; d.dpitch = Cc; h->descs.push_back(d);
+                desc_of(l.tf_proj, PACK_F); d.dst_off = l.pk_proj_f + Cf; d.dpitch = Cc; h->descs.push_back(d);
             }
             if (!h->ig_bwd) {
                 l.pk_proj_b = pk_alloc(h, (long)Cc * Ci);
                 desc_of(l.ffn_proj, PACK_FT); d.dst_off = l.pk_proj_b; h->descs.push_back(d);
-                desc_of(l.tf_proj, PACK_FT); d.dst_off = l.pk_proj_b + (long)Ci * Ci; h->descs.push_back(d);
+                desc_of(l.tf_proj, PACK_FT); d.dst_off = l.pk_proj_b + (long)Cf * Ci; h->descs.push_back(d);
             }
         }
         l.in_ln = make_ln(h, 0, p + "ln.", Ci);
@@ -470,7 +471,7 @@ size_t layout_ws(dist_handle* h, char* base) {
     const size_t es = h->es;
     const long b = c.batch;
     const long rowsX = b * c.frames * h->N, rowsS = b * h->t * h->L, rowsQ = b * h->t * h->N, bt = b * h->t;
-    const int d = c.width, Ci = c.integration_dim, Ct = c.temporal_dim, C4 = h->C4, H = h->iheads;
+    const int d = c.width, Ci = c.integration_dim, Ct = c.temporal_dim, C4 = h->C4, H = h->iheads, Ch = h->Ch, Cf = h->Cf;
     auto T_ = [&](long rows, long cols) { return a.take((size_t)rows * cols * es); };
     auto F_ = [&](long n) { return static_cast<float*>(a.take((size_t)n * sizeof(float))); };
     for (int k = 0; k < 2; ++k) h->slot[k].patches = T_(rowsX, h->Kp);
@@ -502,12 +503,12 @@ size_t layout_ws(dist_handle* h, char* base) {
     h->lw.resize(h->nsel);
     for (int i = 0; i < h->nsel; ++i) {
         DistLayerWs& w = h->lw[i];
-        w.X = T_(rowsX, Ct); w.U = T_(rowsX, Ct); w.z = T_(rowsX, Ct); w.V = T_(rowsX, Ct); w.p = T_(rowsX, Ct); w.Xp = T_(rowsX, Ct);
+        w.X = T_(rowsX, Ct); w.U = T_(rowsX, Ct); w.z = T_(rowsX, Ch); w.V = T_(rowsX, Ch); w.p = T_(rowsX, Ct); w.Xp = T_(rowsX, Ct);
         w.M = T_(rowsS, Ci); w.Mp = T_(rowsS, Ci); w.Na = T_(rowsS, Ci); w.Nb = T_(rowsS, Ci);
         // [zf | h2] and [hf | g2] = their activations live side by side in rows of Ci + C4 elements (see pk_proj_f)
-        w.zf = T_(rowsS, Ci + C4); w.hf = T_(rowsS, Ci + C4);
-        w.h2 = w.zf ? static_cast<char*>(w.zf) + (size_t)Ci * es : nullptr;
-        w.g2 = w.hf ? static_cast<char*>(w.hf) + (size_t)Ci * es : nullptr;
+        w.zf = T_(rowsS, Cf + C4); w.hf = T_(rowsS, Cf + C4);
+        w.h2 = w.zf ? static_cast<char*>(w.zf) + (size_t)Cf * es : nullptr;
+        w.g2 = w.hf ? static_cast<char*>(w.hf) + (size_t)Cf * es : nullptr;
         w.h1 = T_(rowsS, C4); w.R = T_(rowsS, Ci);
         w.tn_mean = F_(rowsX); w.tn_rstd = F_(rowsX); w.in_mean = F_(rowsS); w.in_rstd = F_(rowsS);
     }
@@ -555,9 +556,9 @@ size_t layout_ws(dist_handle* h, char* base) {
     for (int k = 0; k < 2; ++k) {
         dist_handle::BwdSet& q = h->bs[k];
         q.dMp = T_(rowsS, Ci); q.dM = T_(rowsS, Ci); q.dXp = T_(rowsX, Ct); q.dp = T_(rowsX, Ct); q.dXo = T_(rowsX, Ct);
-        q.dz = T_(rowsX, Ct); q.dU = T_(rowsX, Ct); q.dY = T_(rowsQ, Ct); q.dh1 = T_(rowsS, C4);
-        q.dzf = T_(rowsS, Ci + C4);                      // [dzf | dh2], same side-by-side rows
-        q.dh2 = q.dzf ? static_cast<char*>(q.dzf) + (size_t)Ci * es : nullptr;
+        q.dz = T_(rowsX, Ch); q.dU = T_(rowsX, Ct); q.dY = T_(rowsQ, Ct); q.dh1 = T_(rowsS, C4);
+        q.dzf = T_(rowsS, Cf + C4);                      // [dzf | dh2], same side-by-side rows
+        q.dh2 = q.dzf ? static_cast<char*>(q.dzf) + (size_t)Cf * es : nullptr;
         q.dNa = T_(rowsS, Ci); q.dNb = T_(rowsS, Ci);
         q.dcat = T_(rowsS, Ci + 2 * C4);
     }
@@ -792,6 +793,7 @@ extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
     if (c.int_temporal_div <= 0 || c.integration_dim % c.int_temporal_div || (c.integration_dim / c.int_temporal_div) % 8) return DIST_ERR_ARG;
     if (c.temporal_kernel % 2 == 0 || c.temporal_patch % 2 == 0 || c.num_classes <= 0 || c.embed_dim % 8 || c.embed_dim > 1024) return DIST_ERR_ARG;
     if (c.width > 1024 || c.integration_dim > 1024) return DIST_ERR_ARG;
+    if (c.temporal_hidden < 0 || c.temporal_hidden % 8 || c.temporal_hidden > 1024 || c.integration_hidden < 0 || c.integration_hidden % 8 || c.integration_hidden > 4096) return DIST_ERR_ARG;
     if (c.layers > 32 || (c.layers < 32 && ((unsigned)c.selected_mask >> c.layers) != 0)) return DIST_ERR_ARG;      // SELECTED_LAYERS beyond the ViT's blocks
     // vit_fp8: bits 1 | 2 | 4 | 8 select GEMMs, 16 needs all four; bf16 engines only (a binding built against the 17-field struct of
     // ABI <= 6 hands over 4 bytes of garbage here: refuse instead of silently switching the frozen ViT to e4m3)
@@ -801,6 +803,8 @@ extern "C" int dist_create(const dist_config* cfg, dist_handle** out) {
     h->cfg = c;
     for (int i = 0; i < c.layers; ++i) if (!c.selected_mask || ((unsigned)c.selected_mask >> i) & 1u) h->sel.push_back(i);
     h->nsel = (int)h->sel.size();
+    h->Ch = c.temporal_hidden > 0 ? c.temporal_hidden : c.temporal_dim;
+    h->Cf = c.integration_hidden > 0 ? c.integration_hidden : c.integration_dim;
     h->es = c.dtype == DIST_BF16 ? 2 : 4;
     h->G = c.resolution / c.patch; h->N = h->G * h->G; h->L = h->N + 1; h->t = c.frames / c.alpha;
     h->heads = c.width / 64; h->iheads = c.integration_dim / 64; h->C4 = c.integration_dim / c.int_temporal_div;
@@ -1249,6 +1253,7 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
     Ctx x{h, S1, c.dtype};
     const int d = c.width, Ci = c.integration_dim, Ct = c.temporal_dim, C4 = h->C4, N = h->N, L = h->L, T = c.frames, t = h->t, al = c.alpha;
     const long rowsX = (long)b * T * N, rowsS = (long)b * t * L, rowsQ = (long)b * t * N, bt = (long)b * t;
+    const int Ch = h->Ch, Cf = h->Cf;             // hidden widths (== Ct / Ci for MLP ratio 1)
     const int nl = h->nsel, nv = c.layers;       // DiST layers (one per SELECTED ViT block, dist.py:226) / ViT blocks
     stream = S1;
     HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_pre, 0));               // what preceded dist_vit_forward on the caller's stream
@@ -1279,7 +1284,7 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
         void* Xnext = (i + 1 < nl) ? h->lw[i + 1].X : h->Xlast;
         // ---- temporal chain: TemporalNet (dist.py:48-65): one fused launch (tnet.hip) where the geometry allows, else LayerNorm + two GEMMs
         if (h->skip & 4) {
-        } else if (dist_k_tnet_fwd_eligible(c.dtype, Ct, h->G, l.tn_fc1.taps)) {
+        } else if (Ch == Ct && dist_k_tnet_fwd_eligible(c.dtype, Ct, h->G, l.tn_fc1.taps)) {
             dist_tnet_args ta;
             memset(&ta, 0, sizeof(ta));
             ta.X = w.X; ta.W1 = x.pk(l.tn_fc1.pk.f); ta.W2 = x.pk(l.tn_fc2.pk.f);
@@ -1291,9 +1296,9 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
             RUN(dist_op_temporal_net_fwd(&ta, xt.s));
         } else {
             RUN(ln_fwd(xt, h->theta, l.tn_ln, w.X, w.U, rowsX, w.tn_mean, w.tn_rstd));
-            RUN(gemm(xt, w.U, Ct, x.pk(l.tn_fc1.pk.f), rowsX, Ct, Ct, l.tn_fc1.taps, w.z, Ct, x.th(l.tn_fc1.bias), nullptr, nullptr, w.V,
+            RUN(gemm(xt, w.U, Ct, x.pk(l.tn_fc1.pk.f), rowsX, Ch, Ct, l.tn_fc1.taps, w.z, Ch, x.th(l.tn_fc1.bias), nullptr, nullptr, w.V,
                      RM(DIST_RM_SHIFT, T * N, N, 1)));
-            RUN(gemm(xt, w.V, Ct, x.pk(l.tn_fc2.pk.f), rowsX, Ct, Ct, 9, w.p, Ct, x.th(l.tn_fc2.bias), w.X, nullptr, w.Xp, RM(DIST_RM_SPATIAL, h->G, 0, 1)));
+            RUN(gemm(xt, w.V, Ch, x.pk(l.tn_fc2.pk.f), rowsX, Ct, Ch, 9, w.p, Ct, x.th(l.tn_fc2.bias), w.X, nullptr, w.Xp, RM(DIST_RM_SPATIAL, h->G, 0, 1)));
         }
         HIP_CHECK_RET(hipEventRecord(ev_xp(i), xt.s));
         // ---- integration chain: mid_feat = input_linear(F_i) + res_feat (dist.py:229)
@@ -1347,12 +1352,12 @@ extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, i
         RUN(ln_fwd(x, h->theta, l.in_ln, w.Mp, w.Na, rowsS, w.in_mean, w.in_rstd, &l.in_ln_t, w.Nb));
         if (!(h->skip & 8)) {
         // (inference: the pre-activations zf / h2 are what backward needs - only the activated tensors are written)
-        RUN(gemm(x, w.Na, Ci, x.pk(l.ffn_fc.pk.f), rowsS, Ci, Ci, 1, h->inference ? nullptr : w.zf, Ci + C4, x.th(l.ffn_fc.bias), nullptr, nullptr, w.hf));
+        RUN(gemm(x, w.Na, Ci, x.pk(l.ffn_fc.pk.f), rowsS, Cf, Ci, 1, h->inference ? nullptr : w.zf, Cf + C4, x.th(l.ffn_fc.bias), nullptr, nullptr, w.hf));
         RUN(gemm(x, w.Nb, Ci, x.pk(l.tf_fc1.pk.f), rowsS, C4, Ci, 1, w.h1, C4, x.th(l.tf_fc1.bias), nullptr, nullptr, nullptr));
-        RUN(gemm(x, w.h1, C4, x.pk(l.tf_fc2.pk.f), rowsS, C4, C4, l.tf_fc2.taps, h->inference ? nullptr : w.h2, Ci + C4, x.th(l.tf_fc2.bias), nullptr, nullptr, w.g2,
+        RUN(gemm(x, w.h1, C4, x.pk(l.tf_fc2.pk.f), rowsS, C4, C4, l.tf_fc2.taps, h->inference ? nullptr : w.h2, Cf + C4, x.th(l.tf_fc2.bias), nullptr, nullptr, w.g2,
                  RM(DIST_RM_SHIFT, t * L, L, 1)));
         // R = ffn.c_proj(hf) + temporal_ffn.c_proj(g2): one GEMM over [hf | g2] (K = Ci + C4) with the two weights side by side
-        RUN(gemm(x, w.hf, Ci + C4, x.pk(l.pk_proj_f), rowsS, Ci, Ci + C4, 1, w.R, Ci, x.th(l.ffn_proj.bias), nullptr, nullptr, nullptr,
+        RUN(gemm(x, w.hf, Cf + C4, x.pk(l.pk_proj_f), rowsS, Ci, Cf + C4, 1, w.R, Ci, x.th(l.ffn_proj.bias), nullptr, nullptr, nullptr,
                  RM(), OM(), 0, x.th(l.tf_proj.bias)));
         }
         }
@@ -1476,7 +1481,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
     Ctx x{h, static_cast<hipStream_t>(stream), c.dtype};
     const int d = c.width, Ci = c.integration_dim, Ct = c.temporal_dim, C4 = h->C4, N = h->N, L = h->L, T = c.frames, t = h->t, al = c.alpha;
     const long rowsX = (long)b * T * N, rowsS = (long)b * t * L, rowsQ = (long)b * t * N, bt = (long)b * t;
-    const int nl = h->nsel, na = c.ada_layers;
+    const int nl = h->nsel, na = c.ada_layers, Ch = h->Ch, Cf = h->Cf;
     const size_t es = h->es;
 
     mark(h, DIST_MARK_BWD_BEGIN, x.s);
@@ -1578,7 +1583,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
 
         // ---- IntegrationNetwork backward (dist.py:40-45) ----
         // B: dW/db of ffn.c_proj and temporal_ffn.c_proj read dR (produced before this layer started)
-        const int Cc = Ci + C4;            // [zf | h2], [hf | g2], [dzf | dh2] rows
+        const int Cc = Cf + C4;            // [zf | h2], [hf | g2], [dzf | dh2] rows
         RUN(wgrad_pair(xb, l.ffn_proj, l.tf_proj, dR, Ci, w.hf, Cc, rowsS));
         RUN(merge_b2());
         HIP_CHECK_RET(hipEventRecord(h->ev_b_dr[i], B));
@@ -1668,7 +1673,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
         // ---- TemporalNet backward (dist.py:63-65): X' = g(p), p = X + conv3x3(V) + b, V = g(z), z = conv_t(U), U = LN(X) ----
         // bf16: two fused launches (tnet.hip): dz = conv3x3^T(dp) * g'(z); dX = dp + LN'(conv_t^T(dz)) with the LayerNorm parameter
         // gradients as per-workgroup partial rows (no atomics); otherwise two row-mapped GEMMs + the LayerNorm backward kernel
-        const bool tn_fused = dist_k_tnet_fwd_eligible(c.dtype, Ct, h->G, l.tn_fc1.taps) &&
+        const bool tn_fused = Ch == Ct && dist_k_tnet_fwd_eligible(c.dtype, Ct, h->G, l.tn_fc1.taps) &&
                               (dist_knob("DIST_AMD_TNET_BWD_FUSED", 1) != 0);   // measurement knob
         if (h->skip & 2) {
         } else if (tn_fused) {
@@ -1682,12 +1687,12 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
             ta.phase = 1;                                              // dz first: the weight-gradient streams start on it
             RUN(dist_op_temporal_net_bwd(&ta, xt.s));
         } else {
-            RUN(gemm(xt, q.dp, Ct, x.pk(l.tn_fc2.pk.b), rowsX, Ct, Ct, 9, q.dz, Ct, nullptr, nullptr, w.z, nullptr, RM(DIST_RM_SPATIAL, h->G, 0, -1)));
+            RUN(gemm(xt, q.dp, Ct, x.pk(l.tn_fc2.pk.b), rowsX, Ch, Ct, 9, q.dz, Ch, nullptr, nullptr, w.z, nullptr, RM(DIST_RM_SPATIAL, h->G, 0, -1)));
         }
         RUN(fork());
         RUN(fork_t());
-        RUN(wgrad(xb, l.tn_fc2, q.dp, Ct, w.V, Ct, rowsX, RM(), RM(DIST_RM_SPATIAL, h->G, 0, 1), 1, true));
-        RUN(wgrad(xb2, l.tn_fc1, q.dz, Ct, w.U, Ct, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 1, true));
+        RUN(wgrad(xb, l.tn_fc2, q.dp, Ct, w.V, Ch, rowsX, RM(), RM(DIST_RM_SPATIAL, h->G, 0, 1), 1, true));
+        RUN(wgrad(xb2, l.tn_fc1, q.dz, Ch, w.U, Ct, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 1, true));
         RUN(merge_b2());
         if (h->ig_xhat && !(h->skip & 1)) {   // the weight gradients of ffn.c_fc / temporal_ffn.c_fc1 were taken against xhat: unfold them (+ the two LayerNorms' gradients)
             dist_integ_unfold_args ua;
@@ -1722,7 +1727,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
             RUN(dist_op_temporal_net_bwd(&ta, xt.s));
         }
         if (!(h->skip & 2) && !tn_fused) {
-            RUN(gemm(xt, q.dz, Ct, x.pk(l.tn_fc1.pk.b), rowsX, Ct, Ct, l.tn_fc1.taps, q.dU, Ct, nullptr, nullptr, nullptr, nullptr,
+            RUN(gemm(xt, q.dz, Ch, x.pk(l.tn_fc1.pk.b), rowsX, Ct, Ch, l.tn_fc1.taps, q.dU, Ct, nullptr, nullptr, nullptr, nullptr,
                      RM(DIST_RM_SHIFT, T * N, N, -1)));
             RUN(ln_bwd(xt, l.tn_ln, w.X, w.tn_mean, w.tn_rstd, q.dU, q.dXo, false, rowsX, nullptr, nullptr, q.dp));   // dX_i = dp + LN'(dU)
         }

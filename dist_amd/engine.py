@@ -28,6 +28,8 @@ def config_from_geometry(g, batch, dtype, use_tr=True, vit_fp8=0):
     c.ada_layers, c.num_classes, c.embed_dim = g.ada, g.K, g.E
     c.use_tr = int(use_tr)
     c.vit_fp8 = int(vit_fp8)
+    c.temporal_hidden = 0 if getattr(g, "Ch", g.Ct) == g.Ct else int(g.Ch)          # DIST.TEMPORAL_CONV_MLP_RATIO / INTEGRATION_MLP_RATIO: 0 = ratio 1
+    c.integration_hidden = 0 if getattr(g, "Cf", g.Ci) == g.Ci else int(g.Cf)
     sel = tuple(getattr(g, "selected", None) or range(g.layers))           # DIST.SELECTED_LAYERS -> bit mask (0 = every block)
     c.selected_mask = 0 if sel == tuple(range(g.layers)) else sum(1 << i for i in sel)
     return c

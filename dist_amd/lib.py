@@ -102,7 +102,7 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "dtype", "batch", "frames", "alpha", "resolution", "patch", "width", "layers",
         "integration_dim", "temporal_dim", "temporal_kernel", "temporal_patch", "int_temporal_div",
-        "ada_layers", "num_classes", "embed_dim", "use_tr", "vit_fp8", "selected_mask")]
+        "ada_layers", "num_classes", "embed_dim", "use_tr", "vit_fp8", "temporal_hidden", "integration_hidden", "selected_mask")]
 
 
 GRAD_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)

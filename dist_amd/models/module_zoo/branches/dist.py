@@ -21,8 +21,10 @@ def engine_config(cfg, width, layers, patch, resolution, embed_dim, batch, dtype
     if int(d.S_PATCH_SIZE) != int(patch):
         raise L.DistError(f"DIST.S_PATCH_SIZE {d.S_PATCH_SIZE} must equal the ViT patch {patch} "
                           "(the L/14 yamls of the reference carry 16, which fails there as well: SURVEY.md §0)")
-    if float(d.TEMPORAL_CONV_MLP_RATIO) != 1 or float(d.INTEGRATION_MLP_RATIO) != 1:
-        raise L.DistError("TEMPORAL_CONV_MLP_RATIO and INTEGRATION_MLP_RATIO must be 1 (all DiST yamls)")
+    # hidden widths as the reference computes them (dist.py:20-25, 51-58: int(dim * ratio)); ratio 1 (every released yaml) runs the fused kernels
+    ch, cf = int(int(d.TEMPORAL_DIM) * float(d.TEMPORAL_CONV_MLP_RATIO)), int(int(d.INTEGRATION_DIM) * float(d.INTEGRATION_MLP_RATIO))
+    if ch <= 0 or ch % 8 or cf <= 0 or cf % 8:
+        raise L.DistError(f"TEMPORAL_CONV_MLP_RATIO / INTEGRATION_MLP_RATIO give hidden widths {ch} / {cf}: multiples of 8 are needed")
     c = L.Config()
     c.dtype = L.BF16 if dtype == torch.bfloat16 else L.F32
     c.batch, c.frames, c.alpha = batch, int(cfg.DATA.NUM_INPUT_FRAMES), int(cfg.DATA.SPARSE_SAMPLE_ALPHA)
@@ -35,6 +37,8 @@ def engine_config(cfg, width, layers, patch, resolution, embed_dim, batch, dtype
     # BASELINE config 5 (fp8 frozen spatial branch): VIDEO.BACKBONE.FP8_SPATIAL = bit mask of the frozen-ViT GEMMs on e4m3 operands
     # (15 = all four; absent / 0 = bf16).  Not a key of the reference's yamls: pass it as a trailing KEY VAL override.
     c.vit_fp8 = int(getattr(cfg.VIDEO.BACKBONE, "FP8_SPATIAL", 0) or 0) if dtype == torch.bfloat16 else 0
+    c.temporal_hidden = 0 if ch == int(d.TEMPORAL_DIM) else ch
+    c.integration_hidden = 0 if cf == int(d.INTEGRATION_DIM) else cf
     c.selected_mask = 0 if sel == list(range(layers)) else sum(1 << i for i in sel)
     return c
 

@@ -62,6 +62,9 @@ class Geometry(dict):
         g["t"] = g.T // g.alpha
         g["heads"] = g.d // 64
         g["C4"] = int(g.Ci * g.int_t_ratio)
+        # hidden widths of TemporalNet / IntegrationNetwork.ffn: DIST.TEMPORAL_CONV_MLP_RATIO, DIST.INTEGRATION_MLP_RATIO (1 in every released yaml)
+        g["tn_ratio"] = g.get("tn_ratio", 1); g["ffn_ratio"] = g.get("ffn_ratio", 1)
+        g["Ch"] = int(g.Ct * g["tn_ratio"]); g["Cf"] = int(g.Ci * g["ffn_ratio"])
         g["iheads"] = g.Ci // 64
         # VIDEO.BACKBONE.DIST.SELECTED_LAYERS (reference dist.py:170-190, 226): the ViT blocks whose outputs feed the branch, one DiST layer each
         g["selected"] = tuple(g.get("selected") or range(g.layers))
@@ -80,6 +83,9 @@ def geometry(name):
     elif name == "tiny3_sel":
         # a real SUBSET of the ViT blocks: blocks 0 and 2 of three feed two DiST layers (every released yaml selects all; the reference takes any)
         g = Geometry(base, name="tiny3_sel", d=128, layers=3, patch=16, res=48, Ci=128, Ct=32, T=4, K=7, E=64, selected=(0, 2))
+    elif name == "tiny_ratio":
+        # MLP ratios other than 1 (TEMPORAL_CONV_MLP_RATIO 2, INTEGRATION_MLP_RATIO 0.5): the reference takes any (dist.py:20-25, 51-58)
+        g = Geometry(base, name="tiny_ratio", d=128, layers=2, patch=16, res=48, Ci=128, Ct=32, T=4, K=7, E=64, tn_ratio=2, ffn_ratio=0.5)
     elif name == "b16_8+16f":
         g = Geometry(base, name="b16_8+16f", d=768, layers=12, patch=16, res=224, Ci=384, Ct=96, T=16, K=174, E=512)
     elif name == "b16_16+32f":
@@ -97,7 +103,7 @@ def geometry(name):
 def dist_net_shapes(g):
     """Every dist_net.* tensor (reference models/module_zoo/branches/dist.py:165-202)."""
     s = {}
-    Ct, Ci, d, t, C4 = g.Ct, g.Ci, g.d, g.t, g.C4
+    Ct, Ci, d, t, C4, Ch, Cf = g.Ct, g.Ci, g.d, g.t, g.C4, g.Ch, g.Cf
     s["dist_net.temporal_stem.weight"] = (Ct, 3, g.tpatch, g.patch, g.patch)
     s["dist_net.temporal_stem.bias"] = (Ct,)
     for i in range(len(g.selected)):
@@ -109,16 +115,16 @@ def dist_net_shapes(g):
         s[f"dist_net.temporal2integration_nets.{i}.linear_fuse.weight"] = (Ci, Ct, g.alpha, 1, 1)
         s[f"dist_net.temporal2integration_nets.{i}.linear_fuse.bias"] = (Ci,)
         p = f"dist_net.temporal_nets.{i}."
-        s[p + "temporal_net.c_fc1.weight"] = (Ct, Ct, g.tk, 1, 1)
-        s[p + "temporal_net.c_fc1.bias"] = (Ct,)
-        s[p + "temporal_net.c_fc2.weight"] = (Ct, Ct, 1, 3, 3)
+        s[p + "temporal_net.c_fc1.weight"] = (Ch, Ct, g.tk, 1, 1)
+        s[p + "temporal_net.c_fc1.bias"] = (Ch,)
+        s[p + "temporal_net.c_fc2.weight"] = (Ct, Ch, 1, 3, 3)
         s[p + "temporal_net.c_fc2.bias"] = (Ct,)
         s[p + "ln.weight"] = (Ct,)
         s[p + "ln.bias"] = (Ct,)
         p = f"dist_net.integration_nets.{i}."
-        s[p + "ffn.c_fc.weight"] = (Ci, Ci)
-        s[p + "ffn.c_fc.bias"] = (Ci,)
-        s[p + "ffn.c_proj.weight"] = (Ci, Ci)
+        s[p + "ffn.c_fc.weight"] = (Cf, Ci)
+        s[p + "ffn.c_fc.bias"] = (Cf,)
+        s[p + "ffn.c_proj.weight"] = (Ci, Cf)
         s[p + "ffn.c_proj.bias"] = (Ci,)
         s[p + "temporal_ffn.c_fc1.weight"] = (C4, Ci, 1, 1, 1)
         s[p + "temporal_ffn.c_fc1.bias"] = (C4,)

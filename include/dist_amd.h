@@ -418,6 +418,9 @@ typedef struct dist_config {
                            * power-of-two scales from the previous pass's maxima; the first pass after a pack calibrates with the per-token
                            * quantisers) - the hidden tensor of the MLP, the q | k | v tensor and the attention output then exist as e4m3
                            * only */
+    int temporal_hidden;  /* ABI 9: hidden width of a TemporalNet = int(TEMPORAL_DIM * DIST.TEMPORAL_CONV_MLP_RATIO) (dist.py:51-58); 0 = TEMPORAL_DIM (ratio 1: every released yaml) */
+    int integration_hidden; /* ABI 9: hidden width of IntegrationNetwork.ffn = int(INTEGRATION_DIM * DIST.INTEGRATION_MLP_RATIO) (dist.py:20-25); 0 = INTEGRATION_DIM.  Other widths than the
+                           * default run the unfused kernel sequence (the fused TemporalNet / IntegrationNetwork kernels are built for ratio 1). */
     int selected_mask;    /* ABI 9: DIST.SELECTED_LAYERS as a bit mask - bit i set = the output of ViT block i feeds one DiST layer (reference dist.py:170-190, 226:
                            * `for idx, layer_id in enumerate(self.selected_layers)`); 0 = every block (what all released yamls select).  The dist_net.* tables then
                            * hold popcount(mask) layers, numbered 0.. in block order; the frozen ViT always runs all `layers` blocks. */

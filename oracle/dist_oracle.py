@@ -221,7 +221,7 @@ class Oracle:
         U = self.rnd(layer_norm(X, p[pre + "ln.weight"], p[pre + "ln.bias"]))
         keep[f"tn_U.{i}"] = U
         W1 = self.w(pre + "temporal_net.c_fc1.weight")               # [Co,Ct,tk,1,1]
-        z = p[pre + "temporal_net.c_fc1.bias"].expand_as(U)
+        z = p[pre + "temporal_net.c_fc1.bias"].expand(*U.shape[:-1], W1.shape[0])     # hidden width = Ct * TEMPORAL_CONV_MLP_RATIO (dist.py:54)
         for dt in range(g.tk):
             z = z + self.shift_t(U, dt - g.tk // 2) @ W1[:, :, dt, 0, 0].t()
         zr = self.rnd(z)
@@ -229,9 +229,9 @@ class Oracle:
         V = self.rnd(qgelu(z))
         keep[f"tn_V.{i}"] = V
         W2 = self.w(pre + "temporal_net.c_fc2.weight")               # [Ct,Co,1,3,3]
-        Vg = V.reshape(b, g.T, g.grid, g.grid, g.Ct)
+        Vg = V.reshape(b, g.T, g.grid, g.grid, V.shape[-1])
         Vp = F.pad(Vg, (0, 0, 1, 1, 1, 1))
-        acc = p[pre + "temporal_net.c_fc2.bias"].expand_as(Vg)
+        acc = p[pre + "temporal_net.c_fc2.bias"].expand(b, g.T, g.grid, g.grid, g.Ct)
         for dy in range(3):
             for dx in range(3):
                 acc = acc + Vp[:, :, dy:dy + g.grid, dx:dx + g.grid] @ W2[:, :, 0, dy, dx].t()

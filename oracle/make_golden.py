@@ -74,7 +74,7 @@ def make_cfg(g):
             BACKBONE=NS(FREEZE_TEXT=True, FREEZE_VISUAL=True, RECORD_VIS_MID_FEAT=True,
                         ATTEN_BLOCK="ResidualAttentionBlockMid", META_ARCH_NAME="ViT-B-16",
                         DIST=NS(INTEGRATION_DIM=g.Ci, TEMPORAL_DIM=g.Ct, TEMPORAL_KERNEL_SIZE=g.tk,
-                                TEMPORAL_CONV_MLP_RATIO=1, INTEGRATION_MLP_RATIO=1,
+                                TEMPORAL_CONV_MLP_RATIO=g.tn_ratio, INTEGRATION_MLP_RATIO=g.ffn_ratio,
                                 INTEGRATION_TEMPORAL_MLP_RATIO=g.int_t_ratio, ADA_POOLING_LAYERS=g.ada,
                                 SELECTED_LAYERS=list(g.selected), S_PATCH_SIZE=g.patch,
                                 T_PATCH_SIZE=g.tpatch)),
@@ -217,6 +217,8 @@ def main():
     jobs = [("tiny", "tiny", 2, True, True), ("tiny3", "tiny3", 3, False, False),
             # SELECTED_LAYERS = [0, 2] of three ViT blocks (round 4): the reference takes any subset (dist.py:170-190); full tensors
             ("tiny3_sel", "tiny3_sel", 3, True, False),
+            # TEMPORAL_CONV_MLP_RATIO = 2, INTEGRATION_MLP_RATIO = 0.5 (round 4): hidden widths other than the released yamls' (dist.py:20-25, 51-58)
+            ("tiny_ratio", "tiny_ratio", 2, True, False),
             ("b16_b2", "b16_8+16f", 2, False, False), ("l14_t8", "l14_tiny_t", 1, False, False),
             # BASELINE configs 3 and 4 / 5 at their real frame counts (T = 32, T = 64), one clip: the temporal branch at the sizes the bench
             # configurations run (round 3; the full-batch GPU tests compare rows of a b = 32 / 8 / 16 run with these through batch invariance)

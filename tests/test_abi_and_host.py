@@ -76,6 +76,15 @@ def test_integration_md_stub_matches_the_library():
     l.dist_destroy(h)
     cfg.selected_mask = 1 << 12
     assert l.dist_create(pcfg, ctypes.byref(h)) == -1
+    # MLP ratios as hidden widths: the parameter table follows them; widths that are no multiple of 8 are refused
+    cfg.selected_mask, cfg.temporal_hidden, cfg.integration_hidden = 0, 192, 768
+    assert l.dist_create(pcfg, ctypes.byref(h)) == 0
+    dims = {l.dist_param_name(h, 0, i).decode(): tuple(l.dist_param_dim(h, 0, i, d) for d in range(l.dist_param_ndim(h, 0, i))) for i in range(l.dist_param_count(h, 0))}
+    assert dims["dist_net.temporal_nets.0.temporal_net.c_fc1.weight"] == (192, 96, 3, 1, 1) and dims["dist_net.temporal_nets.0.temporal_net.c_fc2.weight"] == (96, 192, 1, 3, 3)
+    assert dims["dist_net.integration_nets.0.ffn.c_fc.weight"] == (768, 384) and dims["dist_net.integration_nets.0.ffn.c_proj.weight"] == (384, 768)
+    l.dist_destroy(h)
+    cfg.temporal_hidden = 100
+    assert l.dist_create(pcfg, ctypes.byref(h)) == -1
 
 
 def test_engine_tables_without_gpu():

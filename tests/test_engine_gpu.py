@@ -67,7 +67,7 @@ def test_param_tables_match_reference_names(gpu_lib):
     assert e2.theta.numel() == 19001184
 
 
-@pytest.mark.parametrize("gname,b", [("tiny", 2), ("tiny3", 3), ("tiny3_sel", 3)])
+@pytest.mark.parametrize("gname,b", [("tiny", 2), ("tiny3", 3), ("tiny3_sel", 3), ("tiny_ratio", 2)])
 def test_fp32_forward_backward_vs_reference_golden(gpu_lib, gname, b):
     g, eng, sd, video, text, tgt = build(gname, b, torch.float32)
     loss, logits = eng.forward_backward(video, text, tgt)
@@ -417,3 +417,27 @@ def test_selected_layers_subset_intermediates_and_import(gpu_lib):
     g2, e2, _, v2, t2, y2 = build("tiny3_sel", 3, torch.bfloat16)
     loss, lg = e2.forward_backward(v2, t2, y2)
     assert torch.isfinite(lg).all() and float((lg.cpu().double() - torch.from_numpy(gold["logits"]).double()).abs().max()) < 0.15
+
+
+def test_mlp_ratios_intermediates_and_bf16(gpu_lib):
+    """DIST.TEMPORAL_CONV_MLP_RATIO = 2 / INTEGRATION_MLP_RATIO = 0.5 (dist_config.temporal_hidden / integration_hidden; reference dist.py:20-25, 51-58):
+    every intermediate of the fp32 engine against the reference's own tensors (tests/golden/tiny_ratio.npz); the bf16 engine of the geometry runs the
+    unfused kernel sequence and stays within bf16 distance."""
+    g, eng, sd, video, text, tgt = build("tiny_ratio", 2, torch.float32)
+    assert eng.cfg.temporal_hidden == 64 and eng.cfg.integration_hidden == 64
+    assert tuple(eng.tables[0]["dist_net.temporal_nets.0.temporal_net.c_fc1.weight"][1]) == (64, 32, 3, 1, 1)
+    assert tuple(eng.tables[0]["dist_net.integration_nets.1.ffn.c_proj.weight"][1]) == (128, 64)
+    eng.vit_forward(video)
+    logits, _ = eng.branch_forward(text)
+    gold = np.load(os.path.join(GOLD, "tiny_ratio.npz"))
+    torch.testing.assert_close(logits.cpu().double(), torch.from_numpy(gold["logits"]).double(), rtol=1e-3, atol=1e-4)
+    for k in gold.files:
+        if k.startswith("act."):
+            got = eng.debug(k[4:]).cpu().double()
+            assert rel_err(got, torch.from_numpy(gold[k]).double().reshape(got.shape)) < 1e-4, k
+    g2, e2, _, v2, t2, y2 = build("tiny_ratio", 2, torch.bfloat16)
+    loss, lg = e2.forward_backward(v2, t2, y2)
+    assert torch.isfinite(lg).all() and float((lg.cpu().double() - torch.from_numpy(gold["logits"]).double()).abs().max()) < 0.15
+    ref = oracle_run(g2, sd, 2, bf16=True)
+    worst = max(rel_err(e2.view(n, grad=True), gr) for n, gr in ref["grads"].items() if gr.abs().max() >= 1e-6)
+    assert worst < 0.06, worst
