@@ -103,3 +103,50 @@ def test_strict_load_of_a_dist_net_only_checkpoint(gpu_lib, tmp_path):
         cu.load_checkpoint(p3, model, None, strict=True)
     cu.load_checkpoint(p3, model, None, strict=False)                  # non-strict like the reference: reported, not raised
     assert "dist_net.no_such_tensor" in cu.load_checkpoint.last_mismatch[1]
+
+
+def _module_from_state_dict(sd):
+    """nested nn.Modules whose state_dict() is exactly `sd` (parameter names with dots become sub-modules), scriptable"""
+    class Node(torch.nn.Module):
+        def forward(self):
+            return 0
+    root = Node()
+    for name, t in sd.items():
+        mod = root
+        parts = name.split(".")
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, Node())
+            mod = getattr(mod, p)
+        mod.register_parameter(parts[-1], torch.nn.Parameter(t.clone(), requires_grad=False))
+    return root
+
+
+@pytest.mark.gpu
+def test_openai_clip_torchscript_file_loads(gpu_lib, tmp_path):
+    """The published CLIP weights are TorchScript archives (`ViT-B-16.pt`): the reference reads them with torch.jit.load(...).state_dict()
+    (clip.py:624-627).  No such file exists in this environment, so one is WRITTEN here - a scripted module whose state-dict is a procedural
+    CLIP state-dict (visual tower + text tower) - and `clip.load(cfg)` must build the model from it: shape inference, every frozen tensor in place."""
+    from dist_amd import synth
+    from dist_amd.models.base import clip as C
+    from tests.test_dropin_gpu import tiny_cfg
+    g = synth.geometry("tiny")
+    sd = {k: torch.from_numpy(v.copy()) for k, v in synth.state_dict(g).items() if not k.startswith("dist_net.")}
+    sd.update({k: torch.from_numpy(v.copy()) for k, v in synth.text_tower_state_dict(embed=g.E).items()})
+    sd["logit_scale"] = sd["logit_scale"].reshape(())
+    path = os.path.join(str(tmp_path), "ViT-tiny.pt")
+    torch.jit.save(torch.jit.script(_module_from_state_dict(sd)), path)
+    assert set(torch.jit.load(path, map_location="cpu").state_dict()) == set(sd)
+    cfg = tiny_cfg("TRAIN.FP32_PARITY", "true", "TRAIN.BATCH_SIZE", "2", "VIDEO.BACKBONE.PRETRAIN_WEIGHT_PATH", path, "VIDEO.BACKBONE.SYNTHETIC_INIT", "false")
+    model = C.load(cfg)
+    got = model.state_dict()
+    for k, v in sd.items():
+        if k.startswith(("visual.", "transformer.", "token_embedding", "positional_embedding", "ln_final", "text_projection")):
+            assert k in got and torch.equal(got[k].cpu().float().reshape(v.shape), v.float()), k
+    assert model.engine.cfg.width == g.d and model.engine.cfg.layers == g.layers and model.engine.cfg.embed_dim == g.E
+    # and it runs: the frozen towers feed a forward pass
+    video = torch.from_numpy(synth.video(g, 2)).cuda()
+    tokens = torch.from_numpy(synth.label_tokens(g.K)).cuda()
+    with torch.no_grad():
+        out = model.cuda()(video.permute(0, 2, 1, 3, 4).reshape(2 * g.T, 3, g.res, g.res).contiguous(), tokens)
+    assert out["logits_per_image"].shape == (2, g.K) and torch.isfinite(out["logits_per_image"]).all()
