@@ -133,7 +133,7 @@ def main():
     torch.cuda.set_device(local_rank % torch.cuda.device_count() if os.environ.get("DIST_AMD_BACKEND") == "gloo" else local_rank)
 
     from dist_amd import synth
-    from dist_amd import distributed as du
+    from dist_amd.utils import distributed as du
     from dist_amd.engine import Engine, config_from_geometry
 
     force_reducer = bool(os.environ.get("DIST_AMD_FORCE_REDUCER"))    # measurement knob: RCCL group + gradient reducer at world size 1

@@ -158,7 +158,7 @@ def test_synth_is_deterministic_and_well_scaled():
 WORKER = r'''
 import os, sys, torch
 sys.path.insert(0, sys.argv[1])
-from dist_amd import distributed as du
+from dist_amd.utils import distributed as du
 rank, world, port = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = port
 du.init_process_group(rank, world, 0, backend="gloo")
@@ -195,7 +195,7 @@ def test_distributed_wrappers_gloo_world2(tmp_path):
 
 
 def test_distributed_single_process_defaults():
-    from dist_amd import distributed as du
+    from dist_amd.utils import distributed as du
     assert du.get_world_size() == 1 and du.get_rank() == 0 and du.is_master_proc()
     t = [torch.tensor(2.0)]
     assert du.all_reduce(t)[0] is t[0] and du.all_gather(t)[0] is t[0]

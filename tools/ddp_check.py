@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.distributed as dist
 from dist_amd import synth
-from dist_amd import distributed as du
+from dist_amd.utils import distributed as du
 from dist_amd.engine import Engine, config_from_geometry
 
 
