@@ -122,6 +122,15 @@ template <> DEV float qgelu_grad_t<bf16_t>(float x) {
     return s * (1.f + 1.702f * x * (1.f - s));
 }
 
+// The LayerNorm fold of a GEMM epilogue (DIST_EPI_LNFOLD), v = rstd * (acc - mean * colsum) + bias, with its roundings written out: one
+// fma, one multiply, one add, no further contraction - every kernel that applies the fold (gemm_fast.hip, gemm_pp.hip) produces the same bits.
+DEV float lnfold_bias(float acc, float mean, float rstd, float cs, float bias) {
+#pragma clang fp contract(off)
+    const float t = __builtin_fmaf(-mean, cs, acc);
+    const float u = rstd * t;
+    return u + bias;
+}
+
 DEV float wave_sum(float v, int width) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1)

@@ -95,8 +95,10 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
             const int n = nw + j * 16 + lg * 4 + r;
             bias4[j][r] = ((flags & DIST_EPI_BIAS) && n < N) ? p.bias[n] : 0.f;
         }
-    if (flags & DIST_EPI_LNFOLD) {
-        // LayerNorm folded into this GEMM: A held the raw rows, B = W diag(gamma); v = rstd[m] * (acc - mean[m] * colsum[n]) (+ bias')
+    const bool lnf = (flags & DIST_EPI_LNFOLD) != 0;
+    if (lnf) {
+        // LayerNorm folded into this GEMM: A held the raw rows, B = W diag(gamma); v = rstd[m] * (acc - mean[m] * colsum[n]) + bias'
+        // (lnfold_bias: explicit roundings, the bias included - the conversion loop below then adds nothing)
         const float* __restrict__ st = static_cast<const float*>(p.aux);     // [2][M]: mean, rstd
         float cs4[4][4];
 #pragma unroll
@@ -113,7 +115,7 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = rstd * (acc[i][j][r] - mean * cs4[j][r]);
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = lnfold_bias(acc[i][j][r], mean, rstd, cs4[j][r], bias4[j][r]);
         }
     }
     const bool act_only = (flags & DIST_EPI_ACT2) && !C;
@@ -123,7 +125,9 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             bf16_t* slot = reinterpret_cast<bf16_t*>(ew + r * 128 + ((((j << 1) | (lg >> 1)) ^ (r & 7)) << 4) + ((lg & 1) << 3));
-            float v[4] = {acc[i][j][0] + bias4[j][0], acc[i][j][1] + bias4[j][1], acc[i][j][2] + bias4[j][2], acc[i][j][3] + bias4[j][3]};
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = lnf ? acc[i][j][q] : acc[i][j][q] + bias4[j][q];
             if (flags & DIST_EPI_RES) {
                 float x[4];
                 load4(slot, x);
@@ -767,6 +771,9 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
         return 1;
     }
     if (NW == 8 && use_8p && a->K % P8_BK == 0 && a->K >= 2 * P8_BK && a->amap.mode == DIST_RM_PLAIN) {
+        // the ping-pong persistent kernel (gemm_pp.hip) takes the frozen-ViT shapes: N % 256 == 0, K >= 768, the ViT's four epilogues
+        const int pp = dist_k_gemm_pp(a, ng, s);
+        if (pp != 0) return pp;
         static DistSmemOnce attr8;
         RUN_(dist_max_smem(attr8, reinterpret_cast<const void*>(gemm_fast8p_kernel<false>), smem8));
         hipLaunchKernelGGL(gemm_fast8p_kernel<false>, dim3((unsigned)tiles), dim3(512), smem8, s, *a, ng);

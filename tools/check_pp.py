@@ -1,0 +1,109 @@
+"""Ping-pong persistent GEMM (gemm_pp.hip) against gemm_fast8p_kernel: bit-identical outputs + time per launch, every epilogue the ViT uses.
+  python tools/check_pp.py run <tag>      -> /tmp/pp_<tag>.pt (checksums + small tensors + times); run once with DIST_AMD_FAST_PP=0 and once with 1
+  python tools/check_pp.py cmp <a> <b>    -> compares the two records
+Small shapes need DIST_AMD_PP_GRID=8 (the kernel wants >= 2 tiles per block)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+
+def checksum(t):
+    v = t.contiguous().view(torch.int16).to(torch.int64).flatten()
+    idx = torch.arange(v.numel(), device=v.device, dtype=torch.int64) % 65521 + 1
+    return int(v.sum().item()), int((v * idx).sum().item())
+
+
+def timeit_rot(fns, reps=3):
+    for f in fns: f()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            for f in fns: f()
+        e.record(); torch.cuda.synchronize()
+        best = min(best, s.elapsed_time(e) / (reps * len(fns)) * 1e-3)
+    return best
+
+
+def run(tag):
+    from dist_amd import ops, lib as L
+    dt = torch.bfloat16
+    small = int(os.environ.get("DIST_AMD_PP_GRID", "256")) <= 16
+    if small:
+        shapes = [(4000, 512, 768), (4096, 256, 1536), (5120 + 37, 768, 1024), (197 * 24, 768, 768)]
+    else:
+        shapes = [(50432, 2304, 768), (50432, 3072, 768), (50432, 768, 3072), (50432, 768, 768), (65792, 1024, 1024), (65792, 4096, 1024)]
+    rec = {}
+    g = torch.Generator(device="cuda"); g.manual_seed(1234)
+    def rnd(shape, scale=1.0, dtype=dt):
+        return (torch.randn(shape, device="cuda", generator=g) * scale).to(dtype)
+    for (M, N, K) in shapes:
+        nset = 1 if small else 4
+        As = [rnd((M, K)) for _ in range(nset)]
+        W = rnd((N, K), K ** -0.5)
+        bias = rnd((N,), 1.0, torch.float32)
+        stats = torch.stack([rnd((M,), 0.1, torch.float32), rnd((M,), 0.2, torch.float32).abs() + 0.5]).contiguous()
+        colsum = W.float().sum(1).contiguous()
+        res = rnd((M, N))
+        kinds = ["plain", "lnfold", "act", "lnfold_act", "res", "res_rowstats"]
+        Lh, heads = 197, N // 192 if N % 192 == 0 else 0
+        if heads and M % Lh == 0: kinds += ["lnfold_heads", "heads"]
+        for kind in kinds:
+            outs = [torch.full((M, N), 7.0, device="cuda", dtype=dt) for _ in range(nset)]
+            rs = torch.zeros(N // 64, M, 2, device="cuda", dtype=torch.float32) if kind == "res_rowstats" else None
+            def call(a, c):
+                kw = dict(bias=bias)
+                if "lnfold" in kind: kw["lnfold"] = (stats, colsum)
+                if "act" in kind: kw["C2_out"] = c
+                else: kw["C_out"] = c
+                if kind.startswith("res"): kw["res"] = res
+                if rs is not None: kw["rowstats"] = rs
+                if "heads" in kind:
+                    kw["omap"] = ops.outmap(L.OM_HEADS, Lh, heads); kw["ldc"] = 64
+                ops.gemm_nt(a, W, M, N, K, **kw)
+            fns = [(lambda a=a, c=c: call(a, c)) for a, c in zip(As, outs)]
+            t = timeit_rot(fns)
+            torch.cuda.synchronize()
+            key = f"{M}x{N}x{K}:{kind}"
+            rec[key] = dict(cs=[checksum(o) for o in outs], t=t, tf=2 * M * N * K / t / 1e12)
+            if rs is not None: rec[key]["rs"] = checksum(rs.view(torch.int16))
+            if kind == "plain":
+                ref = (As[0].float() @ W.float().t() + bias).to(dt)
+                d = (outs[0].float() - ref.float()).abs().max().item()
+                rec[key]["maxdiff_vs_fp32"] = d
+                rec[key]["neq_vs_fp32"] = int((outs[0] != ref).sum().item())
+            # repeatability: 4 more launches into the same buffer
+            c0 = outs[0].clone()
+            for _ in range(4): call(As[0], outs[0])
+            torch.cuda.synchronize()
+            rec[key]["repeat_ok"] = bool(torch.equal(c0, outs[0]))
+            if small: rec[key]["out"] = outs[0].cpu()
+            print(f"[{tag}] {key:34s} {t*1e6:8.1f} us {rec[key]['tf']:7.1f} TF  repeat={rec[key]['repeat_ok']} " +
+                  (f"maxdiff_fp32={rec[key].get('maxdiff_vs_fp32')}" if kind == "plain" else ""), flush=True)
+            del outs
+        del As
+    torch.save(rec, f"/tmp/pp_{tag}.pt")
+
+
+def cmp(a, b):
+    ra, rb = torch.load(f"/tmp/pp_{a}.pt"), torch.load(f"/tmp/pp_{b}.pt")
+    bad = 0
+    for k in ra:
+        same = ra[k]["cs"] == rb[k]["cs"] and ra[k].get("rs") == rb[k].get("rs")
+        if "out" in ra[k]:
+            same = same and torch.equal(ra[k]["out"], rb[k]["out"])
+            if not same:
+                ne = (ra[k]["out"] != rb[k]["out"])
+                rows = ne.any(1).nonzero().flatten()
+                cols = ne.any(0).nonzero().flatten()
+                print(f"   {k}: {int(ne.sum())} elements differ, rows {rows[:8].tolist()}..{rows[-4:].tolist()} ({rows.numel()}), cols {cols[:8].tolist()}..{cols[-4:].tolist()} ({cols.numel()})")
+        bad += not same
+        print(f"{k:34s} {'SAME' if same else 'DIFF'}  {a} {ra[k]['t']*1e6:8.1f} us ({ra[k]['tf']:6.1f} TF)   {b} {rb[k]['t']*1e6:8.1f} us ({rb[k]['tf']:6.1f} TF)  x{ra[k]['t']/rb[k]['t']:.3f}")
+    print("RESULT:", "all bit-identical" if bad == 0 else f"{bad} cases differ")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run": run(sys.argv[2])
+    else: cmp(sys.argv[2], sys.argv[3])
