@@ -28,9 +28,13 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic work per clip, SURVEY.md §8(d) / BASELINE.md §2 (2*MAC, analytic)
+# algorithmic work per clip, SURVEY.md §8(d) / BASELINE.md §2 (2*MAC, analytic): what the REFERENCE's graph executes
 GF_PER_CLIP = {"b16_8+16f": dict(fwd=325.73, fwd_bwd=398.0), "b16_16+32f": dict(fwd=651.45, fwd_bwd=796.0),
                "l14_32+64f": dict(fwd=5665.9, fwd_bwd=6444.0)}
+# ... of which the engine does NOT execute: the reference embeds the patches of all T frames and then keeps every alpha-th one (clip.py:263-300);
+# dist_vit_forward embeds only the kept t frames (csrc/engine.hip).  GF per clip = (T - t) frames x patches x 3 P^2 x width x 2.  Every
+# `*_tflops` / `*_mfma_frac` of the line is computed from GF_PER_CLIP minus this.
+GF_SKIPPED_PER_CLIP = {"b16_8+16f": 8 * 196 * 768 * 768 * 2 / 1e9, "b16_16+32f": 16 * 196 * 768 * 768 * 2 / 1e9, "l14_32+64f": 32 * 256 * 588 * 1024 * 2 / 1e9}
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -235,6 +239,7 @@ def main():
     #                              kernel's workgroups wait for CUs held by the branch / backward kernels of the other streams;
     #   roofline.alone           : the same launches of one frozen-ViT pass with no other stream active (the kernel's own duration).
     roof = None
+    cu_floor = None
     if not args.no_roofline:
         def measure(fn, reps):
             eng.profile_begin()
@@ -250,18 +255,20 @@ def main():
         # HBM bytes per launch of this kernel: PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes, corrected
         # as MI355X_MICROARCH.md prescribes), collected offline by tools/pmc_pass.sh and committed; null when the file is absent
         traffic = None
-        pmc = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_fast_gemm.json") for r in ("r04", "r03")) if os.path.exists(q)), "")
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_fast_gemm.json") for r in ("r05", "r04", "r03")) if os.path.exists(q)), "")
         pmc_tag = os.path.basename(pmc)[:3] if pmc else "r04"
         if args.config == "b16_8+16f" and os.path.exists(pmc):
             with open(pmc) as f:
                 traffic = json.load(f).get("traffic_bytes_per_launch_avg")
+        cu_floor = None
         prof_avg = None            # the rocprofv3 --kernel-trace --stats average of this kernel from the committed summary of the same command
-        pj = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_bench_kernel_stats.json") for r in ("r04", "r03")) if os.path.exists(q)), "")
+        pj = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_bench_kernel_stats.json") for r in ("r05", "r04", "r03")) if os.path.exists(q)), "")
         prof_tag = os.path.basename(pj)[:3] if pj else "r04"
         if args.config == "b16_8+16f" and pj:
             with open(pj) as f:
                 pjd = json.load(f)
             prof_avg = pjd.get("in_situ_avg_us", pjd.get("dominant_kernel_avg_us"))
+            cu_floor = pjd.get("cu_time_floor_ms")
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "traffic_note": f"bytes per launch, mean of the four ViT GEMM shapes (48 of the launches), profiles/{pmc_tag}_pmc_fast_gemm.{{md,json}}",
@@ -270,6 +277,8 @@ def main():
                 "profile_note": f"in-situ average duration of the same kernel in profiles/{prof_tag}_bench_kernel_stats.{{md,json}} (rocprofv3 --kernel-trace --stats of the TIMED LOOP of this "
                                 "command: --no-cpu-baseline --no-serial-ref --no-roofline, tools/snapshot.sh); algorithmic FLOPs per launch = achieved x avg_launch_us",
                 "flops_per_launch": round(ach * 1e12 * avg_us * 1e-6, 0),
+                # the same algorithmic FLOPs per launch over the PROFILE's in-situ duration (kernel time only, no queue wait): re-derivable by division
+                "frac_profile": round(ach * avg_us / prof_avg / PEAK_BF16_TFLOPS, 4) if prof_avg else None,
                 "note": "in situ: launch durations while the kernels of the other streams share the CUs (the timed loop's schedule)",
                 "alone": {"achieved": round(ach1, 1), "frac": round(ach1 / PEAK_BF16_TFLOPS, 4), "launches": lps1, "avg_launch_us": round(avg1, 1),
                           "note": "the launches of one frozen-ViT pass with no other stream active"}}
@@ -298,6 +307,7 @@ def main():
         dtf = (time.perf_counter() - tf0) / nf
         eng.set_inference(False)
         gff = GF_PER_CLIP.get(args.config, {}).get("fwd")
+        gff = gff - GF_SKIPPED_PER_CLIP.get(args.config, 0.0) if gff else gff
         fwd_only = {"ms_per_iteration": round(dtf * 1e3, 3), "value": round(b / dtf, 1), "unit": "clips/s", "iterations": nf,
                     "mode": "inference (dist_set_inference: same logits, no tensors kept for backward), frozen ViT + branch forward per iteration"}
         if gff:
@@ -308,6 +318,7 @@ def main():
         clips = world * b * args.steps
         value = clips / dt
         gf = GF_PER_CLIP.get(args.config, {}).get("fwd_bwd")
+        gf = gf - GF_SKIPPED_PER_CLIP.get(args.config, 0.0) if gf else gf
         out = {
             "metric": "video clips/sec/node (train fwd+bwd), ViT-B/16 8+16f B=32/GPU" if (args.config == "b16_8+16f" and b == 32)
                       else f"video clips/sec/node (train fwd+bwd), {args.config} B={b}/GPU",
@@ -323,6 +334,9 @@ def main():
         if gf:
             out["path_tflops_per_gpu"] = round(value / world * gf / 1e3, 1)
             out["path_mfma_frac"] = round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4)
+            out["path_gflop_per_clip"] = {"executed": round(gf, 2), "reference_graph": GF_PER_CLIP[args.config]["fwd_bwd"],
+                                          "note": "executed = the reference graph's algorithmic FLOPs minus the patch embedding of the T - t frames the frozen ViT drops "
+                                                  "right behind it (the engine embeds only the kept frames); path_tflops / path_mfma_frac use `executed`"}
         # whole-step HBM-side traffic from the committed PMC passes (tools/pmc_step.sh: FETCH_SIZE x2 + WRITE_SIZE over every kernel of
         # one step, Infinity-Cache hits included) against this run's step time; null when the file is absent or the config differs
         tj = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_step_traffic.json") for r in ("r04", "r03")) if os.path.exists(q)), "")
@@ -350,6 +364,11 @@ def main():
             out["serial_order"] = serial
         if roof:
             out["roofline"] = roof
+            if cu_floor:
+                # the step's packing bound from the committed profile (tools/prof_summary.py --serial-db): what the step would take with the 256 CUs
+                # packed perfectly with its kernels as they are; ms_per_step over it = how much of the step is schedule rather than kernel time
+                out["cu_time_floor_ms"] = cu_floor
+                out["cu_time_floor_source"] = f"profiles/{prof_tag}_bench_kernel_stats.{{md,json}}: sum over kernels of alone us x launches per step x min(1, blocks / 256)"
         if fwd_only:
             out["forward_only"] = fwd_only
         if world == 1 and not args.no_cpu_baseline:

@@ -5,6 +5,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdist_amd.so")
+MEASURE_LIB = os.path.join(CSRC, "libdist_amd_measure.so")
 SOURCES = ["gemm_nt.hip", "gemm_fast.hip", "gemm_pp.hip", "gemm_small.hip", "gemm_tn.hip", "gemm_tn8p.hip", "tnet.hip", "integ.hip", "norm.hip", "attn.hip", "misc.hip", "metrics.hip", "quant.hip", "engine.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "dist_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
@@ -17,10 +18,25 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_library(force=False, verbose=True):
+def build_library(force=False, verbose=True, measure=False):
+    """Product build: csrc/*.o -> csrc/libdist_amd.so.  measure=True: the timing-only build (-DDIST_AMD_MEASURE plus DIST_AMD_BUILD_DEFS: kernels
+    can be skipped, dummy work, the rejected A/B variants) goes to ITS OWN objects (*.m.o) and library (libdist_amd_measure.so, selected with
+    DIST_AMD_LIB=...), so a measurement can never leave a wrong-result library where the product one is expected.  The extra definitions are part of
+    the staleness key of either build (csrc/.defs[.measure]): changing them rebuilds everything."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
+    defs = os.environ.get("DIST_AMD_BUILD_DEFS", "").split()
+    if measure and "-DDIST_AMD_MEASURE" not in defs:
+        defs = ["-DDIST_AMD_MEASURE"] + defs
+    if not measure and "-DDIST_AMD_MEASURE" in defs:
+        raise RuntimeError("a -DDIST_AMD_MEASURE build is `python -m dist_amd.build --measure` (its own library), not the product build")
+    lib = MEASURE_LIB if measure else LIB
+    osuf = ".m.o" if measure else ".o"
+    key_file = os.path.join(CSRC, ".defs.measure" if measure else ".defs")
+    key = " ".join(defs)
+    if (open(key_file).read() if os.path.exists(key_file) else "") != key:
+        force = True
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     procs = []
@@ -28,10 +44,10 @@ def build_library(force=False, verbose=True):
         s = os.path.join(CSRC, src)
         if not os.path.exists(s):
             continue
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, src.replace(".hip", osuf))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + os.environ.get("DIST_AMD_BUILD_DEFS", "").split() + ["-c", s, "-o", o]     # e.g. -DDIST_INTEG_ABLATE (tools/integ_ablate.sh)
+            cmd = [hipcc] + FLAGS + defs + ["-c", s, "-o", o]
             if verbose:
                 print("[dist_amd.build]", " ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -40,13 +56,15 @@ def build_library(force=False, verbose=True):
         if p.returncode != 0:
             sys.stderr.write(out.decode(errors="replace"))
             raise RuntimeError(f"hipcc failed on {src}")
-    if procs or force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if procs or force or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print("[dist_amd.build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    with open(key_file, "w") as f:
+        f.write(key)
+    return lib
 
 
 if __name__ == "__main__":
-    build_library(force="--force" in sys.argv)
+    build_library(force="--force" in sys.argv, measure="--measure" in sys.argv)

@@ -233,9 +233,11 @@ DEV RowPrep rowmap_step(const dist_rowmap& rm, RowPrep q, int delta) {      // =
 //   dist_knob():         algorithm selectors - every value computes the SAME results through another kernel sequence (a fused kernel off, a tile
 //                        shape, a stream layout); tests/test_fallbacks_gpu.py runs the engine tests under the ones that switch a kernel off,
 //                        bench.py reports every DIST_AMD_* variable that was set ("knobs").
-//   dist_measure_knob(): timing-only switches whose results are WRONG (kernels skipped, dummy work, debug phases).  They exist only in a
-//                        -DDIST_AMD_MEASURE build (DIST_AMD_BUILD_DEFS=-DDIST_AMD_MEASURE python -m dist_amd.build --force, what tools/skip_step.sh
-//                        and the ablation scripts do; dist_measure_build() reports it): the shipped library cannot be driven wrong by the environment.
+//   dist_measure_knob(): timing-only switches whose results are WRONG (kernels skipped, dummy work, debug phases).  They exist only in the
+//                        timing-only library: `python -m dist_amd.build --measure` compiles -DDIST_AMD_MEASURE objects (*.m.o) into
+//                        csrc/libdist_amd_measure.so beside the product library, `. tools/measure_build.sh` builds it, points DIST_AMD_LIB at it and
+//                        asserts dist_measure_build() == 1 (tools/skip_step.sh, tools/r05_pp_dbg.sh, the ablation scripts): the shipped library
+//                        cannot be driven wrong by the environment, and a measurement cannot leave a wrong-result library in its place.
 #include <stdlib.h>
 inline int dist_knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 #ifdef DIST_AMD_MEASURE

@@ -136,6 +136,7 @@ struct dist_handle {
         void* patches = nullptr; std::vector<void*> feat; std::vector<hipEvent_t> ev_feat; hipEvent_t ev_pre = nullptr;
         int b = 0; bool prefetched = false;
         int next_layer = 0, pending_b = 0;       // a prefetch pass issued in parts (dist_vit_prefetch_layers)
+        std::vector<char> valid;                 // feat[i] holds block i of the clip this slot was last filled with (dist_features_import only writes the blocks it is given)
     } slot[2];
     int cur = 0;
     hipEvent_t ev_vit_done = nullptr, ev_after = nullptr, ev_bpre = nullptr; bool vit_ran = false;
@@ -498,6 +499,7 @@ size_t layout_ws(dist_handle* h, char* base) {
     for (int k = 0; k < 2; ++k) {
         h->slot[k].feat.resize(c.layers);
         for (int i = 0; i < c.layers; ++i) h->slot[k].feat[i] = T_(rowsS, d);
+        h->slot[k].valid.assign(c.layers, 0);
     }
     h->patches = h->slot[h->cur].patches; h->feat = h->slot[h->cur].feat;
     h->lw.resize(h->nsel);
@@ -1126,6 +1128,7 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
         if (!done8) RUN(gemm(x, h->mlp, 4 * d, x.pk(v.proj.pk.f), rowsS, d, 4 * d, 1, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr, RM(), OM(), 0, nullptr, rs ? h->lnpart : nullptr));
         part_of_xin = rs;
         HIP_CHECK_RET(hipEventRecord(S.ev_feat[i], x.s));               // mid_feat[i] complete: the branch may consume it
+        S.valid[i] = 1;
         if (h->dummy & 1) for (int r = 0; r < h->dummy_reps; ++r) RUN(ln_fwd(x, h->visual, v.ln1, S.feat[i], nullptr, rowsS, h->lnstats2, h->lnstats2 + rowsS));
         xin = S.feat[i];
     }
@@ -1174,6 +1177,7 @@ extern "C" int dist_features_import(dist_handle* h, const void* const* mid_feat,
     HIP_CHECK_RET(hipEventRecord(S.ev_feat[c.layers], s));
     for (int i = 0; i < c.layers; ++i) {
         if (mid_feat[i]) RUN(dist_k_import_feat(mid_feat[i], src_dtype, S.feat[i], c.dtype, b * h->t, h->L, c.width, s));
+        S.valid[i] = mid_feat[i] ? 1 : 0;                               // a block the caller did not supply still holds an OLDER clip: not readable
         HIP_CHECK_RET(hipEventRecord(S.ev_feat[i], s));
     }
     S.next_layer = c.layers; S.pending_b = b; S.b = b;
@@ -1814,7 +1818,11 @@ extern "C" int dist_debug_tensor(dist_handle* h, const char* name, const void** 
     const std::string key(name, dot ? (size_t)(dot - name) : strlen(name));
     auto vit_ok = [&]() { return i >= 0 && i < c.layers; };            // "feat.i": ViT block i; every other name: DiST layer i (< number of selected blocks)
     auto layer_ok = [&]() { return i >= 0 && i < h->nsel; };
-    if (key == "feat" && vit_ok()) { *ptr = h->feat[i]; *rows = rowsS; *cols = c.width; return DIST_OK; }
+    if (key == "feat" && vit_ok()) {
+        if (!h->slot[h->cur].valid[i])
+            return fail(h, DIST_ERR_STATE, "feat.%d: the current feature slot was filled by dist_features_import without block %d (it still holds an older clip)", i, i);
+        *ptr = h->feat[i]; *rows = rowsS; *cols = c.width; return DIST_OK;
+    }
     if (key == "stem") { *ptr = h->lw[0].X; *rows = rowsX; *cols = c.temporal_dim; return DIST_OK; }
     if (key == "tn_out" && layer_ok()) { *ptr = h->lw[i].Xp; *rows = rowsX; *cols = c.temporal_dim; return DIST_OK; }
     if (key == "int_out" && layer_ok()) { *ptr = h->lw[i].R; *rows = rowsS; *cols = c.integration_dim; return DIST_OK; }

@@ -104,8 +104,11 @@ __global__ __launch_bounds__(512, 1) void gemm_tn8r_kernel(const dist_gemm_tn_ar
     // ---- LDS-DMA sources: this wave moves rows 4*wid + (lane >> 4) of every half-tile (one 1 KB piece)
     const bf16_t* Ab = static_cast<const bf16_t*>(p.A) + ((long)mbeg * p.lda + i0);
     const bf16_t* Bb = static_cast<const bf16_t*>(p.B) + ((long)mbeg * p.ldb + c0);
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ab), 0, (int)(((long)rows * p.lda - i0) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Bb), 0, (int)(((long)rows * p.ldb - c0) * 2), 0x00020000);
+    // The descriptors end behind the LAST COLUMN THE VIEW OWNS in the block's last row, (rows - 1) * ld + (width - first column): A / B may be
+    // column-offset views of a wider buffer (ld > width), and a range of rows * ld elements would reach `offset` elements past that buffer's end
+    // for the last row block.  Every row behind the block's range still starts at >= rows * ld - first column > the bound and reads as zero.
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ab), 0, (int)(((long)(rows - 1) * p.lda + (p.NI - i0)) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Bb), 0, (int)(((long)(rows - 1) * p.ldb + (p.K - c0)) * 2), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     unsigned ga, gb;
     {
@@ -337,7 +340,8 @@ int dist_k_gemm_tn8p(const dist_gemm_tn_args* a, hipStream_t s) {
     if (!a->partial) return 0;
     if (a->NI < 192 || a->K < 192 || a->M < 8192) return 0;
     if (a->lda % 8 || a->ldb % 8 || ((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15)) return 0;
-    if ((long)a->M * a->lda >= (1l << 30) || (long)a->M * a->ldb >= (1l << 30)) return 0;     // 32-bit byte offsets inside a row range
+    // 32-bit byte offsets inside a row range; the scalar offsets of K-tiles staged behind a block's last row reach up to ~480 rows further
+    if ((long)(a->M + 512) * a->lda >= (1l << 30) || (long)(a->M + 512) * a->ldb >= (1l << 30)) return 0;
     static const int mode = dist_knob("DIST_AMD_TN8P", 1);        // 0: gemm_tn_kernel for everything (the A/B reference)
     if (!mode) return 0;
     static const int max_blocks = dist_knob("DIST_AMD_TN8P_BLOCKS", 96);    // partial bytes = blocks x 196 KB, written and read again, and a block holds its CU for the whole

@@ -1090,8 +1090,8 @@ __global__ __launch_bounds__(1024) void integ_unfold_kernel(const IgUnfold a, co
     const int per = (d.N + 15) / 16, n0 = wv * per, n1 = min(n0 + per, d.N);
     // accumulating form: this pass's G' / db come from scratch (Gs / dbs), the slots d.G / d.db hold earlier passes' gradients and are added to
     const bool acc = d.Gs != nullptr;
-    const float* __restrict__ Gin = acc ? d.Gs : d.G;
-    const float* __restrict__ dbin = acc ? d.dbs : d.db;
+    const float* Gin = acc ? d.Gs : d.G;                 // (no __restrict__: in the plain form they ARE d.G / d.db, which this loop writes - each thread's
+    const float* dbin = acc ? d.dbs : d.db;             //  store follows its own load of the same element, which is all the ordering the kernel needs)
     for (int n = n0; n < n1; n += 8) {
         float w[8], gp[8], dbn[8], old[8];
 #pragma unroll

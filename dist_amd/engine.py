@@ -70,6 +70,7 @@ class Engine:
         self._text = None
         self._pf_video = None
         self._feat_stamp = 0                 # bumped whenever the current feature slot receives another pass
+        self._branch_stamp = 0               # bumped by every branch forward: the loss path checks that the logits it is given are the last ones
         self._cur_video = None
         self._cur_ver = self._pf_ver = -1
         self.b = 0
@@ -217,6 +218,7 @@ class Engine:
     def branch_forward(self, text_features):
         assert text_features.dtype == torch.float32 and text_features.is_contiguous()
         self._text = text_features            # keep alive: the engine borrows the pointer until backward
+        self._branch_stamp = getattr(self, "_branch_stamp", 0) + 1     # which forward the engine's video embedding belongs to (losses.py checks it)
         logits = torch.empty(self.b, self.cfg.num_classes, dtype=torch.float32, device=self.device)
         vid = torch.empty(self.b, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
         L.check(self.lib.dist_branch_forward(self.h, text_features.data_ptr(), self.b, logits.data_ptr(), vid.data_ptr(), ops._stream()), self.h)

@@ -296,7 +296,8 @@ class CLIP(nn.Module):
         # computed on first access, from the feature slot this forward left (a gather, a LayerNorm, a GEMM and a copy less per train step)
         out = _OutputDict({"logits_per_image": logits, "logits_per_text": logits.t(), "vid_logits": vid[:, None, :]})
         out._lazy_img = (self, self.engine._feat_stamp)
-        dict.__setitem__(out, "_dist_engine", self.engine)      # for models/utils/losses.py: the loss of these logits is dist_loss
+        dict.__setitem__(out, "_dist_engine", self.engine)      # for models/utils/losses.py: the loss of these logits is dist_loss ...
+        dict.__setitem__(out, "_dist_branch_stamp", self.engine._branch_stamp)      # ... as long as no other branch forward ran in between
         return out
 
     @torch.no_grad()

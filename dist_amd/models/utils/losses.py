@@ -22,6 +22,31 @@ class _EngineSoftTargetCE(torch.autograd.Function):
         return (g * dlogits).view(ctx.shape), None, None
 
 
+def _engine_of(out, preds):
+    """The engine whose LAST branch forward produced `preds`, or None.  dist_loss reads the video embedding that forward left in the engine, so the
+    HIP path is only taken when (a) the output dictionary's stamp is still the engine's branch-forward counter (no other forward - a second view,
+    an evaluation pass - ran in between) and (b) `preds` is computed from this dictionary's `logits_per_image` (its autograd graph reaches that
+    tensor's node within a few steps: the head's mean / activation).  Anything else takes the torch expression on `preds` itself."""
+    if not isinstance(out, dict) or not torch.is_grad_enabled():
+        return None
+    engine, stamp = out.get("_dist_engine"), out.get("_dist_branch_stamp")
+    if engine is None or stamp is None or stamp != getattr(engine, "_branch_stamp", None):
+        return None
+    src = out["logits_per_image"]
+    if preds is src:
+        return engine
+    root, todo, seen = src.grad_fn, [preds.grad_fn], 0
+    while todo and seen < 16 and root is not None:
+        fn = todo.pop()
+        if fn is None:
+            continue
+        if fn is root:
+            return engine
+        seen += 1
+        todo.extend(f for f, _ in fn.next_functions)
+    return None
+
+
 class SoftTargetCrossEntropy(nn.Module):
     """mean_b sum_k -target * log_softmax(x) (reference losses.py:20-31, timm's SoftTargetCrossEntropy).  `engine`: the logits are the ones
     that engine's branch forward just produced -> dist_loss (HIP); tensors of any other origin (unit tests on the host) take the
@@ -39,12 +64,12 @@ def calculate_loss(cfg, preds, logits, labels, cur_epoch):
     target = labels["supervised"] if isinstance(labels, dict) else labels
     if target.dtype in (torch.float32, torch.float16, torch.bfloat16) and target.dim() == 2:
         # `logits` is the backbone's output dictionary (models.py:forward -> head returns (preds, x)); CLIP.forward_video leaves its engine in it
-        engine = logits.get("_dist_engine") if isinstance(logits, dict) and torch.is_grad_enabled() else None
+        engine = _engine_of(logits, preds)
         loss = SoftTargetCrossEntropy()(preds, target, engine)
         name = "soft_target"
     else:
         # hard labels (no mixup / label smoothing): the same HIP loss on their one-hot form when the logits are the engine's
-        engine = logits.get("_dist_engine") if isinstance(logits, dict) and torch.is_grad_enabled() else None
+        engine = _engine_of(logits, preds)
         if engine is not None and preds.is_cuda and preds.dim() == 2 and preds.shape[0] == engine.b and target.dim() == 1:
             loss = SoftTargetCrossEntropy()(preds, F.one_hot(target.long(), preds.shape[1]).float(), engine)
         else:

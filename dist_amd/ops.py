@@ -278,12 +278,12 @@ def ln_fold(W, bias, gamma, beta):
 
 
 def gemm_tn(A, B, out, M, NI, K, *, taps=1, amap=None, bmap=None, so_i=None, so_tap=None, so_outer=1, inner=1, use_tr=1, colsum=None, partial=None,
-            out2=None, split_c=0, so_i2=0, colsum2=None, max_blocks=0):
+            out2=None, split_c=0, so_i2=0, colsum2=None, max_blocks=0, lda=None, ldb=None):
     lib = L.load()
     a = L.GemmTnArgs()
     a.A, a.B, a.out = _p(A), _p(B), _p(out)
     a.M, a.NI, a.K, a.taps = M, NI, K, taps
-    a.lda, a.ldb = A.shape[-1], B.shape[-1]
+    a.lda, a.ldb = lda if lda is not None else A.shape[-1], ldb if ldb is not None else B.shape[-1]      # (lda / ldb: column-offset views of wider buffers)
     a.amap = amap or rowmap()
     a.bmap = bmap or rowmap()
     a.so_i = so_i if so_i is not None else taps * K

@@ -230,7 +230,7 @@ def test_result_changing_knobs_exist_only_in_a_measure_build():
         assert "getenv" not in open(f).read(), f                # only common.h's dist_knob touches the environment
     txt = "".join(open(f).read() for f in glob.glob(os.path.join(csrc, "*.hip")))
     measure_only = {"DIST_AMD_SKIP", "DIST_AMD_DUMMY", "DIST_AMD_DUMMY_REPS", "DIST_AMD_TN_SKIP_REDUCE", "DIST_AMD_ATTN_DBG", "DIST_AMD_INTEG_DBG",
-                    "DIST_AMD_TNET_DBG", "DIST_AMD_TNET_BWD_NOREDUCE"}
+                    "DIST_AMD_TNET_DBG", "DIST_AMD_TNET_BWD_NOREDUCE", "DIST_AMD_PP_DBG"}
     sel = set(re.findall(r'dist_knob\("(DIST_AMD_[A-Z0-9_]+)"', txt))
     mea = set(re.findall(r'dist_measure_knob\("(DIST_AMD_[A-Z0-9_]+)"', txt))
     assert mea == measure_only and not (sel & measure_only), (mea ^ measure_only, sel & measure_only)

@@ -276,6 +276,41 @@ def test_train_loop_loss_is_the_engines_dist_loss(gpu_lib):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-9, n
 
 
+def test_engine_loss_is_only_taken_for_the_last_forwards_own_logits(gpu_lib):
+    """dist_loss reads the video embedding the LAST branch forward left in the engine.  If another forward ran between producing
+    `out` and calculate_loss (two views, an evaluation pass), or `preds` does not come from that dictionary's logits, the loss must be the torch
+    expression on `preds` - never silently the other batch's."""
+    from dist_amd import synth
+    from dist_amd.models.utils import losses
+    cfg, model, clip, g = _tiny_model()
+    va = torch.from_numpy(synth.video(g, 2)).cuda()
+    vb = torch.from_numpy(synth.video(g, 2, seed=9)).cuda()
+    tgt = torch.from_numpy(synth.soft_target(g, 2)[0]).cuda()
+    texts = torch.zeros(g.K, 77, dtype=torch.long, device="cuda")
+    model.train()
+    calls = []
+    orig = clip.engine.loss
+    clip.engine.loss = lambda t: (calls.append(1), orig(t))[1]
+    try:
+        preds_a, out_a = model({"video": va, "texts": texts})
+        preds_b, out_b = model({"video": vb, "texts": texts})                 # the engine now holds clip B's embedding
+        want_a = float(losses.SoftTargetCrossEntropy()(preds_a.detach(), tgt))
+        la, _, _ = losses.calculate_loss(cfg, preds_a, out_a, {"supervised": tgt}, 0)
+        assert calls == [] and abs(float(la.detach()) - want_a) < 1e-6        # stale stamp -> torch expression, clip A's loss
+        lb, _, _ = losses.calculate_loss(cfg, preds_b, out_b, {"supervised": tgt}, 0)
+        assert calls == [1]                                                    # the last forward's own logits -> dist_loss
+        assert abs(float(lb.detach()) - float(losses.SoftTargetCrossEntropy()(preds_b.detach(), tgt))) < 1e-5
+        # logits that are not derived from this dictionary (a detached copy) take the torch expression too
+        preds_c, out_c = model({"video": va, "texts": texts})
+        foreign = preds_c.detach().clone().requires_grad_(True)
+        lc, _, _ = losses.calculate_loss(cfg, foreign, out_c, {"supervised": tgt}, 0)
+        assert calls == [1] and abs(float(lc.detach()) - want_a) < 1e-5
+        lc.backward()
+        assert foreign.grad is not None
+    finally:
+        clip.engine.loss = orig
+
+
 def test_img_logits_is_lazy_and_guarded(gpu_lib):
     from dist_amd import synth
     cfg, model, clip, g = _tiny_model()

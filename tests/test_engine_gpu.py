@@ -411,6 +411,13 @@ def test_selected_layers_subset_intermediates_and_import(gpu_lib):
     eng.import_features(mid, video)
     logits2, _ = eng.branch_forward(text)
     torch.testing.assert_close(logits2, logits, rtol=0, atol=0)
+    # block 1 was not supplied, so the slot's feat.1 still holds the OTHER clip - it must not be readable as this clip's
+    # (CLIP's lazy img_logits reads feat.<last>: with a selection that leaves the last block out it would silently return another clip's logits)
+    eng.debug("feat.0"); eng.debug("feat.2")
+    with pytest.raises(Exception, match="feat.1"):
+        eng.debug("feat.1")
+    eng.vit_forward(video)
+    eng.debug("feat.1")                                                # a full ViT pass makes every block valid again
     with pytest.raises(Exception):
         eng.import_features({0: mid[0]}, video)                        # block 2 missing
     # bf16 engine of the same geometry: runs, finite, close

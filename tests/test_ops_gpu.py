@@ -316,6 +316,24 @@ def test_gemm_tn_large_plain_two_group_kernel(gpu_lib, M, NI, K, lda, ldb, split
     assert float((o.double() - 0.5 - ref).abs().max() / ref.abs().max()) < 2e-5
 
 
+def test_gemm_tn_large_plain_column_offset_views_end_at_the_allocation(gpu_lib):
+    """dist_op_gemm_tn is public, and its operands may be column-offset views of wider buffers (the engine's [dzf | dh1 | dh2] rows).
+    The buffer descriptors of the ring kernel must end with the view's last owned element: operands whose last row ends exactly at the end of
+    their allocation (384 of 480 columns from column 96, 256 of 320 from column 64), ragged M, against fp64."""
+    from dist_amd import ops
+    M, NI, K, offa, offb = 9000 + 13, 384, 256, 96, 64
+    g = torch.Generator(device="cuda"); g.manual_seed(77)
+    Abig = torch.randn(M, offa + NI, device="cuda", generator=g).to(torch.bfloat16)
+    Bbig = torch.randn(M, offb + K, device="cuda", generator=g).to(torch.bfloat16)
+    A, B = Abig[:, offa:], Bbig[:, offb:]
+    part = torch.empty(16 << 20, dtype=torch.float32, device="cuda")
+    o, cs = torch.zeros(NI, K, device="cuda"), torch.zeros(NI, device="cuda")
+    ops.gemm_tn(A, B, o, M, NI, K, colsum=cs, partial=part, lda=offa + NI, ldb=offb + K)
+    ref = A.double().t() @ B.double()
+    assert float((o.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    assert float((cs.double() - A.double().sum(0)).abs().max() / A.double().sum(0).abs().max()) < 2e-5
+
+
 @pytest.mark.parametrize("dtype,use_tr", [(torch.float32, 0), (torch.bfloat16, 1)])
 @pytest.mark.parametrize("mode,kw,taps", [("shift", dict(p0=8 * 9, p1=9), 3), ("spatial", dict(p0=4), 9), ("strided", dict(p0=2, p1=9), 2),
                                           ("shift", dict(p0=16 * 49, p1=49), 3), ("spatial", dict(p0=14), 9), ("strided", dict(p0=2, p1=196), 2)])

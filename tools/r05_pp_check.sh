@@ -1,5 +1,6 @@
 # ping-pong GEMM vs gemm_fast8p: bit-identity (small shapes with an 8-block grid, full shapes) and time per launch
 cd /root/repo; mkdir -p gpurun_out
+. tools/measure_build.sh      # gemm_pp.hip only exists in the timing-only library
 {
 DIST_AMD_PP_GRID=8 DIST_AMD_FAST_PP=0 timeout 600 python tools/check_pp.py run s_old
 DIST_AMD_PP_GRID=8 DIST_AMD_FAST_PP=1 timeout 600 python tools/check_pp.py run s_new
