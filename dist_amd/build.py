@@ -38,6 +38,9 @@ def build_library(force=False, verbose=True, measure=False):
     if (open(key_file).read() if os.path.exists(key_file) else "") != key:
         force = True
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    srcs = [os.path.join(CSRC, x) for x in SOURCES if os.path.exists(os.path.join(CSRC, x))]
+    if not force and not _stale(lib, srcs + hdrs):
+        return lib                                       # (a snapshot on the GPU box carries the library but not the objects)
     objs = []
     procs = []
     for src in SOURCES:

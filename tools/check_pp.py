@@ -34,7 +34,7 @@ def run(tag):
     if small:
         shapes = [(4000, 512, 768), (4096, 256, 1536), (5120 + 37, 768, 1024), (197 * 24, 768, 768)]
     else:
-        shapes = [(50432, 2304, 768), (50432, 3072, 768), (50432, 768, 3072), (50432, 768, 768), (65792, 1024, 1024), (65792, 4096, 1024)]
+        shapes = [(50432, 2304, 768), (50432, 3072, 768), (50432, 768, 3072), (50432, 768, 768), (65792, 1024, 1024), (65792, 4096, 1024), (20037, 2304, 768), (33000, 1024, 256)]
     rec = {}
     g = torch.Generator(device="cuda"); g.manual_seed(1234)
     def rnd(shape, scale=1.0, dtype=dt):
@@ -50,6 +50,7 @@ def run(tag):
         kinds = ["plain", "lnfold", "act", "lnfold_act", "res", "res_rowstats"]
         Lh, heads = 197, N // 192 if N % 192 == 0 else 0
         if heads and M % Lh == 0: kinds += ["lnfold_heads", "heads"]
+        if os.environ.get("CHECK_KINDS"): kinds = [k for k in kinds if k in os.environ["CHECK_KINDS"].split(",")]
         for kind in kinds:
             outs = [torch.full((M, N), 7.0, device="cuda", dtype=dt) for _ in range(nset)]
             rs = torch.zeros(N // 64, M, 2, device="cuda", dtype=torch.float32) if kind == "res_rowstats" else None
