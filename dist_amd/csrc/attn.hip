@@ -514,7 +514,7 @@ int launch_attn(const void* qkv, void* out, int frames, int L, int heads, int hm
     if (smem > 160 * 1024) return DIST_ERR_ARG;
     const int nq = (L + 15) / 16;
     static const int dbg_env = dist_measure_knob("DIST_AMD_ATTN_DBG", 0);
-    static const int nt_env = dist_knob("DIST_AMD_ATTN_NT", 0);      // measurement knob: 448 / 576
+    static const int nt_env = DIST_AB_KNOB("DIST_AMD_ATTN_NT", 0);      // A/B: force 448 / 576 threads
     // nine waves only where two 7-wave workgroups do not fit a CU's LDS anyway (L = 257: 234 us with nine waves and one workgroup per CU,
     // 190 us with seven waves and two - tools/bench_attn.py)
     const bool nine = nt_env ? nt_env == NT9 : (nq > 14 && nq <= 18 && smem > 80 * 1024);

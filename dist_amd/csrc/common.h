@@ -238,8 +238,19 @@ DEV RowPrep rowmap_step(const dist_rowmap& rm, RowPrep q, int delta) {      // =
 //                        csrc/libdist_amd_measure.so beside the product library, `. tools/measure_build.sh` builds it, points DIST_AMD_LIB at it and
 //                        asserts dist_measure_build() == 1 (tools/skip_step.sh, tools/r05_pp_dbg.sh, the ablation scripts): the shipped library
 //                        cannot be driven wrong by the environment, and a measurement cannot leave a wrong-result library in its place.
+//   DIST_AB_KNOB():      selectors of variants that were MEASURED AND REJECTED (profiles/: another tile shape, wave count, stream layout ...): the A/B
+//                        references of those notes.  In the product library the macro is its default - a constant - and the variant's code sits
+//                        behind `if constexpr (DIST_AB)` / `#ifdef DIST_AMD_MEASURE`, so neither the kernel nor the environment read ship; in the
+//                        timing-only library it is dist_knob().
 #include <stdlib.h>
 inline int dist_knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#ifdef DIST_AMD_MEASURE
+#define DIST_AB_KNOB(name, dflt) dist_knob(name, dflt)
+constexpr bool DIST_AB = true;
+#else
+#define DIST_AB_KNOB(name, dflt) (dflt)
+constexpr bool DIST_AB = false;
+#endif
 #ifdef DIST_AMD_MEASURE
 inline int dist_measure_knob(const char* name, int dflt) { return dist_knob(name, dflt); }
 #else

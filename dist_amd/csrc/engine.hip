@@ -251,16 +251,16 @@ void set_fused_flags(dist_handle* h) {
     const dist_config& c = h->cfg;
     const int Ci = c.integration_dim, Ct = c.temporal_dim, C4 = h->C4;
     h->ig_on = dist_k_integ_eligible(c.dtype, Ci, C4, h->t, c.temporal_kernel) && h->Cf == Ci && (dist_knob("DIST_AMD_INTEG_FUSED", 1) != 0);
-    h->ig_xhat = h->ig_on && (dist_knob("DIST_AMD_INTEG_XHAT", 1) != 0);
+    h->ig_xhat = h->ig_on && (DIST_AB_KNOB("DIST_AMD_INTEG_XHAT", 1) != 0);
     h->ig_bwd = h->ig_xhat && (dist_knob("DIST_AMD_INTEG_BWD_FUSED", 1) != 0);
     // T2I (dist.py:68-86) formed in front of the fused forward instead of a GEMM + a cls-row kernel + a round trip of M' (alpha = 2, temporal width = C4)
-    h->ig_t2i = h->ig_xhat && c.alpha == 2 && Ct == C4 && (dist_knob("DIST_AMD_INTEG_T2I", 1) != 0);
+    h->ig_t2i = h->ig_xhat && c.alpha == 2 && Ct == C4 && (DIST_AB_KNOB("DIST_AMD_INTEG_T2I", 1) != 0);
     // ... and I2T (dist.py:90-105) behind it: the next layer's temporal map leaves the same launch (the I2T GEMM and its second pass over M are gone)
-    h->ig_i2t = h->ig_t2i && (dist_knob("DIST_AMD_INTEG_I2T", 1) != 0);
+    h->ig_i2t = h->ig_t2i && (DIST_AB_KNOB("DIST_AMD_INTEG_I2T", 1) != 0);
     // ... and the I2T backward (pair sums of dX_next, dM = dM' + dY Wi) behind the fused backward: the pair-sum kernel and the I2T data-gradient GEMM are gone
-    h->ig_i2tb = h->ig_bwd && c.alpha == 2 && Ct == C4 && (dist_knob("DIST_AMD_INTEG_I2T_BWD", 1) != 0);
+    h->ig_i2tb = h->ig_bwd && c.alpha == 2 && Ct == C4 && (DIST_AB_KNOB("DIST_AMD_INTEG_I2T_BWD", 1) != 0);
     // ... and the T2I backward (dp = (dX_next + conv^T(dM')) g'(p)) behind that: the T2I data-gradient GEMM leaves the chain as well
-    h->ig_t2ib = h->ig_bwd && c.alpha == 2 && Ct == C4 && (dist_knob("DIST_AMD_INTEG_T2I_BWD", 1) != 0);
+    h->ig_t2ib = h->ig_bwd && c.alpha == 2 && Ct == C4 && (DIST_AB_KNOB("DIST_AMD_INTEG_T2I_BWD", 1) != 0);
     h->keep_mid = (dist_knob("DIST_AMD_KEEP_MID", 0) != 0);     // debugging: M' of every layer stays readable (dist_debug_tensor "mid.i")
 }
 
@@ -746,7 +746,7 @@ int ln_bwd(const Ctx& c, const LNp& l, const void* x, const float* mean, const f
     // Two-phase parameter gradients (dist_ln_bwd_args.partial): measured in the step and NOT the default - 20.03 -> 20.20 ms with the same grid
     // caps, 20.2 with 512 blocks (three alternations): the second launch sits on the data-gradient chain and costs more than the same-line
     // atomics it removes.  DIST_AMD_LN_TWO_PHASE=1 turns it on (the data-gradient chain owns the scratch: its launches are serial).
-    static const bool two_phase = dist_knob("DIST_AMD_LN_TWO_PHASE", 0) == 1;
+    static const bool two_phase = DIST_AB_KNOB("DIST_AMD_LN_TWO_PHASE", 0) == 1;
     if (two_phase && c.s != c.h->side && c.s != c.h->side2) { a.partial = c.h->ln_partial; a.partial_elems = c.h->ln_partial_elems; }
     return dist_op_layernorm_bwd(&a, c.s);
 }
@@ -830,13 +830,13 @@ static int ensure_streams(dist_handle* h) {
     // data-gradient chain): lowest priority, so the caller's stream gets freed CUs first (DIST_AMD_SIDE_PRIO=0: default priority)
     int least = 0, greatest = 0;
     hipDeviceGetStreamPriorityRange(&least, &greatest);
-    const int prio = dist_knob("DIST_AMD_SIDE_PRIO", 1) == 0 ? 0 : least;
+    const int prio = DIST_AB_KNOB("DIST_AMD_SIDE_PRIO", 1) == 0 ? 0 : least;
     bool ok = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio) == hipSuccess &&
               hipStreamCreateWithPriority(&h->side2, hipStreamNonBlocking, prio) == hipSuccess &&
               hipStreamCreateWithPriority(&h->pf, hipStreamNonBlocking, least) == hipSuccess;
     // the optional second data-gradient chain of the backward (DIST_AMD_BWD_TCHAIN=1, a measurement): created only when asked for - an extra
     // stream that merely EXISTS beside the gradient reducer's cost 4.7 ms per step (tests/test_rccl_gpu.py: 23.2 vs 18.5 ms)
-    if (dist_knob("DIST_AMD_BWD_TCHAIN", 0) == 1)
+    if (DIST_AB_KNOB("DIST_AMD_BWD_TCHAIN", 0) == 1)
         ok = ok && hipStreamCreateWithPriority(&h->chain2, hipStreamNonBlocking, 0) == hipSuccess;
     auto mk = [&](hipEvent_t& e) { ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
     h->ev_a.resize(10 * c.layers + 4); h->ev_b_dr.resize(c.layers); h->ev_b_done.resize(c.layers);
@@ -1544,7 +1544,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
     // and dX_{i+1}, the integration chain of layer i-1 needs dM_i = dM'_i + I2T^T(dX_{i+1}) - not dX_i.  DIST_AMD_BWD_TCHAIN=0: one chain.
     // Measured: 18.78 -> 20.23 ms with the fifth stream (any fifth ACTIVE stream costs that much on this system, profiles/r01_streams_and_queues.md),
     // so the default is one chain.  DIST_AMD_BWD_TCHAIN=1: own stream; 2: the second weight-gradient stream carries the temporal chain instead.
-    static const int tchain_env = dist_knob("DIST_AMD_BWD_TCHAIN", 0);
+    static const int tchain_env = DIST_AB_KNOB("DIST_AMD_BWD_TCHAIN", 0);
     const bool tchain = tchain_env > 0 && !(h->serial & 2) && (h->chain2 || tchain_env == 2);
     hipStream_t Tc = tchain ? (tchain_env == 2 ? h->side2 : h->chain2) : A;
     if (tchain && tchain_env == 2) { B2 = B; xb2.s = B; }
@@ -1617,7 +1617,7 @@ extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b,
             RUN(fork());
             Lin both = l.ffn_fc;                              // [Ci + C4][Ci]: ffn.c_fc.weight followed by temporal_ffn.c_fc1.weight (and the two biases)
             both.N = Ci + C4;
-            static const bool merge_env = (dist_knob("DIST_AMD_INTEG_WG_MERGE", 1) != 0);   // measurement knob
+            static const bool merge_env = (DIST_AB_KNOB("DIST_AMD_INTEG_WG_MERGE", 1) != 0);
             // (accumulating backward: G' and db of the two folded Linears go to this layer's scratch, [Ci + C4][Ci] then [Ci + C4])
             float* gs_w = h->bwd_accumulate ? h->ig_gscratch + (long)i * h->ig_gscratch_elems : nullptr;
             float* gs_b = gs_w ? gs_w + (long)(Ci + C4) * Ci : nullptr;

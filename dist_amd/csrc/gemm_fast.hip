@@ -1006,7 +1006,7 @@ static int launch_fast_q(const dist_gemm_args* a, int ng, int grid, hipStream_t 
 
 // 1 = launched, 0 = not this form's call
 static int try_fast_q(const dist_gemm_args* a, int ng, hipStream_t s) {
-    static const int cap = dist_knob("DIST_AMD_FAST_TILES", 0);     // tiles per block at most (0: one tile per block = gemm_fast8p_kernel)
+    static const int cap = DIST_AB_KNOB("DIST_AMD_FAST_TILES", 0);     // tiles per block at most (0: one tile per block = gemm_fast8p_kernel)
     if (cap <= 1) return 0;
     const int f = fast_q_flags(a);
     if (f < 0) return 0;
@@ -1031,9 +1031,9 @@ static int try_fast_q(const dist_gemm_args*, int, hipStream_t) { return 0; }
 // 0 = not eligible, 4 / 8 = waves of the variant that takes the shape
 static int fast_variant(const dist_gemm_args* a) {
     if (!fast_common_ok(a)) return 0;
-    static const int forced = dist_knob("DIST_AMD_FAST_NW", 0);   // measurement knob
+    static const int forced = DIST_AB_KNOB("DIST_AMD_FAST_NW", 0);   // A/B: 4 = the two-blocks-per-CU shape (timing-only library)
     // (a half-empty last column tile only pays with a deep K loop - bf16 has the branch-GEMM kernels for the rest; fp8 has no other kernel)
-    static const int kmin = dist_knob("DIST_AMD_FAST_KMIN", 768);                 // measurement knob
+    static const int kmin = DIST_AB_KNOB("DIST_AMD_FAST_KMIN", 768);
     const bool ok8 = a->N >= 256 && !(a->N % 256 > 0 && (a->N % 256 < 128 || (a->K < kmin && !(a->flags & DIST_EPI_FP8))));
     const bool ok4 = a->N >= 128 && a->N % 128 == 0;
     // measured (tools/bench_fastk.py, profiles/r01_fast_gemm_shapes.md): the two-block shape hides ~40 % of the fixed
@@ -1054,7 +1054,7 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
     RUN_(dist_max_smem(attr, reinterpret_cast<const void*>(gemm_fast_kernel<NW>), smem));
     const long tiles = ((a->M + BM - 1) / BM) * ((a->N + S::BN - 1) / S::BN);
     // column-tile groups: as few groups as keep one group's weight rows under ~2.5 MB (DIST_AMD_FAST_NG forces a count; 1 = off)
-    static const int forced_ng = dist_knob("DIST_AMD_FAST_NG", 0);
+    static const int forced_ng = DIST_AB_KNOB("DIST_AMD_FAST_NG", 0);
     const int tiles_n = (a->N + S::BN - 1) / S::BN;
     int ng = forced_ng > 0 ? forced_ng : 1;
     if (forced_ng == 0) {
@@ -1107,5 +1107,8 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
 int dist_k_gemm_fast(const dist_gemm_args* a, hipStream_t s) {
     const int v = fast_variant(a);
     if (v == 0) return 0;
-    return v == 8 ? launch_fast<8>(a, s) : launch_fast<4>(a, s);
+#ifdef DIST_AMD_MEASURE
+    if (v == 4) return launch_fast<4>(a, s);              // (measured and rejected: profiles/r01_fast_gemm_shapes.md, r04_step_knobs.md)
+#endif
+    return launch_fast<8>(a, s);
 }

@@ -524,7 +524,7 @@ int launch_dma(const dist_gemm_args& a, hipStream_t s) {
     auto kern = gemm_nt_dma_kernel<BM, BN, WM, WN, GENERIC, MINW, OGEN>;
     RUN_(dist_max_smem(attr, reinterpret_cast<const void*>(kern), smem));
     const long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    static const int rotate = dist_knob("DIST_AMD_NT_ROTATE", 0);   // measurement knob: 1 = rotated K order, 2 = no tile prefetch
+    static const int rotate = DIST_AB_KNOB("DIST_AMD_NT_ROTATE", 0);   // measurement knob: 1 = rotated K order, 2 = no tile prefetch
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), smem, s, a, rotate);
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
@@ -554,17 +554,17 @@ int dispatch(const dist_gemm_args& a, hipStream_t s) {
     // 8-wave blocks (16 waves) share a CU where the 4-wave shapes had 2-3 blocks of 4 (conv3x3 69.6 -> 59.3 us, 384x384 Linear
     // 48.6 -> 44.8 us, 384->96 Linear 18.3 -> 16.7 us alone; profiles/r01_nt_8wave.md).  DIST_AMD_NT_W8=0 restores the 4-wave shapes
     // (measurement knob: bit 0 = N % 96 shapes, bit 1 = plain K % 64, bit 2 = generic).
-    static const int w8 = dist_knob("DIST_AMD_NT_W8", 7);
+    static const int w8 = DIST_AB_KNOB("DIST_AMD_NT_W8", 7);
     // DIST_AMD_NT_OCC=0 (measurement knob): the N % 96 shape compiled for 4 instead of 6 waves per SIMD (two 8-wave blocks per CU
     // instead of three).  Measured (profiles/r02_nt_occupancy.md): conv3x3 59.6 -> 55.8 us, step -0.15 ms with three blocks; the
     // generic 128x128x32 shape needs spills at 80 registers and gains nothing, so only N % 96 has the variant.
-    static const int occ = dist_knob("DIST_AMD_NT_OCC", 1);
+    static const int occ = DIST_AB_KNOB("DIST_AMD_NT_OCC", 1);
     if constexpr (std::is_same<T, bf16_t>::value) {
         // LDS-DMA loader (three stages in flight, no staging registers).  DIST_AMD_NT_DMA=0: the register-staged loader.
         static const int dma = dist_knob("DIST_AMD_NT_DMA", 1);
         if (dma && a.K % 32 == 0) {
-            static const bool oplain_on = (dist_knob("DIST_AMD_NT_OPLAIN", 1) != 0);   // measurement knob
-            const bool op = oplain_on && a.omap.mode == DIST_OM_PLAIN;
+            static const bool oplain_on = (DIST_AB_KNOB("DIST_AMD_NT_OPLAIN", 1) != 0);   // A/B: 0 = the generic out-map instantiation for plain outputs too
+            const bool op = (!DIST_AB || oplain_on) && a.omap.mode == DIST_OM_PLAIN;
             if (n96 && a.N == 96 && a.M > 768l * 128)                                                      // 392 blocks: one round of 2 per CU
                 return op ? launch_dma<256, 96, 8, 1, true, 4, false>(a, s) : launch_dma<256, 96, 8, 1, true, 4>(a, s);
             if (n96) return op ? launch_dma<128, 96, 4, 2, true, 6, false>(a, s) : launch_dma<128, 96, 4, 2, true, 6>(a, s);
@@ -573,13 +573,21 @@ int dispatch(const dist_gemm_args& a, hipStream_t s) {
         // A block is a serial chain of latency-bound K-tile steps, so a launch takes (rounds of resident blocks) x (one block's
         // time): 100 352 rows as 128-row tiles are 784 blocks on 768 resident slots (256 CUs x 3) - TWO rounds for 16 blocks.
         // 256-row tiles (8 x 1 waves, 32 x 96 per wave) make the same work 392 blocks = one round.  DIST_AMD_NT_BM256=0: off.
-        static const int bm256 = dist_knob("DIST_AMD_NT_BM256", 1);
+        static const int bm256 = DIST_AB_KNOB("DIST_AMD_NT_BM256", 1);
         if (n96 && a.N == 96 && bm256 && a.M > 768l * 128) return launch<T, 256, 96, 32, 8, 1, true, 4>(a, s);
         if (n96 && (occ & 1)) return launch<T, 128, 96, 32, 4, 2, true, 6>(a, s);
     }
-    if (n96) return (w8 & 1) ? launch<T, 128, 96, 32, 4, 2, true>(a, s) : launch<T, 128, 96, 32, 4, 1, true>(a, s);
-    if (plain && a.K % 64 == 0) return (w8 & 2) ? launch<T, 128, 128, 64, 2, 4, false>(a, s) : launch<T, 128, 128, 64, 2, 2, false>(a, s);
-    return (w8 & 4) ? launch<T, 128, 128, 32, 2, 4, true>(a, s) : launch<T, 128, 128, 32, 2, 2, true>(a, s);
+    // (the rejected shapes - 4-wave blocks, the 4-waves-per-SIMD build of the N % 96 shape - exist in the timing-only library only)
+    if constexpr (DIST_AB) {
+        if (n96 && !(w8 & 1)) return launch<T, 128, 96, 32, 4, 1, true>(a, s);
+        if (!n96 && plain && a.K % 64 == 0 && !(w8 & 2)) return launch<T, 128, 128, 64, 2, 2, false>(a, s);
+        if (!n96 && !(plain && a.K % 64 == 0) && !(w8 & 4)) return launch<T, 128, 128, 32, 2, 2, true>(a, s);
+    }
+    if constexpr (!std::is_same<T, bf16_t>::value || DIST_AB) {        // (bf16 N % 96 shapes all returned above: three blocks per CU)
+        if (n96) return launch<T, 128, 96, 32, 4, 2, true>(a, s);
+    }
+    if (plain && a.K % 64 == 0) return launch<T, 128, 128, 64, 2, 4, false>(a, s);
+    return launch<T, 128, 128, 32, 2, 4, true>(a, s);
 }
 
 }  // namespace

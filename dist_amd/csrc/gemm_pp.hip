@@ -652,12 +652,12 @@ static int launch_pp(const dist_gemm_args* a, int ng, int grid, hipStream_t s) {
 
 // returns 1 if handled, 0 if the call is not this kernel's (the caller falls through to gemm_fast8p_kernel), < 0 on error
 int dist_k_gemm_pp(const dist_gemm_args* a, int ngroups, hipStream_t s) {
-    static const int on = dist_knob("DIST_AMD_FAST_PP", 0);
+    static const int on = DIST_AB_KNOB("DIST_AMD_FAST_PP", 0);
     if (!on) return 0;
     const int f = pp_variant(a);
     if (f < 0) return 0;
     const long tiles = ((a->M + PP_BM - 1) / PP_BM) * (a->N / PP_BN);
-    static const int cap = dist_knob("DIST_AMD_PP_GRID", 256);
+    static const int cap = DIST_AB_KNOB("DIST_AMD_PP_GRID", 256);
     int grid = cap < 8 ? 8 : (cap > 256 ? 256 : cap & ~7);
     if (tiles < 2 * grid) return 0;                       // fewer than two tiles per block: nothing to ping-pong with
     switch (f) {

@@ -381,7 +381,7 @@ int launch(const dist_gemm_tn_args& a, hipStream_t s) {
     if (msplit > max_split) msplit = max_split;
     if (msplit < 1) msplit = 1;
     int chunk = (int)((a.M + msplit - 1) / msplit);
-    static const bool pairs = (dist_knob("DIST_AMD_TN_PAIRS", 1) != 0);   // measurement knob: 0 = no fast path
+    static const bool pairs = (DIST_AB_KNOB("DIST_AMD_TN_PAIRS", 1) != 0);   // A/B: 0 = no fast path
     const int CH = (MODES == 0 && pairs) ? 2 * BR : BR;   // plain maps: whole step pairs per block (the kernel's all-valid fast path)
     chunk = (chunk + CH - 1) / CH * CH;
     msplit = (a.M + chunk - 1) / chunk;
@@ -413,7 +413,7 @@ int dispatch2(const dist_gemm_tn_args& a, hipStream_t s) {
     // (216-280 registers: 1-2 blocks of 4 waves per CU; now 119-152: 8 waves per CU in one block).  10-20 % faster per launch
     // alone (conv3x3 dW 95.5 -> 77.4 us, 384x768 dW 71.9 -> 62.0 us); capping the registers at 128 for two 8-wave blocks spills
     // and loses (92 us).  DIST_AMD_TN_W8=0: the 4-wave shapes (measurement knob; they exist for plain and runtime modes only).
-    static const int w8 = dist_knob("DIST_AMD_TN_W8", 1);
+    static const int w8 = DIST_AB_KNOB("DIST_AMD_TN_W8", 1);
     // (the large plain gradients - both extents >= 192, >= 8192 rows - run on gemm_tn8p_kernel, gemm_tn8p.hip: dist_op_gemm_tn tries it first;
     //  192 x 256 / 192 x 192 register-staged tiles and an LDS-DMA ring in THIS kernel's lock-step schedule were measured and lost, profiles/r03_tn_big_tiles.md)
     if (w8 || MODES > 0) {
@@ -422,7 +422,7 @@ int dispatch2(const dist_gemm_tn_args& a, hipStream_t s) {
         if (j96) return launch<T, 128, 96, 4, 2, TR, MODES>(a, s);
         return launch<T, 128, 128, 2, 4, TR, MODES>(a, s);
     }
-    if constexpr (MODES <= 0) {
+    if constexpr (DIST_AB && MODES <= 0) {                  // the 4-wave shapes: timing-only library
         if (i96 && j96) return launch<T, 96, 96, 2, 2, TR, MODES>(a, s);
         if (i96) return launch<T, 96, 128, 2, 2, TR, MODES>(a, s);
         if (j96) return launch<T, 128, 96, 2, 2, TR, MODES>(a, s);
@@ -436,8 +436,8 @@ int dispatch(const dist_gemm_tn_args& a, hipStream_t s) {
     if (a.amap.mode == DIST_RM_PLAIN && a.bmap.mode == DIST_RM_PLAIN && a.taps == 1) return dispatch2<T, TR, 0>(a, s);
     // the combinations the engine uses (conv_t / temporal-ffn / stem, conv3x3, I2T, T2I weight gradients) with constant modes
     if constexpr (std::is_same<T, bf16_t>::value && TR) {
-        static const int w8 = dist_knob("DIST_AMD_TN_W8", 1);
-        static const int spec = dist_knob("DIST_AMD_TN_MODES", 1);   // 0: runtime modes (measurement knob)
+        static const int w8 = DIST_AB_KNOB("DIST_AMD_TN_W8", 1);
+        static const int spec = DIST_AB_KNOB("DIST_AMD_TN_MODES", 1);   // A/B: 0 = runtime modes for the engine's combinations too
         const int modes = a.amap.mode * 8 + a.bmap.mode;
         auto steppable = [](const dist_rowmap& rm) {       // rowmap_inc_ok for a step of BR rows
             switch (rm.mode) {

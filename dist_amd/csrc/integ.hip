@@ -1269,7 +1269,7 @@ extern "C" int dist_op_integration_fwd(const dist_integ_args* a, void* stream) {
         if (a->Xhat) { if (a->Na || a->Nb) return DIST_ERR_ARG; mode = 2; }
         else { if (!(a->Na && a->Nb && a->ln_w && a->ln_b && a->ln_t_w && a->ln_t_b)) return DIST_ERR_ARG; mode = 1; }
     }
-    static const int bm_env = dist_knob("DIST_AMD_INTEG_BM", 0);     // measurement knob: 64 / 128
+    static const int bm_env = DIST_AB_KNOB("DIST_AMD_INTEG_BM", 0);     // A/B: 64-row tiles, two workgroups per CU (timing-only library)
     int BM = bm_env == 64 || bm_env == 128 ? bm_env : 128;
     if (BM / a->t < 1 || (BM % a->t)) return DIST_ERR_ARG;
     IgArgs k;
@@ -1293,6 +1293,8 @@ extern "C" int dist_op_integration_fwd(const dist_integ_args* a, void* stream) {
     k.groups = (a->L + TOK - 1) / TOK;
     k.eps = a->eps > 0.f ? a->eps : 1e-5f;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (BM == 128) return launch_integ<384, 96, 128>(k, mode, s);
-    return launch_integ<384, 96, 64>(k, mode, s);
+#ifdef DIST_AMD_MEASURE
+    if (BM == 64) return launch_integ<384, 96, 64>(k, mode, s);        // (measured, profiles/r03_integ_fused.md: faster in inference, slower in training)
+#endif
+    return launch_integ<384, 96, 128>(k, mode, s);
 }

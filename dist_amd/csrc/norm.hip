@@ -343,7 +343,7 @@ extern "C" int dist_op_layernorm_bwd(const dist_ln_bwd_args* a, void* stream) {
     // same-line atomic traffic, not HBM, sets the time, so fewer, longer blocks win (measured, tools/bench_ln2.py:
     // dual-input 62 -> 52 us at 256 blocks, single-input 42 -> 33 us at 384); without them 1024 blocks stream best
     const bool want_w = a->dw || a->db || a->dw2 || a->db2;
-    static const int gcap_env = dist_knob("DIST_AMD_LN_GCAP", 0);     // measurement knob
+    static const int gcap_env = DIST_AB_KNOB("DIST_AMD_LN_GCAP", 0);
     const bool two_phase_on = true;                        // (whoever passes `partial` asks for it; the engine does so only under DIST_AMD_LN_TWO_PHASE=1)
     // two-phase parameter gradients (round 3): per-block sums to `partial`, a second launch adds them in block order - no same-line atomics at
     // the end of every block, so the grid no longer has to be capped for them, and the sums are bit-repeatable
@@ -351,7 +351,7 @@ extern "C" int dist_op_layernorm_bwd(const dist_ln_bwd_args* a, void* stream) {
     long gcap = gcap_env > 0 ? gcap_env : (!want_w ? 1024 : (a->dy2 ? 256 : 384));
     bool two_phase = want_w && two_phase_on && a->partial != nullptr;
     if (two_phase) {
-        static const int gcap2_env = dist_knob("DIST_AMD_LN_GCAP2", 0);   // measurement knob
+        static const int gcap2_env = DIST_AB_KNOB("DIST_AMD_LN_GCAP2", 0);
         const long gcap2 = gcap2_env > 0 ? gcap2_env : gcap;       // (512 blocks: +0.4 ms in the step - the caps found for the atomics stay)
         if ((g > gcap2 ? gcap2 : g) * 4 * a->C <= a->partial_elems) gcap = gcap2; else two_phase = false;
     }

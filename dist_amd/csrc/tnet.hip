@@ -719,7 +719,7 @@ extern "C" int dist_op_temporal_net_fwd(const dist_tnet_args* a, void* stream) {
     k.U = static_cast<bf16_t*>(a->U); k.V = static_cast<bf16_t*>(a->V);
     k.mean = a->mean; k.rstd = a->rstd;
     static const int dbg = dist_measure_knob("DIST_AMD_TNET_DBG", 0);
-    static const int stagger = dist_knob("DIST_AMD_TNET_STAGGER", 0);
+    static const int stagger = DIST_AB_KNOB("DIST_AMD_TNET_STAGGER", 0);     // A/B (profiles/r03_tnet_fused.md: flat to +10 %)
     k.dbg = dbg; k.stagger = stagger;
     k.clips = a->clips; k.T = a->T; k.G = a->G; k.N = a->G * a->G; k.tk = a->tk; k.eps = a->eps;
     hipStream_t s = static_cast<hipStream_t>(stream);

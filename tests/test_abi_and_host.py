@@ -234,5 +234,10 @@ def test_result_changing_knobs_exist_only_in_a_measure_build():
     sel = set(re.findall(r'dist_knob\("(DIST_AMD_[A-Z0-9_]+)"', txt))
     mea = set(re.findall(r'dist_measure_knob\("(DIST_AMD_[A-Z0-9_]+)"', txt))
     assert mea == measure_only and not (sel & measure_only), (mea ^ measure_only, sel & measure_only)
+    # round 5: the product library reads at most 15 selectors - one per fused / fast kernel that has a fallback, the grid caps, the
+    # serial-order switch; every A/B reference of a measured-and-rejected variant is a DIST_AB_KNOB (a constant outside the timing-only library)
+    ab = set(re.findall(r'DIST_AB_KNOB\("(DIST_AMD_[A-Z0-9_]+)"', txt))
+    assert len(sel) <= 15 and not (sel & ab) and len(ab) >= 20, (sorted(sel), sorted(sel & ab))
     common = open(os.path.join(csrc, "common.h")).read()
+    assert "#define DIST_AB_KNOB(name, dflt) (dflt)" in common
     assert "#ifdef DIST_AMD_MEASURE" in common and "inline int dist_measure_knob(const char*, int dflt) { return dflt; }" in common
