@@ -472,6 +472,10 @@ extern "C" int dist_op_gemm_tn(const dist_gemm_tn_args* a, void* stream) {
         const int rc = dist_k_gemm_tn8p(a, s);
         if (rc != 0) return rc < 0 ? rc : DIST_OK;
     }
+    {   // the 3x3 frame convolution's gradient: all nine taps from one LDS-resident frame (conv_dw.hip)
+        const int rc = dist_k_conv3x3_dw(a, s);
+        if (rc != 0) return rc < 0 ? rc : DIST_OK;
+    }
     if (a->dtype == DIST_BF16) return a->use_tr ? dispatch<bf16_t, true>(*a, s) : dispatch<bf16_t, false>(*a, s);
     return dispatch<float, false>(*a, s);
 }

@@ -41,6 +41,8 @@ int dist_k_gemm_pp(const dist_gemm_args* a, int ngroups, hipStream_t s);
 int dist_k_gemm_small(const dist_gemm_args* a, hipStream_t s);       // M < 1024 (gemm_small.hip)
 // two-group LDS-DMA weight-gradient GEMM for the large plain gradients (gemm_tn8p.hip): 1 = launched, 0 = not its shape, <0 = error
 int dist_k_gemm_tn8p(const dist_gemm_tn_args* a, hipStream_t s);
+// frame-resident nine-tap weight gradient of the 3x3 frame convolution (conv_dw.hip): 1 = launched, 0 = not its call, <0 = error
+int dist_k_conv3x3_dw(const dist_gemm_tn_args* a, hipStream_t s);
 // fused TemporalNet (tnet.hip): does dist_op_temporal_net_fwd take this geometry?
 bool dist_k_tnet_fwd_eligible(int dtype, int Ct, int G, int tk);
 // fused IntegrationNetwork forward (integ.hip): eligibility, and the all-layers form of dist_op_integration_pack (`descs_dev`: n descriptors

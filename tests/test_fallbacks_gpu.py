@@ -7,7 +7,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KNOBS = ["DIST_AMD_TN8P", "DIST_AMD_INTEG_FUSED", "DIST_AMD_INTEG_BWD_FUSED", "DIST_AMD_TNET_FUSED", "DIST_AMD_TNET_BWD_FUSED", "DIST_AMD_ATTN_FULLROW",
-         "DIST_AMD_LNFOLD", "DIST_AMD_ROWSTATS", "DIST_AMD_NT_DMA", "DIST_AMD_FAST_8P"]
+         "DIST_AMD_LNFOLD", "DIST_AMD_ROWSTATS", "DIST_AMD_NT_DMA", "DIST_AMD_FAST_8P", "DIST_AMD_CONV9"]
 # (round 5: the selectors of measured-and-rejected variants - DIST_AMD_INTEG_XHAT / _T2I / _I2T / ..., the 4-wave GEMM shapes, the stream-layout experiments -
 #  are DIST_AB_KNOB constants in the product library and exist only in the timing-only one: python -m dist_amd.build --measure)
 

@@ -352,6 +352,41 @@ def test_gemm_tn_taps_conv_layout(gpu_lib, dtype, use_tr, mode, kw, taps):
         torch.testing.assert_close(out[:, :, tap].double(), ref, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("frames,sign", [(8, 1), (37, -1), (512, 1), (203, 1)])
+def test_gemm_tn_conv3x3_frame_resident_kernel(gpu_lib, frames, sign):
+    """The 3x3 frame convolution's weight gradient (dist.py:54-60 c_fc2, 96 -> 96 channels on the 14 x 14 plane) runs on conv_dw.hip: all nine taps
+    from one LDS-resident frame (padded-plane image, taps = row shifts, zeros from the buffer descriptor).  Against fp64 for every tap in the
+    reference's [Co][Ci][taps] layout with the fused bias gradient, both tap directions, frame counts that leave blocks with unequal shares;
+    accumulates INTO the destination; bit-repeatable; equal to the generic tap-per-tile kernel up to fp32 summation order."""
+    from dist_amd import ops
+    G, NI, K, taps = 14, 96, 96, 9
+    M = frames * G * G
+    g = torch.Generator(device="cuda"); g.manual_seed(frames)
+    A = (torch.randn(M, NI, device="cuda", generator=g) + 0.03).to(torch.bfloat16)
+    B = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    part = torch.empty(16 << 20, dtype=torch.float32, device="cuda")
+    bm = ops.rowmap(MODES["spatial"], G, 0, sign)
+
+    def run(init=0.0, **kw):
+        out = torch.full((NI, K, taps), init, dtype=torch.float32, device="cuda")
+        cs = torch.full((NI,), init, dtype=torch.float32, device="cuda")
+        ops.gemm_tn(A, B, out, M, NI, K, taps=taps, bmap=bm, so_i=K * taps, so_tap=1, so_outer=taps, inner=1, colsum=cs, partial=part, **kw)
+        return out, cs
+    out, cs = run()
+    scale = float((A.double().t() @ B.double()).abs().max())
+    for tap in range(taps):
+        ref = A.double().t() @ gather(B, "spatial", M, tap, taps, p0=G, sign=sign)
+        assert float((out[:, :, tap].double() - ref).abs().max()) < 2e-5 * scale, tap
+    refb = A.double().sum(0)
+    assert float((cs.double() - refb).abs().max() / refb.abs().max()) < 2e-5
+    out2, cs2 = run()
+    assert torch.equal(out, out2) and torch.equal(cs, cs2)            # the second phase adds the blocks in index order
+    out3, cs3 = run(init=0.25)
+    assert float((out3 - 0.25 - out).abs().max()) < 1e-5 * scale and float((cs3 - 0.25 - cs).abs().max()) < 1e-4 * float(refb.abs().max())
+    out4, _ = run(max_blocks=256)                                       # any block count: the same sums up to fp32 order
+    assert float((out4 - out).abs().max()) < 2e-5 * scale
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("Nn", [9, 196])
 def test_gemm_tn_skipcls_a(gpu_lib, dtype, Nn):
