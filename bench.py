@@ -339,7 +339,7 @@ def main():
                                                   "right behind it (the engine embeds only the kept frames); path_tflops / path_mfma_frac use `executed`"}
         # whole-step HBM-side traffic from the committed PMC passes (tools/pmc_step.sh: FETCH_SIZE x2 + WRITE_SIZE over every kernel of
         # one step, Infinity-Cache hits included) against this run's step time; null when the file is absent or the config differs
-        tj = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_step_traffic.json") for r in ("r04", "r03")) if os.path.exists(q)), "")
+        tj = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_step_traffic.json") for r in ("r05", "r04", "r03")) if os.path.exists(q)), "")
         if args.config == "b16_8+16f" and b == 32 and tj:
             with open(tj) as f:
                 tr = json.load(f)

@@ -56,7 +56,7 @@ if "--json" in opt:
            "in_situ_launches": dom[1], "in_situ_launches_per_step": round(dom[1] / steps, 2), "in_situ_avg_us": round(dom[3], 1),
            "total_kernel_ms_per_step": round(tot / 1e3 / steps, 2)}
     fam = lambda key: sum(r[2] for r in rows if key(r[0])) / 1e3 / steps
-    out["ms_per_step_in_situ"] = {"gemm_tn_family": round(fam(lambda n: "gemm_tn" in n or "tn_reduce" in n or "tn8p_reduce" in n), 3),
+    out["ms_per_step_in_situ"] = {"gemm_tn_family": round(fam(lambda n: "gemm_tn" in n or "tn_reduce" in n or "tn8p_reduce" in n or "conv3x3_dw" in n), 3),
                                   "gemm_fast8p": round(fam(lambda n: "gemm_fast8p" in n), 3), "attn": round(fam(lambda n: "attn_kernel" in n), 3),
                                   "integ": round(fam(lambda n: "integ_" in n), 3), "tnet": round(fam(lambda n: "tnet_" in n), 3)}
     if serial is not None:
