@@ -50,8 +50,13 @@ struct FragSet { bf16x8 a[8]; bf16x8 b[4]; };
 
 // Epilogue shared by the two main loops: accumulators -> (LayerNorm fold, bias, residual, QuickGELU) -> bf16 -> per-wave LDS
 // staging -> full 128-byte rows.  acc[i][j][r] is output row mw + i*16 + (lane & 15), column nw + j*16 + (lane >> 4)*4 + r.
+// EARLY_OK: the primary output may leave row block by row block behind its conversion (the bf16 two-group kernel; in the e4m3 instantiation the
+// longer epilogue made hipcc spill inside the K loop, so it keeps the old order)
+// AUX (with EARLY_OK, the same kernel): bias / column sums / row statistics of the tile were prefetched into LDS by the kernel's prologue
+// (`aux`: bias[256] | colsum[256] | mean[256] | rstd[256] floats), so the epilogue starts without a global-load latency
+template <bool EARLY_OK = false>
 DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, const int wid, const int lane,
-                       const int m0, const int n0, const int wm, const int wn) {
+                       const int m0, const int n0, const int wm, const int wn, const bool late_flush = false, const char* aux = nullptr) {
     const int li = lane & 15, lg = lane >> 4;
     const int M = (int)p.M, N = p.N;
     // ---- epilogue through LDS: per-wave region of 128 rows x 128 B, 16-B chunk c of row r at chunk c ^ (r & 7) ----
@@ -87,14 +92,22 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
             *reinterpret_cast<uint4*>(ew + r * 128 + ((cchunk ^ (r & 7)) << 4)) = rv[it];
         }
     }
+    const bool from_lds = EARLY_OK && aux != nullptr;
     float bias4[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
+        if (from_lds) {
+            const f32x4 b = (flags & DIST_EPI_BIAS) ? *reinterpret_cast<const f32x4*>(aux + (wn * 64 + j * 16 + lg * 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = nw + j * 16 + lg * 4 + r;
-            bias4[j][r] = ((flags & DIST_EPI_BIAS) && n < N) ? p.bias[n] : 0.f;
+            for (int r = 0; r < 4; ++r) bias4[j][r] = b[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = nw + j * 16 + lg * 4 + r;
+                bias4[j][r] = ((flags & DIST_EPI_BIAS) && n < N) ? p.bias[n] : 0.f;
+            }
         }
+    }
     const bool lnf = (flags & DIST_EPI_LNFOLD) != 0;
     if (lnf) {
         // LayerNorm folded into this GEMM: A held the raw rows, B = W diag(gamma); v = rstd[m] * (acc - mean[m] * colsum[n]) + bias'
@@ -102,16 +115,27 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
         const float* __restrict__ st = static_cast<const float*>(p.aux);     // [2][M]: mean, rstd
         float cs4[4][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+            if (from_lds) {
+                const f32x4 c = *reinterpret_cast<const f32x4*>(aux + 1024 + (wn * 64 + j * 16 + lg * 4) * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = nw + j * 16 + lg * 4 + r;
-                cs4[j][r] = n < N ? p.bias2[n] : 0.f;
+                for (int r = 0; r < 4; ++r) cs4[j][r] = c[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = nw + j * 16 + lg * 4 + r;
+                    cs4[j][r] = n < N ? p.bias2[n] : 0.f;
+                }
             }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int m = min(mw + i * 16 + li, M - 1);
-            const float mean = st[m], rstd = st[(long)M + m];
+            float mean, rstd;
+            if (from_lds) {
+                mean = *reinterpret_cast<const float*>(aux + 2048 + (wm * 128 + i * 16 + li) * 4);
+                rstd = *reinterpret_cast<const float*>(aux + 3072 + (wm * 128 + i * 16 + li) * 4);
+            } else { mean = st[m]; rstd = st[(long)M + m]; }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -119,6 +143,26 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
         }
     }
     const bool act_only = (flags & DIST_EPI_ACT2) && !C;
+    // The primary output (C, or C2 when only the activated tensor is kept) leaves row block by row block, right behind its conversion:
+    // the two 8-row pieces of block i are stored while blocks i + 1 ... are still being converted, instead of all 16 behind the last
+    // conversion (round 5: the stores of a tile start ~1 us earlier; same values, same addresses).
+    // measured (tools/r05_ef_check.sh, two alternations): in_proj (LN fold + head-major) +2...4 %, c_fc 0...+1 %; with a residual tile in the
+    // staging region (out_proj / c_proj) -1...+0.5 %: those keep the old order.  (DIST_AMD_FAST_EARLY_FLUSH=0 in the timing-only library: the old order)
+    const bool early = EARLY_OK && (!DIST_AB || !late_flush) && !(flags & DIST_EPI_RES);
+    bf16_t* __restrict__ const dst1 = act_only ? C2 : C;
+    const int ld1 = act_only ? p.ldc2 : p.ldc;
+    int hfr1 = 0, htok1 = 0;
+    if (heads_om) { hfr1 = (mw + crow) / p.omap.p0; htok1 = (mw + crow) - hfr1 * p.omap.p0; }
+    auto flush_piece = [&](const int it) __attribute__((always_inline)) {
+        const int r = it * 8 + crow;
+        const int m = mw + r, n = nw + cchunk * 8;
+        const uint4 v = *reinterpret_cast<const uint4*>(ew + r * 128 + ((cchunk ^ (r & 7)) << 4));
+        if (m < M && n < N) {
+            if (heads_om) store16_nt(dst1 + ((((long)hfr1 * p.omap.p1 + hp_head) * 3 + hp_part) * p.omap.p0 + htok1) * 64 + cchunk * 8, v);
+            else store16_nt(dst1 + dest_row(m) * ld1 + n, v);
+        }
+        if (heads_om) { htok1 += 8; if (htok1 >= p.omap.p0) { htok1 -= p.omap.p0; ++hfr1; } }      // (the launcher checks p0 >= 16)
+    };
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int r = i * 16 + li;
@@ -140,6 +184,11 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
             }
             store4(slot, v);
         }
+        if (dst1 && early) { flush_piece(2 * i); flush_piece(2 * i + 1); }
+    }
+    if (dst1 && !early) {                                 // all 16 pieces behind the last conversion
+#pragma unroll
+        for (int it = 0; it < 16; ++it) flush_piece(it);
     }
     // C tiles are written once and read by a later kernel: streaming stores keep them from evicting the A / B panels that
     // the other column tiles on this XCD are still re-reading from L2 (QKV: 208 -> 189 us, FETCH_SIZE 350 -> 264 MB)
@@ -212,11 +261,9 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
                 atomicMax(reinterpret_cast<unsigned*>(p.out8_amax), __float_as_uint(amax));
         }
     };
-    if (act_only) {
-        if (C2) flush(C2, p.ldc2);
+    if (act_only) {                                       // (C2 left with the conversion loop above)
         if (flags & DIST_EPI_OUT8) out8_pass();
-    } else {
-        if (C) flush(C, p.ldc);                           // (NULL with DIST_EPI_OUT8: the e4m3 image is the only output)
+    } else {                                              // (C left with the conversion loop above; NULL with DIST_EPI_OUT8: the e4m3 image is the only output)
         if ((flags & DIST_EPI_ROWSTATS) && nw < N) {
             // DIST_EPI_ROWSTATS: sum and sum of squares of the wave's 64 stored columns (one slice; N % 64 == 0), read back from the
             // staged bf16 tile while its stores drain - the accumulators are dead here (inside the conversion loop above the same
@@ -260,7 +307,8 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
 // XCD ranges an XCD works on ONE group for (nearly) its whole share: the group's weight rows (<= ~2.4 MB) stay in its 4 MB
 // L2 while the activation panels stream through, instead of all of W (3.5 - 4.7 MB for the QKV / MLP GEMMs) being evicted
 // and re-fetched for every batch of row tiles.
-DEV void fast_tile(const dist_gemm_args& p, const int ngroups, const int BN, int& tm, int& tn) {
+DEV void fast_tile(const dist_gemm_args& p, const int ngroups_flags, const int BN, int& tm, int& tn) {
+    const int ngroups = ngroups_flags & 0xffff;           // (bit 16: the late-flush A/B switch of the timing-only library)
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (int)((p.M + BM - 1) / BM);
     const int nblk = tiles_m * tiles_n;
@@ -454,6 +502,7 @@ constexpr int P8_HALF = 128 * P8_BK * 2;                  // 16 KB
 constexpr int P8_BUF = P8_HALF;                           // second buffer of a half-tile: right behind the first
 constexpr int P8_A0 = 0, P8_A1 = 2 * P8_HALF, P8_B0 = 4 * P8_HALF, P8_B1 = 6 * P8_HALF;
 constexpr int P8_LDS = 8 * P8_HALF;                       // 128 KB
+constexpr int P8_AUX = P8_LDS;                            // + 4 KB behind the ring in the bf16 kernel: the epilogue's vectors
 
 template <int N> DEV void wait_vm() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -641,6 +690,23 @@ __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_arg
         close_phase();
     };
 
+    // the epilogue's per-column / per-row vectors of this tile go to LDS first (4-byte LDS-DMA, 16 x 256 B over the 8 waves: wave w moves
+    // floats (w & 1) * 128 ... + 128 of array w >> 1 = bias | column sums | mean | rstd); they are older than every operand piece, so the
+    // first counted wait retires them and the prologue's barrier publishes them.  Entries beyond N / M read as zero (never stored).
+    const bool aux_lds = !FP8 && (!DIST_AB || !(ngroups & 0x20000));
+    if (aux_lds) {
+        const int arr = wid >> 1;
+        const bool lnf = (p.flags & DIST_EPI_LNFOLD) != 0;
+        if (arr == 0 ? (p.flags & DIST_EPI_BIAS) != 0 : lnf) {
+            const float* st = static_cast<const float*>(p.aux);
+            const float* src = arr == 0 ? p.bias : arr == 1 ? p.bias2 : arr == 2 ? st : st + M;
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (arr < 2 ? N : M) * 4, 0x00020000);
+            const unsigned v = (unsigned)((arr < 2 ? n0 : m0) + (wid & 1) * 128 + lane) * 4;
+            char* d = smem + P8_AUX + arr * 1024 + (wid & 1) * 512;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)d, 4, v, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(d + 256), 4, v, 256, 0, 0);
+        }
+    }
     // prologue: tiles 0 and 1 in the steady-state issue order; A-h0, B-h0, B-h1 of tile 0 must have landed (five half-tiles behind)
     stage(P8_A0, 0); stage(P8_B0, 0); stage(P8_B1, 0); stage(P8_A1, 0);
     stage(P8_A0, 1); stage(P8_B0, 1); stage(P8_B1, 1); stage(P8_A1, 1);
@@ -680,7 +746,7 @@ __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_arg
                 for (int r = 0; r < 4; ++r) acc[i][j][r] *= sa * sb4[j][r];
         }
     }
-    fast_epilogue(p, acc, smem, wid, lane, m0, n0, wr, wc);
+    fast_epilogue<!FP8>(p, acc, smem, wid, lane, m0, n0, wr, wc, (ngroups & 0x10000) != 0, aux_lds ? smem + P8_AUX : nullptr);
 }
 
 
@@ -1093,8 +1159,10 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
         const int q = try_fast_q(a, ng, s);
         if (q != 0) return q;
         static DistSmemOnce attr8;
-        RUN_(dist_max_smem(attr8, reinterpret_cast<const void*>(gemm_fast8p_kernel<false>), smem8));
-        hipLaunchKernelGGL(gemm_fast8p_kernel<false>, dim3((unsigned)tiles), dim3(512), smem8, s, *a, ng);
+        RUN_(dist_max_smem(attr8, reinterpret_cast<const void*>(gemm_fast8p_kernel<false>), smem8 + 4096));
+        static const int late = DIST_AB_KNOB("DIST_AMD_FAST_EARLY_FLUSH", 1) == 0 ? 0x10000 : 0;      // A/B: the primary output's stores behind the last conversion
+        static const int gaux = DIST_AB_KNOB("DIST_AMD_FAST_AUX_LDS", 1) == 0 ? 0x20000 : 0;          // A/B: the epilogue's vectors by global loads
+        hipLaunchKernelGGL(gemm_fast8p_kernel<false>, dim3((unsigned)tiles), dim3(512), smem8 + 4096, s, *a, ng | late | gaux);
         HIP_CHECK_RET(hipGetLastError());
         return 1;
     }
