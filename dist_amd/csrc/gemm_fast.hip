@@ -54,25 +54,37 @@ struct FragSet { bf16x8 a[8]; bf16x8 b[4]; };
 // longer epilogue made hipcc spill inside the K loop, so it keeps the old order)
 // AUX (with EARLY_OK, the same kernel): bias / column sums / row statistics of the tile were prefetched into LDS by the kernel's prologue
 // (`aux`: bias[256] | colsum[256] | mean[256] | rstd[256] floats), so the epilogue starts without a global-load latency
-template <bool EARLY_OK = false>
+// CF >= 0: the epilogue's shape is known at compile time (low 16 bits = p.flags, bit 16 = head-major output, bit 17 = C is NULL; plain or
+// head-major output map) - the ViT's three epilogues run straight-line code instead of the generic one's flag branches (round 5)
+constexpr int CF_HEADS = 1 << 16, CF_NOC = 1 << 17;
+template <bool EARLY_OK = false, int CF = -1>
 DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, const int wid, const int lane,
-                       const int m0, const int n0, const int wm, const int wn, const bool late_flush = false, const char* aux = nullptr) {
+                       const int m0, const int n0, const int wm, const int wn, const bool late_flush = false, const char* aux = nullptr, const int dbg = 0) {
     const int li = lane & 15, lg = lane >> 4;
-    const int M = (int)p.M, N = p.N;
+    const int M = (int)p.M, N = (DIST_AB && (dbg & 1)) ? 0 : p.N;      // (timing-only library, dbg bit 0: no output stores; bit 1: no epilogue at all)
+    if (DIST_AB && (dbg & 2)) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (sacc == 12345.678f) static_cast<bf16_t*>(p.C ? p.C : p.C2)[lane] = (bf16_t)sacc;
+        return;
+    }
     // ---- epilogue through LDS: per-wave region of 128 rows x 128 B, 16-B chunk c of row r at chunk c ^ (r & 7) ----
     __syncthreads();                                      // every wave is done reading the operand ring
     char* ew = smem + wid * EPI_BYTES;
-    bf16_t* __restrict__ C = static_cast<bf16_t*>(p.C);
+    bf16_t* __restrict__ C = (CF >= 0 && (CF & CF_NOC)) ? nullptr : static_cast<bf16_t*>(p.C);
     bf16_t* __restrict__ C2 = static_cast<bf16_t*>(p.C2);
     const bf16_t* __restrict__ R = static_cast<const bf16_t*>(p.res);
-    const int flags = p.flags;
+    const int flags = CF >= 0 ? (CF & 0xffff) : p.flags;
     const int mw = m0 + wm * 128, nw = n0 + wn * 64;
     const int crow = lane >> 3, cchunk = lane & 7;        // coalesced pass: 8 lanes cover one 128-B row
-    const int icls = p.omap.mode == DIST_OM_INSERTCLS ? p.omap.p0 : 0;
+    const int icls = CF >= 0 ? 0 : (p.omap.mode == DIST_OM_INSERTCLS ? p.omap.p0 : 0);
     auto dest_row = [&](int m) -> long { return icls ? (long)(m / icls) * (icls + 1) + 1 + m % icls : (long)m; };
     // DIST_OM_HEADS: this wave's 64 columns are exactly one (q|k|v, head) slice; row (frame, token) goes to
     // [frame][head][part][token][64], so the 8 rows of a store instruction are 1 KB contiguous
-    const bool heads_om = p.omap.mode == DIST_OM_HEADS;
+    const bool heads_om = CF >= 0 ? (CF & CF_HEADS) != 0 : p.omap.mode == DIST_OM_HEADS;
     const int hp_part = (nw >> 6) / max(p.omap.p1, 1), hp_head = (nw >> 6) - hp_part * max(p.omap.p1, 1);
 
     if (flags & DIST_EPI_RES) {
@@ -92,7 +104,7 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
             *reinterpret_cast<uint4*>(ew + r * 128 + ((cchunk ^ (r & 7)) << 4)) = rv[it];
         }
     }
-    const bool from_lds = EARLY_OK && aux != nullptr;
+    const bool from_lds = EARLY_OK && (!DIST_AB || aux != nullptr);      // (product: always in the bf16 two-group kernel)
     float bias4[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -532,7 +544,7 @@ DEV void regs_ready(v8i32_t (&f)[2][1]) { asm volatile("" : "+v"(f[0][0]), "+v"(
 // per-row scales of A and B multiply the accumulators in front of the shared epilogue.
 DEV v8i32_t fp8_operand(const v4i32_t& lo, const v4i32_t& hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 
-template <bool FP8>
+template <bool FP8, int CF = -1>
 __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_args p, const int ngroups) {
     constexpr int BN = 256;
     constexpr unsigned ES = FP8 ? 1u : 2u;                // bytes per operand element
@@ -696,8 +708,9 @@ __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_arg
     const bool aux_lds = !FP8 && (!DIST_AB || !(ngroups & 0x20000));
     if (aux_lds) {
         const int arr = wid >> 1;
-        const bool lnf = (p.flags & DIST_EPI_LNFOLD) != 0;
-        if (arr == 0 ? (p.flags & DIST_EPI_BIAS) != 0 : lnf) {
+        const int flags = CF >= 0 ? (CF & 0xffff) : p.flags;
+        const bool lnf = (flags & DIST_EPI_LNFOLD) != 0;
+        if (arr == 0 ? (flags & DIST_EPI_BIAS) != 0 : lnf) {
             const float* st = static_cast<const float*>(p.aux);
             const float* src = arr == 0 ? p.bias : arr == 1 ? p.bias2 : arr == 2 ? st : st + M;
             const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (arr < 2 ? N : M) * 4, 0x00020000);
@@ -746,7 +759,7 @@ __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_arg
                 for (int r = 0; r < 4; ++r) acc[i][j][r] *= sa * sb4[j][r];
         }
     }
-    fast_epilogue<!FP8>(p, acc, smem, wid, lane, m0, n0, wr, wc, (ngroups & 0x10000) != 0, aux_lds ? smem + P8_AUX : nullptr);
+    fast_epilogue<!FP8, CF>(p, acc, smem, wid, lane, m0, n0, wr, wc, (ngroups & 0x10000) != 0, aux_lds ? smem + P8_AUX : nullptr, (ngroups >> 18) & 3);
 }
 
 
@@ -1162,7 +1175,22 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
         RUN_(dist_max_smem(attr8, reinterpret_cast<const void*>(gemm_fast8p_kernel<false>), smem8 + 4096));
         static const int late = DIST_AB_KNOB("DIST_AMD_FAST_EARLY_FLUSH", 1) == 0 ? 0x10000 : 0;      // A/B: the primary output's stores behind the last conversion
         static const int gaux = DIST_AB_KNOB("DIST_AMD_FAST_AUX_LDS", 1) == 0 ? 0x20000 : 0;          // A/B: the epilogue's vectors by global loads
-        hipLaunchKernelGGL(gemm_fast8p_kernel<false>, dim3((unsigned)tiles), dim3(512), smem8 + 4096, s, *a, ng | late | gaux);
+        static const int dbg8 = (DIST_AB_KNOB("DIST_AMD_FAST_DBG", 0) & 3) << 18;                     // timing only: 1 no output stores, 2 no epilogue
+        // the ViT's three epilogues as straight-line instantiations (same arithmetic, same order: bit-identical to the generic one)
+        static const bool spec = DIST_AB_KNOB("DIST_AMD_FAST_SPEC", 1) != 0;
+        const int key = (a->omap.mode == DIST_OM_PLAIN || a->omap.mode == DIST_OM_HEADS)
+                            ? ((a->flags & 0xffff) | (a->omap.mode == DIST_OM_HEADS ? CF_HEADS : 0) | (a->C ? 0 : CF_NOC)) : -1;
+        constexpr int K_INPROJ = DIST_EPI_BIAS | DIST_EPI_LNFOLD | CF_HEADS, K_FC = DIST_EPI_BIAS | DIST_EPI_LNFOLD | DIST_EPI_ACT2 | CF_NOC,
+                      K_PROJ = DIST_EPI_BIAS | DIST_EPI_RES | DIST_EPI_ROWSTATS;
+        const int na = ng | late | gaux | dbg8;
+#define LAUNCH8_(CFV) do { RUN_(dist_max_smem(attr8s[CFV == K_INPROJ ? 0 : CFV == K_FC ? 1 : 2], reinterpret_cast<const void*>(gemm_fast8p_kernel<false, CFV>), smem8 + 4096)); \
+                           hipLaunchKernelGGL((gemm_fast8p_kernel<false, CFV>), dim3((unsigned)tiles), dim3(512), smem8 + 4096, s, *a, na); } while (0)
+        static DistSmemOnce attr8s[3];
+        if (spec && key == K_INPROJ) LAUNCH8_(K_INPROJ);
+        else if (spec && key == K_FC) LAUNCH8_(K_FC);
+        else if (spec && key == K_PROJ) LAUNCH8_(K_PROJ);
+        else hipLaunchKernelGGL(gemm_fast8p_kernel<false>, dim3((unsigned)tiles), dim3(512), smem8 + 4096, s, *a, na);
+#undef LAUNCH8_
         HIP_CHECK_RET(hipGetLastError());
         return 1;
     }
