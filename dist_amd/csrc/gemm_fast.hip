@@ -87,16 +87,32 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
     const bool heads_om = CF >= 0 ? (CF & CF_HEADS) != 0 : p.omap.mode == DIST_OM_HEADS;
     const int hp_part = (nw >> 6) / max(p.omap.p1, 1), hp_head = (nw >> 6) - hp_part * max(p.omap.p1, 1);
 
+    // SPEC (compile-time epilogue): plain row maps, N % 64 == 0 and tensors below 4 GB (the launcher checks) - rows are addressed through
+    // buffer descriptors that end behind row M - 1 (a wave whose columns lie beyond N gets an empty one), so the pieces of a ragged last row
+    // tile are dropped / read as zero by the bounds check: no 64-bit address arithmetic, no exec masking per piece
+    constexpr bool SPEC = CF >= 0;
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
     if (flags & DIST_EPI_RES) {
         // all 16 row-pieces of the residual tile are requested back to back (the operand fragment registers are
         // dead by now), so ONE memory latency is exposed instead of one per batch
         uint4 rv[16];
+        if constexpr (SPEC) {
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(R), 0, nw < N ? M * p.ldres * 2 : 0, 0x00020000);
+            const unsigned offr = (unsigned)(mw + crow) * (unsigned)p.ldres * 2u + (unsigned)(nw + cchunk * 8) * 2u;
+            const int stepr = 8 * p.ldres * 2;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rr, offr, it * stepr, 0);
+                rv[it] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+        } else {
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int r = it * 8 + crow;
             const int m = mw + r, n = nw + cchunk * 8;
             rv[it] = make_uint4(0, 0, 0, 0);
             if (m < M && n < N) rv[it] = *reinterpret_cast<const uint4*>(R + dest_row(m) * p.ldres + n);
+        }
         }
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
@@ -175,6 +191,35 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
         }
         if (heads_om) { htok1 += 8; if (htok1 >= p.omap.p0) { htok1 -= p.omap.p0; ++hfr1; } }      // (the launcher checks p0 >= 16)
     };
+    // SPEC: the primary output through a buffer descriptor; a piece is READ from the staging region right behind its row block's conversion and
+    // STORED behind the next block's (the LDS round trip hides behind that block's arithmetic instead of stalling every piece)
+    __amdgpu_buffer_rsrc_t rd1 = __builtin_amdgcn_make_buffer_rsrc(dst1, 0, 0, 0x00020000);
+    unsigned off1 = 0, fs_adj = 0;
+    int step1 = 0;
+    if constexpr (SPEC) {
+        if (heads_om) {
+            const unsigned fs = (unsigned)p.omap.p1 * 3u * (unsigned)p.omap.p0 * 128u;      // bytes per frame: [head][q|k|v][token][64]
+            rd1 = __builtin_amdgcn_make_buffer_rsrc(dst1, 0, nw < N ? (int)((unsigned)(M / p.omap.p0) * fs) : 0, 0x00020000);
+            off1 = (unsigned)hfr1 * fs + (unsigned)((hp_head * 3 + hp_part) * p.omap.p0 + htok1) * 128u + (unsigned)cchunk * 16u;
+            fs_adj = fs - (unsigned)p.omap.p0 * 128u;
+        } else {
+            rd1 = __builtin_amdgcn_make_buffer_rsrc(dst1, 0, nw < N ? M * ld1 * 2 : 0, 0x00020000);
+            off1 = (unsigned)(mw + crow) * (unsigned)ld1 * 2u + (unsigned)(nw + cchunk * 8) * 2u;
+            step1 = 8 * ld1 * 2;
+        }
+    }
+    auto ld_piece = [&](const int it) __attribute__((always_inline)) {
+        const int r = it * 8 + crow;
+        return *reinterpret_cast<const v4u_t*>(ew + r * 128 + ((cchunk ^ (r & 7)) << 4));
+    };
+    auto st_piece = [&](const int it, const v4u_t& v) __attribute__((always_inline)) {      // (pieces in order 0 ... 15: the head-major offset is stepped)
+        if (heads_om) {
+            __builtin_amdgcn_raw_buffer_store_b128(v, rd1, off1, 0, 2);
+            htok1 += 8; off1 += 1024u;
+            if (htok1 >= p.omap.p0) { htok1 -= p.omap.p0; off1 += fs_adj; }                 // (the launcher checks p0 >= 16)
+        } else __builtin_amdgcn_raw_buffer_store_b128(v, rd1, off1, it * step1, 2);
+    };
+    v4u_t pend0 = {0, 0, 0, 0}, pend1 = {0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int r = i * 16 + li;
@@ -196,9 +241,23 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
             }
             store4(slot, v);
         }
-        if (dst1 && early) { flush_piece(2 * i); flush_piece(2 * i + 1); }
+        if constexpr (SPEC) {
+            if (dst1 && early) {
+                if (i > 0) { st_piece(2 * i - 2, pend0); st_piece(2 * i - 1, pend1); }
+                pend0 = ld_piece(2 * i); pend1 = ld_piece(2 * i + 1);
+            }
+        } else if (dst1 && early) { flush_piece(2 * i); flush_piece(2 * i + 1); }
     }
-    if (dst1 && !early) {                                 // all 16 pieces behind the last conversion
+    if constexpr (SPEC) {
+        if (dst1 && early) { st_piece(14, pend0); st_piece(15, pend1); }
+        else if (dst1) {                                  // all 16 pieces behind the last conversion: 16 reads, then 16 stores
+            v4u_t pv[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) pv[it] = ld_piece(it);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) st_piece(it, pv[it]);
+        }
+    } else if (dst1 && !early) {                          // all 16 pieces behind the last conversion
 #pragma unroll
         for (int it = 0; it < 16; ++it) flush_piece(it);
     }
@@ -1178,8 +1237,13 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
         static const int dbg8 = (DIST_AB_KNOB("DIST_AMD_FAST_DBG", 0) & 3) << 18;                     // timing only: 1 no output stores, 2 no epilogue
         // the ViT's three epilogues as straight-line instantiations (same arithmetic, same order: bit-identical to the generic one)
         static const bool spec = DIST_AB_KNOB("DIST_AMD_FAST_SPEC", 1) != 0;
-        const int key = (a->omap.mode == DIST_OM_PLAIN || a->omap.mode == DIST_OM_HEADS)
-                            ? ((a->flags & 0xffff) | (a->omap.mode == DIST_OM_HEADS ? CF_HEADS : 0) | (a->C ? 0 : CF_NOC)) : -1;
+        // (they address rows through buffer descriptors: N % 64 == 0, every tensor below 2 GB, whole frames in the head-major map)
+        const bool heads = a->omap.mode == DIST_OM_HEADS;
+        const long ld_out = a->C ? a->ldc : a->ldc2;
+        const bool spec_ok = (a->omap.mode == DIST_OM_PLAIN || heads) && a->N % 64 == 0 &&
+                             (heads ? (a->M % a->omap.p0 == 0 && a->M * (long)a->omap.p1 * 384 < (1L << 31)) : a->M * ld_out * 2 < (1L << 31)) &&
+                             (!(a->flags & DIST_EPI_RES) || a->M * (long)a->ldres * 2 < (1L << 31));
+        const int key = spec_ok ? ((a->flags & 0xffff) | (heads ? CF_HEADS : 0) | (a->C ? 0 : CF_NOC)) : -1;
         constexpr int K_INPROJ = DIST_EPI_BIAS | DIST_EPI_LNFOLD | CF_HEADS, K_FC = DIST_EPI_BIAS | DIST_EPI_LNFOLD | DIST_EPI_ACT2 | CF_NOC,
                       K_PROJ = DIST_EPI_BIAS | DIST_EPI_RES | DIST_EPI_ROWSTATS;
         const int na = ng | late | gaux | dbg8;
