@@ -57,9 +57,20 @@ struct FragSet { bf16x8 a[8]; bf16x8 b[4]; };
 // CF >= 0: the epilogue's shape is known at compile time (low 16 bits = p.flags, bit 16 = head-major output, bit 17 = C is NULL; plain or
 // head-major output map) - the ViT's three epilogues run straight-line code instead of the generic one's flag branches (round 5)
 constexpr int CF_HEADS = 1 << 16, CF_NOC = 1 << 17;
+// qgelu_t<bf16_t> on two values with its multiplies and the add as packed fp32 instructions (same operations, same roundings: 4 packed + 4
+// transcendental instructions per pair instead of 6 + 4)
+DEV void qgelu2_bf16(float& a, float& b) {
+#pragma clang fp contract(off)
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t x = {a, b};
+    const f32x2_t u = (x * -1.702f) * 1.44269504088896340736f;
+    const f32x2_t d = f32x2_t{__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])} + 1.f;
+    const f32x2_t y = x * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    a = y[0]; b = y[1];
+}
 template <bool EARLY_OK = false, int CF = -1>
 DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, const int wid, const int lane,
-                       const int m0, const int n0, const int wm, const int wn, const bool late_flush = false, const char* aux = nullptr, const int dbg = 0) {
+                       const int m0, const int n0, const int wm, const int wn, const bool late_flush = false, const char* aux = nullptr, const int dbg = 0, const int respf_par = 0) {
     const int li = lane & 15, lg = lane >> 4;
     const int M = (int)p.M, N = (DIST_AB && (dbg & 1)) ? 0 : p.N;      // (timing-only library, dbg bit 0: no output stores; bit 1: no epilogue at all)
     if (DIST_AB && (dbg & 2)) {
@@ -73,7 +84,13 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
     }
     // ---- epilogue through LDS: per-wave region of 128 rows x 128 B, 16-B chunk c of row r at chunk c ^ (r & 7) ----
     __syncthreads();                                      // every wave is done reading the operand ring
-    char* ew = smem + wid * EPI_BYTES;
+    // RESPF (the residual epilogue of the bf16 two-group kernel): the kernel's last K-tile already moved rows 0 ... 63 of this wave's residual tile
+    // by LDS-DMA into the ring buffer that K-tile no longer reads (`respf_par`: its parity) - the staging region of a wave is then the same 8 KB
+    // (slot wid / 2, half wid % 2) of BOTH parities: rows 0 ... 63 in the free one, rows 64 ... 127 in the other
+    constexpr bool RESPF = EARLY_OK && CF >= 0 && (CF & DIST_EPI_RES) != 0;
+    char* const ew = RESPF ? smem + (wid >> 1) * (2 * EPI_BYTES) + respf_par * EPI_BYTES + (wid & 1) * (EPI_BYTES / 2) : smem + wid * EPI_BYTES;
+    char* const ew_hi = RESPF ? smem + (wid >> 1) * (2 * EPI_BYTES) + (respf_par ^ 1) * EPI_BYTES + (wid & 1) * (EPI_BYTES / 2) - 64 * 128 : ew;
+    auto erow = [&](const int r) __attribute__((always_inline)) -> char* { return (RESPF && r >= 64 ? ew_hi : ew) + r * 128; };
     bf16_t* __restrict__ C = (CF >= 0 && (CF & CF_NOC)) ? nullptr : static_cast<bf16_t*>(p.C);
     bf16_t* __restrict__ C2 = static_cast<bf16_t*>(p.C2);
     const bf16_t* __restrict__ R = static_cast<const bf16_t*>(p.res);
@@ -92,16 +109,16 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
     // tile are dropped / read as zero by the bounds check: no 64-bit address arithmetic, no exec masking per piece
     constexpr bool SPEC = CF >= 0;
     typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    uint4 rv[16];
     if (flags & DIST_EPI_RES) {
         // all 16 row-pieces of the residual tile are requested back to back (the operand fragment registers are
         // dead by now), so ONE memory latency is exposed instead of one per batch
-        uint4 rv[16];
         if constexpr (SPEC) {
             const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(R), 0, nw < N ? M * p.ldres * 2 : 0, 0x00020000);
             const unsigned offr = (unsigned)(mw + crow) * (unsigned)p.ldres * 2u + (unsigned)(nw + cchunk * 8) * 2u;
             const int stepr = 8 * p.ldres * 2;
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
+            for (int it = RESPF ? 8 : 0; it < 16; ++it) {   // (RESPF: rows 0 ... 63 are in the staging region already)
                 const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rr, offr, it * stepr, 0);
                 rv[it] = make_uint4(v[0], v[1], v[2], v[3]);
             }
@@ -114,10 +131,12 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
             if (m < M && n < N) rv[it] = *reinterpret_cast<const uint4*>(R + dest_row(m) * p.ldres + n);
         }
         }
+        if constexpr (!RESPF) {
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int r = it * 8 + crow;
-            *reinterpret_cast<uint4*>(ew + r * 128 + ((cchunk ^ (r & 7)) << 4)) = rv[it];
+            *reinterpret_cast<uint4*>(erow(r) + ((cchunk ^ (r & 7)) << 4)) = rv[it];
+        }
         }
     }
     const bool from_lds = EARLY_OK && (!DIST_AB || aux != nullptr);      // (product: always in the bf16 two-group kernel)
@@ -176,7 +195,7 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
     // conversion (round 5: the stores of a tile start ~1 us earlier; same values, same addresses).
     // measured (tools/r05_ef_check.sh, two alternations): in_proj (LN fold + head-major) +2...4 %, c_fc 0...+1 %; with a residual tile in the
     // staging region (out_proj / c_proj) -1...+0.5 %: those keep the old order.  (DIST_AMD_FAST_EARLY_FLUSH=0 in the timing-only library: the old order)
-    const bool early = EARLY_OK && (!DIST_AB || !late_flush) && !(flags & DIST_EPI_RES);
+    const bool early = EARLY_OK && (!DIST_AB || !late_flush) && (SPEC || !(flags & DIST_EPI_RES));
     bf16_t* __restrict__ const dst1 = act_only ? C2 : C;
     const int ld1 = act_only ? p.ldc2 : p.ldc;
     int hfr1 = 0, htok1 = 0;
@@ -184,7 +203,7 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
     auto flush_piece = [&](const int it) __attribute__((always_inline)) {
         const int r = it * 8 + crow;
         const int m = mw + r, n = nw + cchunk * 8;
-        const uint4 v = *reinterpret_cast<const uint4*>(ew + r * 128 + ((cchunk ^ (r & 7)) << 4));
+        const uint4 v = *reinterpret_cast<const uint4*>(erow(r) + ((cchunk ^ (r & 7)) << 4));
         if (m < M && n < N) {
             if (heads_om) store16_nt(dst1 + ((((long)hfr1 * p.omap.p1 + hp_head) * 3 + hp_part) * p.omap.p0 + htok1) * 64 + cchunk * 8, v);
             else store16_nt(dst1 + dest_row(m) * ld1 + n, v);
@@ -210,7 +229,7 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
     }
     auto ld_piece = [&](const int it) __attribute__((always_inline)) {
         const int r = it * 8 + crow;
-        return *reinterpret_cast<const v4u_t*>(ew + r * 128 + ((cchunk ^ (r & 7)) << 4));
+        return *reinterpret_cast<const v4u_t*>(erow(r) + ((cchunk ^ (r & 7)) << 4));
     };
     auto st_piece = [&](const int it, const v4u_t& v) __attribute__((always_inline)) {      // (pieces in order 0 ... 15: the head-major offset is stepped)
         if (heads_om) {
@@ -220,24 +239,49 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
         } else __builtin_amdgcn_raw_buffer_store_b128(v, rd1, off1, it * step1, 2);
     };
     v4u_t pend0 = {0, 0, 0, 0}, pend1 = {0, 0, 0, 0};
+    // the residual values of row block i + 1 are read from the staging region BEFORE block i's results are written to it (the compiler keeps LDS
+    // reads behind earlier LDS writes it cannot tell apart: read inside the j loop, every slot cost an exposed LDS round trip)
+    float xr[2][4][4];
+    auto ld_res = [&](const int i, float (&x)[4][4]) __attribute__((always_inline)) {
+        const int r = i * 16 + li;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load4(reinterpret_cast<const bf16_t*>(erow(r) + ((((j << 1) | (lg >> 1)) ^ (r & 7)) << 4) + ((lg & 1) << 3)), x[j]);
+    };
+    constexpr bool RES_AHEAD = EARLY_OK;                  // (the bf16 two-group kernel; the e4m3 instantiation and the lock-step kernel keep the reads in the j loop:
+                                                          //  with 32 more live registers here hipcc spilled in front of the e4m3 kernel's tail K-tile)
+    if (RES_AHEAD && (flags & DIST_EPI_RES)) ld_res(0, xr[0]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int r = i * 16 + li;
+        if (RES_AHEAD && (flags & DIST_EPI_RES) && i < 7) {
+            if constexpr (RESPF) {
+                if (i == 3) {                             // rows 64 ... 127 of the residual tile (requested at the top) have had row blocks 0 ... 2 to arrive
+#pragma unroll
+                    for (int it = 8; it < 16; ++it) {
+                        const int r2 = it * 8 + crow;
+                        *reinterpret_cast<uint4*>(erow(r2) + ((cchunk ^ (r2 & 7)) << 4)) = rv[it];
+                    }
+                }
+            }
+            ld_res(i + 1, xr[(i + 1) & 1]);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            bf16_t* slot = reinterpret_cast<bf16_t*>(ew + r * 128 + ((((j << 1) | (lg >> 1)) ^ (r & 7)) << 4) + ((lg & 1) << 3));
+            bf16_t* slot = reinterpret_cast<bf16_t*>(erow(r) + ((((j << 1) | (lg >> 1)) ^ (r & 7)) << 4) + ((lg & 1) << 3));
             float v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = lnf ? acc[i][j][q] : acc[i][j][q] + bias4[j][q];
             if (flags & DIST_EPI_RES) {
-                float x[4];
-                load4(slot, x);
+                if constexpr (!RES_AHEAD) load4(slot, xr[0][j]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] += x[q];
+                for (int q = 0; q < 4; ++q) v[q] += xr[RES_AHEAD ? (i & 1) : 0][j][q];
             }
             if (act_only) {
+                if constexpr (SPEC) { qgelu2_bf16(v[0], v[1]); qgelu2_bf16(v[2], v[3]); }
+                else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = qgelu_t<bf16_t>(v[q]);
+                }
             }
             store4(slot, v);
         }
@@ -272,7 +316,7 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
         for (int it = 0; it < 16; ++it) {
             const int r = it * 8 + crow;
             const int m = mw + r, n = nw + cchunk * 8;
-            const uint4 v = *reinterpret_cast<const uint4*>(ew + r * 128 + ((cchunk ^ (r & 7)) << 4));
+            const uint4 v = *reinterpret_cast<const uint4*>(erow(r) + ((cchunk ^ (r & 7)) << 4));
             if (m < M && n < N) {
                 if (heads_om) store16_nt(dst + ((((long)hfr * p.omap.p1 + hp_head) * 3 + hp_part) * p.omap.p0 + htok) * 64 + cchunk * 8, v);
                 else store16_nt(dst + dest_row(m) * ld + n, v);
@@ -293,7 +337,7 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
             float x[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                load4(reinterpret_cast<const bf16_t*>(ew + r * 128 + ((((j << 1) | (lg >> 1)) ^ (r & 7)) << 4) + ((lg & 1) << 3)), x[j]);
+                load4(reinterpret_cast<const bf16_t*>(erow(r) + ((((j << 1) | (lg >> 1)) ^ (r & 7)) << 4) + ((lg & 1) << 3)), x[j]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -306,7 +350,7 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
                 int w = 0;
                 w = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], w, false);
                 w = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], w, true);
-                *reinterpret_cast<int*>(ew + r * 128 + (((j ^ (r & 3)) + ((r >> 2) & 1) * 4) << 4) + lg * 4) = w;   // piece j of row r: spread over the banks
+                *reinterpret_cast<int*>(erow(r) + (((j ^ (r & 3)) + ((r >> 2) & 1) * 4) << 4) + lg * 4) = w;   // piece j of row r: spread over the banks
             }
         }
         int hfr = 0, htok = 0;
@@ -315,7 +359,7 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
         for (int it = 0; it < 8; ++it) {
             const int r = it * 16 + (lane >> 2), pc = lane & 3;
             const int m = mw + r, n = nw + pc * 16;
-            const uint4 v = *reinterpret_cast<const uint4*>(ew + r * 128 + (((pc ^ (r & 3)) + ((r >> 2) & 1) * 4) << 4));
+            const uint4 v = *reinterpret_cast<const uint4*>(erow(r) + (((pc ^ (r & 3)) + ((r >> 2) & 1) * 4) << 4));
             if (m < M && n < N) {
                 // [frame][head][q|k|v][token][64] bytes: this wave's 64 columns are one (part, head) slice
                 if (heads_om) store16_nt(C8 + ((((long)hfr * p.omap.p1 + hp_head) * 3 + hp_part) * p.omap.p0 + htok) * 64 + pc * 16, v);
@@ -345,7 +389,7 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
                 float rs = 0.f, rq = 0.f;
                 bf16x8 v[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = *reinterpret_cast<const bf16x8*>(ew + r * 128 + ((c ^ (r & 7)) << 4));
+                for (int c = 0; c < 8; ++c) v[c] = *reinterpret_cast<const bf16x8*>(erow(r) + ((c ^ (r & 7)) << 4));
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
 #pragma unroll
@@ -360,7 +404,7 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
                 const int r = i * 16 + li;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    bf16_t* slot = reinterpret_cast<bf16_t*>(ew + r * 128 + ((((j << 1) | (lg >> 1)) ^ (r & 7)) << 4) + ((lg & 1) << 3));
+                    bf16_t* slot = reinterpret_cast<bf16_t*>(erow(r) + ((((j << 1) | (lg >> 1)) ^ (r & 7)) << 4) + ((lg & 1) << 3));
                     float x[4];
                     load4(slot, x);
 #pragma unroll
@@ -727,13 +771,29 @@ __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_arg
     // instead of peeled copies of the body: peeled copies made hipcc rename accumulators across their joins and spill
     // INSIDE the loop - and a scratch reload is a vmcnt(0).
     const int nk = K / (FP8 ? 2 * P8_BK : P8_BK);         // >= 2 (checked by the launcher); a K-tile is 128 bytes per row
+    constexpr bool RESPF = !FP8 && CF >= 0 && (CF & DIST_EPI_RES) != 0;     // residual epilogue: half of the residual tile is prefetched by the last K-tile
+    auto lane_now = [&]() __attribute__((always_inline)) { int l = lane; asm volatile("" : "+v"(l)); return l; };
     auto ktile = [&](auto buf_c, const int kt) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_c)::value, NB = BUF ^ 1;
         const bool s1 = kt + 1 < nk, s2 = kt + 2 < nk;
         // phase 0
         read_b(sb_[NB], BUF, P8_B1);
         __builtin_amdgcn_sched_barrier(0);
-        if (s2) { stage(P8_A0, kt + 2); wait_vm<10>(); } else if (s1) wait_vm<8>(); else wait_vm<0>();
+        if (s2) { stage(P8_A0, kt + 2); wait_vm<10>(); } else if (s1) wait_vm<8>(); else {
+            wait_vm<0>();
+            if constexpr (RESPF) {
+                // the LAST K-tile: buffer NB is read no more - rows 0 ... 63 of this wave's residual tile go there now (8 pieces of 8 rows x 128 B, the
+                // staging layout of fast_epilogue: 16-byte chunk c of row r at chunk c ^ (r & 7)), a K-tile ahead of the epilogue that adds them
+                const int l = lane_now();
+                const int pcrow = l >> 3, pc = (l & 7) ^ pcrow;
+                const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, n0 + wc * 64 < N ? M * p.ldres * 2 : 0, 0x00020000);
+                const unsigned offr = (unsigned)(m0 + wr * 128 + pcrow) * (unsigned)p.ldres * 2u + (unsigned)(n0 + wc * 64 + pc * 8) * 2u;
+                const int stepr = 8 * p.ldres * 2;
+                char* d = smem + (wid >> 1) * (2 * P8_HALF) + NB * P8_BUF + (wid & 1) * (P8_HALF / 2);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_ptr)(d + k * 1024), 16, offr, k * stepr, 0, 0);
+            }
+        }
         mma16q(0, 0, fa[0], sb_[BUF]);
         regs_ready(sb_[NB]);
         close_phase();
@@ -818,7 +878,7 @@ __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_arg
                 for (int r = 0; r < 4; ++r) acc[i][j][r] *= sa * sb4[j][r];
         }
     }
-    fast_epilogue<!FP8, CF>(p, acc, smem, wid, lane, m0, n0, wr, wc, (ngroups & 0x10000) != 0, aux_lds ? smem + P8_AUX : nullptr, (ngroups >> 18) & 3);
+    fast_epilogue<!FP8, CF>(p, acc, smem, wid, lane, m0, n0, wr, wc, (ngroups & 0x10000) != 0, aux_lds ? smem + P8_AUX : nullptr, (ngroups >> 18) & 3, nk & 1);
 }
 
 
@@ -1230,8 +1290,6 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
         // several tiles per block with the operand stream running through the tile seams (the ViT's in_proj / c_fc epilogues)
         const int q = try_fast_q(a, ng, s);
         if (q != 0) return q;
-        static DistSmemOnce attr8;
-        RUN_(dist_max_smem(attr8, reinterpret_cast<const void*>(gemm_fast8p_kernel<false>), smem8 + 4096));
         static const int late = DIST_AB_KNOB("DIST_AMD_FAST_EARLY_FLUSH", 1) == 0 ? 0x10000 : 0;      // A/B: the primary output's stores behind the last conversion
         static const int gaux = DIST_AB_KNOB("DIST_AMD_FAST_AUX_LDS", 1) == 0 ? 0x20000 : 0;          // A/B: the epilogue's vectors by global loads
         static const int dbg8 = (DIST_AB_KNOB("DIST_AMD_FAST_DBG", 0) & 3) << 18;                     // timing only: 1 no output stores, 2 no epilogue
@@ -1245,15 +1303,30 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
                              (!(a->flags & DIST_EPI_RES) || a->M * (long)a->ldres * 2 < (1L << 31));
         const int key = spec_ok ? ((a->flags & 0xffff) | (heads ? CF_HEADS : 0) | (a->C ? 0 : CF_NOC)) : -1;
         constexpr int K_INPROJ = DIST_EPI_BIAS | DIST_EPI_LNFOLD | CF_HEADS, K_FC = DIST_EPI_BIAS | DIST_EPI_LNFOLD | DIST_EPI_ACT2 | CF_NOC,
-                      K_PROJ = DIST_EPI_BIAS | DIST_EPI_RES | DIST_EPI_ROWSTATS;
+                      K_PROJ = DIST_EPI_BIAS | DIST_EPI_RES | DIST_EPI_ROWSTATS;       // the frozen ViT's in_proj, c_fc, out_proj / c_proj
+        constexpr int K_NONE = 0, K_BIAS = DIST_EPI_BIAS, K_BIASRES = DIST_EPI_BIAS | DIST_EPI_RES;   // the branch's plain Linears (input_linear, data gradients)
         const int na = ng | late | gaux | dbg8;
-#define LAUNCH8_(CFV) do { RUN_(dist_max_smem(attr8s[CFV == K_INPROJ ? 0 : CFV == K_FC ? 1 : 2], reinterpret_cast<const void*>(gemm_fast8p_kernel<false, CFV>), smem8 + 4096)); \
+#ifdef DIST_AMD_MEASURE
+        if (dist_knob("DIST_AMD_FAST_DBG", 0) & 4) {          // timing-only library: which epilogue shapes a workload launches
+            static int seen[64]; static int nseen = 0;
+            const int k2 = key ^ (int)(a->N * 131 + a->K);
+            bool found = false;
+            for (int i = 0; i < nseen; ++i) found |= seen[i] == k2;
+            if (!found && nseen < 64) { seen[nseen++] = k2; fprintf(stderr, "[fast8p] M=%ld N=%d K=%d flags=0x%x omap=%d C=%d C2=%d key=%d\n", (long)a->M, a->N, a->K, a->flags, a->omap.mode, a->C != nullptr, a->C2 != nullptr, key); }
+        }
+#endif
+#define LAUNCH8_(CFV) do { static DistSmemOnce attr_; RUN_(dist_max_smem(attr_, reinterpret_cast<const void*>(gemm_fast8p_kernel<false, CFV>), smem8 + 4096)); \
                            hipLaunchKernelGGL((gemm_fast8p_kernel<false, CFV>), dim3((unsigned)tiles), dim3(512), smem8 + 4096, s, *a, na); } while (0)
-        static DistSmemOnce attr8s[3];
-        if (spec && key == K_INPROJ) LAUNCH8_(K_INPROJ);
-        else if (spec && key == K_FC) LAUNCH8_(K_FC);
-        else if (spec && key == K_PROJ) LAUNCH8_(K_PROJ);
-        else hipLaunchKernelGGL(gemm_fast8p_kernel<false>, dim3((unsigned)tiles), dim3(512), smem8 + 4096, s, *a, na);
+        if (!spec) LAUNCH8_(-1);
+        else switch (key) {
+            case K_INPROJ: LAUNCH8_(K_INPROJ); break;
+            case K_FC: LAUNCH8_(K_FC); break;
+            case K_PROJ: LAUNCH8_(K_PROJ); break;
+            case K_NONE: LAUNCH8_(K_NONE); break;
+            case K_BIAS: LAUNCH8_(K_BIAS); break;
+            case K_BIASRES: LAUNCH8_(K_BIASRES); break;
+            default: LAUNCH8_(-1);
+        }
 #undef LAUNCH8_
         HIP_CHECK_RET(hipGetLastError());
         return 1;
