@@ -51,7 +51,13 @@ else:
     for r in rows[:nrows]:
         print(f"| {r[2]/tot*100:.1f} | {r[1]/steps:.1f} | {r[3]:.1f} | {r[4]:.1f} | {r[5]:.1f} | {r[2]/1e3/steps:.2f} | `{short(r[0])}` |")
 if "--json" in opt:
-    dom = next(r for r in rows if "gemm_fast8p_kernel" in r[0] and "true" not in r[0].split("gemm_fast8p_kernel")[1][:8])
+    # the dominant kernel = gemm_fast8p_kernel<false, *>: the bf16 two-group GEMM with its epilogue instantiations (one loop, compile-time epilogues) taken together
+    is_dom = lambda n: "gemm_fast8p_kernel" in n and "true" not in n.split("gemm_fast8p_kernel")[1][:8]
+    def agg(rs, name="gemm_fast8p_kernel<false, *> (the bf16 two-group GEMM, all epilogue instantiations)"):
+        rs = [r for r in rs if is_dom(r[0])]
+        calls, total = sum(r[1] for r in rs), sum(r[2] for r in rs)
+        return (name, calls, total, total / max(calls, 1), min(r[4] for r in rs), max(r[5] for r in rs), sum(r[6] * r[1] for r in rs) / max(calls, 1))
+    dom = agg(rows)
     out = {"dominant_kernel": dom[0], "command": opt.get("--command", ""), "steps_profiled": steps,
            "in_situ_launches": dom[1], "in_situ_launches_per_step": round(dom[1] / steps, 2), "in_situ_avg_us": round(dom[3], 1),
            "total_kernel_ms_per_step": round(tot / 1e3 / steps, 2)}
@@ -66,13 +72,14 @@ if "--json" in opt:
         out["sum_alone_ms_per_step"] = round(alone_ms, 3)
         out["wall_ms_per_step"] = wall
         out["stretch"] = {short(r[0])[:60]: round(r[3] / a[3], 3) for r, a, _, _ in floor_rows[:16]}
-        sd = serial.get(dom[0])
-        if sd is not None:
-            out["dominant_serial_avg_us"] = round(sd[3], 1)
+        if any(is_dom(n) for n in serial):
+            out["dominant_serial_avg_us"] = round(agg(serial.values())[3], 1)
+        out["dominant_instantiations"] = {short(r[0])[:70]: {"launches_per_step": round(r[1] / steps, 2), "in_situ_avg_us": round(r[3], 1),
+                                                             "alone_avg_us": round(serial[r[0]][3], 1) if r[0] in serial else None} for r in rows if is_dom(r[0])}
     if "--alone-db" in opt:
         adb = sqlite3.connect(opt["--alone-db"])
         arows = list(adb.cursor().execute(Q))
-        ad = next(r for r in arows if r[0] == dom[0])
+        ad = agg(arows)
         out.update({"alone_launches": ad[1], "alone_avg_us": round(ad[3], 1), "alone_passes": int(opt.get("--alone-passes", 0)),
                     "alone_command": "rocprofv3 --kernel-trace --stats -- python3 tools/vit_pass_alone.py " + opt.get("--alone-passes", "")})
     json.dump(out, open(opt["--json"], "w"), indent=1)
