@@ -1308,7 +1308,7 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
     if (a->flags & DIST_EPI_FP8) {                        // fast_common_ok checked the shape; only the two-group loop has the fp8 MFMAs
         if (NW != 8) return DIST_ERR_ARG;
 #ifdef DIST_AMD_MEASURE
-        if (dist_knob("DIST_AMD_FAST_DBG", 0) & 4) {          // timing-only library: which epilogue shapes a workload launches
+        if (DIST_AB_KNOB("DIST_AMD_FAST_DBG", 0) & 4) {          // timing-only library: which epilogue shapes a workload launches
             static int seen[64]; static int nseen = 0;
             const int k2 = a->flags ^ (int)(a->N * 131 + a->K) ^ (a->omap.mode << 20) ^ (a->C ? 1 << 24 : 0) ^ (a->C2 ? 1 << 25 : 0);
             bool found = false;
@@ -1364,7 +1364,7 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
         constexpr int K_NONE = 0, K_BIAS = DIST_EPI_BIAS, K_BIASRES = DIST_EPI_BIAS | DIST_EPI_RES;   // the branch's plain Linears (input_linear, data gradients)
         const int na = ng | late | gaux | dbg8;
 #ifdef DIST_AMD_MEASURE
-        if (dist_knob("DIST_AMD_FAST_DBG", 0) & 4) {          // timing-only library: which epilogue shapes a workload launches
+        if (DIST_AB_KNOB("DIST_AMD_FAST_DBG", 0) & 4) {          // timing-only library: which epilogue shapes a workload launches
             static int seen[64]; static int nseen = 0;
             const int k2 = key ^ (int)(a->N * 131 + a->K);
             bool found = false;
