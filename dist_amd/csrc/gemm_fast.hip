@@ -233,10 +233,12 @@ DEV void fast_epilogue(const dist_gemm_args& p, f32x4 (&acc)[8][4], char* smem, 
     };
     auto st_piece = [&](const int it, const v4u_t& v) __attribute__((always_inline)) {      // (pieces in order 0 ... 15: the head-major offset is stepped)
         if (heads_om) {
-            __builtin_amdgcn_raw_buffer_store_b128(v, rd1, off1, 0, 2);
+            if (DIST_AB && (dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rd1, off1, 0, 0);      // (timing-only library: without the streaming hint)
+            else __builtin_amdgcn_raw_buffer_store_b128(v, rd1, off1, 0, 2);
             htok1 += 8; off1 += 1024u;
             if (htok1 >= p.omap.p0) { htok1 -= p.omap.p0; off1 += fs_adj; }                 // (the launcher checks p0 >= 16)
-        } else __builtin_amdgcn_raw_buffer_store_b128(v, rd1, off1, it * step1, 2);
+        } else if (DIST_AB && (dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rd1, off1, it * step1, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(v, rd1, off1, it * step1, 2);
     };
     v4u_t pend0 = {0, 0, 0, 0}, pend1 = {0, 0, 0, 0};
     // the residual values of row block i + 1 are read from the staging region BEFORE block i's results are written to it (the compiler keeps LDS
@@ -473,6 +475,39 @@ DEV void fast_tile(const dist_gemm_args& p, const int ngroups_flags, const int B
     }
 }
 
+// fast_tile with its run-time divisions done on the host (the two-group kernel: five reciprocal sequences of ~20 instructions sat in front of a
+// tile's first LDS-DMA request): q = mulhi(n, ceil(2^32 / d)) is exact while n * d < 2^32 - block ids and tile counts are far below that.
+struct TileMap {
+    int q8, r8, tiles_n, ngroups, gq, gr, big, mid, grbig;
+    unsigned mg_tn, mg_big, mg_mid, mg_gq1, mg_gq;
+};
+static TileMap make_tile_map(const long M, const int N, const int BN, const int ngroups) {
+    TileMap t;
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (int)((M + BM - 1) / BM), nblk = tiles_m * tiles_n;
+    auto magic = [](const int d) -> unsigned { return d > 1 ? (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d) : 0u; };   // (d = 1: handled as n itself)
+    t.q8 = nblk / 8; t.r8 = nblk % 8; t.tiles_n = tiles_n; t.ngroups = ngroups;
+    t.gq = tiles_n / (ngroups > 0 ? ngroups : 1); t.gr = tiles_n % (ngroups > 0 ? ngroups : 1);
+    t.big = tiles_m * (t.gq + 1); t.mid = tiles_m * t.gq; t.grbig = t.gr * t.big;
+    t.mg_tn = magic(tiles_n); t.mg_big = magic(t.big); t.mg_mid = magic(t.mid); t.mg_gq1 = magic(t.gq + 1); t.mg_gq = magic(t.gq);
+    return t;
+}
+DEV int tm_div(const int n, const int d, const unsigned mg) { return d > 1 ? (int)__umulhi((unsigned)n, mg) : n; }
+DEV void fast_tile_mapped(const TileMap& t, int& tm, int& tn) {
+    int bid = blockIdx.x;
+    {
+        const int x = bid & 7, y = bid >> 3;
+        bid = (x < t.r8 ? x * (t.q8 + 1) : t.r8 * (t.q8 + 1) + (x - t.r8) * t.q8) + y;
+    }
+    if (t.ngroups <= 1) { tm = tm_div(bid, t.tiles_n, t.mg_tn); tn = bid - tm * t.tiles_n; }
+    else if (bid < t.grbig) {
+        const int g = tm_div(bid, t.big, t.mg_big), idg = bid - g * t.big;
+        tm = tm_div(idg, t.gq + 1, t.mg_gq1); tn = g * (t.gq + 1) + idg - tm * (t.gq + 1);
+    } else {
+        const int b2 = bid - t.grbig, g = tm_div(b2, t.mid, t.mg_mid), idg = b2 - g * t.mid;
+        tm = tm_div(idg, t.gq, t.mg_gq); tn = t.gr * (t.gq + 1) + g * t.gq + idg - tm * t.gq;
+    }
+}
+
 template <int NW>
 __global__ __launch_bounds__(Shape<NW>::NT, Shape<NW>::MINB) void gemm_fast_kernel(const dist_gemm_args p, const int ngroups) {
     using S = Shape<NW>;
@@ -678,7 +713,7 @@ DEV void regs_ready(v8i32_t (&f)[2][1]) { asm volatile("" : "+v"(f[0][0]), "+v"(
 DEV v8i32_t fp8_operand(const v4i32_t& lo, const v4i32_t& hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 
 template <bool FP8, int CF = -1>
-__global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_args p, const int ngroups) {
+__global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_args p, const int ngroups, const TileMap tmap) {
     constexpr int BN = 256;
     constexpr unsigned ES = FP8 ? 1u : 2u;                // bytes per operand element
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -688,7 +723,8 @@ __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_arg
     const int li = lane & 15, lg = lane >> 4;
 
     int tm, tn;
-    fast_tile(p, ngroups, BN, tm, tn);
+    if (DIST_AB && (ngroups & 0x200000)) fast_tile(p, ngroups, BN, tm, tn);      // (timing-only library: the divisions in the kernel)
+    else fast_tile_mapped(tmap, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int M = (int)p.M, N = p.N, K = p.K;
 
@@ -908,7 +944,7 @@ __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_arg
                 for (int r = 0; r < 4; ++r) acc[i][j][r] *= sa * sb4[j][r];
         }
     }
-    fast_epilogue<!FP8, CF>(p, acc, smem, wid, lane, m0, n0, wr, wc, (ngroups & 0x10000) != 0, aux_lds ? smem + P8_AUX : nullptr, (ngroups >> 18) & 3, nk & 1);
+    fast_epilogue<!FP8, CF>(p, acc, smem, wid, lane, m0, n0, wr, wc, (ngroups & 0x10000) != 0, aux_lds ? smem + P8_AUX : nullptr, (ngroups >> 18) & 7, nk & 1);
 }
 
 
@@ -1303,6 +1339,7 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
     // two-group 256x256x64 main loop (gemm_fast8p_kernel) when K is a multiple of 64; DIST_AMD_FAST_8P=0 keeps the
     // lock-step 256x256x32 loop (measurement knob, and the A/B reference of tools/bench_fast8p.py)
     static const bool use_8p = (dist_knob("DIST_AMD_FAST_8P", 1) != 0);
+    const TileMap tmap = make_tile_map(a->M, a->N, 256, ng);
     constexpr size_t smem8 = (size_t)P8_LDS;
     static_assert(8 * EPI_BYTES <= P8_LDS, "epilogue staging fits in the operand buffers");
     if (a->flags & DIST_EPI_FP8) {                        // fast_common_ok checked the shape; only the two-group loop has the fp8 MFMAs
@@ -1329,7 +1366,7 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
         constexpr int K8_INPROJ = F8 | DIST_EPI_LNFOLD | CF_HEADS | CF_NOC, K8_FC = F8 | DIST_EPI_LNFOLD | DIST_EPI_ACT2 | CF_NOC,
                       K8_PROJ = F8 | DIST_EPI_RES | DIST_EPI_ROWSTATS;
 #define LAUNCH8F_(CFV) do { static DistSmemOnce attr_; RUN_(dist_max_smem(attr_, reinterpret_cast<const void*>(gemm_fast8p_kernel<true, CFV>), smem8)); \
-                            hipLaunchKernelGGL((gemm_fast8p_kernel<true, CFV>), dim3((unsigned)tiles), dim3(512), smem8, s, *a, ng); } while (0)
+                            hipLaunchKernelGGL((gemm_fast8p_kernel<true, CFV>), dim3((unsigned)tiles), dim3(512), smem8, s, *a, ng, tmap); } while (0)
         switch (key8) {
             case K8_INPROJ: LAUNCH8F_(K8_INPROJ); break;
             case K8_FC: LAUNCH8F_(K8_FC); break;
@@ -1349,7 +1386,7 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
         if (q != 0) return q;
         static const int late = DIST_AB_KNOB("DIST_AMD_FAST_EARLY_FLUSH", 1) == 0 ? 0x10000 : 0;      // A/B: the primary output's stores behind the last conversion
         static const int gaux = DIST_AB_KNOB("DIST_AMD_FAST_AUX_LDS", 1) == 0 ? 0x20000 : 0;          // A/B: the epilogue's vectors by global loads
-        static const int dbg8 = (DIST_AB_KNOB("DIST_AMD_FAST_DBG", 0) & 3) << 18;                     // timing only: 1 no output stores, 2 no epilogue
+        static const int dbg8 = (DIST_AB_KNOB("DIST_AMD_FAST_DBG", 0) & 3) << 18 | (DIST_AB_KNOB("DIST_AMD_FAST_PLAIN_ST", 0) ? 4 << 18 : 0);                     // timing only: 1 no output stores, 2 no epilogue
         // the ViT's three epilogues as straight-line instantiations (same arithmetic, same order: bit-identical to the generic one)
         static const bool spec = DIST_AB_KNOB("DIST_AMD_FAST_SPEC", 1) != 0;
         // (they address rows through buffer descriptors: N % 64 == 0, every tensor below 2 GB, whole frames in the head-major map)
@@ -1362,7 +1399,8 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
         constexpr int K_INPROJ = DIST_EPI_BIAS | DIST_EPI_LNFOLD | CF_HEADS, K_FC = DIST_EPI_BIAS | DIST_EPI_LNFOLD | DIST_EPI_ACT2 | CF_NOC,
                       K_PROJ = DIST_EPI_BIAS | DIST_EPI_RES | DIST_EPI_ROWSTATS;       // the frozen ViT's in_proj, c_fc, out_proj / c_proj
         constexpr int K_NONE = 0, K_BIAS = DIST_EPI_BIAS, K_BIASRES = DIST_EPI_BIAS | DIST_EPI_RES;   // the branch's plain Linears (input_linear, data gradients)
-        const int na = ng | late | gaux | dbg8;
+        static const int kdiv = DIST_AB_KNOB("DIST_AMD_FAST_TILEMAP", 1) == 0 ? 0x200000 : 0;       // A/B: the tile map's divisions in the kernel
+        const int na = ng | late | gaux | dbg8 | kdiv;
 #ifdef DIST_AMD_MEASURE
         if (DIST_AB_KNOB("DIST_AMD_FAST_DBG", 0) & 4) {          // timing-only library: which epilogue shapes a workload launches
             static int seen[64]; static int nseen = 0;
@@ -1373,7 +1411,7 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
         }
 #endif
 #define LAUNCH8_(CFV) do { static DistSmemOnce attr_; RUN_(dist_max_smem(attr_, reinterpret_cast<const void*>(gemm_fast8p_kernel<false, CFV>), smem8 + 4096)); \
-                           hipLaunchKernelGGL((gemm_fast8p_kernel<false, CFV>), dim3((unsigned)tiles), dim3(512), smem8 + 4096, s, *a, na); } while (0)
+                           hipLaunchKernelGGL((gemm_fast8p_kernel<false, CFV>), dim3((unsigned)tiles), dim3(512), smem8 + 4096, s, *a, na, tmap); } while (0)
         if (!spec) LAUNCH8_(-1);
         else switch (key) {
             case K_INPROJ: LAUNCH8_(K_INPROJ); break;
