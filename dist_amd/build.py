@@ -6,7 +6,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdist_amd.so")
 MEASURE_LIB = os.path.join(CSRC, "libdist_amd_measure.so")
-SOURCES = ["gemm_nt.hip", "gemm_fast.hip", "gemm_pp.hip", "gemm_small.hip", "gemm_tn.hip", "gemm_tn8p.hip", "conv_dw.hip", "tnet.hip", "integ.hip", "norm.hip", "attn.hip", "misc.hip", "metrics.hip", "quant.hip", "engine.hip"]
+SOURCES = ["gemm_nt.hip", "gemm_fast.hip", "gemm_pp.hip", "gemm_small.hip", "gemm_tn.hip", "gemm_tn8p.hip", "conv_dw.hip", "conv_t_dw.hip", "tnet.hip", "integ.hip", "norm.hip", "attn.hip", "misc.hip", "metrics.hip", "quant.hip", "engine.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "dist_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 

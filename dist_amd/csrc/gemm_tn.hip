@@ -476,6 +476,10 @@ extern "C" int dist_op_gemm_tn(const dist_gemm_tn_args* a, void* stream) {
         const int rc = dist_k_conv3x3_dw(a, s);
         if (rc != 0) return rc < 0 ? rc : DIST_OK;
     }
+    {   // the temporal convolutions' gradients (3 / 5 frame taps, 96 output channels): a ring of frame slots in LDS (conv_t_dw.hip)
+        const int rc = dist_k_conv_t_dw(a, s);
+        if (rc != 0) return rc < 0 ? rc : DIST_OK;
+    }
     if (a->dtype == DIST_BF16) return a->use_tr ? dispatch<bf16_t, true>(*a, s) : dispatch<bf16_t, false>(*a, s);
     return dispatch<float, false>(*a, s);
 }

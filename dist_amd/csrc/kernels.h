@@ -43,6 +43,7 @@ int dist_k_gemm_small(const dist_gemm_args* a, hipStream_t s);       // M < 1024
 int dist_k_gemm_tn8p(const dist_gemm_tn_args* a, hipStream_t s);
 // frame-resident nine-tap weight gradient of the 3x3 frame convolution (conv_dw.hip): 1 = launched, 0 = not its call, <0 = error
 int dist_k_conv3x3_dw(const dist_gemm_tn_args* a, hipStream_t s);
+int dist_k_conv_t_dw(const dist_gemm_tn_args* a, hipStream_t s);        // conv_t_dw.hip: 1 launched, 0 not its call, < 0 error
 // fused TemporalNet (tnet.hip): does dist_op_temporal_net_fwd take this geometry?
 bool dist_k_tnet_fwd_eligible(int dtype, int Ct, int G, int tk);
 // fused IntegrationNetwork forward (integ.hip): eligibility, and the all-layers form of dist_op_integration_pack (`descs_dev`: n descriptors

@@ -387,6 +387,51 @@ def test_gemm_tn_conv3x3_frame_resident_kernel(gpu_lib, frames, sign):
     assert float((out4 - out).abs().max()) < 2e-5 * scale
 
 
+@pytest.mark.parametrize("clips,T,N,taps,K,sign,wide", [(5, 16, 196, 3, 96, 1, False), (3, 8, 197, 3, 96, -1, True), (2, 16, 196, 5, 768, 1, False),
+                                                         (33, 16, 196, 3, 96, 1, False), (2, 5, 50, 5, 192, -1, True)])
+def test_gemm_tn_temporal_taps_frame_ring_kernel(gpu_lib, clips, T, N, taps, K, sign, wide):
+    """The temporal convolutions' weight gradients (dist.py:23-36 TemporalNet.c_fc1 / temporal_ffn.c_fc2: (3, 1, 1) Conv3d, 96 channels; dist.py:178-181 the
+    (5, 1, 1) stem over the 768 patch columns) run on conv_t_dw.hip: a ring of frame slots in LDS, a tap = a slot, frames outside the clip = an empty
+    buffer descriptor (taken for 5 taps / several 96-column tiles; the 3-tap 96 x 96 cases run the generic kernel).  Against fp64 for every tap in the reference's weight layouts (Conv3d [Co][Ci][taps]; the stem's [Co][3][taps][P][P]) with
+    the fused bias gradient, both tap directions, dY as a column-offset view of wider rows (the engine's [dzf | dh2] buffer), more items than blocks;
+    accumulates INTO the destination; bit-repeatable; equal to the generic tap-per-tile kernel up to fp32 summation order."""
+    from dist_amd import ops
+    NI = 96
+    M = clips * T * N
+    g = torch.Generator(device="cuda"); g.manual_seed(clips * 100 + taps)
+    Aw = (torch.randn(M, NI + (384 if wide else 0), device="cuda", generator=g) + 0.03).to(torch.bfloat16)
+    A = Aw[:, 384:] if wide else Aw
+    B = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    part = torch.empty(16 << 20, dtype=torch.float32, device="cuda")
+    bm = ops.rowmap(MODES["shift"], T * N, N, sign)
+    stem = K == 768
+    lay = dict(so_i=K * taps, so_tap=K // 3, so_outer=(K // 3) * taps, inner=K // 3) if stem else dict(so_i=K * taps, so_tap=1, so_outer=taps, inner=1)
+
+    def run(init=0.0, **kw):
+        out = torch.full((NI, K * taps), init, dtype=torch.float32, device="cuda")
+        cs = torch.full((NI,), init, dtype=torch.float32, device="cuda")
+        ops.gemm_tn(A, B, out, M, NI, K, taps=taps, bmap=bm, colsum=cs, partial=part, lda=Aw.shape[1], **lay, **kw)
+        return out, cs
+    out, cs = run()
+    Ad = A.double()
+    scale = float((Ad.t() @ B.double()).abs().max())
+    for tap in range(taps):
+        ref = Ad.t() @ gather(B, "shift", M, tap, taps, p0=T * N, p1=N, sign=sign)
+        got = out.view(NI, 3, taps, K // 3)[:, :, tap].reshape(NI, K) if stem else out.view(NI, K, taps)[:, :, tap]
+        assert float((got.double() - ref).abs().max()) < 2e-5 * scale, tap
+    refb = Ad.sum(0)
+    assert float((cs.double() - refb).abs().max() / refb.abs().max()) < 2e-5
+    out2, cs2 = run()
+    if taps == 5:                                                     # (3 taps on one 96-column tile stay on the generic kernel - as fast, measured - whose
+        assert torch.equal(out, out2) and torch.equal(cs, cs2)        #  split groups meet in atomics) the second phase adds the blocks in index order
+    else:
+        assert float((out2 - out).abs().max()) < 2e-5 * scale
+    out3, cs3 = run(init=0.25)
+    assert float((out3 - 0.25 - out).abs().max()) < 2e-5 * scale and float((cs3 - 0.25 - cs).abs().max()) < 1e-4 * float(refb.abs().max())
+    out4, _ = run(max_blocks=7)                                         # any block count: the same sums up to fp32 order
+    assert float((out4 - out).abs().max()) < 2e-5 * scale
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("Nn", [9, 196])
 def test_gemm_tn_skipcls_a(gpu_lib, dtype, Nn):
