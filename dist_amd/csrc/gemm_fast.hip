@@ -1386,7 +1386,7 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
         if (q != 0) return q;
         static const int late = DIST_AB_KNOB("DIST_AMD_FAST_EARLY_FLUSH", 1) == 0 ? 0x10000 : 0;      // A/B: the primary output's stores behind the last conversion
         static const int gaux = DIST_AB_KNOB("DIST_AMD_FAST_AUX_LDS", 1) == 0 ? 0x20000 : 0;          // A/B: the epilogue's vectors by global loads
-        static const int dbg8 = (DIST_AB_KNOB("DIST_AMD_FAST_DBG", 0) & 3) << 18 | (DIST_AB_KNOB("DIST_AMD_FAST_PLAIN_ST", 0) ? 4 << 18 : 0);                     // timing only: 1 no output stores, 2 no epilogue
+        static const int dbg8 = (DIST_AB_KNOB("DIST_AMD_FAST_DBG", 0) & 3) << 18 | (DIST_AB_KNOB("DIST_AMD_FAST_PLAIN_ST", 0) == 1 ? 4 << 18 : 0);                     // timing only: 1 no output stores, 2 no epilogue
         // the ViT's three epilogues as straight-line instantiations (same arithmetic, same order: bit-identical to the generic one)
         static const bool spec = DIST_AB_KNOB("DIST_AMD_FAST_SPEC", 1) != 0;
         // (they address rows through buffer descriptors: N % 64 == 0, every tensor below 2 GB, whole frames in the head-major map)
@@ -1400,7 +1400,8 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
                       K_PROJ = DIST_EPI_BIAS | DIST_EPI_RES | DIST_EPI_ROWSTATS;       // the frozen ViT's in_proj, c_fc, out_proj / c_proj
         constexpr int K_NONE = 0, K_BIAS = DIST_EPI_BIAS, K_BIASRES = DIST_EPI_BIAS | DIST_EPI_RES;   // the branch's plain Linears (input_linear, data gradients)
         static const int kdiv = DIST_AB_KNOB("DIST_AMD_FAST_TILEMAP", 1) == 0 ? 0x200000 : 0;       // A/B: the tile map's divisions in the kernel
-        const int na = ng | late | gaux | dbg8 | kdiv;
+        static const int plain_st = DIST_AB_KNOB("DIST_AMD_FAST_PLAIN_ST", 0);     // 1: every output without the streaming hint; 2 / 3 / 4: only in_proj's / c_fc's / the residual GEMMs'
+        const int na = ng | late | gaux | dbg8 | kdiv | (((plain_st == 2 && key == K_INPROJ) || (plain_st == 3 && key == K_FC) || (plain_st == 4 && key == K_PROJ)) ? 4 << 18 : 0);
 #ifdef DIST_AMD_MEASURE
         if (DIST_AB_KNOB("DIST_AMD_FAST_DBG", 0) & 4) {          // timing-only library: which epilogue shapes a workload launches
             static int seen[64]; static int nseen = 0;
