@@ -831,9 +831,12 @@ static int ensure_streams(dist_handle* h) {
     int least = 0, greatest = 0;
     hipDeviceGetStreamPriorityRange(&least, &greatest);
     const int prio = DIST_AB_KNOB("DIST_AMD_SIDE_PRIO", 1) == 0 ? 0 : least;
+    // the frozen ViT's stream (DIST_AMD_PF_PRIO in the timing-only library: 0 = default priority, 2 = the highest)
+    const int pf_knob = DIST_AB_KNOB("DIST_AMD_PF_PRIO", 1);
+    const int pf_prio = pf_knob == 0 ? 0 : (pf_knob == 2 ? greatest : least);
     bool ok = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio) == hipSuccess &&
               hipStreamCreateWithPriority(&h->side2, hipStreamNonBlocking, prio) == hipSuccess &&
-              hipStreamCreateWithPriority(&h->pf, hipStreamNonBlocking, least) == hipSuccess;
+              hipStreamCreateWithPriority(&h->pf, hipStreamNonBlocking, pf_prio) == hipSuccess;
     // the optional second data-gradient chain of the backward (DIST_AMD_BWD_TCHAIN=1, a measurement): created only when asked for - an extra
     // stream that merely EXISTS beside the gradient reducer's cost 4.7 ms per step (tests/test_rccl_gpu.py: 23.2 vs 18.5 ms)
     if (DIST_AB_KNOB("DIST_AMD_BWD_TCHAIN", 0) == 1)

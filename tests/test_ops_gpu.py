@@ -739,3 +739,62 @@ def test_row_statistics_from_the_producer_gemm(gpu_lib, M, N, K):
     # only the LDS-DMA kernel leaves partials: other shapes refuse instead of silently skipping them
     with pytest.raises(L.DistError):
         ops.gemm_nt(A[:512], W, 512, N, K, bias=bias, res=res[:512], C_out=X[:512], rowstats=part)
+
+
+@pytest.mark.parametrize("kind,frames,L_,N,K", [("in_proj", 9, 197, 2304, 768), ("in_proj", 5, 257, 3072, 1024), ("c_fc", 6, 197, 3072, 768), ("proj", 7, 197, 768, 3072),
+                                              ("proj", 6, 197, 768, 768), ("none", 11, 197, 384, 768), ("bias", 11, 197, 384, 768), ("bias_res", 11, 197, 384, 768),
+                                              ("bias_res", 5, 257, 1024, 256)])
+def test_gemm_compile_time_epilogues_vs_fp32(gpu_lib, kind, frames, L_, N, K):
+    """The straight-line instantiations of the 256 x 256 kernel's epilogue (gemm_fast8p_kernel<false, CF>: the frozen ViT's in_proj = LayerNorm fold + head-major
+    q | k | v, c_fc = LayerNorm fold + QuickGELU only, out_proj / c_proj = bias + residual + row statistics; the branch's none / bias / bias + residual; reference
+    clip.py:155-176, dist.py:23-45) against fp32 torch on the same bf16 operands, with a ragged last row tile (M = frames x L is not a multiple of 256) and a
+    half-empty column tile (N = 384): rows beyond M and columns beyond N are cut off by buffer descriptors there, not by masks."""
+    from dist_amd import ops, lib as L
+    torch.manual_seed(7)
+    dev, dt = "cuda", torch.bfloat16
+    M = frames * L_
+    assert M % 256 and M >= 1024
+    x = (torch.randn(M, K, device=dev) * 1.3 + 0.5).to(dt)
+    W = torch.randn(N, K, device=dev) * K ** -0.5
+    bias = torch.randn(N, device=dev)
+    res = (torch.randn(M, N, device=dev) * 1.5).to(dt)
+    Wb = W.to(dt)
+    lin = x.float() @ Wb.float().t()
+    guard = 3.0                                            # canary rows behind the output: nothing may be written past row M - 1
+    if kind in ("in_proj", "c_fc"):
+        gamma, beta = 1.0 + 0.3 * torch.randn(K, device=dev), 0.2 * torch.randn(K, device=dev)
+        Wp, cs, bf = ops.ln_fold(W, bias, gamma, beta)
+        stats = torch.empty(2 * M, device=dev)
+        ops.layernorm(x, gamma, beta, y=False, mean=stats[:M], rstd=stats[M:])
+        ref = torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ W.t() + bias
+        scale = float(ref.abs().max())
+        if kind == "in_proj":
+            heads = N // 192
+            buf = torch.full((frames + 1, heads, 3, L_, 64), guard, dtype=dt, device=dev)
+            ops.gemm_nt(x, Wp, M, N, K, bias=bf, lnfold=(stats, cs), C_out=buf, ldc=64, omap=ops.outmap(L.OM_HEADS, L_, heads))
+            got = buf[:frames].permute(0, 3, 2, 1, 4).reshape(M, N).float()
+            assert bool((buf[frames] == guard).all())
+        else:
+            buf = torch.full((M + 64, N), guard, dtype=dt, device=dev)
+            ops.gemm_nt(x, Wp, M, N, K, bias=bf, lnfold=(stats, cs), C2_out=buf[:M])
+            got = buf[:M].float()
+            ref = ref * torch.sigmoid(1.702 * ref)
+            assert bool((buf[M:] == guard).all())
+        assert float((got - ref).abs().max()) < 1.5e-2 * scale
+        return
+    buf = torch.full((M + 64, N), guard, dtype=dt, device=dev)
+    if kind == "proj":
+        part = torch.full((N // 64, M, 2), float("nan"), device=dev)
+        ops.gemm_nt(x, Wb, M, N, K, bias=bias, res=res, C_out=buf[:M], rowstats=part)
+        ref = lin + bias + res.float()
+        xs = buf[:M].float().reshape(M, N // 64, 64)
+        torch.testing.assert_close(part[:, :, 0].t(), xs.sum(2), rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(part[:, :, 1].t(), (xs * xs).sum(2), rtol=1e-5, atol=1e-3)
+    elif kind == "none":
+        ops.gemm_nt(x, Wb, M, N, K, C_out=buf[:M]); ref = lin
+    elif kind == "bias":
+        ops.gemm_nt(x, Wb, M, N, K, bias=bias, C_out=buf[:M]); ref = lin + bias
+    else:
+        ops.gemm_nt(x, Wb, M, N, K, bias=bias, res=res, C_out=buf[:M]); ref = lin + bias + res.float()
+    torch.testing.assert_close(buf[:M].float(), ref, rtol=1.2e-2, atol=1.2e-2 * float(ref.abs().max()) / 4)
+    assert bool((buf[M:] == guard).all())
