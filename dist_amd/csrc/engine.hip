@@ -1047,7 +1047,7 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
         // W diag(gamma) and normalises in its epilogue - the normalised tensor is never written or read back.
         int folded = 0;
         if (h->vit_fold) {
-            if (part_of_xin) RUN(dist_op_ln_stats_from_partials(h->lnpart, d / 64, rowsS, d, 1e-5f, h->lnstats, h->lnstats + rowsS, stream));
+            if (part_of_xin) { if (!(h->skip & 128)) RUN(dist_op_ln_stats_from_partials(h->lnpart, d / 64, rowsS, d, 1e-5f, h->lnstats, h->lnstats + rowsS, stream)); }   // (skip 128, timing only: stale statistics)
             else RUN(ln_fwd(x, h->visual, v.ln1, xin, nullptr, rowsS, h->lnstats, h->lnstats + rowsS));
             if (f8 & 1) {                                  // e4m3 image of the raw rows, then the folded GEMM on the block-scaled fp8 MFMA
                 Out8 q8o;                                  // image mode: q | k | v leave as e4m3 ONLY (head-major bytes in h->qkv)
@@ -1091,7 +1091,7 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
         if (!done8) RUN(gemm(x, h->att, d, x.pk(v.out.pk.f), rowsS, d, d, 1, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr, RM(), OM(), 0, nullptr, rs ? h->lnpart : nullptr));
         folded = 0;
         if (h->vit_fold) {
-            if (rs) RUN(dist_op_ln_stats_from_partials(h->lnpart, d / 64, rowsS, d, 1e-5f, h->lnstats, h->lnstats + rowsS, stream));
+            if (rs) { if (!(h->skip & 128)) RUN(dist_op_ln_stats_from_partials(h->lnpart, d / 64, rowsS, d, 1e-5f, h->lnstats, h->lnstats + rowsS, stream)); }
             else RUN(ln_fwd(x, h->visual, v.ln2, h->xa, nullptr, rowsS, h->lnstats, h->lnstats + rowsS));
             if (f8 & 4) {
                 if (fused) {                               // input: the image out_proj left; output: the QuickGELU'd hidden tensor as e4m3 ONLY (h->aq)
