@@ -6,8 +6,12 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdist_amd.so")
 MEASURE_LIB = os.path.join(CSRC, "libdist_amd_measure.so")
-SOURCES = ["gemm_nt.hip", "gemm_fast.hip", "gemm_pp.hip", "gemm_small.hip", "gemm_tn.hip", "gemm_tn8p.hip", "conv_dw.hip", "conv_t_dw.hip", "tnet.hip", "integ.hip", "norm.hip", "attn.hip", "misc.hip", "metrics.hip", "quant.hip", "engine.hip"]
-HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "dist_amd.h")]
+SOURCES = ["gemm_nt.hip", "gemm_fast.hip", "gemm_small.hip", "gemm_tn.hip", "gemm_tn8p.hip", "conv_dw.hip", "conv_t_dw.hip", "tnet.hip", "integ.hip", "norm.hip", "attn.hip", "misc.hip",
+           "metrics.hip", "quant.hip", "engine.hip", "engine_vit.hip", "engine_fwd.hip", "engine_bwd.hip"]
+# kernels of the timing-only library alone (measured-and-rejected variants kept as A/B references): never compiled into libdist_amd.so
+MEASURE_SOURCES = [os.path.join("measure", "gemm_pp.hip")]
+HEADERS = ["common.h", "kernels.h", "engine_internal.h", os.path.join("..", "..", "include", "dist_amd.h"),
+           os.path.join("measure", "gemm_fast8q.inl"), os.path.join("measure", "gemm_fast8q_launch.inl")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 
@@ -38,12 +42,13 @@ def build_library(force=False, verbose=True, measure=False):
     if (open(key_file).read() if os.path.exists(key_file) else "") != key:
         force = True
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
-    srcs = [os.path.join(CSRC, x) for x in SOURCES if os.path.exists(os.path.join(CSRC, x))]
+    sources = SOURCES + (MEASURE_SOURCES if measure else [])
+    srcs = [os.path.join(CSRC, x) for x in sources if os.path.exists(os.path.join(CSRC, x))]
     if not force and not _stale(lib, srcs + hdrs):
         return lib                                       # (a snapshot on the GPU box carries the library but not the objects)
     objs = []
     procs = []
-    for src in SOURCES:
+    for src in sources:
         s = os.path.join(CSRC, src)
         if not os.path.exists(s):
             continue

@@ -249,7 +249,7 @@ int dist_k_conv3x3_dw(const dist_gemm_tn_args* a, hipStream_t s) {
     if (!on) return 0;
     if (a->dtype != DIST_BF16 || !a->use_tr || a->taps != 9 || a->amap.mode != DIST_RM_PLAIN || a->bmap.mode != DIST_RM_SPATIAL) return 0;
     if (a->bmap.p0 != C9_G || (a->bmap.sign != 1 && a->bmap.sign != -1)) return 0;
-    if (a->NI != C9_C || a->K != C9_C || a->lda != C9_C || a->ldb != C9_C || a->inner <= 0 || a->out2) return 0;
+    if (a->NI != C9_C || a->K != C9_C || a->lda != C9_C || a->ldb != C9_C || a->inner <= 0 || a->out2 || a->colsum2) return 0;
     if (a->M % C9_N || a->M < 8 * C9_N || !a->partial) return 0;
     if (((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15)) return 0;
     const long frames = a->M / C9_N;

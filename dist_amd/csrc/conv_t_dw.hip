@@ -255,7 +255,7 @@ int dist_k_conv_t_dw(const dist_gemm_tn_args* a, hipStream_t s) {
     static const int on = dist_knob("DIST_AMD_CONV9", 1);           // (one selector for the two multi-tap kernels) 0: the generic tap-per-tile kernel
     if (!on) return 0;
     if (a->dtype != DIST_BF16 || !a->use_tr || (a->taps != 3 && a->taps != 5) || a->amap.mode != DIST_RM_PLAIN || a->bmap.mode != DIST_RM_SHIFT) return 0;
-    if (a->NI != TD_C || a->K % TD_C || a->K < TD_C || a->lda < TD_C || a->ldb < a->K || a->lda % 8 || a->ldb % 8 || a->inner <= 0 || a->out2) return 0;
+    if (a->NI != TD_C || a->K % TD_C || a->K < TD_C || a->lda < TD_C || a->ldb < a->K || a->lda % 8 || a->ldb % 8 || a->inner <= 0 || a->out2 || a->colsum2) return 0;     // (a pair gradient - two outputs, two bias sums - is the generic kernel's)
     const int N = a->bmap.p1;                             // tokens per frame (the shift of one tap), p0 = rows of a clip
     if (N < 16 || N > 4 * TD_ROWS || a->bmap.p0 <= 0 || a->bmap.p0 % N || a->M % a->bmap.p0 || (a->bmap.sign != 1 && a->bmap.sign != -1)) return 0;
     const int T = a->bmap.p0 / N, PT = (N + 3) / 4;
@@ -272,7 +272,9 @@ int dist_k_conv_t_dw(const dist_gemm_tn_args* a, hipStream_t s) {
     if (clips < 2 || clips > (1 << 20)) return 0;
     static const int max_blocks = dist_knob("DIST_AMD_TN_BLOCKS", 96);
     // one column tile: the caller's cap (a launch beside a critical chain); several (the stem, the last kernel of the backward): a CU per block
+    // (ABI 9: max_blocks bounds the main kernel's workgroups - also here; the engine passes 0 = a CU per block for the stem)
     long bpt = tiles > 1 ? 256 / tiles : (a->max_blocks > 0 ? a->max_blocks : max_blocks);
+    if (tiles > 1 && a->max_blocks > 0 && bpt > a->max_blocks / tiles) bpt = a->max_blocks / tiles > 0 ? a->max_blocks / tiles : 1;
     if (bpt > 256) bpt = 256;
     if (bpt > items) bpt = items;
     const long part = (long)a->taps * TD_C * TD_C + TD_C;

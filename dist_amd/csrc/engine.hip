@@ -10,218 +10,9 @@
 // Conv3d is one launch of the row-mapped MFMA GEMM (gemm_nt.hip) with fused epilogues; no
 // im2col, permute or upsample tensor is ever materialised.  The host side only sequences
 // launches on the caller's stream; it never allocates device memory and never syncs.
-#include <stdarg.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include <string>
-#include <unordered_map>
-#include <vector>
-
-#include "common.h"
-#include "kernels.h"
+#include "engine_internal.h"
 
 namespace {
-
-struct Param {
-    std::string name;
-    int ndim = 0;
-    int64_t dim[5] = {0, 0, 0, 0, 0};
-    int64_t offset = 0;
-    int64_t numel = 0;
-    int group = -1;
-};
-
-struct PW { long f = -1, b = -1; };          // packed working copies (element offsets): forward / data-gradient layout
-
-struct Lin {                                 // y = x W^T + bias, W [N][K] (optionally conv taps)
-    long w = -1, bias = -1;                  // offsets into theta / visual (fp32 master)
-    PW pk;
-    int N = 0, K = 0, taps = 1;
-};
-struct LNp { long w = -1, b = -1; int C = 0; };
-
-struct VitLayer {
-    LNp ln1, ln2; Lin qkv, out, fc, proj;
-    // LayerNorm fold (DIST_EPI_LNFOLD): W diag(gamma) in bf16 (packed-buffer element offsets), column sums and folded biases
-    long pk_fold_qkv = -1, pk_fold_fc = -1;
-    float *cs_qkv = nullptr, *b_qkv = nullptr, *cs_fc = nullptr, *b_fc = nullptr;
-    // fp8 frozen spatial branch (dist_config.vit_fp8, BASELINE config 5): e4m3 copies [N][K] of the four GEMM weights (the folded ones for
-    // qkv / fc) with per-output-channel scales, and the column sums of the DEQUANTISED folded weights (what the fold's mean term must use)
-    struct Fp8W { unsigned char* q = nullptr; float* s = nullptr; };
-    Fp8W q_qkv, q_out, q_fc, q_proj;
-    float *cs8_qkv = nullptr, *cs8_fc = nullptr;
-};
-struct DistLayer {
-    LNp tn_ln; Lin tn_fc1, tn_fc2;           // TemporalNet
-    Lin in_lin, i2t, t2i; long cls_token = -1;
-    LNp in_ln, in_ln_t; Lin ffn_fc, ffn_proj, tf_fc1, tf_fc2, tf_proj;   // IntegrationNetwork
-    long pk_proj_f = -1, pk_proj_b = -1;     // the two c_proj weights side by side: [Ci][Ci+C4] forward, [Ci+C4][Ci] data-gradient
-    // fused IntegrationNetwork forward (integ.hip): MFMA-operand-ordered weights with the two LayerNorms folded in (workspace pointers)
-    void *ig_W1 = nullptr, *ig_W2 = nullptr, *ig_W3 = nullptr; float *ig_b1 = nullptr, *ig_b2 = nullptr, *ig_b3 = nullptr;
-    void *ig_B1 = nullptr, *ig_B2 = nullptr, *ig_B3 = nullptr;      // ... and the data-gradient side (fused backward)
-    void* ig_Wt = nullptr;                                          // ... and the T2I weight (T2I formed in front of the fused forward)
-    void* ig_Wi = nullptr;                                          // ... and the I2T weight (I2T behind it)
-    void* ig_W4 = nullptr;                                          // ... and its transpose (I2T backward behind the fused backward)
-    void* ig_W5 = nullptr;                                          // ... and the T2I weight transposed (T2I backward behind that)
-};
-struct XAttn { LNp ln1; Lin q, kv, out; };   // CrossAttentionBlockGenral (in_proj split into q / kv rows)
-struct AdaLayer { long pos = -1; XAttn sp, tm; LNp ln_sp, ln_tm; Lin sp_fc, sp_proj, tm_fc, tm_proj; };
-
-template <typename T> struct Buf { T* p = nullptr; };
-
-struct Arena {
-    char* base = nullptr;
-    size_t off = 0;
-    void* take(size_t bytes) {
-        off = (off + 255) & ~(size_t)255;
-        void* p = base ? base + off : nullptr;
-        off += bytes;
-        return p;
-    }
-};
-
-struct DistLayerWs {
-    void *X, *U, *z, *V, *p, *Xp, *M, *Mp, *Na, *Nb, *zf, *hf, *h1, *h2, *g2, *R;
-    float *tn_mean, *tn_rstd, *in_mean, *in_rstd;
-};
-struct AdaWs {
-    void *kn, *kv, *qn, *q, *o, *s1, *sn, *zs, *hs, *c, *kn2, *kv2, *qn2, *q2, *o2, *u1, *un, *zu, *hu;
-    float *kn_mean, *kn_rstd, *qn_mean, *qn_rstd, *s1_mean, *s1_rstd, *kn2_mean, *kn2_rstd, *qn2_mean, *qn2_rstd, *u1_mean, *u1_rstd;
-    float *probs, *probs2;
-};
-
-}  // namespace
-
-struct dist_handle {
-    dist_config cfg;
-    int es = 2;                                  // element size of cfg.dtype
-    // derived geometry
-    int G = 0, N = 0, L = 0, t = 0, heads = 0, C4 = 0, Kp = 0, PP3 = 0, iheads = 0;
-    std::vector<Param> params[2];
-    std::unordered_map<std::string, int> index[2];
-    int64_t total[2] = {0, 0};
-    // model tables
-    Lin conv1; long class_emb = -1, pos_emb = -1; LNp ln_pre;
-    std::vector<VitLayer> vit;
-    Lin stem; std::vector<DistLayer> dl; std::vector<AdaLayer> ada;
-    Lin cls_proj; LNp ln_post; Lin proj; long agg_cls = -1, agg_sp_cls = -1;
-    // packing
-    std::vector<PackDesc> descs; std::vector<int> blk_desc, blk_first;
-    int nblk_visual = 0;                         // blocks [0, nblk_visual) pack visual.*, the rest dist_net.*
-    size_t packed_hdr = 0, packed_total = 0; long packed_elems = 0;
-    // bound buffers
-    float *theta = nullptr, *grads = nullptr, *logit_scale = nullptr, *dlogit_scale = nullptr;
-    const float* visual = nullptr;
-    char *packed = nullptr, *ws = nullptr;
-    size_t ws_bytes = 0;
-    // workspace
-    void *patches, *x0, *xa, *hbuf, *qkv, *att, *mlp;
-    float *lnstats2 = nullptr, *lnstats3 = nullptr; int dummy = 0, dummy_reps = 1;   // perturbation experiment (DIST_AMD_DUMMY)
-    float* lnstats = nullptr;                    // [2][rowsS] mean / rstd of the LayerNorm folded into the next ViT GEMM
-    float* lnpart = nullptr;                     // [width / 64][rowsS][2] partial (sum, sum of squares) of the residual stream, left by the GEMM that wrote it
-    unsigned char* aq = nullptr; float* sa = nullptr;   // vit_fp8: e4m3 image [rowsS][<= 4 width] + per-row scales of the GEMM input being consumed
-    // vit_fp8 & 16: the producing epilogues write the e4m3 images themselves (DIST_EPI_OUT8) with per-tensor scales of the PREVIOUS pass:
-    // per block four tensors - 0 = attention-block output (c_fc input), 1 = hidden (c_proj input), 2 = block output (next in_proj input),
-    // 3 = attention output (out_proj input; written as e4m3 by the attention kernel itself), 4 = q | k | v (in_proj output, head-major e4m3 only)
-    unsigned char *x8 = nullptr, *xa8 = nullptr; float *f8_amax = nullptr, *f8_scale = nullptr;
-    long f8_passes = 0; int x8_layer = -1;
-    bool vit_fold = false;                       // ln_1 -> in_proj and ln_2 -> c_fc folded (bf16, shapes the LDS-DMA GEMM takes)
-    std::vector<void*> feat;
-    // Two feature slots (patch rows + the 12 mid_feat tensors + their events): the frozen ViT of the NEXT batch can fill the
-    // spare slot (dist_vit_prefetch) while the branch forward / backward of the current batch read the other one.
-    // `patches`, `feat`, `ev_feat`, `ev_pre` above / below always alias slot[cur].
-    struct FeatSlot {
-        void* patches = nullptr; std::vector<void*> feat; std::vector<hipEvent_t> ev_feat; hipEvent_t ev_pre = nullptr;
-        int b = 0; bool prefetched = false;
-        int next_layer = 0, pending_b = 0;       // a prefetch pass issued in parts (dist_vit_prefetch_layers)
-        std::vector<char> valid;                 // feat[i] holds block i of the clip this slot was last filled with (dist_features_import only writes the blocks it is given)
-    } slot[2];
-    int cur = 0;
-    hipEvent_t ev_vit_done = nullptr, ev_after = nullptr, ev_bpre = nullptr; bool vit_ran = false;
-    void use_slot(int k) { cur = k; patches = slot[k].patches; feat = slot[k].feat; ev_feat = slot[k].ev_feat; ev_pre = slot[k].ev_pre; }
-    std::vector<DistLayerWs> lw; std::vector<AdaWs> aw;
-    void* Xlast;
-    std::vector<void*> sbuf, ubuf;
-    void *Fz, *mean_cls, *ysum, *zpost, *v;
-    float *y_mean, *y_rstd, *logits, *dlogits, *loss;
-    // backward scratch
-    // layer-loop scratch, double-buffered by layer parity (the weight-gradient stream lags the data-gradient chain)
-    struct BwdSet { void *dMp, *dM, *dXp, *dp, *dXo, *dz, *dU, *dY, *dh2, *dh1, *dzf, *dNa, *dNb, *dcat; } bs[2];   // dcat: [dzf | dh1 | dh2] rows of Ci + 2 C4 (fused IntegrationNetwork backward)
-    void *dR, *dkv, *dkn;
-    float* ln_partial = nullptr; long ln_partial_elems = 0;     // per-block parameter-gradient sums of the LayerNorm backward (two-phase, no atomics)
-    float* tnb_scratch = nullptr; long tnb_scratch_elems = 0;   // parameter-gradient partial rows of the fused TemporalNet backward
-    bool ig_on = false, ig_xhat = false, ig_bwd = false, ig_t2i = false, ig_i2t = false, ig_i2tb = false, ig_t2ib = false, keep_mid = false; void* ig_descs = nullptr;   // ig_xhat: the forward keeps xhat (in the Na buffer) instead of Na / Nb; the weight gradients of the two folded Linears are unfolded afterwards
-                  // fused IntegrationNetwork forward: taken for this geometry; its pack descriptors (device)
-    float* tn_partial[3] = {nullptr, nullptr, nullptr};   // two-phase dW reduction scratch, one per stream that launches dW GEMMs
-    long tn_partial_elems = 0;
-    float* ig_gscratch = nullptr;              // [layers][(Ci + C4) * Ci + (Ci + C4)]: G' = dz^T xhat and db of the two folded Linears when dist_branch_backward ACCUMULATES (zero_grads = 0)
-    long ig_gscratch_elems = 0;                // per layer
-    std::vector<int> sel;                      // DIST.SELECTED_LAYERS: ViT block of DiST layer i (dist_config.selected_mask)
-    int nsel = 0;                              // number of DiST layers
-    int Ch = 0, Cf = 0;                        // hidden widths: TemporalNet (Ct * TEMPORAL_CONV_MLP_RATIO), IntegrationNetwork.ffn (Ci * INTEGRATION_MLP_RATIO)
-    int wgrad_blocks = 0;                      // dist_gemm_tn_args.max_blocks of the engine's weight gradients (0 = the library's default, 96; one block per CU for the last
-                                               // layers of the pass - whose gradients finish behind the chain - was measured: 17.85 -> 17.90 ms, not kept)
-    bool bwd_accumulate = false;               // the running dist_branch_backward was called with zero_grads = 0
-    // weight-gradient side stream (created once per handle; host-side objects only)
-    hipStream_t side = nullptr, side2 = nullptr, pf = nullptr;   // pf: the handle's own ViT prefetch stream
-    hipStream_t chain2 = nullptr;                                // backward: the temporal data-gradient chain (T2I data gradient + TemporalNet backward), beside the integration chain
-    std::vector<hipEvent_t> ev_dmp, ev_dx;                       // chain -> chain2: dM'_i written; chain2 -> chain: dX_i written
-    hipEvent_t ev_c2 = nullptr;
-    int skip = 0;                              // DIST_AMD_SKIP (measurement knob, results WRONG): 1 = no weight-gradient GEMMs, 2 = no TemporalNet backward data-gradient kernels, 4 = no TemporalNet forward, 8 = no IntegrationNetwork forward GEMMs, 16 = no large-wgrad (in_lin / proj pair / ffn_fc) only, 32 = no ViT attention, 64 = no ViT MLP (fc + proj GEMMs)
-    int serial = 0;                            // DIST_AMD_SERIAL (measurement knob): bit 0 = branch forward, bit 1 = backward on the caller's stream only
-    std::vector<hipEvent_t> ev_a;              // chain -> side: "buffer produced"
-    std::vector<hipEvent_t> ev_b_dr, ev_b_done; // side -> chain: per layer "dR consumed", "all weight gradients of the layer issued and done"
-    hipEvent_t ev_join = nullptr, ev_pre = nullptr, ev_b2 = nullptr;
-    std::vector<hipEvent_t> ev_feat;           // chain -> side: ViT layer i output (mid_feat[i]) is complete
-    void *dv, *dzp, *dy, *du, *ds, *dc, *dzu, *dun, *do2, *dq2, *dkv2, *dqn2, *dkn2, *dzs, *dsn, *do_, *dq, *dqn;
-    int fwd_b = 0, branch_b = 0;
-    bool inference = false, branch_infer = false;   // dist_set_inference: the next branch forwards keep nothing for a backward pass
-    const float* text = nullptr;               // borrowed: text features of the last branch_forward
-    // gradient-ready hook + the slices it reports
-    dist_grad_ready_fn grad_hook = nullptr; void* grad_hook_user = nullptr;
-    std::vector<int64_t> layer_begin, layer_end; int64_t tail_begin = 0;
-    // phase marks (dist_marks_enable / dist_marks_read): device-side timestamps of the last step on the streams the work runs
-    // on, taken WITHOUT a profiler (rocprofv3 makes the ~700 launches of a step host-bound and shows a schedule that the
-    // un-profiled run does not have)
-    bool marks_on = false;
-    hipEvent_t mark_ev[DIST_NMARKS] = {};
-    // measurement hook (dist_profile_begin/end)
-    bool prof_on = false;
-    std::vector<hipEvent_t> prof_ev;           // pairs (start, stop)
-    int prof_n = 0;
-    double prof_flops = 0.0;
-    char err[512] = {0};
-};
-
-namespace {
-
-int fail(dist_handle* h, int rc, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(h->err, sizeof(h->err), fmt, ap);
-    va_end(ap);
-    return rc;
-}
-
-inline void mark(dist_handle* h, int which, hipStream_t st) {
-    if (h->marks_on && h->mark_ev[which]) hipEventRecord(h->mark_ev[which], st);
-}
-#define RUN(call)                                                        \
-    do {                                                                 \
-        int rc_ = (call);                                                \
-        if (rc_ != DIST_OK) return fail(h, rc_, "%s failed (%d) at %s:%d", #call, rc_, __FILE__, __LINE__); \
-    } while (0)
-
-std::string fmt(const char* f, ...) {
-    char buf[256];
-    va_list ap;
-    va_start(ap, f);
-    vsnprintf(buf, sizeof(buf), f, ap);
-    va_end(ap);
-    return buf;
-}
 
 long add_param(dist_handle* h, int kind, const std::string& name, std::initializer_list<int64_t> dims) {
     Param p;
@@ -570,187 +361,6 @@ size_t layout_ws(dist_handle* h, char* base) {
     return a.off + 256;
 }
 
-// ---- launch helpers ---------------------------------------------------------------------------------------
-struct Ctx {
-    dist_handle* h;
-    hipStream_t s;
-    int dtype;
-    const char* pk(long off) const { return h->packed + h->packed_hdr + (size_t)off * h->es; }
-    const float* th(long off) const { return h->theta + off; }
-    const float* vs(long off) const { return h->visual + off; }
-    float* gr(long off) const { return h->grads + off; }
-};
-
-dist_rowmap RM(int mode = DIST_RM_PLAIN, int p0 = 0, int p1 = 0, int sign = 1) { return dist_rowmap{mode, p0, p1, sign}; }
-dist_outmap OM(int mode = DIST_OM_PLAIN, int p0 = 0, int p1 = 0, int p2 = 0) { return dist_outmap{mode, p0, p1, p2}; }
-
-// C (and/or C2) = epi(A[amap] . W^T): thin positional wrapper over dist_op_gemm_nt
-int gemm(const Ctx& c, const void* A, int lda, const void* W, long M, int N, int K, int taps, void* C, int ldc,
-         const float* bias, const void* res, const void* aux, void* C2, dist_rowmap am = RM(), dist_outmap om = OM(), int extra_flags = 0, const float* bias2 = nullptr,
-         float* rowstats = nullptr) {
-    dist_gemm_args g;
-    memset(&g, 0, sizeof(g));
-    g.A = A; g.B = W; g.C = C; g.C2 = C2; g.bias = bias; g.bias2 = bias2; g.res = res; g.aux = aux;
-    if (rowstats) { g.rowstats = rowstats; extra_flags |= DIST_EPI_ROWSTATS; }
-    g.M = M; g.N = N; g.K = K; g.taps = taps;
-    g.lda = lda; g.ldb = taps * K; g.ldc = ldc; g.ldc2 = ldc; g.ldres = ldc; g.ldaux = ldc;
-    g.amap = am; g.omap = om;
-    g.flags = (bias ? DIST_EPI_BIAS : 0) | (res ? DIST_EPI_RES : 0) | (aux ? DIST_EPI_MULG : 0) | (C2 ? DIST_EPI_ACT2 : 0) | extra_flags;
-    g.dtype = c.dtype;
-    dist_handle* h = c.h;
-    const bool dominant = h->prof_on && dist_k_gemm_fast_eligible(&g);
-    if (!dominant) return dist_op_gemm_nt(&g, c.s);
-    if (h->prof_n + 2 > (int)h->prof_ev.size()) {
-        for (int i = 0; i < 256; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return DIST_ERR_STATE; h->prof_ev.push_back(e); }
-    }
-    hipEventRecord(h->prof_ev[h->prof_n], c.s);
-    const int rc = dist_op_gemm_nt(&g, c.s);
-    hipEventRecord(h->prof_ev[h->prof_n + 1], c.s);
-    h->prof_n += 2;
-    h->prof_flops += 2.0 * (double)M * N * K;
-    return rc;
-}
-
-// weight gradient of a Lin into the flat grads buffer, in the reference parameter layout
-// C = epi(LN(A) . W^T) with the LayerNorm folded into the GEMM (DIST_EPI_LNFOLD): A holds the RAW rows, Wf = W diag(gamma),
-// stats = [2][M] mean / rstd, colsum / biasf from dist_op_ln_fold.  Returns 1 when the LDS-DMA kernel took it, 0 when the shape
-// is not eligible (the caller runs LayerNorm + GEMM instead), < 0 on error.
-int gemm_lnfold(const Ctx& c, const void* A, int lda, const void* Wf, long M, int N, int K, void* C, int ldc, const float* biasf,
-                const float* stats, const float* colsum, void* C2, dist_outmap om = OM()) {
-    dist_gemm_args g;
-    memset(&g, 0, sizeof(g));
-    g.A = A; g.B = Wf; g.C = C; g.C2 = C2; g.bias = biasf; g.bias2 = colsum; g.aux = stats;
-    g.M = M; g.N = N; g.K = K; g.taps = 1;
-    g.lda = lda; g.ldb = K; g.ldc = ldc; g.ldc2 = ldc; g.ldres = ldc; g.ldaux = ldc;
-    g.amap = RM(); g.omap = om;
-    g.flags = DIST_EPI_BIAS | DIST_EPI_LNFOLD | (C2 ? DIST_EPI_ACT2 : 0);
-    g.dtype = c.dtype;
-    if (!dist_k_gemm_fast_eligible(&g)) return 0;
-    dist_handle* h = c.h;
-    if (h->prof_on) {
-        if (h->prof_n + 2 > (int)h->prof_ev.size()) {
-            for (int i = 0; i < 256; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return DIST_ERR_STATE; h->prof_ev.push_back(e); }
-        }
-        hipEventRecord(h->prof_ev[h->prof_n], c.s);
-    }
-    const int rc = dist_op_gemm_nt(&g, c.s);
-    if (h->prof_on) {
-        hipEventRecord(h->prof_ev[h->prof_n + 1], c.s);
-        h->prof_n += 2;
-        h->prof_flops += 2.0 * (double)M * N * K;
-    }
-    return rc < 0 ? rc : 1;
-}
-// C (or C2 = quickgelu) = epi(Aq . Wq^T) on e4m3 operands (DIST_EPI_FP8): Aq / sa from dist_op_quant_rows_fp8 over the bf16 input, Wq / its
-// scales from the pack.  `stats` != nullptr: LayerNorm fold (bias = folded bias, colsum of the dequantised weights).  Returns 1 when
-// launched, 0 when the shape is not eligible (the caller runs the bf16 GEMM), < 0 on error.
-struct Out8 { unsigned char* img = nullptr; const float* scale = nullptr; float* amax = nullptr; bool act = false; };   // DIST_EPI_OUT8 (act: QuickGELU'd, e4m3 only)
-int gemm_fp8(const Ctx& c, const unsigned char* Aq, const float* sa, bool sa_scalar, const VitLayer::Fp8W& W, long M, int N, int K, void* C, int ldc,
-             const float* bias, const void* res, void* C2, const float* stats, const float* colsum, float* rowstats, dist_outmap om = OM(), Out8 o8 = Out8()) {
-    dist_gemm_args g;
-    memset(&g, 0, sizeof(g));
-    g.A = Aq; g.B = W.q; g.C = C; g.C2 = C2; g.bias = bias; g.bias2 = colsum; g.aux = stats; g.res = res;
-    g.a_scale = sa; g.b_scale = W.s; g.rowstats = rowstats;
-    g.M = M; g.N = N; g.K = K; g.taps = 1;
-    g.lda = K; g.ldb = K; g.ldc = ldc; g.ldc2 = ldc; g.ldres = ldc; g.ldaux = ldc;
-    g.amap = RM(); g.omap = om;
-    g.flags = DIST_EPI_FP8 | (sa_scalar ? DIST_EPI_FP8_ASCALAR : 0) | (bias ? DIST_EPI_BIAS : 0) | (res ? DIST_EPI_RES : 0) | (stats ? DIST_EPI_LNFOLD : 0) |
-              ((C2 || o8.act) ? DIST_EPI_ACT2 : 0) | (rowstats ? DIST_EPI_ROWSTATS : 0);
-    if (o8.img) { g.C8 = o8.img; g.ldc8 = om.mode == DIST_OM_HEADS ? 64 : N; g.out8_scale = o8.scale; g.out8_amax = o8.amax; g.flags |= DIST_EPI_OUT8; }
-    g.dtype = DIST_BF16;
-    if (!dist_k_gemm_fast_eligible(&g)) return 0;
-    const int rc = dist_op_gemm_nt(&g, c.s);
-    return rc < 0 ? rc : 1;
-}
-// does the e4m3 mode of the LDS-DMA kernel take C [M][N] = A [M][K] W^T ?
-bool fp8_shape_ok(const Ctx& c, long M, int N, int K) {
-    dist_gemm_args g;
-    memset(&g, 0, sizeof(g));
-    void* nz = reinterpret_cast<void*>(16);
-    g.A = nz; g.B = nz; g.C = nz; g.a_scale = static_cast<const float*>(nz); g.b_scale = static_cast<const float*>(nz);
-    g.M = M; g.N = N; g.K = K; g.taps = 1; g.lda = K; g.ldb = K; g.ldc = g.ldc2 = g.ldres = g.ldaux = N;
-    g.amap = RM(); g.omap = OM(); g.flags = DIST_EPI_FP8; g.dtype = DIST_BF16;
-    return dist_k_gemm_fast_eligible(&g);
-}
-// can C = A W^T + bias + res (plain maps) leave DIST_EPI_ROWSTATS partials, i.e. does the LDS-DMA kernel take this shape?
-bool rowstats_ok(const Ctx& c, long M, int N, int K) {
-    dist_gemm_args g;
-    memset(&g, 0, sizeof(g));
-    void* nz = reinterpret_cast<void*>(16);
-    g.A = nz; g.B = nz; g.C = nz; g.res = nz; g.bias = static_cast<const float*>(nz); g.rowstats = static_cast<float*>(nz);
-    g.M = M; g.N = N; g.K = K; g.taps = 1; g.lda = K; g.ldb = K; g.ldc = g.ldc2 = g.ldres = g.ldaux = N;
-    g.amap = RM(); g.omap = OM(); g.flags = DIST_EPI_BIAS | DIST_EPI_RES | DIST_EPI_ROWSTATS; g.dtype = c.dtype;
-    return N % 64 == 0 && dist_k_gemm_fast_eligible(&g);
-}
-int wgrad(const Ctx& c, const Lin& l, const void* dY, int ld_dy, const void* X, int ldx, long M,
-          dist_rowmap am = RM(), dist_rowmap bm = RM(), int style = 0, bool with_bias = false, float* out_w = nullptr, float* out_b = nullptr) {
-    dist_gemm_tn_args g;
-    memset(&g, 0, sizeof(g));
-    g.A = dY; g.B = X; g.out = c.gr(l.w);
-    g.M = M; g.NI = l.N; g.K = l.K; g.taps = l.taps; g.lda = ld_dy; g.ldb = ldx; g.amap = am; g.bmap = bm;
-    if (style == 0) { g.so_i = l.K; g.so_tap = 0; g.so_outer = 1; g.inner = 1; }
-    else if (style == 1 || style == 2) { g.so_i = (long)l.K * l.taps; g.so_tap = 1; g.so_outer = l.taps; g.inner = 1; }
-    else if (style == 4) { g.NI = l.K; g.K = l.N; g.so_i = l.N; g.so_tap = 0; g.so_outer = 1; g.inner = 1; }   // [K][N] matrix used as x @ W
-    else { const int PP3 = c.h->PP3, PP = PP3 / 3; g.K = PP3; g.so_i = (long)PP3 * l.taps; g.so_tap = PP; g.so_outer = (long)PP * l.taps; g.inner = PP; }
-    g.dtype = c.dtype; g.use_tr = c.h->cfg.use_tr; g.max_blocks = c.h->wgrad_blocks;
-    if (c.h->skip & 1) return DIST_OK;
-    if ((c.h->skip & 16) && l.N >= 384 && l.K >= 384) return DIST_OK;
-    g.colsum = (with_bias && l.bias >= 0) ? c.gr(l.bias) : nullptr;       // db fused into the same pass over dY
-    if (out_w) { g.out = out_w; if (g.colsum) g.colsum = out_b; }         // (the accumulating backward: G' of a folded Linear goes to scratch)
-    {   // two-phase reduction scratch of the stream this launch goes to
-        dist_handle* h = c.h;
-        const int k = c.s == h->side ? 1 : (c.s == h->side2 ? 2 : 0);
-        g.partial = h->tn_partial[k]; g.partial_elems = h->tn_partial_elems;
-    }
-    return dist_op_gemm_tn(&g, c.s);
-}
-// weight (+ bias) gradients of two Linears that consume the SAME dY and whose inputs are stored side by side
-// ([X1 | X2], ldx = K1 + K2): one pass over dY, columns < K1 go to l1's weight, the rest to l2's; both biases get colsum(dY)
-int wgrad_pair(const Ctx& c, const Lin& l1, const Lin& l2, const void* dY, int ld_dy, const void* X12, int ldx, long M) {
-    dist_gemm_tn_args g;
-    memset(&g, 0, sizeof(g));
-    g.A = dY; g.B = X12; g.out = c.gr(l1.w);
-    g.M = M; g.NI = l1.N; g.K = l1.K + l2.K; g.taps = 1; g.lda = ld_dy; g.ldb = ldx; g.amap = RM(); g.bmap = RM();
-    g.so_i = l1.K; g.so_tap = 0; g.so_outer = 1; g.inner = 1;
-    g.split_c = l1.K; g.out2 = c.gr(l2.w); g.so_i2 = l2.K;
-    if (c.h->skip & 17) return DIST_OK;
-    g.dtype = c.dtype; g.use_tr = c.h->cfg.use_tr; g.max_blocks = c.h->wgrad_blocks;
-    g.colsum = c.gr(l1.bias); g.colsum2 = c.gr(l2.bias);
-    dist_handle* h = c.h;
-    const int k = c.s == h->side ? 1 : (c.s == h->side2 ? 2 : 0);
-    g.partial = h->tn_partial[k]; g.partial_elems = h->tn_partial_elems;
-    return dist_op_gemm_tn(&g, c.s);
-}
-int bgrad(const Ctx& c, long bias_off, const void* dY, long rows, int C, dist_rowmap m = RM()) {
-    return dist_op_colsum(dY, c.gr(bias_off), rows, C, C, m, c.dtype, c.s);
-}
-int ln_fwd(const Ctx& c, const float* wbase, const LNp& l, const void* x, void* y, long rows, float* mean, float* rstd,
-           const LNp* l2 = nullptr, void* y2 = nullptr, const float* addend = nullptr, int period = 0) {
-    dist_ln_args a;
-    memset(&a, 0, sizeof(a));
-    a.x = x; a.y = y; a.y2 = y2; a.w = wbase + l.w; a.b = wbase + l.b;
-    if (l2) { a.w2 = wbase + l2->w; a.b2 = wbase + l2->b; }
-    a.addend = addend; a.addend_period = period; a.mean = mean; a.rstd = rstd;
-    a.rows = rows; a.C = l.C; a.dtype = c.dtype; a.eps = 1e-5f;
-    return dist_op_layernorm(&a, c.s);
-}
-int ln_bwd(const Ctx& c, const LNp& l, const void* x, const float* mean, const float* rstd, const void* dy, void* dx, bool accumulate,
-           long rows, const LNp* l2 = nullptr, const void* dy2 = nullptr, const void* dx_add = nullptr, void* dx_copy = nullptr, bool param_grads = true) {
-    dist_ln_bwd_args a;
-    memset(&a, 0, sizeof(a));
-    a.x = x; a.mean = mean; a.rstd = rstd; a.dy = dy; a.w = c.th(l.w); a.dx = dx; a.accumulate_dx = accumulate ? 1 : 0;
-    if (param_grads) { a.dw = c.gr(l.w); a.db = c.gr(l.b); }
-    if (l2) { a.dy2 = dy2; a.w2 = c.th(l2->w); if (param_grads) { a.dw2 = c.gr(l2->w); a.db2 = c.gr(l2->b); } }
-    a.rows = rows; a.C = l.C; a.dtype = c.dtype;
-    a.dx_add = dx_add; a.dx_copy = dx_copy;
-    // Two-phase parameter gradients (dist_ln_bwd_args.partial): measured in the step and NOT the default - 20.03 -> 20.20 ms with the same grid
-    // caps, 20.2 with 512 blocks (three alternations): the second launch sits on the data-gradient chain and costs more than the same-line
-    // atomics it removes.  DIST_AMD_LN_TWO_PHASE=1 turns it on (the data-gradient chain owns the scratch: its launches are serial).
-    static const bool two_phase = DIST_AB_KNOB("DIST_AMD_LN_TWO_PHASE", 0) == 1;
-    if (two_phase && c.s != c.h->side && c.s != c.h->side2) { a.partial = c.h->ln_partial; a.partial_elems = c.h->ln_partial_elems; }
-    return dist_op_layernorm_bwd(&a, c.s);
-}
-
 }  // namespace
 
 // =============================================================================================================
@@ -987,774 +597,6 @@ extern "C" int dist_pack_weights(dist_handle* h, int what, void* stream) {
         }
     }
     if (what == 2) mark(h, DIST_MARK_STEP_END, s);
-    return DIST_OK;
-}
-
-// -------------------------------------------------------------------------------------------------------------
-// The frozen ViT of one batch into feature slot `k` on `stream`.  `after` (when ordered_after): a stream whose already queued work must
-// finish first (pipelined use: the backward of the batch that last used this slot, the weight re-pack).
-static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, void* stream, bool ordered_after, void* after, int l0, int l1) {
-    const dist_config& c = h->cfg;
-    Ctx x{h, static_cast<hipStream_t>(stream), c.dtype};
-    dist_handle::FeatSlot& S = h->slot[k];
-    const int d = c.width, N = h->N, L = h->L;
-    const long rowsS = (long)b * h->t * L, rowsQ = (long)b * h->t * N;
-
-    if (ordered_after && after != stream) {
-        HIP_CHECK_RET(hipEventRecord(h->ev_after, static_cast<hipStream_t>(after)));
-        HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_after, 0));
-    }
-    const void* xin = h->x0;
-    if (l0 == 0) {
-        // the ViT-internal scratch (x0, xa, hbuf, qkv, att, mlp) exists once: consecutive ViT passes are ordered, whatever their streams
-        if (h->vit_ran) HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_vit_done, 0));
-        HIP_CHECK_RET(hipEventRecord(S.ev_pre, x.s));                   // everything queued before this pass (re-pack, previous step)
-        mark(h, DIST_MARK_VIT_BEGIN, x.s);
-        RUN(dist_op_patchify(video, S.patches, b, c.frames, c.resolution, c.resolution, c.patch, c.dtype, stream));
-        HIP_CHECK_RET(hipEventRecord(S.ev_feat[c.layers], x.s));       // patch rows ready (temporal stem input)
-        // patch embedding of the frames k = alpha*j only (the reference embeds all T frames and drops the
-        // others at clip.py:284); rows land behind their frame's cls row
-        RUN(gemm(x, S.patches, h->Kp, x.pk(h->conv1.pk.f), rowsQ, d, h->Kp, 1, h->xa, d, nullptr, nullptr, nullptr, nullptr,
-                 RM(DIST_RM_STRIDED, c.alpha, N), OM(DIST_OM_INSERTCLS, N)));
-        RUN(dist_k_cls_rows(h->xa, nullptr, x.vs(h->class_emb), b * h->t, L, d, 1, c.dtype, x.s));
-        RUN(ln_fwd(x, h->visual, h->ln_pre, h->xa, h->x0, rowsS, nullptr, nullptr, nullptr, nullptr, x.vs(h->pos_emb), L));
-    } else {
-        xin = S.feat[l0 - 1];
-    }
-    // Row statistics of the residual stream from the GEMM that writes it (DIST_EPI_ROWSTATS): `out` leaves the partials ln_2 / c_fc
-    // need, `proj` those of the next block's ln_1 / in_proj; dist_op_ln_stats_from_partials (5 MB in, 0.4 MB out) replaces the
-    // statistics pass over the 77 MB tensor (23 of 24 per ViT pass).  The first block of a call still runs the statistics pass (its input comes from ln_pre, or from an
-    // earlier partial pass).  DIST_AMD_ROWSTATS=0: off (measurement knob).
-    static const bool rs_env = (dist_knob("DIST_AMD_ROWSTATS", 1) != 0);
-    const bool rs = rs_env && h->vit_fold && rowstats_ok(x, rowsS, d, d) && rowstats_ok(x, rowsS, d, 4 * d);
-    bool part_of_xin = false;                          // lnpart holds the partials of `xin`
-    // dist_config.vit_fp8 (BASELINE config 5): which of the four GEMMs of a block run on e4m3 operands - bit 0 in_proj, 1 out_proj, 2 c_fc,
-    // 3 c_proj.  Needs the LayerNorm fold (bf16 engine); a GEMM whose shape the fp8 kernel does not take runs in bf16.
-    const int f8 = (h->aq && h->vit_fold) ? c.vit_fp8 : 0;
-    // producers write the e4m3 images (bit 16): needs all four GEMMs on e4m3, scales from an earlier pass, shapes the fp8 kernel takes
-    const bool img_mode = (f8 & 31) == 31 && h->x8 && fp8_shape_ok(x, rowsS, 3 * d, d) && fp8_shape_ok(x, rowsS, d, d) && fp8_shape_ok(x, rowsS, 4 * d, d) &&
-                          fp8_shape_ok(x, rowsS, d, 4 * d);
-    if (img_mode && l0 == 0) {
-        if (h->f8_passes > 0) RUN(dist_op_fp8_scale_update(h->f8_amax, h->f8_scale, 5 * c.layers, 4.0f, stream));   // last pass's maxima -> this pass's scales
-        h->x8_layer = -1;
-    }
-    const bool fused = img_mode && h->f8_passes > 0;      // the first pass after a pack calibrates: per-token quantisers + dist_op_amax
-    for (int i = l0; i < l1; ++i) {
-        const VitLayer& v = h->vit[i];
-        // the QKV GEMM writes [frame][head][q|k|v][L][64] (DIST_OM_HEADS, leading dimension 64): every (frame, head) operand of
-        // the attention kernel is one contiguous block instead of 128-byte pieces at a 3d row stride.
-        // LayerNorm fold: ln_1 only computes the row statistics (reads 77 MB, writes 0.4 MB); the GEMM consumes the raw rows with
-        // W diag(gamma) and normalises in its epilogue - the normalised tensor is never written or read back.
-        int folded = 0;
-        if (h->vit_fold) {
-            if (part_of_xin) { if (!(h->skip & 128)) RUN(dist_op_ln_stats_from_partials(h->lnpart, d / 64, rowsS, d, 1e-5f, h->lnstats, h->lnstats + rowsS, stream)); }   // (skip 128, timing only: stale statistics)
-            else RUN(ln_fwd(x, h->visual, v.ln1, xin, nullptr, rowsS, h->lnstats, h->lnstats + rowsS));
-            if (f8 & 1) {                                  // e4m3 image of the raw rows, then the folded GEMM on the block-scaled fp8 MFMA
-                Out8 q8o;                                  // image mode: q | k | v leave as e4m3 ONLY (head-major bytes in h->qkv)
-                if (fused) { q8o.img = static_cast<unsigned char*>(h->qkv); q8o.scale = h->f8_scale + 5 * i + 4; q8o.amax = h->f8_amax + 5 * i + 4; }
-                void* qkv16 = fused ? nullptr : h->qkv;
-                if (fused && i > 0 && h->x8_layer == i - 1) {     // the previous block's c_proj left the image
-                    folded = gemm_fp8(x, h->x8, h->f8_scale + 5 * (i - 1) + 2, true, v.q_qkv, rowsS, 3 * d, d, qkv16, 64, v.b_qkv, nullptr, nullptr, h->lnstats, v.cs8_qkv, nullptr,
-                                      OM(DIST_OM_HEADS, L, h->heads), q8o);
-                } else {
-                    RUN(dist_op_quant_rows_fp8(xin, DIST_BF16, rowsS, d, d, h->aq, d, h->sa, stream));
-                    folded = gemm_fp8(x, h->aq, h->sa, false, v.q_qkv, rowsS, 3 * d, d, qkv16, 64, v.b_qkv, nullptr, nullptr, h->lnstats, v.cs8_qkv, nullptr, OM(DIST_OM_HEADS, L, h->heads), q8o);
-                }
-                if (img_mode && !fused && folded > 0) RUN(dist_op_amax(h->qkv, DIST_BF16, rowsS * 3 * d, h->f8_amax + 5 * i + 4, stream));
-                if (folded < 0) return fail(h, folded, "fp8 QKV GEMM failed");
-            }
-            if (!folded) folded = gemm_lnfold(x, xin, d, x.pk(v.pk_fold_qkv), rowsS, 3 * d, d, h->qkv, 64, v.b_qkv, h->lnstats, v.cs_qkv, nullptr, OM(DIST_OM_HEADS, L, h->heads));
-            if (folded < 0) return fail(h, folded, "folded QKV GEMM failed");
-        }
-        if (!folded) {
-            RUN(ln_fwd(x, h->visual, v.ln1, xin, h->hbuf, rowsS, nullptr, nullptr));
-            RUN(gemm(x, h->hbuf, d, x.pk(v.qkv.pk.f), rowsS, 3 * d, d, 1, h->qkv, 64, x.vs(v.qkv.bias), nullptr, nullptr, nullptr, RM(), OM(DIST_OM_HEADS, L, h->heads)));
-        }
-        if (fused) RUN(dist_op_attention_fp8(h->qkv, h->f8_scale + 5 * i + 4, nullptr, h->aq, h->f8_scale + 5 * i + 3, h->f8_amax + 5 * i + 3, b * h->t, L, h->heads, stream));
-        else if (!(h->skip & 32)) RUN(dist_op_attention(h->qkv, h->att, b * h->t, L, h->heads, DIST_QKV_HEADS, c.dtype, stream));
-        int done8 = 0;
-        if (f8 & 2) {
-            if (fused) {                                   // the attention kernel left the e4m3 image in h->aq
-                Out8 o8;
-                o8.img = h->xa8; o8.scale = h->f8_scale + 5 * i; o8.amax = h->f8_amax + 5 * i;
-                done8 = gemm_fp8(x, h->aq, h->f8_scale + 5 * i + 3, true, v.q_out, rowsS, d, d, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr, nullptr, rs ? h->lnpart : nullptr, OM(), o8);
-            } else {
-                RUN(dist_op_quant_rows_fp8(h->att, DIST_BF16, rowsS, d, d, h->aq, d, h->sa, stream));
-                done8 = gemm_fp8(x, h->aq, h->sa, false, v.q_out, rowsS, d, d, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr, nullptr, rs ? h->lnpart : nullptr);
-                if (img_mode && done8 > 0) {
-                    RUN(dist_op_amax(h->xa, DIST_BF16, rowsS * d, h->f8_amax + 5 * i, stream));
-                    RUN(dist_op_amax(h->att, DIST_BF16, rowsS * d, h->f8_amax + 5 * i + 3, stream));
-                }
-            }
-            if (done8 < 0) return fail(h, done8, "fp8 out-projection GEMM failed");
-        }
-        if (!done8) RUN(gemm(x, h->att, d, x.pk(v.out.pk.f), rowsS, d, d, 1, h->xa, d, x.vs(v.out.bias), xin, nullptr, nullptr, RM(), OM(), 0, nullptr, rs ? h->lnpart : nullptr));
-        folded = 0;
-        if (h->vit_fold) {
-            if (rs) { if (!(h->skip & 128)) RUN(dist_op_ln_stats_from_partials(h->lnpart, d / 64, rowsS, d, 1e-5f, h->lnstats, h->lnstats + rowsS, stream)); }
-            else RUN(ln_fwd(x, h->visual, v.ln2, h->xa, nullptr, rowsS, h->lnstats, h->lnstats + rowsS));
-            if (f8 & 4) {
-                if (fused) {                               // input: the image out_proj left; output: the QuickGELU'd hidden tensor as e4m3 ONLY (h->aq)
-                    Out8 o8;
-                    o8.img = h->aq; o8.scale = h->f8_scale + 5 * i + 1; o8.amax = h->f8_amax + 5 * i + 1; o8.act = true;
-                    folded = gemm_fp8(x, h->xa8, h->f8_scale + 5 * i, true, v.q_fc, rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, nullptr, nullptr, h->lnstats, v.cs8_fc, nullptr, OM(), o8);
-                } else {
-                    RUN(dist_op_quant_rows_fp8(h->xa, DIST_BF16, rowsS, d, d, h->aq, d, h->sa, stream));
-                    folded = gemm_fp8(x, h->aq, h->sa, false, v.q_fc, rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, nullptr, h->mlp, h->lnstats, v.cs8_fc, nullptr);
-                    if (img_mode && folded > 0) RUN(dist_op_amax(h->mlp, DIST_BF16, rowsS * 4 * d, h->f8_amax + 5 * i + 1, stream));
-                }
-                if (folded < 0) return fail(h, folded, "fp8 MLP GEMM failed");
-            }
-            if (!folded && !(h->skip & 64)) folded = gemm_lnfold(x, h->xa, d, x.pk(v.pk_fold_fc), rowsS, 4 * d, d, nullptr, 4 * d, v.b_fc, h->lnstats, v.cs_fc, h->mlp);
-            if (h->skip & 64) folded = 1;
-            if (folded < 0) return fail(h, folded, "folded MLP GEMM failed");
-        }
-        if (!folded) {
-            RUN(ln_fwd(x, h->visual, v.ln2, h->xa, h->hbuf, rowsS, nullptr, nullptr));
-            RUN(gemm(x, h->hbuf, d, x.pk(v.fc.pk.f), rowsS, 4 * d, d, 1, nullptr, 4 * d, x.vs(v.fc.bias), nullptr, nullptr, h->mlp));
-        }
-        done8 = 0;
-        if (f8 & 8) {
-            if (fused) {
-                Out8 o8;
-                o8.img = h->x8; o8.scale = h->f8_scale + 5 * i + 2; o8.amax = h->f8_amax + 5 * i + 2;
-                done8 = gemm_fp8(x, h->aq, h->f8_scale + 5 * i + 1, true, v.q_proj, rowsS, d, 4 * d, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr, nullptr,
-                                 rs ? h->lnpart : nullptr, OM(), o8);
-                if (done8 > 0) h->x8_layer = i;
-            } else {
-                RUN(dist_op_quant_rows_fp8(h->mlp, DIST_BF16, rowsS, 4 * d, 4 * d, h->aq, 4 * d, h->sa, stream));
-                done8 = gemm_fp8(x, h->aq, h->sa, false, v.q_proj, rowsS, d, 4 * d, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr, nullptr, rs ? h->lnpart : nullptr);
-                if (img_mode && done8 > 0) RUN(dist_op_amax(S.feat[i], DIST_BF16, rowsS * d, h->f8_amax + 5 * i + 2, stream));
-            }
-            if (done8 < 0) return fail(h, done8, "fp8 MLP projection GEMM failed");
-        }
-        if (!done8) RUN(gemm(x, h->mlp, 4 * d, x.pk(v.proj.pk.f), rowsS, d, 4 * d, 1, S.feat[i], d, x.vs(v.proj.bias), h->xa, nullptr, nullptr, RM(), OM(), 0, nullptr, rs ? h->lnpart : nullptr));
-        part_of_xin = rs;
-        HIP_CHECK_RET(hipEventRecord(S.ev_feat[i], x.s));               // mid_feat[i] complete: the branch may consume it
-        S.valid[i] = 1;
-        if (h->dummy & 1) for (int r = 0; r < h->dummy_reps; ++r) RUN(ln_fwd(x, h->visual, v.ln1, S.feat[i], nullptr, rowsS, h->lnstats2, h->lnstats2 + rowsS));
-        xin = S.feat[i];
-    }
-    S.next_layer = l1;
-    S.pending_b = b;
-    if (l1 == c.layers && img_mode) ++h->f8_passes;
-    if (l1 == c.layers) {
-        HIP_CHECK_RET(hipEventRecord(h->ev_vit_done, x.s));
-        mark(h, DIST_MARK_VIT_END, x.s);
-        h->vit_ran = true;
-        S.b = b;
-    }
-    return DIST_OK;
-}
-
-static int vit_args_ok(dist_handle* h, const float* video, int b, const char* who) {
-    if (!h || !video) return DIST_ERR_ARG;
-    if (!h->ws) return fail(h, DIST_ERR_UNBOUND, "%s before dist_bind", who);
-    if (b <= 0 || b > h->cfg.batch) return fail(h, DIST_ERR_ARG, "batch %d outside (0, %d]", b, h->cfg.batch);
-    return DIST_OK;
-}
-
-extern "C" int dist_vit_forward(dist_handle* h, const float* video, int b, void* stream) {
-    RUN(vit_args_ok(h, video, b, "dist_vit_forward"));
-    h->slot[h->cur].prefetched = false;
-    RUN(vit_forward_slot(h, video, b, h->cur, stream, false, nullptr, 0, h->cfg.layers));
-    h->fwd_b = b;
-    h->branch_b = 0;
-    return DIST_OK;
-}
-
-// The caller's own frozen-ViT features instead of a dist_vit_forward pass (reference DiSTNetwork.forward reads input['mid_feat']['img'][layer_id]
-// and input['images'], dist.py:222-247): copied into the current feature slot, converted to the engine's storage type and token-major rows.
-extern "C" int dist_features_import(dist_handle* h, const void* const* mid_feat, int src_dtype, const float* video, int b, void* stream) {
-    RUN(vit_args_ok(h, video, b, "dist_features_import"));
-    if (!mid_feat || (src_dtype != DIST_F32 && src_dtype != DIST_BF16)) return fail(h, DIST_ERR_ARG, "dist_features_import: mid_feat / src_dtype");
-    const dist_config& c = h->cfg;
-    for (int i : h->sel)
-        if (!mid_feat[i]) return fail(h, DIST_ERR_ARG, "dist_features_import: mid_feat[%d] is NULL (every selected block is needed; the others may be NULL)", i);
-    dist_handle::FeatSlot& S = h->slot[h->cur];
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    S.prefetched = false;
-    if (h->vit_ran) HIP_CHECK_RET(hipStreamWaitEvent(s, h->ev_vit_done, 0));      // a ViT pass still in flight may be writing this slot
-    HIP_CHECK_RET(hipEventRecord(S.ev_pre, s));
-    RUN(dist_op_patchify(video, S.patches, b, c.frames, c.resolution, c.resolution, c.patch, c.dtype, stream));
-    HIP_CHECK_RET(hipEventRecord(S.ev_feat[c.layers], s));
-    for (int i = 0; i < c.layers; ++i) {
-        if (mid_feat[i]) RUN(dist_k_import_feat(mid_feat[i], src_dtype, S.feat[i], c.dtype, b * h->t, h->L, c.width, s));
-        S.valid[i] = mid_feat[i] ? 1 : 0;                               // a block the caller did not supply still holds an OLDER clip: not readable
-        HIP_CHECK_RET(hipEventRecord(S.ev_feat[i], s));
-    }
-    S.next_layer = c.layers; S.pending_b = b; S.b = b;
-    h->fwd_b = b;
-    h->branch_b = 0;
-    return DIST_OK;
-}
-
-// Software pipelining over batches: the ViT is frozen, so its forward for batch n+1 does not depend on the optimizer step of
-// batch n.  dist_vit_prefetch runs it into the spare feature slot on its own (low-priority) stream while the branch
-// forward / backward / AdamW of batch n run on the caller's stream; dist_vit_adopt makes that slot the current one.
-extern "C" int dist_vit_prefetch_layers(dist_handle* h, const float* video, int b, int layer_end, void* stream, void* after) {
-    if (!h) return DIST_ERR_ARG;
-    const int k = h->cur ^ 1;
-    dist_handle::FeatSlot& S = h->slot[k];
-    int l0 = 0;
-    if (video) {                                       // a new pass into the spare slot
-        RUN(vit_args_ok(h, video, b, "dist_vit_prefetch"));
-        S.prefetched = true;
-        S.b = 0;
-    } else {                                           // continue the pass in flight
-        if (!h->ws) return fail(h, DIST_ERR_UNBOUND, "dist_vit_prefetch_layers before dist_bind");
-        if (!S.prefetched || S.b != 0 || S.pending_b <= 0) return fail(h, DIST_ERR_STATE, "dist_vit_prefetch_layers(video = NULL): no prefetch pass in flight");
-        l0 = S.next_layer;
-        b = S.pending_b;
-    }
-    if (layer_end < l0 || layer_end > h->cfg.layers) return fail(h, DIST_ERR_ARG, "layer_end %d outside [%d, %d]", layer_end, l0, h->cfg.layers);
-    if (!video && layer_end == l0) return DIST_OK;
-    return vit_forward_slot(h, video, b, k, stream ? stream : h->pf, true, after, l0, layer_end);
-}
-extern "C" int dist_vit_prefetch(dist_handle* h, const float* video, int b, void* stream, void* after) {
-    if (!h || !video) return DIST_ERR_ARG;
-    return dist_vit_prefetch_layers(h, video, b, h->cfg.layers, stream, after);
-}
-extern "C" int dist_vit_adopt(dist_handle* h) {
-    if (!h) return DIST_ERR_ARG;
-    if (!h->ws) return fail(h, DIST_ERR_UNBOUND, "dist_vit_adopt before dist_bind");
-    const int k = h->cur ^ 1;
-    if (!h->slot[k].prefetched || h->slot[k].b <= 0) return fail(h, DIST_ERR_STATE, "dist_vit_adopt needs dist_vit_prefetch first");
-    h->use_slot(k);
-    h->fwd_b = h->slot[k].b;
-    h->branch_b = 0;
-    return DIST_OK;
-}
-
-// one-query cross attention block: s_out = s_in + out_proj(attn(q = W_q LN(s_in), kv = W_kv LN(keys))).
-// The key side (LayerNorm + K/V projection of all keys: the only large kernels of the ada-pooling tail) does not depend
-// on the query, so it is a separate call: for the spatial blocks it runs on the second side stream for all ada layers at
-// once, beside the chain of small query-side kernels.
-static int xattn_keys(dist_handle* h, const Ctx& x, const XAttn& A, const void* keys, long nkeys_total, void* kn, float* kn_mean, float* kn_rstd, void* kv) {
-    const int Ci = h->cfg.integration_dim;
-    RUN(ln_fwd(x, h->theta, A.ln1, keys, kn, nkeys_total, kn_mean, kn_rstd));
-    RUN(gemm(x, kn, Ci, x.pk(A.kv.pk.f), nkeys_total, 2 * Ci, Ci, 1, kv, 2 * Ci, x.th(A.kv.bias), nullptr, nullptr, nullptr));
-    return DIST_OK;
-}
-static int xattn_query(dist_handle* h, const Ctx& x, const XAttn& A, const void* s_in, long nq, int S, const void* kv, hipEvent_t kv_ready,
-                       void* qn, float* qn_mean, float* qn_rstd, void* q, void* o, float* probs, void* s_out) {
-    const int Ci = h->cfg.integration_dim;
-    RUN(ln_fwd(x, h->theta, A.ln1, s_in, qn, nq, qn_mean, qn_rstd));
-    RUN(gemm(x, qn, Ci, x.pk(A.q.pk.f), nq, Ci, Ci, 1, q, Ci, x.th(A.q.bias), nullptr, nullptr, nullptr));
-    if (kv_ready) HIP_CHECK_RET(hipStreamWaitEvent(x.s, kv_ready, 0));
-    RUN(dist_op_xattn1q(q, kv, o, probs, (int)nq, S, Ci, x.dtype, x.s));
-    RUN(gemm(x, o, Ci, x.pk(A.out.pk.f), nq, Ci, Ci, 1, s_out, Ci, x.th(A.out.bias), s_in, nullptr, nullptr));
-    return DIST_OK;
-}
-
-extern "C" int dist_branch_forward(dist_handle* h, const float* text_features, int b, float* logits, float* vid_logits, void* stream) {
-    if (!h || !text_features) return DIST_ERR_ARG;
-    if (!h->ws) return fail(h, DIST_ERR_UNBOUND, "dist_branch_forward before dist_bind");
-    if (h->fwd_b != b) return fail(h, DIST_ERR_STATE, "dist_branch_forward(b=%d) needs dist_vit_forward with the same batch first (have %d)", b, h->fwd_b);
-    const dist_config& c = h->cfg;
-    // The branch runs on the handle's side stream: layer i only needs mid_feat[i], so it executes underneath the
-    // remaining frozen-ViT layers still queued on the caller's stream (their LayerNorm / attention phases and the
-    // tails of the GEMM rounds leave CUs idle); the caller's stream joins at the end.
-    hipStream_t A = static_cast<hipStream_t>(stream);
-    hipStream_t S1 = (h->serial & 1) ? A : h->side, S2 = (h->serial & 1) ? A : h->side2;
-    Ctx x{h, S1, c.dtype};
-    const int d = c.width, Ci = c.integration_dim, Ct = c.temporal_dim, C4 = h->C4, N = h->N, L = h->L, T = c.frames, t = h->t, al = c.alpha;
-    const long rowsX = (long)b * T * N, rowsS = (long)b * t * L, rowsQ = (long)b * t * N, bt = (long)b * t;
-    const int Ch = h->Ch, Cf = h->Cf;             // hidden widths (== Ct / Ci for MLP ratio 1)
-    const int nl = h->nsel, nv = c.layers;       // DiST layers (one per SELECTED ViT block, dist.py:226) / ViT blocks
-    stream = S1;
-    HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_pre, 0));               // what preceded dist_vit_forward on the caller's stream
-    HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_feat[nv], 0));          // patch rows
-    const bool pref = h->slot[h->cur].prefetched && !(h->serial & 1);
-    if (pref) {                                                         // the features come from another stream: the side streams
-        HIP_CHECK_RET(hipEventRecord(h->ev_bpre, A));                   // must also follow the caller's stream (re-pack of the last step)
-        HIP_CHECK_RET(hipStreamWaitEvent(S1, h->ev_bpre, 0));
-        HIP_CHECK_RET(hipStreamWaitEvent(S2, h->ev_bpre, 0));
-    }
-
-    // Two streams inside the branch: the temporal chain (TemporalNet_i, I2T_i) on `xt`, the integration chain
-    // (input_linear_i, T2I_i, IntegrationNetwork_i) on `x`.  TemporalNet_{i+1} only needs X_{i+1} = X'_i + I2T(M_i),
-    // not R_i, so it runs underneath IntegrationNetwork_i; the two chains meet at M_i (-> I2T) and X'_i (-> T2I).
-    Ctx xt{h, S2, c.dtype};
-    HIP_CHECK_RET(hipStreamWaitEvent(xt.s, h->ev_pre, 0));
-    HIP_CHECK_RET(hipStreamWaitEvent(xt.s, h->ev_feat[nv], 0));
-    auto ev_xp = [&](int i) { return h->ev_a[i]; };
-    auto ev_m = [&](int i) { return h->ev_a[nl + i]; };
-
-    // temporal stem: Conv3d k=(tp,P,P) as a 5-tap row-shifted GEMM over the shared patch rows (dist.py:178-181,225)
-    mark(h, DIST_MARK_FWD_BEGIN, xt.s);
-    RUN(gemm(xt, h->patches, h->Kp, x.pk(h->stem.pk.f), rowsX, Ct, h->Kp, h->stem.taps, h->lw[0].X, Ct, x.th(h->stem.bias), nullptr, nullptr, nullptr,
-             RM(DIST_RM_SHIFT, T * N, N, 1)));
-    for (int i = 0; i < nl; ++i) {
-        const DistLayer& l = h->dl[i];
-        DistLayerWs& w = h->lw[i];
-        void* Xnext = (i + 1 < nl) ? h->lw[i + 1].X : h->Xlast;
-        // ---- temporal chain: TemporalNet (dist.py:48-65): one fused launch (tnet.hip) where the geometry allows, else LayerNorm + two GEMMs
-        if (h->skip & 4) {
-        } else if (Ch == Ct && dist_k_tnet_fwd_eligible(c.dtype, Ct, h->G, l.tn_fc1.taps)) {
-            dist_tnet_args ta;
-            memset(&ta, 0, sizeof(ta));
-            ta.X = w.X; ta.W1 = x.pk(l.tn_fc1.pk.f); ta.W2 = x.pk(l.tn_fc2.pk.f);
-            ta.b1 = x.th(l.tn_fc1.bias); ta.b2 = x.th(l.tn_fc2.bias); ta.ln_w = x.th(l.tn_ln.w); ta.ln_b = x.th(l.tn_ln.b);
-            ta.z = w.z; ta.p = w.p; ta.Xp = w.Xp;
-            if (!h->inference) { ta.U = w.U; ta.V = w.V; }                      // (U, V: the weight-gradient GEMMs of backward read them)
-            ta.mean = w.tn_mean; ta.rstd = w.tn_rstd;
-            ta.clips = b; ta.T = T; ta.G = h->G; ta.Ct = Ct; ta.tk = l.tn_fc1.taps; ta.dtype = c.dtype; ta.eps = 1e-5f;
-            RUN(dist_op_temporal_net_fwd(&ta, xt.s));
-        } else {
-            RUN(ln_fwd(xt, h->theta, l.tn_ln, w.X, w.U, rowsX, w.tn_mean, w.tn_rstd));
-            RUN(gemm(xt, w.U, Ct, x.pk(l.tn_fc1.pk.f), rowsX, Ch, Ct, l.tn_fc1.taps, w.z, Ch, x.th(l.tn_fc1.bias), nullptr, nullptr, w.V,
-                     RM(DIST_RM_SHIFT, T * N, N, 1)));
-            RUN(gemm(xt, w.V, Ch, x.pk(l.tn_fc2.pk.f), rowsX, Ct, Ch, 9, w.p, Ct, x.th(l.tn_fc2.bias), w.X, nullptr, w.Xp, RM(DIST_RM_SPATIAL, h->G, 0, 1)));
-        }
-        HIP_CHECK_RET(hipEventRecord(ev_xp(i), xt.s));
-        // ---- integration chain: mid_feat = input_linear(F_i) + res_feat (dist.py:229)
-        HIP_CHECK_RET(hipStreamWaitEvent(x.s, h->ev_feat[h->sel[i]], 0));
-        RUN(gemm(x, h->feat[h->sel[i]], d, x.pk(l.in_lin.pk.f), rowsS, Ci, d, 1, w.M, Ci, x.th(l.in_lin.bias), i ? h->lw[i - 1].R : nullptr, nullptr, nullptr));
-        // I2T (dist.py:90-105,231): Linear on the non-cls rows, nearest-upsampled x alpha in T, + x_temporal - inside the fused IntegrationNetwork launch below
-        // (behind its T2I stage), or as a GEMM on the temporal chain.  (the last layer's result is discarded by the reference, dist.py:235 -> skipped)
-        const bool i2t_fused = h->ig_i2t && i + 1 < nl && !(h->skip & 8);
-        if (!i2t_fused) HIP_CHECK_RET(hipEventRecord(ev_m(i), x.s));
-        if (i + 1 < nl && !i2t_fused) {
-            HIP_CHECK_RET(hipStreamWaitEvent(xt.s, ev_m(i), 0));
-            RUN(gemm(xt, w.M, Ci, x.pk(l.i2t.pk.f), rowsQ, Ct, Ci, 1, Xnext, Ct, x.th(l.i2t.bias), w.Xp, nullptr, nullptr,
-                     RM(DIST_RM_SKIPCLS, N), OM(DIST_OM_DUP, al, N)));
-        }
-        // T2I (dist.py:68-86,232): strided temporal conv into the patch rows of M', learnable cls row
-        HIP_CHECK_RET(hipStreamWaitEvent(x.s, ev_xp(i), 0));
-        const bool t2i_in_front = h->ig_t2i;                // (with DIST_AMD_SKIP & 8 nothing forms M': the knob's results are wrong by design)
-        if (!t2i_in_front) {
-        RUN(gemm(x, w.Xp, Ct, x.pk(l.t2i.pk.f), rowsQ, Ci, Ct, al, w.Mp, Ci, x.th(l.t2i.bias), w.M, nullptr, nullptr,
-                 RM(DIST_RM_STRIDED, al, N), OM(DIST_OM_INSERTCLS, N)));
-        RUN(dist_k_cls_rows(w.Mp, w.M, x.th(l.cls_token), (int)bt, L, Ci, t, c.dtype, x.s));
-        }
-        // IntegrationNetwork (dist.py:16-45): one fused launch (integ.hip) where the geometry allows, else LayerNorm + four GEMMs
-        if (h->ig_on) {
-            if (!(h->skip & 8)) {
-                dist_integ_args ia;
-                memset(&ia, 0, sizeof(ia));
-                if (t2i_in_front) {       // M' is formed in the kernel; it is written out only where something else reads it (the last layer's residual, the unfused backward)
-                    ia.t2i_M = w.M; ia.t2i_Xp = w.Xp; ia.t2i_W = l.ig_Wt; ia.t2i_bias = x.th(l.t2i.bias); ia.t2i_cls = x.th(l.cls_token);
-                    if (i == nl - 1 || !h->ig_bwd || h->keep_mid) ia.Mp_out = w.Mp;
-                    if (i2t_fused) { ia.i2t_W = l.ig_Wi; ia.i2t_bias = x.th(l.i2t.bias); ia.i2t_Xnext = Xnext; }
-                } else ia.Mp = w.Mp;
-                ia.W1 = l.ig_W1; ia.W2 = l.ig_W2; ia.W3 = l.ig_W3; ia.b1 = l.ig_b1; ia.b2 = l.ig_b2; ia.b3 = l.ig_b3;
-                ia.R = w.R;
-                if (!h->inference) {                                            // (what backward reads)
-                    if (h->ig_xhat) ia.Xhat = w.Na;
-                    else {
-                        ia.ln_w = x.th(l.in_ln.w); ia.ln_b = x.th(l.in_ln.b); ia.ln_t_w = x.th(l.in_ln_t.w); ia.ln_t_b = x.th(l.in_ln_t.b);
-                        ia.Na = w.Na; ia.Nb = w.Nb;
-                    }
-                    ia.mean = w.in_mean; ia.rstd = w.in_rstd; ia.zf_h2 = w.zf; ia.hf_g2 = w.hf; ia.h1 = w.h1;
-                }
-                ia.clips = (int)b; ia.t = t; ia.L = L; ia.Ci = Ci; ia.C4 = C4; ia.tk = l.tf_fc2.taps; ia.dtype = c.dtype; ia.eps = 1e-5f;
-                RUN(dist_op_integration_fwd(&ia, x.s));
-                if (i2t_fused) {                                                // X of the next layer is written by this launch: the temporal chain continues behind it
-                    HIP_CHECK_RET(hipEventRecord(ev_m(i), x.s));
-                    HIP_CHECK_RET(hipStreamWaitEvent(xt.s, ev_m(i), 0));
-                }
-            }
-        } else {
-        RUN(ln_fwd(x, h->theta, l.in_ln, w.Mp, w.Na, rowsS, w.in_mean, w.in_rstd, &l.in_ln_t, w.Nb));
-        if (!(h->skip & 8)) {
-        // (inference: the pre-activations zf / h2 are what backward needs - only the activated tensors are written)
-        RUN(gemm(x, w.Na, Ci, x.pk(l.ffn_fc.pk.f), rowsS, Cf, Ci, 1, h->inference ? nullptr : w.zf, Cf + C4, x.th(l.ffn_fc.bias), nullptr, nullptr, w.hf));
-        RUN(gemm(x, w.Nb, Ci, x.pk(l.tf_fc1.pk.f), rowsS, C4, Ci, 1, w.h1, C4, x.th(l.tf_fc1.bias), nullptr, nullptr, nullptr));
-        RUN(gemm(x, w.h1, C4, x.pk(l.tf_fc2.pk.f), rowsS, C4, C4, l.tf_fc2.taps, h->inference ? nullptr : w.h2, Cf + C4, x.th(l.tf_fc2.bias), nullptr, nullptr, w.g2,
-                 RM(DIST_RM_SHIFT, t * L, L, 1)));
-        // R = ffn.c_proj(hf) + temporal_ffn.c_proj(g2): one GEMM over [hf | g2] (K = Ci + C4) with the two weights side by side
-        RUN(gemm(x, w.hf, Cf + C4, x.pk(l.pk_proj_f), rowsS, Ci, Cf + C4, 1, w.R, Ci, x.th(l.ffn_proj.bias), nullptr, nullptr, nullptr,
-                 RM(), OM(), 0, x.th(l.tf_proj.bias)));
-        }
-        }
-        if (i == nl / 2 - 1) mark(h, DIST_MARK_FWD_MID, x.s);
-    }
-    // current_layer_feat = res_feat + updated_mid_feat (dist.py:239)
-    RUN(dist_op_add(h->lw[nl - 1].R, h->lw[nl - 1].Mp, h->Fz, rowsS * Ci, c.dtype, stream));
-    // key side of every spatial ada block on the (now idle) temporal stream: needs Fz only
-    hipEvent_t ev_fz = h->ev_a[2 * nl];
-    HIP_CHECK_RET(hipEventRecord(ev_fz, x.s));
-    HIP_CHECK_RET(hipStreamWaitEvent(xt.s, ev_fz, 0));
-    for (int a = 0; a < c.ada_layers; ++a) {
-        AdaWs& w = h->aw[a];
-        RUN(xattn_keys(h, xt, h->ada[a].sp, h->Fz, rowsS, w.kn, w.kn_mean, w.kn_rstd, w.kv));
-        HIP_CHECK_RET(hipEventRecord(h->ev_a[2 * nl + 1 + a], xt.s));
-    }
-    RUN(dist_k_bcast_rows(x.th(h->agg_sp_cls), h->sbuf[0], bt, Ci, c.dtype, x.s));
-    RUN(dist_k_bcast_rows(x.th(h->agg_cls), h->ubuf[0], b, Ci, c.dtype, x.s));
-    for (int a = 0; a < c.ada_layers; ++a) {
-        const AdaLayer& A = h->ada[a];
-        AdaWs& w = h->aw[a];
-        // spatial: per-frame cls query over the L tokens of its frame (dist.py:144-146)
-        RUN(xattn_query(h, x, A.sp, h->sbuf[a], bt, L, w.kv, h->ev_a[2 * nl + 1 + a], w.qn, w.qn_mean, w.qn_rstd, w.q, w.o, w.probs, w.s1));
-        RUN(ln_fwd(x, h->theta, A.ln_sp, w.s1, w.sn, bt, w.s1_mean, w.s1_rstd));
-        RUN(gemm(x, w.sn, Ci, x.pk(A.sp_fc.pk.f), bt, 4 * Ci, Ci, 1, w.zs, 4 * Ci, x.th(A.sp_fc.bias), nullptr, nullptr, w.hs));
-        RUN(gemm(x, w.hs, 4 * Ci, x.pk(A.sp_proj.pk.f), bt, Ci, 4 * Ci, 1, h->sbuf[a + 1], Ci, x.th(A.sp_proj.bias), w.s1, nullptr, nullptr));
-        // temporal: per-clip cls query over its t frame tokens (+ positional embedding) (dist.py:153-160)
-        RUN(dist_k_add_table(h->sbuf[a + 1], x.th(A.pos), w.c, bt, Ci, t, c.dtype, x.s));
-        RUN(xattn_keys(h, x, A.tm, w.c, bt, w.kn2, w.kn2_mean, w.kn2_rstd, w.kv2));
-        RUN(xattn_query(h, x, A.tm, h->ubuf[a], b, t, w.kv2, nullptr, w.qn2, w.qn2_mean, w.qn2_rstd, w.q2, w.o2, w.probs2, w.u1));
-        RUN(ln_fwd(x, h->theta, A.ln_tm, w.u1, w.un, b, w.u1_mean, w.u1_rstd));
-        RUN(gemm(x, w.un, Ci, x.pk(A.tm_fc.pk.f), b, 4 * Ci, Ci, 1, w.zu, 4 * Ci, x.th(A.tm_fc.bias), nullptr, nullptr, w.hu));
-        RUN(gemm(x, w.hu, 4 * Ci, x.pk(A.tm_proj.pk.f), b, Ci, 4 * Ci, 1, h->ubuf[a + 1], Ci, x.th(A.tm_proj.bias), w.u1, nullptr, nullptr));
-    }
-    // x_logits = ln_post(top_cls + proj_spatial_cls_token(mean_t vit_cls)); cls_x = x_logits @ proj (dist.py:242-246)
-    RUN(dist_k_mean_cls(h->feat[h->sel[nl - 1]], h->mean_cls, b, t, L, d, c.dtype, x.s));
-    RUN(gemm(x, h->mean_cls, d, x.pk(h->cls_proj.pk.f), b, Ci, d, 1, h->ysum, Ci, x.th(h->cls_proj.bias), h->ubuf[c.ada_layers], nullptr, nullptr));
-    RUN(ln_fwd(x, h->theta, h->ln_post, h->ysum, h->zpost, b, h->y_mean, h->y_rstd));
-    RUN(gemm(x, h->zpost, Ci, x.pk(h->proj.pk.f), b, c.embed_dim, Ci, 1, h->v, c.embed_dim, nullptr, nullptr, nullptr, nullptr));
-    // join: the caller's stream continues after the branch; the logits kernel runs there (it reads caller-produced text features)
-    HIP_CHECK_RET(hipEventRecord(h->ev_join, x.s));
-    mark(h, DIST_MARK_FWD_END, x.s);
-    HIP_CHECK_RET(hipStreamWaitEvent(A, h->ev_join, 0));
-    // cosine logits (clip.py:509-518)
-    RUN(dist_k_logits_loss(h->v, text_features, h->logit_scale, nullptr, h->logits, vid_logits, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           b, c.embed_dim, c.num_classes, c.dtype, A));
-    if (logits) HIP_CHECK_RET(hipMemcpyAsync(logits, h->logits, (size_t)b * c.num_classes * sizeof(float), hipMemcpyDeviceToDevice, A));
-    h->branch_b = b;
-    h->branch_infer = h->inference;
-    h->text = text_features;
-    return DIST_OK;
-}
-
-extern "C" int dist_loss(dist_handle* h, const float* soft_target, int b, float* loss, float* dlogits, void* stream) {
-    if (!h || !soft_target) return DIST_ERR_ARG;
-    if (h->branch_b != b || !h->text) return fail(h, DIST_ERR_STATE, "dist_loss(b=%d) needs dist_branch_forward with the same batch first", b);
-    const dist_config& c = h->cfg;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    HIP_CHECK_RET(hipMemsetAsync(h->loss, 0, sizeof(float), s));
-    RUN(dist_k_logits_loss(h->v, h->text, h->logit_scale, soft_target, nullptr, nullptr, h->loss, nullptr, nullptr, nullptr, h->dlogits,
-                           b, c.embed_dim, c.num_classes, c.dtype, stream));
-    if (loss) HIP_CHECK_RET(hipMemcpyAsync(loss, h->loss, sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (dlogits) HIP_CHECK_RET(hipMemcpyAsync(dlogits, h->dlogits, (size_t)b * c.num_classes * sizeof(float), hipMemcpyDeviceToDevice, s));
-    return DIST_OK;
-}
-
-// -------------------------------------------------------------------------------------------------------------
-// backward helpers: y = act?(x W^T + b) given dY (already multiplied by act' where needed)
-namespace {
-
-// bias + weight gradients of a plain Linear: db += colsum(dY), dW += dY^T X
-int lin_wb(dist_handle* h, const Ctx& x, const Lin& l, const void* dY, const void* X, long rows) {
-    RUN(wgrad(x, l, dY, l.N, X, l.K, rows, RM(), RM(), 0, true));
-    return DIST_OK;
-}
-// dX = dY W (optionally * gelu'(aux), optionally accumulated through `res`)
-int lin_dx(dist_handle* h, const Ctx& x, const Lin& l, const void* dY, long rows, void* dX, const void* aux = nullptr, const void* res = nullptr, int ld_dy = 0) {
-    RUN(gemm(x, dY, ld_dy ? ld_dy : l.N, x.pk(l.pk.b), rows, l.K, l.N, 1, dX, l.K, nullptr, res, aux, nullptr));
-    return DIST_OK;
-}
-
-// backward of s_out = s_in + MLP(LN(s_in)) with MLP = c_proj(gelu(c_fc(.))); d (rows x Ci) holds dL/ds_out on entry
-// and dL/ds_in on exit
-int mlp_block_bwd(dist_handle* h, const Ctx& x, const Lin& fc, const Lin& proj, const LNp& ln, const void* s_in, const float* mean, const float* rstd,
-                  const void* sn, const void* zs, const void* hs, void* d, long rows, void* dzs, void* dsn) {
-    RUN(lin_wb(h, x, proj, d, hs, rows));
-    RUN(lin_dx(h, x, proj, d, rows, dzs, zs));
-    RUN(lin_wb(h, x, fc, dzs, sn, rows));
-    RUN(lin_dx(h, x, fc, dzs, rows, dsn));
-    RUN(ln_bwd(x, ln, s_in, mean, rstd, dsn, d, true, rows));
-    return DIST_OK;
-}
-
-// backward of s_out = s_in + out_proj(attn1q(W_q LN(s_in), W_kv LN(keys))); d holds dL/ds_out -> dL/ds_in;
-// dkeys receives (or accumulates) the gradient w.r.t. the key/value source rows.
-int xattn_bwd(dist_handle* h, const Ctx& x, const XAttn& A, const void* s_in, long nq, const void* keys, long nkeys_total, int S,
-              const void* kn, const float* kn_mean, const float* kn_rstd, const void* kv, const void* qn, const float* qn_mean, const float* qn_rstd,
-              const void* q, const void* o, const float* probs, void* d, void* dkeys, bool acc_keys,
-              void* d_o, void* dq, void* dkv, void* dqn, void* dkn) {
-    const int Ci = h->cfg.integration_dim;
-    RUN(lin_wb(h, x, A.out, d, o, nq));
-    RUN(lin_dx(h, x, A.out, d, nq, d_o));
-    RUN(dist_op_xattn1q_bwd(q, kv, probs, d_o, dq, dkv, (int)nq, S, Ci, x.dtype, x.s));
-    RUN(lin_wb(h, x, A.q, dq, qn, nq));
-    RUN(lin_wb(h, x, A.kv, dkv, kn, nkeys_total));
-    RUN(lin_dx(h, x, A.q, dq, nq, dqn));
-    RUN(lin_dx(h, x, A.kv, dkv, nkeys_total, dkn));
-    RUN(ln_bwd(x, A.ln1, s_in, qn_mean, qn_rstd, dqn, d, true, nq));
-    RUN(ln_bwd(x, A.ln1, keys, kn_mean, kn_rstd, dkn, dkeys, acc_keys, nkeys_total));
-    return DIST_OK;
-}
-
-}  // namespace
-
-extern "C" int dist_branch_backward(dist_handle* h, const float* dlogits, int b, int zero_grads, void* stream) {
-    if (!h || !dlogits) return DIST_ERR_ARG;
-    if (!h->grads || !h->dlogit_scale) return fail(h, DIST_ERR_UNBOUND, "dist_branch_backward needs grads and dlogit_scale bound");
-    if (h->branch_b != b || !h->text) return fail(h, DIST_ERR_STATE, "dist_branch_backward(b=%d) needs dist_branch_forward with the same batch first", b);
-    if (h->branch_infer) return fail(h, DIST_ERR_STATE, "dist_branch_backward after an inference-mode forward (dist_set_inference): nothing was kept for it");
-    const dist_config& c = h->cfg;
-    Ctx x{h, static_cast<hipStream_t>(stream), c.dtype};
-    const int d = c.width, Ci = c.integration_dim, Ct = c.temporal_dim, C4 = h->C4, N = h->N, L = h->L, T = c.frames, t = h->t, al = c.alpha;
-    const long rowsX = (long)b * T * N, rowsS = (long)b * t * L, rowsQ = (long)b * t * N, bt = (long)b * t;
-    const int nl = h->nsel, na = c.ada_layers, Ch = h->Ch, Cf = h->Cf;
-    const size_t es = h->es;
-
-    mark(h, DIST_MARK_BWD_BEGIN, x.s);
-    if (zero_grads) {
-        HIP_CHECK_RET(hipMemsetAsync(h->grads, 0, (size_t)h->total[0] * sizeof(float), x.s));
-        HIP_CHECK_RET(hipMemsetAsync(h->dlogit_scale, 0, sizeof(float), x.s));
-    }
-    // Accumulating backward with the LayerNorm fold: the weight-gradient GEMMs of ffn.c_fc / temporal_ffn.c_fc1 leave G' = dz^T xhat, which the
-    // unfold turns into dW - in place only when the slots were zero.  With earlier gradients in them G' goes to per-layer scratch and the unfold adds.
-    h->bwd_accumulate = !zero_grads && h->ig_xhat;
-    if (h->bwd_accumulate) HIP_CHECK_RET(hipMemsetAsync(h->ig_gscratch, 0, (size_t)h->ig_gscratch_elems * nl * sizeof(float), x.s));
-    // logits -> v (cosine normalisation backward, clip.py:511-517); logit_scale gets its (never applied) gradient
-    RUN(dist_k_logits_loss(h->v, h->text, h->logit_scale, nullptr, nullptr, nullptr, nullptr, h->dv, h->dlogit_scale, dlogits, nullptr,
-                           b, c.embed_dim, c.num_classes, c.dtype, stream));
-    // cls_x = z @ proj ; z = ln_post(u + cls_proj(mean_cls))
-    RUN(wgrad(x, h->proj, h->zpost, Ci, h->dv, c.embed_dim, b, RM(), RM(), 4));          // dProj[ci][e] = sum_b z[b][ci] dv[b][e]
-    RUN(gemm(x, h->dv, c.embed_dim, x.pk(h->proj.pk.b), b, Ci, c.embed_dim, 1, h->dzp, Ci, nullptr, nullptr, nullptr, nullptr));
-    RUN(ln_bwd(x, h->ln_post, h->ysum, h->y_mean, h->y_rstd, h->dzp, h->du, false, b));
-    RUN(lin_wb(h, x, h->cls_proj, h->du, h->mean_cls, b));
-    // ada-pooling layers in reverse (dist.py:139-162)
-    for (int a = na - 1; a >= 0; --a) {
-        const AdaLayer& A = h->ada[a];
-        AdaWs& w = h->aw[a];
-        const bool first = (a == na - 1);
-        // temporal MLP + temporal cross attention (du: dL/du_{a+1} -> dL/du_a)
-        RUN(mlp_block_bwd(h, x, A.tm_fc, A.tm_proj, A.ln_tm, w.u1, w.u1_mean, w.u1_rstd, w.un, w.zu, w.hu, h->du, b, h->dzu, h->dun));
-        RUN(xattn_bwd(h, x, A.tm, h->ubuf[a], b, w.c, bt, t, w.kn2, w.kn2_mean, w.kn2_rstd, w.kv2, w.qn2, w.qn2_mean, w.qn2_rstd, w.q2, w.o2, w.probs2,
-                      h->du, h->dc, false, h->do2, h->dq2, h->dkv2, h->dqn2, h->dkn2));
-        // c = s_{a+1} + pos: dpos[j] = sum_b dc[b,j]; ds_{a+1} (+)= dc
-        RUN(dist_k_cls_rows_bwd(h->dc, x.gr(A.pos), (int)bt, 1, Ci, t, c.dtype, x.s));
-        if (first) HIP_CHECK_RET(hipMemcpyAsync(h->ds, h->dc, (size_t)bt * Ci * es, hipMemcpyDeviceToDevice, x.s));
-        else RUN(dist_op_add(h->ds, h->dc, h->ds, bt * Ci, c.dtype, stream));
-        // spatial MLP + spatial cross attention (ds: dL/ds_{a+1} -> dL/ds_a; dFz accumulates)
-        RUN(mlp_block_bwd(h, x, A.sp_fc, A.sp_proj, A.ln_sp, w.s1, w.s1_mean, w.s1_rstd, w.sn, w.zs, w.hs, h->ds, bt, h->dzs, h->dsn));
-        RUN(xattn_bwd(h, x, A.sp, h->sbuf[a], bt, h->Fz, rowsS, L, w.kn, w.kn_mean, w.kn_rstd, w.kv, w.qn, w.qn_mean, w.qn_rstd, w.q, w.o, w.probs,
-                      h->ds, h->dR, !first, h->do_, h->dq, h->dkv, h->dqn, h->dkn));
-    }
-    if (na > 0) {
-        RUN(bgrad(x, h->agg_cls, h->du, b, Ci));
-        RUN(bgrad(x, h->agg_sp_cls, h->ds, bt, Ci));
-    } else {
-        HIP_CHECK_RET(hipMemsetAsync(h->dR, 0, (size_t)rowsS * Ci * es, x.s));
-        RUN(bgrad(x, h->agg_cls, h->du, b, Ci));
-    }
-    // ---- layer loop on two streams -------------------------------------------------------------------------
-    // The data-gradient chain (dX GEMMs, LayerNorm / activation backward) is the critical path and stays on the
-    // caller's stream `A`.  Every weight / bias gradient GEMM only CONSUMES chain buffers, so it runs on the handle's
-    // side stream `B` behind an event of its producer, up to ~2 layers behind the chain: two latency-bound kernel
-    // sequences share the CUs instead of one.  Hazards: (1) chain scratch is double-buffered by layer parity and A
-    // waits for B's "layer i+2 done" event before reusing a set; (2) the two in-place updates of the single-stream
-    // version are out-of-place here (dM = copy of dM' from the LayerNorm backward, dX_out = dp + LN'(dU)).
-    hipStream_t A = x.s, B = (h->serial & 2) ? A : h->side, B2 = (h->serial & 2) ? A : h->side2;
-    Ctx xb{h, B, c.dtype}, xb2{h, B2, c.dtype};          // two weight-gradient streams: independent dW GEMMs also overlap each other
-    // Two data-gradient chains (round 3): the integration chain (fused IntegrationNetwork backward, I2T data gradient) stays on A, the temporal
-    // chain (T2I data gradient + TemporalNet backward of the SAME layer) runs on `Tc` one layer behind it: layer i's temporal chain needs dM'_i
-    // and dX_{i+1}, the integration chain of layer i-1 needs dM_i = dM'_i + I2T^T(dX_{i+1}) - not dX_i.  DIST_AMD_BWD_TCHAIN=0: one chain.
-    // Measured: 18.78 -> 20.23 ms with the fifth stream (any fifth ACTIVE stream costs that much on this system, profiles/r01_streams_and_queues.md),
-    // so the default is one chain.  DIST_AMD_BWD_TCHAIN=1: own stream; 2: the second weight-gradient stream carries the temporal chain instead.
-    static const int tchain_env = DIST_AB_KNOB("DIST_AMD_BWD_TCHAIN", 0);
-    const bool tchain = tchain_env > 0 && !(h->serial & 2) && (h->chain2 || tchain_env == 2);
-    hipStream_t Tc = tchain ? (tchain_env == 2 ? h->side2 : h->chain2) : A;
-    if (tchain && tchain_env == 2) { B2 = B; xb2.s = B; }
-    Ctx xt{h, Tc, c.dtype};
-    int evn = 0;
-    auto fork_t = [&]() -> int {         // B and B2 wait for everything enqueued on the temporal chain so far
-        if (!tchain) return DIST_OK;
-        if (hipEventRecord(h->ev_c2, Tc) != hipSuccess || hipStreamWaitEvent(B, h->ev_c2, 0) != hipSuccess || hipStreamWaitEvent(B2, h->ev_c2, 0) != hipSuccess)
-            return DIST_ERR_STATE;
-        return DIST_OK;
-    };
-    auto fork = [&]() -> int {           // B and B2 wait for everything enqueued on A so far
-        hipEvent_t e = h->ev_a[evn++];
-        if (hipEventRecord(e, A) != hipSuccess || hipStreamWaitEvent(B, e, 0) != hipSuccess || hipStreamWaitEvent(B2, e, 0) != hipSuccess)
-            return DIST_ERR_STATE;
-        return DIST_OK;
-    };
-    auto merge_b2 = [&]() -> int {       // fold B2 into B so one event on B covers both
-        if (hipEventRecord(h->ev_b2, B2) != hipSuccess || hipStreamWaitEvent(B, h->ev_b2, 0) != hipSuccess) return DIST_ERR_STATE;
-        return DIST_OK;
-    };
-    // the ada / head part above ran on A and produced dFz in h->dR; B must also see the zeroed gradient buffer
-    RUN(fork());
-    if (h->grad_hook) h->grad_hook(h->grad_hook_user, h->tail_begin, h->total[0]);      // ada-pooling + head gradients are final on A
-
-    const void* dR = h->dR;               // dL/dR_i (for the last layer: dFz)
-    const void* dXn = nullptr;            // dL/dX_{i+1} (none for the last layer)
-    int hook_next = nl - 1;               // next layer slice to report through the gradient-ready hook
-    for (int i = nl - 1; i >= 0; --i) {
-        const DistLayer& l = h->dl[i];
-        DistLayerWs& w = h->lw[i];
-        dist_handle::BwdSet& q = h->bs[i & 1];
-        const bool last = (i == nl - 1);
-        if (i + 2 < nl) {                 // set (i & 1) was last used by layer i+2: its weight gradients must be done
-            HIP_CHECK_RET(hipStreamWaitEvent(A, h->ev_b_done[i + 2], 0));
-            for (; hook_next >= i + 2; --hook_next)
-                if (h->grad_hook) h->grad_hook(h->grad_hook_user, h->layer_begin[hook_next], h->layer_end[hook_next]);
-        }
-        if (i + 1 < nl) HIP_CHECK_RET(hipStreamWaitEvent(A, h->ev_b_dr[i + 1], 0));    // dR_{i+1} (set (i & 1) of layer i+2 ... see below)
-
-        // ---- IntegrationNetwork backward (dist.py:40-45) ----
-        // B: dW/db of ffn.c_proj and temporal_ffn.c_proj read dR (produced before this layer started)
-        const int Cc = Cf + C4;            // [zf | h2], [hf | g2], [dzf | dh2] rows
-        RUN(wgrad_pair(xb, l.ffn_proj, l.tf_proj, dR, Ci, w.hf, Cc, rowsS));
-        RUN(merge_b2());
-        HIP_CHECK_RET(hipEventRecord(h->ev_b_dr[i], B));
-        if (h->ig_bwd) {
-            // one fused launch (integ.hip): [dzf | dh2], dh1 and dM' = LN'(dzf Wa' + dh1 Wb') (+ dFz for the last layer; a second copy becomes dM)
-            dist_integ_bwd_args ba;
-            memset(&ba, 0, sizeof(ba));
-            ba.dR = dR; ba.zf_h2 = w.zf; ba.Xhat = w.Na; ba.rstd = w.in_rstd; ba.B1 = l.ig_B1; ba.B2 = l.ig_B2; ba.B3 = l.ig_B3;
-            // the three gradients leave in ONE buffer, rows [dzf | dh1 | dh2] of Ci + 2 C4: the weight gradients of ffn.c_fc and temporal_ffn.c_fc1 (both
-            // against xhat, their parameters side by side in the flat buffers) are one GEMM over its first Ci + C4 columns
-            const int Cd = Ci + 2 * C4;
-            char* dcat = static_cast<char*>(q.dcat);
-            void* d_h1 = dcat + (size_t)Ci * es; void* d_h2 = dcat + (size_t)(Ci + C4) * es;
-            ba.dzf_dh2 = q.dcat; ba.ld_dzf = Cd; ba.dh2 = d_h2; ba.ld_dh2 = Cd; ba.dh1 = d_h1; ba.ld_dh1 = Cd;
-            // (dM = dM' + I2T term: the I2T data-gradient GEMM below reads dM' as its residual and writes every patch row of dM; only the cls rows come from here)
-            ba.dMp = q.dMp; ba.dM_copy = last ? nullptr : q.dM; ba.dM_cls_only = 1; ba.add_dR = last ? 1 : 0;
-            ba.t2i_dcls = x.gr(l.cls_token);
-            if (h->ig_i2tb && !last && !tchain) {             // I2T backward in the same launch: dY (for the I2T weight gradient) and dM = dM' + [0 ; dY Wi] leave it
-                ba.i2t_dXnext = dXn; ba.i2t_B = l.ig_W4; ba.i2t_dY = q.dY; ba.dM_cls_only = 0;
-            }
-            if (h->ig_t2ib && !tchain) {                      // ... and the T2I backward: dp = (dX_next + conv^T(dM')) g'(p), what the TemporalNet backward starts from
-                ba.t2i_B = l.ig_W5; ba.t2i_p = w.p; ba.t2i_dp = q.dp;
-                if (!last) ba.i2t_dXnext = dXn;
-            }
-            ba.clips = (int)b; ba.t = t; ba.L = L; ba.Ci = Ci; ba.C4 = C4; ba.tk = l.tf_fc2.taps; ba.dtype = c.dtype;
-            RUN(dist_op_integration_bwd(&ba, x.s));
-            RUN(fork());
-            Lin both = l.ffn_fc;                              // [Ci + C4][Ci]: ffn.c_fc.weight followed by temporal_ffn.c_fc1.weight (and the two biases)
-            both.N = Ci + C4;
-            static const bool merge_env = (DIST_AB_KNOB("DIST_AMD_INTEG_WG_MERGE", 1) != 0);
-            // (accumulating backward: G' and db of the two folded Linears go to this layer's scratch, [Ci + C4][Ci] then [Ci + C4])
-            float* gs_w = h->bwd_accumulate ? h->ig_gscratch + (long)i * h->ig_gscratch_elems : nullptr;
-            float* gs_b = gs_w ? gs_w + (long)(Ci + C4) * Ci : nullptr;
-            if (merge_env && l.tf_fc1.w == l.ffn_fc.w + (long)Ci * Ci && l.tf_fc1.bias == l.ffn_fc.bias + Ci) {
-                RUN(wgrad(xb, both, q.dcat, Cd, w.Na, Ci, rowsS, RM(), RM(), 0, true, gs_w, gs_b));
-            } else {
-                RUN(wgrad(xb, l.ffn_fc, q.dcat, Cd, w.Na, Ci, rowsS, RM(), RM(), 0, true, gs_w, gs_b));
-                RUN(wgrad(xb2, l.tf_fc1, d_h1, Cd, w.Na, Ci, rowsS, RM(), RM(), 0, true, gs_w ? gs_w + (long)Ci * Ci : nullptr, gs_b ? gs_b + Ci : nullptr));
-            }
-            RUN(wgrad(xb2, l.tf_fc2, d_h2, Cd, w.h1, C4, rowsS, RM(), RM(DIST_RM_SHIFT, t * L, L, 1), 1, true));
-        } else {
-        // [dzf | dh2] = (dR [Wp ; W3]) * g'([zf | h2]): one data-gradient GEMM for the two projections
-        RUN(gemm(x, dR, Ci, x.pk(l.pk_proj_b), rowsS, Cc, Ci, 1, q.dzf, Cc, nullptr, nullptr, w.zf, nullptr));
-        RUN(fork());
-        float* gs_w = h->bwd_accumulate ? h->ig_gscratch + (long)i * h->ig_gscratch_elems : nullptr;
-        float* gs_b = gs_w ? gs_w + (long)(Ci + C4) * Ci : nullptr;
-        RUN(wgrad(xb, l.ffn_fc, q.dzf, Cc, w.Na, Ci, rowsS, RM(), RM(), 0, true, gs_w, gs_b));
-        RUN(wgrad(xb2, l.tf_fc2, q.dh2, Cc, w.h1, C4, rowsS, RM(), RM(DIST_RM_SHIFT, t * L, L, 1), 1, true));
-        RUN(gemm(x, q.dh2, Cc, x.pk(l.tf_fc2.pk.b), rowsS, C4, C4, l.tf_fc2.taps, q.dh1, C4, nullptr, nullptr, nullptr, nullptr,
-                 RM(DIST_RM_SHIFT, t * L, L, -1)));
-        RUN(fork());
-        RUN(wgrad(xb2, l.tf_fc1, q.dh1, C4, h->ig_xhat ? w.Na : w.Nb, Ci, rowsS, RM(), RM(), 0, true,     // (ig_xhat: w.Na holds xhat, see the unfold below)
-                  gs_w ? gs_w + (long)Ci * Ci : nullptr, gs_b ? gs_b + Ci : nullptr));
-        RUN(lin_dx(h, x, l.ffn_fc, q.dzf, rowsS, q.dNa, nullptr, nullptr, Cc));
-        RUN(lin_dx(h, x, l.tf_fc1, q.dh1, rowsS, q.dNb));
-        // dM' = LN'(dNa, dNb) (+ dFz for the last layer); a second copy becomes dM (updated in place by the I2T term)
-        RUN(ln_bwd(x, l.in_ln, w.Mp, w.in_mean, w.in_rstd, q.dNa, q.dMp, false, rowsS, &l.in_ln_t, q.dNb, last ? dR : nullptr, last ? nullptr : q.dM, !h->ig_xhat));
-        }
-        // ---- T2I backward (dist.py:81-86): M' = M + [cls_token ; conv_strided(X')] ----
-        RUN(fork());
-        if (!h->ig_bwd) RUN(dist_k_cls_rows_bwd(q.dMp, x.gr(l.cls_token), (int)bt, L, Ci, t, c.dtype, B));      // (the fused backward adds the cls rows of dM' itself)
-        RUN(wgrad(xb2, l.t2i, q.dMp, Ci, w.Xp, Ct, rowsQ, RM(DIST_RM_SKIPCLS, N), RM(DIST_RM_STRIDED, al, N), 2, true));
-        // dX' = dX_next (identity, absent for the last layer) + conv^T(dQ): column block a of row (bj,n) -> frame bj*alpha+a
-        // ... and straight through X' = g(p): dp = (dX_next + conv^T(dQ)) * g'(p) in the same epilogue (no dX' tensor, no
-        // separate activation-backward pass)
-        if (tchain) {
-            HIP_CHECK_RET(hipEventRecord(h->ev_dmp[i], A));
-            HIP_CHECK_RET(hipStreamWaitEvent(Tc, h->ev_dmp[i], 0));
-        }
-        if (!(h->ig_bwd && h->ig_t2ib && !tchain))
-        RUN(gemm(xt, q.dMp, Ci, x.pk(l.t2i.pk.b), rowsQ, al * Ct, Ci, 1, q.dp, Ct, nullptr, last ? nullptr : dXn, w.p, nullptr,
-                 RM(DIST_RM_SKIPCLS, N), OM(DIST_OM_SPLITCOLS, al, N, Ct), DIST_EPI_MULG_POST));
-        // ---- I2T backward (dist.py:100-105): X_next = X' + upsample(Linear(M[1:])) ----
-        const void* dM = q.dMp;            // last layer: no I2T path, dM = dM'
-        if (!last) {
-            if (!(h->ig_i2tb && h->ig_bwd && !tchain)) {
-                if (tchain) HIP_CHECK_RET(hipStreamWaitEvent(A, h->ev_dx[i + 1], 0));       // dX_{i+1} comes from the temporal chain
-                RUN(dist_k_pair_sum(dXn, q.dY, bt, N * Ct, al, c.dtype, A));
-                RUN(gemm(x, q.dY, Ct, x.pk(l.i2t.pk.b), rowsQ, Ci, Ct, 1, q.dM, Ci, nullptr, h->ig_bwd ? q.dMp : q.dM, nullptr, nullptr, RM(), OM(DIST_OM_INSERTCLS, N)));
-            }
-            dM = q.dM;
-        }
-        RUN(fork());
-        if (!last) RUN(wgrad(xb2, l.i2t, q.dY, Ct, w.M, Ci, rowsQ, RM(), RM(DIST_RM_SKIPCLS, N), 0, true));
-        // ---- mid_feat = input_linear(F_i) + R_{i-1}: no dF_i (frozen ViT) ----
-        RUN(wgrad(xb, l.in_lin, dM, Ci, h->feat[h->sel[i]], d, rowsS, RM(), RM(), 0, true));
-        // ---- TemporalNet backward (dist.py:63-65): X' = g(p), p = X + conv3x3(V) + b, V = g(z), z = conv_t(U), U = LN(X) ----
-        // bf16: two fused launches (tnet.hip): dz = conv3x3^T(dp) * g'(z); dX = dp + LN'(conv_t^T(dz)) with the LayerNorm parameter
-        // gradients as per-workgroup partial rows (no atomics); otherwise two row-mapped GEMMs + the LayerNorm backward kernel
-        const bool tn_fused = Ch == Ct && dist_k_tnet_fwd_eligible(c.dtype, Ct, h->G, l.tn_fc1.taps) &&
-                              (dist_knob("DIST_AMD_TNET_BWD_FUSED", 1) != 0);   // measurement knob
-        if (h->skip & 2) {
-        } else if (tn_fused) {
-            dist_tnet_bwd_args ta;
-            memset(&ta, 0, sizeof(ta));
-            ta.dp = q.dp; ta.z = w.z; ta.X = w.X; ta.mean = w.tn_mean; ta.rstd = w.tn_rstd; ta.ln_w = x.th(l.tn_ln.w);
-            ta.W1b = x.pk(l.tn_fc1.pk.b); ta.W2b = x.pk(l.tn_fc2.pk.b);
-            ta.dz = q.dz; ta.dX = q.dXo; ta.dgamma = x.gr(l.tn_ln.w); ta.dbeta = x.gr(l.tn_ln.b);
-            ta.scratch = h->tnb_scratch; ta.scratch_elems = h->tnb_scratch_elems;
-            ta.clips = b; ta.T = T; ta.G = h->G; ta.Ct = Ct; ta.tk = l.tn_fc1.taps; ta.dtype = c.dtype;
-            ta.phase = 1;                                              // dz first: the weight-gradient streams start on it
-            RUN(dist_op_temporal_net_bwd(&ta, xt.s));
-        } else {
-            RUN(gemm(xt, q.dp, Ct, x.pk(l.tn_fc2.pk.b), rowsX, Ch, Ct, 9, q.dz, Ch, nullptr, nullptr, w.z, nullptr, RM(DIST_RM_SPATIAL, h->G, 0, -1)));
-        }
-        RUN(fork());
-        RUN(fork_t());
-        RUN(wgrad(xb, l.tn_fc2, q.dp, Ct, w.V, Ch, rowsX, RM(), RM(DIST_RM_SPATIAL, h->G, 0, 1), 1, true));
-        RUN(wgrad(xb2, l.tn_fc1, q.dz, Ch, w.U, Ct, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 1, true));
-        RUN(merge_b2());
-        if (h->ig_xhat && !(h->skip & 1)) {   // the weight gradients of ffn.c_fc / temporal_ffn.c_fc1 were taken against xhat: unfold them (+ the two LayerNorms' gradients)
-            dist_integ_unfold_args ua;
-            memset(&ua, 0, sizeof(ua));
-            if (h->bwd_accumulate) {
-                const float* gs_w = h->ig_gscratch + (long)i * h->ig_gscratch_elems; const float* gs_b = gs_w + (long)(Ci + C4) * Ci;
-                ua.g_ffn_fc_w = gs_w; ua.g_ffn_fc_b = gs_b; ua.g_tf_fc1_w = gs_w + (long)Ci * Ci; ua.g_tf_fc1_b = gs_b + Ci;
-            }
-            ua.ffn_fc_w = x.th(l.ffn_fc.w); ua.ln_w = x.th(l.in_ln.w); ua.ln_b = x.th(l.in_ln.b);
-            ua.d_ffn_fc_w = x.gr(l.ffn_fc.w); ua.d_ffn_fc_b = x.gr(l.ffn_fc.bias); ua.d_ln_w = x.gr(l.in_ln.w); ua.d_ln_b = x.gr(l.in_ln.b);
-            ua.tf_fc1_w = x.th(l.tf_fc1.w); ua.ln_t_w = x.th(l.in_ln_t.w); ua.ln_t_b = x.th(l.in_ln_t.b);
-            ua.d_tf_fc1_w = x.gr(l.tf_fc1.w); ua.d_tf_fc1_b = x.gr(l.tf_fc1.bias); ua.d_ln_t_w = x.gr(l.in_ln_t.w); ua.d_ln_t_b = x.gr(l.in_ln_t.b);
-            ua.Ci = Ci; ua.C4 = C4;
-            RUN(dist_op_integration_unfold(&ua, B));
-        }
-        HIP_CHECK_RET(hipEventRecord(h->ev_b_done[i], B));
-        if (h->dummy & 2) for (int r = 0; r < h->dummy_reps; ++r) RUN(ln_fwd(x, h->visual, h->vit[0].ln1, h->feat[h->sel[i]], nullptr, rowsS, h->lnstats2, h->lnstats2 + rowsS));
-        if (h->dummy & 4) for (int r = 0; r < h->dummy_reps; ++r) RUN(ln_fwd(xb, h->visual, h->vit[0].ln1, h->feat[h->sel[i]], nullptr, rowsS, h->lnstats3, h->lnstats3 + rowsS));
-        if (!(h->skip & 2) && tn_fused) {
-            dist_tnet_bwd_args ta;
-            memset(&ta, 0, sizeof(ta));
-            ta.dp = q.dp; ta.z = w.z; ta.X = w.X; ta.mean = w.tn_mean; ta.rstd = w.tn_rstd; ta.ln_w = x.th(l.tn_ln.w);
-            ta.W1b = x.pk(l.tn_fc1.pk.b); ta.W2b = x.pk(l.tn_fc2.pk.b);
-            ta.dz = q.dz; ta.dX = q.dXo; ta.dgamma = x.gr(l.tn_ln.w); ta.dbeta = x.gr(l.tn_ln.b);
-            ta.scratch = h->tnb_scratch + (long)i * h->tnb_scratch_elems; ta.scratch_elems = h->tnb_scratch_elems;
-            ta.clips = b; ta.T = T; ta.G = h->G; ta.Ct = Ct; ta.tk = l.tn_fc1.taps; ta.dtype = c.dtype;
-            ta.phase = 2;
-            // measurement knob: leave the LayerNorm parameter gradients unsummed (phase 3).  The step does not change (19.64 vs 19.70 ms),
-            // so one multi-layer dist_op_temporal_net_bwd_reduce at the end of backward would buy nothing: the per-layer sum stays here
-            static const bool no_reduce = (dist_measure_knob("DIST_AMD_TNET_BWD_NOREDUCE", 0) != 0);
-            if (no_reduce) ta.phase = 3;
-            RUN(dist_op_temporal_net_bwd(&ta, xt.s));
-        }
-        if (!(h->skip & 2) && !tn_fused) {
-            RUN(gemm(xt, q.dz, Ch, x.pk(l.tn_fc1.pk.b), rowsX, Ct, Ch, l.tn_fc1.taps, q.dU, Ct, nullptr, nullptr, nullptr, nullptr,
-                     RM(DIST_RM_SHIFT, T * N, N, -1)));
-            RUN(ln_bwd(xt, l.tn_ln, w.X, w.tn_mean, w.tn_rstd, q.dU, q.dXo, false, rowsX, nullptr, nullptr, q.dp));   // dX_i = dp + LN'(dU)
-        }
-        if (tchain) HIP_CHECK_RET(hipEventRecord(h->ev_dx[i], Tc));
-        dR = dM;                          // dL/dR_{i-1}
-        dXn = q.dXo;
-    }
-    // temporal stem (dist.py:178-181): no input gradient
-    RUN(fork());
-    RUN(fork_t());
-    RUN(wgrad(xb, h->stem, dXn, Ct, h->patches, h->Kp, rowsX, RM(), RM(DIST_RM_SHIFT, T * N, N, 1), 3, true));
-    RUN(merge_b2());
-    // join: the caller's stream continues only after every weight gradient is complete
-    HIP_CHECK_RET(hipEventRecord(h->ev_join, B));
-    HIP_CHECK_RET(hipStreamWaitEvent(A, h->ev_join, 0));
-    mark(h, DIST_MARK_BWD_END, A);
-    if (h->grad_hook) {
-        for (; hook_next >= 0; --hook_next) h->grad_hook(h->grad_hook_user, h->layer_begin[hook_next], h->layer_end[hook_next]);
-        h->grad_hook(h->grad_hook_user, 0, h->layer_begin[0]);
-    }
     return DIST_OK;
 }
 

@@ -36,8 +36,10 @@ int dist_k_logits_loss(const void* v, const float* text, const float* logit_scal
 // 256x256x32 LDS-DMA GEMM (gemm_fast.hip): 1 = launched, 0 = shape not eligible, <0 = error
 bool dist_k_gemm_fast_eligible(const dist_gemm_args* a);
 int dist_k_gemm_fast(const dist_gemm_args* a, hipStream_t s);
-// ping-pong persistent 256x256x64 GEMM (gemm_pp.hip), tried first by dist_k_gemm_fast for its shapes: 1 = launched, 0 = not its call, <0 = error
+#ifdef DIST_AMD_MEASURE
+// timing-only library: ping-pong persistent 256x256x64 GEMM (measure/gemm_pp.hip), tried first by dist_k_gemm_fast: 1 = launched, 0 = not its call, <0 = error
 int dist_k_gemm_pp(const dist_gemm_args* a, int ngroups, hipStream_t s);
+#endif
 int dist_k_gemm_small(const dist_gemm_args* a, hipStream_t s);       // M < 1024 (gemm_small.hip)
 // two-group LDS-DMA weight-gradient GEMM for the large plain gradients (gemm_tn8p.hip): 1 = launched, 0 = not its shape, <0 = error
 int dist_k_gemm_tn8p(const dist_gemm_tn_args* a, hipStream_t s);

@@ -39,18 +39,18 @@
 //        its compute slot (vmcnt 12, 9, 6, 3, 0); the epilogue's stores are issued at least eight phases before the swap.
 #include <stdlib.h>
 #include <type_traits>
-#include "common.h"
-#include "kernels.h"
+#include "../common.h"
+#include "../kernels.h"
 
 // Round 5 verdict on this design (profiles/r05_gemm_pingpong.md): bit-identical to gemm_fast8p_kernel on every epilogue, and 25-35 % SLOWER
 // per launch.  One wave per SIMD issues v_mfma_f32_16x16x32_bf16 at ~27 cycles instead of 16-17 (compute role alone, no DMA, no epilogue:
 // 1244-1322 TF against ~1850 TF-equivalent inside the two-waves-per-SIMD loop), and a 128 x 256 half-tile needs 48 KB of operands per
 // 64 MFMAs per wave against 64 KB per 128: at the ~50 GB/s per CU that LDS-DMA sustains in these GEMMs (~64 KB in flight per CU over
 // 1.2-1.4 us of latency, whatever the ring depth or the waits) the operand stream, not the matrix pipe, bounds the loop.
-// The kernel is therefore NOT part of the product library: it is compiled only into -DDIST_AMD_MEASURE builds (the A/B reference of
-// tools/check_pp.py and tools/r05_pp_dbg.sh) and dist_k_gemm_pp returns 0 otherwise.
+// The kernel is therefore NOT part of the product library: this file is a source of the timing-only build alone (dist_amd/build.py
+// MEASURE_SOURCES; the A/B reference of tools/check_pp.py) and gemm_fast.hip calls dist_k_gemm_pp only under -DDIST_AMD_MEASURE.
 #ifndef DIST_AMD_MEASURE
-int dist_k_gemm_pp(const dist_gemm_args*, int, hipStream_t) { return 0; }
+#error "measure/gemm_pp.hip belongs to the timing-only library (python -m dist_amd.build --measure)"
 #else
 
 namespace {

@@ -131,6 +131,12 @@ def _sig(lib, name, argtypes=None, restype=None):
         fn.restype = restype
 
 
+# every DIST_AMD_* variable the PRODUCT library or its Python host side reads (csrc/common.h dist_knob(); bench.py / utils/distributed.py / build.py)
+PRODUCT_ENV = frozenset("DIST_AMD_" + k for k in (
+    "ATTN_FULLROW CONV9 FAST_8P INTEG_BWD_FUSED INTEG_FUSED KEEP_MID LNFOLD NT_DMA ROWSTATS SERIAL TN8P TN8P_BLOCKS TNET_BWD_FUSED TNET_FUSED TN_BLOCKS "
+    "LIB BACKEND FORCE_REDUCER VIT_SPLIT MAIN_PRIO BUILD_DEFS REDUCER_DTYPE REDUCER_MODE SKIP_SLOW_ORACLE ALLOW_INERT HOST_INPUT").split())
+
+
 def load():
     """Load the HIP library or fail loudly (there is no fallback path)."""
     global _lib
@@ -152,6 +158,13 @@ def load():
         if lib.dist_abi_sizeof(cname.encode()) != C.sizeof(mirror):
             raise DistError(f"{LIB_PATH}: sizeof({cname}) = {lib.dist_abi_sizeof(cname.encode())}, the ctypes mirror has {C.sizeof(mirror)}")
     _sig(lib, "dist_measure_build", argtypes=[])
+    # a measurement knob (DIST_AB_KNOB / dist_measure_knob in csrc/common.h) is a constant in the product library: a run that sets one against
+    # libdist_amd.so would time the SAME kernels under different labels - refuse instead of producing a vacuous A/B
+    if not lib.dist_measure_build() and os.environ.get("DIST_AMD_ALLOW_INERT") != "1":      # (ALLOW_INERT: the test that proves the C library ignores them)
+        inert = sorted(k for k in os.environ if k.startswith("DIST_AMD_") and k not in PRODUCT_ENV)
+        if inert:
+            raise DistError(f"{', '.join(inert)}: measurement knobs exist only in the timing-only library (`. tools/measure_build.sh`, DIST_AMD_LIB); "
+                            f"{LIB_PATH} is the product build and would ignore them")
     _sig(lib, "dist_strerror", restype=C.c_char_p)
     _sig(lib, "dist_strerror", argtypes=[C.c_int])
     _sig(lib, "dist_abi_sizeof", argtypes=[C.c_char_p])

@@ -226,9 +226,10 @@ def test_result_changing_knobs_exist_only_in_a_measure_build():
     l = lib.load()
     assert l.dist_measure_build() == 0                          # the in-tree library is the product build
     csrc = os.path.join(ROOT, "dist_amd", "csrc")
-    for f in glob.glob(os.path.join(csrc, "*.hip")):
-        assert "getenv" not in open(f).read(), f                # only common.h's dist_knob touches the environment
-    txt = "".join(open(f).read() for f in glob.glob(os.path.join(csrc, "*.hip")))
+    srcs = glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "measure", "*.hip")) + glob.glob(os.path.join(csrc, "measure", "*.inl"))
+    for f in srcs:
+        assert "getenv" not in open(f).read() or f.endswith("common.h"), f     # only common.h's dist_knob touches the environment
+    txt = "".join(open(f).read() for f in srcs if not f.endswith("common.h"))
     measure_only = {"DIST_AMD_SKIP", "DIST_AMD_DUMMY", "DIST_AMD_DUMMY_REPS", "DIST_AMD_TN_SKIP_REDUCE", "DIST_AMD_ATTN_DBG", "DIST_AMD_INTEG_DBG",
                     "DIST_AMD_TNET_DBG", "DIST_AMD_TNET_BWD_NOREDUCE", "DIST_AMD_PP_DBG"}
     sel = set(re.findall(r'dist_knob\("(DIST_AMD_[A-Z0-9_]+)"', txt))
@@ -238,6 +239,14 @@ def test_result_changing_knobs_exist_only_in_a_measure_build():
     # serial-order switch; every A/B reference of a measured-and-rejected variant is a DIST_AB_KNOB (a constant outside the timing-only library)
     ab = set(re.findall(r'DIST_AB_KNOB\("(DIST_AMD_[A-Z0-9_]+)"', txt))
     assert len(sel) <= 15 and not (sel & ab) and len(ab) >= 20, (sorted(sel), sorted(sel & ab))
+    assert sel <= lib.PRODUCT_ENV and not (lib.PRODUCT_ENV & (ab | mea))
+    # round 6: the measure-only kernels are not sources of the product library, and a process that sets a measurement knob against the
+    # product library is refused by the loader (it would time the same kernels under two labels)
+    from dist_amd import build
+    assert not any("measure" in x or "gemm_pp" in x for x in build.SOURCES) and all(x.startswith("measure") for x in build.MEASURE_SOURCES)
+    r = subprocess.run([sys.executable, "-c", "from dist_amd import lib; lib.load()"], cwd=ROOT, capture_output=True, text=True,
+                       env=dict(os.environ, DIST_AMD_FAST_TILES="2"), timeout=300)
+    assert r.returncode != 0 and "measurement knobs exist only in the timing-only library" in r.stderr, r.stderr[-400:]
     common = open(os.path.join(csrc, "common.h")).read()
     assert "#define DIST_AB_KNOB(name, dflt) (dflt)" in common
     assert "#ifdef DIST_AMD_MEASURE" in common and "inline int dist_measure_knob(const char*, int dflt) { return dflt; }" in common

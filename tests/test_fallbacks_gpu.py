@@ -26,8 +26,9 @@ def test_engine_parity_with_a_fused_kernel_switched_off(knob):
 @pytest.mark.gpu
 def test_result_changing_knobs_are_inert_in_the_shipped_library():
     """DIST_AMD_SKIP = 1 (no weight-gradient GEMMs) used to yield wrong gradients through the C ABI with rc 0; in the product build the variable is not
-    read at all: the engine's gradient tests pass with it (and with the other measure-only switches) set."""
-    env = dict(os.environ, DIST_AMD_SKIP="1", DIST_AMD_DUMMY="7", DIST_AMD_TN_SKIP_REDUCE="1", DIST_AMD_TNET_DBG="3", DIST_AMD_ATTN_DBG="1",
+    read at all: the engine's gradient tests pass with it (and with the other measure-only switches) set.  (dist_amd.lib.load() itself REFUSES such a
+    process - tests/test_abi_and_host.py - so this test asks it not to: the point here is the C library.)"""
+    env = dict(os.environ, DIST_AMD_ALLOW_INERT="1", DIST_AMD_SKIP="1", DIST_AMD_DUMMY="7", DIST_AMD_TN_SKIP_REDUCE="1", DIST_AMD_TNET_DBG="3", DIST_AMD_ATTN_DBG="1",
                DIST_AMD_TNET_BWD_NOREDUCE="1")
     cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_engine_gpu.py"), "-q", "-x", "-k", "b16_bf16_vs_reference_golden"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
