@@ -36,6 +36,22 @@ GF_PER_CLIP = {"b16_8+16f": dict(fwd=325.73, fwd_bwd=398.0), "b16_16+32f": dict(
 # `*_tflops` / `*_mfma_frac` of the line is computed from GF_PER_CLIP minus this.
 GF_SKIPPED_PER_CLIP = {"b16_8+16f": 8 * 196 * 768 * 768 * 2 / 1e9, "b16_16+32f": 16 * 196 * 768 * 768 * 2 / 1e9, "l14_32+64f": 32 * 256 * 588 * 1024 * 2 / 1e9}
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_FP8_TFLOPS = 5000.0       # dense MFMA e4m3 (block-scaled 16x16x128), same guide
+
+
+def path_peak_tflops(g, vit_fp8, gf_per_clip):
+    """The peak the path's FLOPs are priced against.  bf16 run: the bf16 MFMA peak.  --vit-fp8 (BASELINE config 5): the frozen-ViT GEMMs selected by the mask
+    run on the e4m3 pipe (5 PF), everything else on bf16 - the FLOP-weighted harmonic mean total / (f8 / 5000 + rest / 2500), so that a fraction of it
+    is a fraction of what the two pipes could deliver for THIS mix (0.44 of the bf16 peak was ~0.25 of this)."""
+    if not vit_fp8 or not gf_per_clip:
+        return PEAK_BF16_TFLOPS, None
+    d2 = float(g.d) * g.d
+    per_gemm = {1: 3 * d2, 2: d2, 4: 4 * d2, 8: 4 * d2}                      # in_proj, out_proj, c_fc, c_proj: N x K per token row
+    f8 = sum(v for bit, v in per_gemm.items() if vit_fp8 & bit) * 2.0 * g.t * g.L * g.layers / 1e9       # GF per clip on e4m3 operands
+    f8 = min(f8, gf_per_clip)
+    peak = gf_per_clip / (f8 / PEAK_FP8_TFLOPS + (gf_per_clip - f8) / PEAK_BF16_TFLOPS)
+    return peak, {"fp8_gflop_per_clip": round(f8, 2), "bf16_gflop_per_clip": round(gf_per_clip - f8, 2), "peak_tflops": round(peak, 1),
+                  "note": "FLOP-weighted peak: total / (fp8 GF / 5000 + bf16 GF / 2500); path_mfma_frac is a fraction of THIS"}
 
 
 def cpu_baseline(gname, seconds_budget=12.0):
@@ -123,6 +139,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="serial order: ViT forward of a batch inside its own step")
     ap.add_argument("--no-serial-ref", action="store_true", help="skip the short serial-order reference run after the timed loop")
+    ap.add_argument("--host-input", action="store_true", help="the batches live in (pinned) HOST memory as the reference's loader hands them over: every step copies the "
+                    "308 MB of batch n+2 to the GPU on a copy stream, two steps ahead of its frozen-ViT pass (dist_amd/utils/staging.py).  NOT the headline `value` "
+                    "(inputs resident, as the contract says): reported under `host_input` by the default run")
     ap.add_argument("--vit-fp8", type=int, default=0, help="BASELINE config 5: bit mask of the frozen-ViT GEMMs on e4m3 operands "
                     "(1 in_proj, 2 out_proj, 4 c_fc, 8 c_proj, 16 producers write the images: 31 = everything).  Not the headline configuration: the line's dtype says so")
     args = ap.parse_args()
@@ -146,6 +165,8 @@ def main():
 
     g = synth.geometry(args.config)
     b = args.batch
+    # the CPU leg runs FIRST (the reference CPU path timed on the host cores in the same run, before the GPU leg)
+    cpu_leg = cpu_baseline(args.config) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     eng = Engine(config_from_geometry(g, b, torch.bfloat16, True, args.vit_fp8))
     eng.load_state_dict(synth.state_dict(g))
     # clips are sharded per rank (independent units); every rank gets its own synthetic shard
@@ -156,17 +177,42 @@ def main():
     lr, wd, mult = 3.2e-5, 1e-4, 10.0      # configs/projects/dist/ssv2/vit-b16-8+16f.yaml:52-58
     reducer = du.GradReducer(eng, world) if (world > 1 or force_reducer) else None
     pipelined = not args.no_pipeline
+    if args.host_input:
+        args.no_serial_ref = args.no_roofline = True   # (the extras read the resident tensors; this mode reports the step only)
     it = [0]
     split = int(os.environ.get("DIST_AMD_VIT_SPLIT", g.layers))   # ViT layers issued before the branch forward (the rest before the backward)
+
+    H, tickets = {"stager": None, "host": None}, {}
+
+    def host_input_on():
+        from dist_amd.utils.staging import HostStager
+        H["stager"] = HostStager(depth=3)
+        H["host"] = [v.cpu().pin_memory() for v in videos]
+        tickets.clear()
+    if args.host_input:
+        host_input_on()
+
+    def batch_video(n):
+        """frames of batch n on the device: the resident tensor, or (--host-input) the staged copy that was submitted two steps ago"""
+        if H["stager"] is None:
+            return videos[n % 2]
+        if n not in tickets:
+            tickets[n] = H["stager"].submit(H["host"][n % 2])
+        return H["stager"].wait(tickets[n])
 
     def step():
         n = it[0]
         it[0] += 1
+        stager = H["stager"]
+        if stager is not None and pipelined and (n + 2) not in tickets:
+            tickets[n + 2] = stager.submit(H["host"][(n + 2) % 2])          # H2D of batch n+2 beside this step (its ViT pass is issued by step n+1)
         if pipelined:
-            eng.vit_prefetch(videos[(n + 1) % 2], layer_end=split)   # frozen ViT of the NEXT batch, beside this batch's branch work
+            eng.vit_prefetch(batch_video(n + 1), layer_end=split)   # frozen ViT of the NEXT batch, beside this batch's branch work
         else:
-            eng.vit_forward(videos[n % 2])
+            eng.vit_forward(batch_video(n))
         eng.branch_forward(text)
+        if stager is not None and n in tickets:
+            stager.release(tickets.pop(n))             # the branch forward waited for every feature of batch n: its frames (read by the patch gather only) are dead
         _, dlogits = eng.loss(tgts[n % 2])
         if pipelined and split < g.layers:
             eng.vit_prefetch_more()                    # the remaining ViT layers run beside the backward
@@ -181,7 +227,7 @@ def main():
     if os.environ.get("DIST_AMD_MAIN_PRIO"):           # measurement knob: run the step on a torch stream of this priority
         torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["DIST_AMD_MAIN_PRIO"])))
     if pipelined:
-        eng.vit_forward(videos[0])                     # pipeline prologue: features of batch 0
+        eng.vit_forward(batch_video(0))                # pipeline prologue: features of batch 0
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -239,7 +285,7 @@ def main():
     #                              kernel's workgroups wait for CUs held by the branch / backward kernels of the other streams;
     #   roofline.alone           : the same launches of one frozen-ViT pass with no other stream active (the kernel's own duration).
     roof = None
-    cu_floor = None
+    roof_floor = None
     if not args.no_roofline:
         def measure(fn, reps):
             eng.profile_begin()
@@ -252,36 +298,47 @@ def main():
         ach, lps, avg_us = measure(step, nprof)
         torch.cuda.synchronize()
         ach1, lps1, avg1 = measure(lambda: (eng.vit_forward(videos[0]), torch.cuda.synchronize()), 3)
-        # HBM bytes per launch of this kernel: PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes, corrected
-        # as MI355X_MICROARCH.md prescribes), collected offline by tools/pmc_pass.sh and committed; null when the file is absent
-        traffic = None
-        pmc = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_fast_gemm.json") for r in ("r05", "r04", "r03")) if os.path.exists(q)), "")
-        pmc_tag = os.path.basename(pmc)[:3] if pmc else "r04"
-        if args.config == "b16_8+16f" and os.path.exists(pmc):
+        # Files of the round's committed profile (tools/snapshot_all.sh on ONE box): every field of the line that comes from one of them carries `from`
+        # and that box's own step time, so that it is never read against THIS run's clock
+        def latest(name):
+            return next((q for q in (os.path.join(ROOT, "profiles", f"{r}_{name}") for r in ("r06", "r05", "r04", "r03")) if os.path.exists(q)), "")
+        headline = args.config == "b16_8+16f" and b == 32 and not args.vit_fp8
+        pj, pmc = (latest("bench_kernel_stats.json"), latest("pmc_fast_gemm.json")) if headline else ("", "")
+        prof, traffic = {}, None
+        if pj:
+            with open(pj) as f:
+                prof = json.load(f)
+        if pmc:
             with open(pmc) as f:
                 traffic = json.load(f).get("traffic_bytes_per_launch_avg")
-        cu_floor = None
-        prof_avg = None            # the rocprofv3 --kernel-trace --stats average of this kernel from the committed summary of the same command
-        pj = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_bench_kernel_stats.json") for r in ("r05", "r04", "r03")) if os.path.exists(q)), "")
-        prof_tag = os.path.basename(pj)[:3] if pj else "r04"
-        if args.config == "b16_8+16f" and pj:
-            with open(pj) as f:
-                pjd = json.load(f)
-            prof_avg = pjd.get("in_situ_avg_us", pjd.get("dominant_kernel_avg_us"))
-            cu_floor = pjd.get("cu_time_floor_ms")
-        roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": f"bytes per launch, mean of the four ViT GEMM shapes (48 of the launches), profiles/{pmc_tag}_pmc_fast_gemm.{{md,json}}",
-                "kernel": "gemm_fast8p_kernel 256x256x64 LDS-DMA, two wave groups (ViT QKV/out/MLP + large DiST Linears; the strided patch embedding on the 256x256x32 loop)", "launches_per_step": lps,
-                "avg_launch_us": round(avg_us, 1), "profile_avg_us": prof_avg,
-                "profile_note": f"in-situ average duration of the same kernel in profiles/{prof_tag}_bench_kernel_stats.{{md,json}} (rocprofv3 --kernel-trace --stats of the TIMED LOOP of this "
-                                "command: --no-cpu-baseline --no-serial-ref --no-roofline, tools/snapshot.sh); algorithmic FLOPs per launch = achieved x avg_launch_us",
-                "flops_per_launch": round(ach * 1e12 * avg_us * 1e-6, 0),
-                # the same algorithmic FLOPs per launch over the PROFILE's in-situ duration (kernel time only, no queue wait): re-derivable by division
-                "frac_profile": round(ach * avg_us / prof_avg / PEAK_BF16_TFLOPS, 4) if prof_avg else None,
-                "note": "in situ: launch durations while the kernels of the other streams share the CUs (the timed loop's schedule)",
-                "alone": {"achieved": round(ach1, 1), "frac": round(ach1 / PEAK_BF16_TFLOPS, 4), "launches": lps1, "avg_launch_us": round(avg1, 1),
-                          "note": "the launches of one frozen-ViT pass with no other stream active"}}
+        prof_avg = prof.get("in_situ_avg_us")          # rocprofv3 --kernel-trace --stats average of this kernel over the TIMED LOOP of this command
+        cu_floor = prof.get("cu_time_floor_ms")
+        fpl = ach * 1e12 * avg_us * 1e-6                 # algorithmic FLOPs per launch (sum of 2 M N K over the launches of this run / launches)
+        ev = {"achieved": round(ach, 1), "frac": round(ach / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(avg_us, 1),
+              "note": "live in this run: HIP-event brackets around every launch on the kernel's own stream, in the timed loop's schedule; a bracket also holds "
+                      "the wait of its two barrier packets behind the other queues, so it reads longer than the kernel's own duration"}
+        if prof_avg:
+            ach_p = fpl / (prof_avg * 1e-6) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach_p, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_p / PEAK_BF16_TFLOPS, 4),
+                    "avg_launch_us": prof_avg, "flops_per_launch": round(fpl, 0),
+                    "from": "profiles/" + os.path.basename(pj) + ": in_situ_avg_us = rocprofv3 --kernel-trace --stats average duration of this kernel in the timed loop of this "
+                            "command (--no-cpu-baseline --no-serial-ref --no-roofline, tools/snapshot.sh); achieved = flops_per_launch / avg_launch_us",
+                    "from_box_ms_per_step": prof.get("wall_ms_per_step")}
+        else:
+            roof = {"bound": "mfma", "achieved": ev["achieved"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ev["frac"], "avg_launch_us": ev["avg_launch_us"],
+                    "flops_per_launch": round(fpl, 0), "from": "this run's HIP events (no committed rocprofv3 summary for this configuration)"}
+        roof.update({"kernel": "gemm_fast8p_kernel 256x256x64 LDS-DMA, two wave groups (ViT QKV/out/MLP + large DiST Linears; the strided patch embedding on the 256x256x32 loop)",
+                     "launches_per_step": lps, "events": ev,
+                     "traffic": traffic,
+                     "traffic_from": ("profiles/" + os.path.basename(pmc) + ": bytes per launch, mean of the four ViT GEMM shapes (48 of the launches); rocprofv3 --pmc FETCH_SIZE (x2) and "
+                                      "--pmc WRITE_SIZE in separate passes, tools/pmc_pass.sh") if pmc else None,
+                     "alone": {"achieved": round(ach1, 1), "frac": round(ach1 / PEAK_BF16_TFLOPS, 4), "launches": lps1, "avg_launch_us": round(avg1, 1),
+                               "note": "live in this run (HIP events): the launches of one frozen-ViT pass with no other stream active"}})
+        if cu_floor:
+            roof_floor = {"value": cu_floor, "from": "profiles/" + os.path.basename(pj) + ": sum over kernels of alone us x launches per step x min(1, blocks / 256)",
+                          "from_box_ms_per_step": prof.get("wall_ms_per_step")}
+        else:
+            roof_floor = None
 
     # forward only (what the multi-view evaluation loop runs; SURVEY §8(d) quotes a forward-only roofline fraction): frozen ViT of
     # batch n+1 beside the branch forward of batch n, no loss / backward / AdamW
@@ -311,8 +368,31 @@ def main():
         fwd_only = {"ms_per_iteration": round(dtf * 1e3, 3), "value": round(b / dtf, 1), "unit": "clips/s", "iterations": nf,
                     "mode": "inference (dist_set_inference: same logits, no tensors kept for backward), frozen ViT + branch forward per iteration"}
         if gff:
+            pk_f, pk_note = path_peak_tflops(g, args.vit_fp8, gff)
             fwd_only["path_tflops_per_gpu"] = round(b / dtf * gff / 1e3, 1)
-            fwd_only["path_mfma_frac"] = round(b / dtf * gff / 1e3 / PEAK_BF16_TFLOPS, 4)
+            fwd_only["path_mfma_frac"] = round(b / dtf * gff / 1e3 / pk_f, 4)
+            if pk_note:
+                fwd_only["path_peak"] = pk_note
+
+    # the same step fed from HOST memory (the reference's loader hands over host batches, runs/train.py:81-101): pinned staging + a copy stream two steps
+    # ahead of the frozen-ViT pass (dist_amd/utils/staging.py).  Reported beside `value`, never as it (the contract: inputs resident)
+    host_leg = None
+    if not args.no_roofline and world == 1 and pipelined and not args.host_input:
+        host_input_on()
+        eng.vit_forward(batch_video(it[0]))
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        th0 = time.perf_counter()
+        nh = max(1, min(10, args.steps))
+        for _ in range(nh):
+            step()
+        torch.cuda.synchronize()
+        dth = (time.perf_counter() - th0) / nh
+        H["stager"] = None
+        host_leg = {"ms_per_step": round(dth * 1e3, 3), "value": round(b / dth, 1), "unit": "clips/s", "steps": nh,
+                    "vs_resident": round((dt / args.steps) / dth, 4),
+                    "note": "batches in pinned host memory; the 308 MB H2D copy of batch n+2 runs on a copy stream beside step n (python bench.py --host-input)"}
 
     if rank == 0:
         clips = world * b * args.steps
@@ -325,27 +405,31 @@ def main():
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if not args.vit_fp8 else f"bf16, frozen-ViT GEMMs mask {args.vit_fp8} on fp8 e4m3 operands (fp32 accumulate)",
-            "data": "synthetic",
+            "data": "synthetic" if not args.host_input else "synthetic, batches in pinned host memory (H2D copy of 308 MB per step on a copy stream, two steps ahead)",
             "pipeline": ("frozen-ViT forward of batch n+1 on a low-priority stream beside branch fwd/bwd/AdamW of batch n "
                          "(2 feature slots; one ViT forward per timed step)") if pipelined else "serial (--no-pipeline)",
             "config": {"workload": f"ViT-{args.config} bf16, synthetic 224^2 frames, batch={b}/GPU, fwd+bwd+AdamW, DP{world}",
                        "global_batch": b * world, "frames": f"{g.t}+{g.T}", "parallelism": f"dp{world}"},
         }
         if gf:
+            pk_t, pk_note = path_peak_tflops(g, args.vit_fp8, gf)
             out["path_tflops_per_gpu"] = round(value / world * gf / 1e3, 1)
-            out["path_mfma_frac"] = round(value / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4)
+            out["path_mfma_frac"] = round(value / world * gf / 1e3 / pk_t, 4)
+            if pk_note:
+                out["path_peak"] = pk_note
             out["path_gflop_per_clip"] = {"executed": round(gf, 2), "reference_graph": GF_PER_CLIP[args.config]["fwd_bwd"],
                                           "note": "executed = the reference graph's algorithmic FLOPs minus the patch embedding of the T - t frames the frozen ViT drops "
                                                   "right behind it (the engine embeds only the kept frames); path_tflops / path_mfma_frac use `executed`"}
         # whole-step HBM-side traffic from the committed PMC passes (tools/pmc_step.sh: FETCH_SIZE x2 + WRITE_SIZE over every kernel of
         # one step, Infinity-Cache hits included) against this run's step time; null when the file is absent or the config differs
-        tj = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_step_traffic.json") for r in ("r05", "r04", "r03")) if os.path.exists(q)), "")
-        if args.config == "b16_8+16f" and b == 32 and tj:
+        tj = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_step_traffic.json") for r in ("r06", "r05", "r04", "r03")) if os.path.exists(q)), "")
+        if args.config == "b16_8+16f" and b == 32 and tj and not args.vit_fp8:
             with open(tj) as f:
                 tr = json.load(f)
             gbps = tr["bytes_per_step"] / (dt / args.steps) / 1e9
             out["hbm"] = {"bytes_per_step_per_gpu": tr["bytes_per_step"], "achieved_gbps_per_gpu": round(gbps, 1), "peak_gbps": 8000.0,
-                          "frac": round(gbps / 8000.0, 4), "source": "profiles/" + os.path.basename(tj)}
+                          "frac": round(gbps / 8000.0, 4),
+                          "from": "profiles/" + os.path.basename(tj) + ": bytes_per_step (PMC passes over every kernel of a step, Infinity-Cache hits included) over THIS run's ms_per_step"}
         if reducer is not None:
             import torch.distributed as tdist
             out["reducer"] = {"backend": tdist.get_backend(), "world": world, "collectives_per_step": reducer.n_collectives,
@@ -364,15 +448,16 @@ def main():
             out["serial_order"] = serial
         if roof:
             out["roofline"] = roof
-            if cu_floor:
+            if roof_floor:
                 # the step's packing bound from the committed profile (tools/prof_summary.py --serial-db): what the step would take with the 256 CUs
-                # packed perfectly with its kernels as they are; ms_per_step over it = how much of the step is schedule rather than kernel time
-                out["cu_time_floor_ms"] = cu_floor
-                out["cu_time_floor_source"] = f"profiles/{prof_tag}_bench_kernel_stats.{{md,json}}: sum over kernels of alone us x launches per step x min(1, blocks / 256)"
+                # packed perfectly with its kernels as they are - a number of the PROFILE's box: read it against from_box_ms_per_step, not against ms_per_step
+                out["cu_time_floor_ms"] = roof_floor
         if fwd_only:
             out["forward_only"] = fwd_only
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.config)
+        if host_leg:
+            out["host_input"] = host_leg
+        if cpu_leg is not None:
+            out["cpu_baseline"] = cpu_leg
         # RCCL's version banner sits in the C stdio buffer until exit: flush it first so that the JSON line is the LAST line of stdout
         try:
             import ctypes

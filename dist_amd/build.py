@@ -9,8 +9,8 @@ MEASURE_LIB = os.path.join(CSRC, "libdist_amd_measure.so")
 SOURCES = ["gemm_nt.hip", "gemm_fast.hip", "gemm_small.hip", "gemm_tn.hip", "gemm_tn8p.hip", "conv_dw.hip", "conv_t_dw.hip", "tnet.hip", "integ.hip", "norm.hip", "attn.hip", "misc.hip",
            "metrics.hip", "quant.hip", "engine.hip", "engine_vit.hip", "engine_fwd.hip", "engine_bwd.hip"]
 # kernels of the timing-only library alone (measured-and-rejected variants kept as A/B references): never compiled into libdist_amd.so
-MEASURE_SOURCES = [os.path.join("measure", "gemm_pp.hip")]
-HEADERS = ["common.h", "kernels.h", "engine_internal.h", os.path.join("..", "..", "include", "dist_amd.h"),
+MEASURE_SOURCES = [os.path.join("measure", "gemm_pp.hip"), os.path.join("measure", "integ4.hip")]
+HEADERS = ["common.h", "kernels.h", "engine_internal.h", "integ_common.h", os.path.join("..", "..", "include", "dist_amd.h"),
            os.path.join("measure", "gemm_fast8q.inl"), os.path.join("measure", "gemm_fast8q_launch.inl")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 

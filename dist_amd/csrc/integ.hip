@@ -36,42 +36,9 @@
 #include "common.h"
 #include "kernels.h"
 
+#include "integ_common.h"
+
 namespace {
-
-struct IgArgs {
-    const bf16_t* Mp;
-    const bf16_t *W1, *W2, *W3;
-    const float *b1, *b2, *b3;
-    const float *ga, *ba, *gb, *bb;
-    bf16_t *R, *Na, *Nb, *Xh, *zfh2, *hfg2, *h1;
-    float *mean, *rstd;
-    int clips, t, L, groups, tokshift;
-    float eps;
-    // T2I in front (template T2I): M' = M + [cls_token ; conv_strided(X')] is formed here instead of being read
-    const bf16_t *M, *Xp, *Wt; const float *bt, *cls; bf16_t* Mpo;
-    // ... and I2T behind it (dist.py:90-105): X_next[frames 2f, 2f+1; position j-1] = X' + (M[f, j] Wi^T + bi), when Xn is given
-    const bf16_t* Wi; const float* bi; bf16_t* Xn;
-};
-
-DEV int ig_pchunk(const int row, const int c) { return (c & ~3) | ((c & 3) ^ (((row >> 2) & 1) << 1)); }
-// sum over the 8 lanes that share a row in stage 0 (lanes 8 k .. 8 k + 7)
-DEV float ig_sum8(float v) {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));   // row_half_mirror
-    return v;
-}
-DEV f32x4 ig_mma(const bf16x8& w, const bf16x8& x, const f32x4& acc) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc, 0, 0, 0); }
-DEV bf16x8 ig_ldw(const bf16_t* base, const long frag, const int lane) { return *reinterpret_cast<const bf16x8*>(base + (frag * 64 + lane) * 8); }
-#define IG_LDW(base, frag) ((DBG & 1) ? bf16x8{(bf16_t)(float)lane, 0, 0, 0, 0, 0, 0, 0} : ig_ldw(base, frag, lane))
-#define IG_MMA(w, x, acc) ((DBG & 2) ? (acc) : ig_mma(w, x, acc))
-#define IG_GELU(x) ((DBG & 4) ? (x) : qgelu_t<bf16_t>(x))
-#define IG_LDS(ptr) ((DBG & 16) ? bf16x8{(bf16_t)(float)li, 0, 0, 0, 0, 0, 0, 0} : *reinterpret_cast<const bf16x8*>(ptr))
-#define IG_ST(v, ptr) do { if (!(DBG & 8)) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(ptr)); } while (0)
-DEV void ig_load8(const float* p, float (&o)[8]) {
-    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
-    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
-}
 
 template <int CI, int C4, int BM, int MODE, int DBG, bool T2I>
 __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_fwd_kernel(const IgArgs p) {
@@ -555,20 +522,6 @@ __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_fwd_kernel(con
 // runs on them in registers: row sums over a lane's columns, over the 4 lanes of a row (ds_bpermute), over the 8 waves through LDS.
 // Written: [dzf | dh2] and dh1 (the weight-gradient GEMMs read them), dM' (+ a second copy, + dR for the last layer).  The LayerNorm
 // parameter gradients come from dist_op_integration_unfold, not from here.
-struct IgBwdArgs {
-    const bf16_t *dR, *zfh2, *Xh; const float* rstd;
-    const bf16_t *W1, *W2, *W3;
-    bf16_t *dzfh2, *dh2, *dh1, *dMp, *dM;
-    int ldz, ld2, ld1;       // row pitches of dzf, dh2 (a pointer to ITS first column), dh1
-    int add_dR, dm_cls;      // dm_cls: the second copy of dM' only receives the cls rows (token 0)
-    // I2T backward behind the LayerNorm backward (dist.py:100-105 through autograd): dY = dX_next[2f] + dX_next[2f+1] (written out: the I2T weight gradient reads it),
-    // dM = dM' + dY Wi on the patch rows - dM then holds the WHOLE gradient w.r.t. M, not a copy of dM'
-    const bf16_t *dXn, *W4; bf16_t* dY;
-    // T2I backward behind that (dist.py:81-86 through autograd, and through X' = g(p)): dp[2f+a][j-1] = (dX_next[2f+a][j-1] + dM'[f][j] W5_a^T) g'(p[2f+a][j-1])
-    const bf16_t *W5, *pact; bf16_t* dp;
-    float* dcls;             // optional: the T2I cls-token gradient [t][Ci] += dM' of the cls rows (token 0 of every frame), fp32 atomics
-    int clips, t, L, groups, tokshift;
-};
 
 template <int CI, int C4, int BM>
 __global__ __launch_bounds__(512, (BM == 128 ? 2 : 4)) void integ_bwd_kernel(const IgBwdArgs p) {
@@ -1210,7 +1163,10 @@ extern "C" int dist_op_integration_bwd(const dist_integ_bwd_args* a, void* strea
     if (!a || !a->dR || !a->zf_h2 || !a->Xhat || !a->rstd || !a->B1 || !a->B2 || !a->B3 || !a->dzf_dh2 || !a->dh1 || !a->dMp) return DIST_ERR_ARG;
     if (a->clips <= 0 || a->t <= 0 || a->L <= 0) return DIST_ERR_ARG;
     if (!dist_k_integ_eligible(a->dtype, a->Ci, a->C4, a->t, a->tk)) return DIST_ERR_ARG;
-    constexpr int BM = 128;
+    // (timing-only library: 64-row tiles walked by four waves, two workgroups per CU - measure/integ4.hip, measured and rejected in round 6)
+    static const int w4_env = DIST_AB_KNOB("DIST_AMD_INTEG_W4", 0);
+    const bool w4 = w4_env != 0 && a->t <= 64 && 64 % a->t == 0;
+    const int BM = w4 ? 64 : 128;
     if (BM % a->t) return DIST_ERR_ARG;
     IgBwdArgs k;
     k.dR = static_cast<const bf16_t*>(a->dR); k.zfh2 = static_cast<const bf16_t*>(a->zf_h2); k.Xh = static_cast<const bf16_t*>(a->Xhat); k.rstd = a->rstd;
@@ -1235,10 +1191,13 @@ extern "C" int dist_op_integration_bwd(const dist_integ_bwd_args* a, void* strea
     while ((1 << sh) < TOK) ++sh;
     k.tokshift = sh;
     k.groups = (a->L + TOK - 1) / TOK;
-    const int smem = BM * 384 * 2 + 2 * BM * 96 * 2 + 9 * BM * 2 * 4;
+#ifdef DIST_AMD_MEASURE
+    if (w4) { const int rc = integ_bwd4_launch(k, static_cast<hipStream_t>(stream)); return rc < 0 ? rc : DIST_OK; }
+#endif
+    const int smem = 128 * 384 * 2 + 2 * 128 * 96 * 2 + 9 * 128 * 2 * 4;
     static DistSmemOnce attr;
-    RUN_(dist_max_smem(attr, (const void*)integ_bwd_kernel<384, 96, BM>, (size_t)smem));
-    hipLaunchKernelGGL((integ_bwd_kernel<384, 96, BM>), dim3((unsigned)(k.clips * k.groups)), dim3(512), smem, static_cast<hipStream_t>(stream), k);
+    RUN_(dist_max_smem(attr, (const void*)integ_bwd_kernel<384, 96, 128>, (size_t)smem));
+    hipLaunchKernelGGL((integ_bwd_kernel<384, 96, 128>), dim3((unsigned)(k.clips * k.groups)), dim3(512), smem, static_cast<hipStream_t>(stream), k);
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
 }
@@ -1271,6 +1230,11 @@ extern "C" int dist_op_integration_fwd(const dist_integ_args* a, void* stream) {
     }
     static const int bm_env = DIST_AB_KNOB("DIST_AMD_INTEG_BM", 0);     // A/B: 64-row tiles, two workgroups per CU (timing-only library)
     int BM = bm_env == 64 || bm_env == 128 ? bm_env : 128;
+    // round 6 (timing-only library): the T2I-in-front forms on 64-row tiles walked by FOUR waves, two independent workgroups per CU at 256 registers each
+    // (measure/integ4.hip; measured and rejected, profiles/r06_integ_w4.md)
+    static const int w4_env = DIST_AB_KNOB("DIST_AMD_INTEG_W4", 0);
+    const bool w4 = w4_env != 0 && t2i && (mode == 0 || mode == 2) && a->t <= 64 && 64 % a->t == 0 && bm_env == 0;
+    if (w4) BM = 64;
     if (BM / a->t < 1 || (BM % a->t)) return DIST_ERR_ARG;
     IgArgs k;
     k.Mp = static_cast<const bf16_t*>(a->Mp);
@@ -1285,7 +1249,7 @@ extern "C" int dist_op_integration_fwd(const dist_integ_args* a, void* stream) {
     k.bt = a->t2i_bias; k.cls = a->t2i_cls; k.Mpo = static_cast<bf16_t*>(a->Mp_out);
     k.Wi = static_cast<const bf16_t*>(a->i2t_W); k.bi = a->i2t_bias; k.Xn = static_cast<bf16_t*>(a->i2t_Xnext);
     if (k.Xn && !(t2i && k.Wi && k.bi)) return DIST_ERR_ARG;           // I2T behind needs T2I in front (its X' tile) and its own operands
-    if (t2i && (BM != 128 || a->Na)) return DIST_ERR_ARG;
+    if (t2i && ((BM != 128 && !w4) || a->Na)) return DIST_ERR_ARG;
     const int TOK = BM / a->t;
     int sh = 0;
     while ((1 << sh) < TOK) ++sh;
@@ -1294,6 +1258,7 @@ extern "C" int dist_op_integration_fwd(const dist_integ_args* a, void* stream) {
     k.eps = a->eps > 0.f ? a->eps : 1e-5f;
     hipStream_t s = static_cast<hipStream_t>(stream);
 #ifdef DIST_AMD_MEASURE
+    if (w4) { const int rc = integ_fwd4_launch(k, mode, s); return rc < 0 ? rc : (rc == 1 ? DIST_OK : DIST_ERR_ARG); }
     if (BM == 64) return launch_integ<384, 96, 64>(k, mode, s);        // (measured, profiles/r03_integ_fused.md: faster in inference, slower in training)
 #endif
     return launch_integ<384, 96, 128>(k, mode, s);

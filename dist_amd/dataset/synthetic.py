@@ -1,6 +1,6 @@
 """Synthetic clip loader (there are no datasets in this environment): yields the reference loader's batch
 structure (dataset/base/base_dataset.py:441): (inputs {"video": [b,3,T,H,W]}, labels {"supervised": [b]},
-index, meta), already on the GPU, sharded by rank."""
+index, meta), already on the GPU (DATA.SYNTHETIC_HOST: in host memory, as the reference's loader yields them), sharded by rank."""
 import torch
 
 
@@ -28,6 +28,8 @@ class SyntheticLoader:
                 labels = ((idx // self.views) * 7919) % self.K
             else:
                 labels = torch.randint(0, self.K, (self.batch,), device="cuda", generator=self.gen)
+            if getattr(self.cfg.DATA, "SYNTHETIC_HOST", False):      # the reference loader's hand-over: host tensors (the same values as the resident form)
+                video, labels, idx = video.cpu(), labels.cpu(), idx.cpu()
             yield {"video": video}, {"supervised": labels}, idx, {}
 
 

@@ -30,27 +30,47 @@ def train_epoch(train_loader, model, model_ema, optimizer, cur_epoch, mixup_fn, 
     # over it runs beside this step (TRAIN.PIPELINE_VIT, default on; the order of loader / mixup draws is unchanged).
     pipe = bool(getattr(cfg.TRAIN, "PIPELINE_VIT", True)) and hasattr(model, "prefetch")
     it = iter(train_loader)
+    # Host-resident batches (what the reference's loader yields; runs/train.py:81-101 copies them inside the step): the copy of batch n+2 is started beside
+    # step n on a copy stream (dist_amd/utils/staging.py), so that step n+1 finds the frames of the batch it prefetches resident.  One more batch of
+    # look-ahead on the LOADER only: mixup still draws in batch order, right before the batch's ViT pass is issued.
+    stager = [None]
 
-    def fetch():
-        item = next(it, None)
-        if item is not None and mixup_fn is not None:             # reference runs/train.py:92-93
-            if not item[0]["video"].is_cuda:
-                item[0]["video"] = item[0]["video"].cuda(non_blocking=True)
-            _, item[1]["supervised"] = mixup_fn(item[0], item[1]["supervised"].to(item[0]["video"].device))   # the clips are mixed in place
+    def stage(item):
+        if item is not None and not item[0]["video"].is_cuda:
+            if stager[0] is None:
+                from dist_amd.utils.staging import HostStager
+                stager[0] = HostStager(depth=3)
+            item[0]["_ticket"] = stager[0].submit(item[0]["video"])
         return item
 
-    nxt = fetch()
+    def fetch(item):
+        if item is None:
+            return None
+        if "_ticket" in item[0]:
+            item[0]["video"] = stager[0].wait(item[0]["_ticket"])     # (copied a step ago: nothing waits)
+        if mixup_fn is not None:                                       # reference runs/train.py:92-93
+            _, item[1]["supervised"] = mixup_fn(item[0], item[1]["supervised"].to(item[0]["video"].device))   # the clips are mixed in place
+        else:
+            item[1]["supervised"] = item[1]["supervised"].to(item[0]["video"].device)
+        return item
+
+    ahead = stage(next(it, None))
+    nxt = fetch(ahead)
+    ahead = stage(next(it, None))
     cur_iter = -1
     while nxt is not None:
         cur_iter += 1
         inputs, labels, _, meta = nxt
-        nxt = fetch()
+        nxt = fetch(ahead)
+        ahead = stage(next(it, None))
         if pipe and nxt is not None:
             model.prefetch(nxt[0])
         inputs["texts"] = texts
         lr = optim.get_epoch_lr(cur_epoch + cfg.TRAIN.NUM_FOLDS * float(cur_iter) / data_size, cfg)
         optim.set_lr(optimizer, lr)
         preds, logits = model(inputs)
+        if "_ticket" in inputs:
+            stager[0].release(inputs.pop("_ticket"))               # the forward waited for this batch's features: its frames are dead, the buffer may be refilled
         loss, _, _ = losses.calculate_loss(cfg, preds, logits, labels, cur_epoch + cfg.TRAIN.NUM_FOLDS * float(cur_iter) / data_size)
         optimizer.zero_grad()
         loss.backward()

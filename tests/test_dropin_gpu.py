@@ -163,9 +163,9 @@ def test_train_loop_pipelines_the_frozen_vit_without_changing_results(gpu_lib):
     sys.path.insert(0, ROOT)
     from runs import train as T
 
-    def run(pipe):
+    def run(pipe, host=False):
         cfg = tiny_cfg("TRAIN.FP32_PARITY", "true", "TRAIN.PIPELINE_VIT", "true" if pipe else "false", "TRAIN.EVAL_PERIOD", "0",
-                       "TRAIN.CHECKPOINT_PERIOD", "0", "OPTIMIZER.MAX_EPOCH", "1")
+                       "TRAIN.CHECKPOINT_PERIOD", "0", "OPTIMIZER.MAX_EPOCH", "1", "DATA.SYNTHETIC_HOST", "true" if host else "false")
         logs = []
         orig = T.train_epoch
 
@@ -183,6 +183,12 @@ def test_train_loop_pipelines_the_frozen_vit_without_changing_results(gpu_lib):
     for x, y in zip(a, b):
         assert abs(x["loss"] - y["loss"]) < 1e-4 * max(1.0, abs(x["loss"])), (x, y)
         assert x["top1_err"] == y["top1_err"] and x["lr"] == y["lr"]
+    # round 6: the same batches handed over in HOST memory (the reference loader's form): pinned staging + a copy stream two batches ahead
+    # (dist_amd/utils/staging.py) - the same clips reach the same kernels, so the statistics are identical, pipelined or not
+    for c in (run(True, host=True), run(False, host=True)):
+        assert len(c) == 4
+        for x, y in zip(b, c):
+            assert x["loss"] == y["loss"] and x["top1_err"] == y["top1_err"] and x["lr"] == y["lr"], (x, y)
 
 
 def _tiny_model(*extra):
