@@ -186,7 +186,9 @@ def main():
 
     def host_input_on():
         from dist_amd.utils.staging import HostStager
-        H["stager"] = HostStager(depth=3)
+        # a copy stream of its own that never sees an event (host-ordered: dist_amd/utils/staging.py) - with events on it the copy stream becomes a fifth
+        # compute queue and the step pays 1-2.6 ms (DIST_AMD_HOST_INPUT=events selects that form for the A/B; profiles/r06_host_input.md)
+        H["stager"] = HostStager(depth=3, host_ordered=os.environ.get("DIST_AMD_HOST_INPUT", "") != "events")
         H["host"] = [v.cpu().pin_memory() for v in videos]
         tickets.clear()
     if args.host_input:
@@ -197,17 +199,17 @@ def main():
         if H["stager"] is None:
             return videos[n % 2]
         if n not in tickets:
-            tickets[n] = H["stager"].submit(H["host"][n % 2])
+            tickets[n] = H["stager"].submit(H["host"][n % 2], pinned=True)
         return H["stager"].wait(tickets[n])
 
     def step():
         n = it[0]
         it[0] += 1
         stager = H["stager"]
-        if stager is not None and pipelined and (n + 2) not in tickets:
-            tickets[n + 2] = stager.submit(H["host"][(n + 2) % 2])          # H2D of batch n+2 beside this step (its ViT pass is issued by step n+1)
         if pipelined:
             eng.vit_prefetch(batch_video(n + 1), layer_end=split)   # frozen ViT of the NEXT batch, beside this batch's branch work
+            if stager is not None and (n + 2) not in tickets:
+                tickets[n + 2] = stager.submit(H["host"][(n + 2) % 2], pinned=True)      # H2D of batch n+2 (its ViT pass is issued by step n+1)
         else:
             eng.vit_forward(batch_video(n))
         eng.branch_forward(text)
@@ -392,7 +394,7 @@ def main():
         H["stager"] = None
         host_leg = {"ms_per_step": round(dth * 1e3, 3), "value": round(b / dth, 1), "unit": "clips/s", "steps": nh,
                     "vs_resident": round((dt / args.steps) / dth, 4),
-                    "note": "batches in pinned host memory; the 308 MB H2D copy of batch n+2 runs on a copy stream beside step n (python bench.py --host-input)"}
+                    "note": "batches in pinned host memory; the 308 MB H2D copy of batch n+2 runs on a host-ordered copy stream beside step n (python bench.py --host-input)"}
 
     if rank == 0:
         clips = world * b * args.steps

@@ -22,7 +22,10 @@ static int vit_forward_slot(dist_handle* h, const float* video, int b, int k, vo
         HIP_CHECK_RET(hipEventRecord(S.ev_pre, x.s));                   // everything queued before this pass (re-pack, previous step)
         S.valid.assign(c.layers, 0);                                    // a new clip enters the slot: block i is readable again once ITS launch below is issued (a pass issued in parts)
         mark(h, DIST_MARK_VIT_BEGIN, x.s);
-        RUN(dist_op_patchify(video, S.patches, b, c.frames, c.resolution, c.resolution, c.patch, c.dtype, stream));
+        // (dist_vit_mix_next: the batch-mode Mixup / CutMix of this batch is applied while its frames are gathered - one pass over them instead of three)
+        RUN(dist_op_patchify_mixed(video, S.patches, b, c.frames, c.resolution, c.resolution, c.patch, c.dtype, h->mix.kind, h->mix.lam, h->mix.oml,
+                                   h->mix.yl, h->mix.yh, h->mix.xl, h->mix.xh, stream));
+        h->mix.kind = 0;
         HIP_CHECK_RET(hipEventRecord(S.ev_feat[c.layers], x.s));       // patch rows ready (temporal stem input)
         // patch embedding of the frames k = alpha*j only (the reference embeds all T frames and drops the
         // others at clip.py:284); rows land behind their frame's cls row
@@ -163,6 +166,14 @@ static int vit_args_ok(dist_handle* h, const float* video, int b, const char* wh
     if (!h || !video) return DIST_ERR_ARG;
     if (!h->ws) return fail(h, DIST_ERR_UNBOUND, "%s before dist_bind", who);
     if (b <= 0 || b > h->cfg.batch) return fail(h, DIST_ERR_ARG, "batch %d outside (0, %d]", b, h->cfg.batch);
+    return DIST_OK;
+}
+
+extern "C" int dist_vit_mix_next(dist_handle* h, int kind, float lam, float one_minus_lam, int yl, int yh, int xl, int xh) {
+    if (!h || kind < 0 || kind > 2) return DIST_ERR_ARG;
+    const int R = h->cfg.resolution;
+    if (kind == 2 && (yl < 0 || yh > R || xl < 0 || xh > R || yl > yh || xl > xh)) return fail(h, DIST_ERR_ARG, "dist_vit_mix_next: box [%d,%d) x [%d,%d) outside the %d x %d frame", yl, yh, xl, xh, R, R);
+    h->mix.kind = kind; h->mix.lam = lam; h->mix.oml = one_minus_lam; h->mix.yl = yl; h->mix.yh = yh; h->mix.xl = xl; h->mix.xh = xh;
     return DIST_OK;
 }
 

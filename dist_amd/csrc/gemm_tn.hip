@@ -323,42 +323,63 @@ __global__ __launch_bounds__(WI * WJ * 64) void gemm_tn_kernel(const dist_gemm_t
     }
 }
 
-// sums the row-split partial tiles and adds the result into the parameter-layout gradient.  blockIdx.y owns a group of
-// `per` splits (small tiles are split hundreds of ways: one thread walking all of them serially was latency-bound and
-// cost more than the GEMM itself); four independent accumulators keep four loads in flight per thread.
+// sums the row-split partial tiles and adds the result into the parameter-layout gradient.  A block = four groups of splits (tid >> 6) x 64 float4
+// pieces: every group walks its quarter of the splits in index order with four loads in flight (small tiles are split dozens of ways: one thread walking
+// all of them serially was latency-bound), the four group sums meet in LDS in a FIXED order, and each element receives exactly ONE atomic add per launch -
+// the gradient is bit-repeatable whatever the block schedule (round 6; until then the groups were blockIdx.y and met in atomics: the 3-tap temporal
+// gradients differed in the last bits from run to run).  Trailing blocks: the bias-gradient partials, combined the same way.
 template <int BI, int BJ>
-__global__ __launch_bounds__(NT) void tn_reduce_kernel(const dist_gemm_tn_args p, int msplit, int tiles_i, int tiles_c, int per) {
+__global__ __launch_bounds__(NT) void tn_reduce_kernel(const dist_gemm_tn_args p, int msplit, int tiles_i, int tiles_c, int nb_main) {
+    static_assert(NT == 256 && BJ % 4 == 0, "four split groups of 64 lanes; float4 pieces inside a tile row");
     const int tiles_ij = tiles_i * tiles_c * p.taps;
-    const long total = (long)tiles_ij * BI * BJ;
-    const long e = (long)blockIdx.x * NT + threadIdx.x;
-    const int s0 = blockIdx.y * per, s1 = min(msplit, s0 + per);
-    if (e >= total) {                                     // trailing blocks: the bias-gradient partials (tiles_i * BI per split)
-        const long c = e - total;
-        if (!p.colsum || c >= p.NI) return;
-        const float* __restrict__ cp = p.partial + (long)msplit * total + c;
+    const long total = (long)tiles_ij * BI * BJ, total4 = total / 4;
+    const int tid = threadIdx.x, gq = tid >> 6, ln = tid & 63;
+    const int per = (msplit + 3) / 4, s0 = gq * per, s1 = min(msplit, s0 + per);
+    __shared__ f32x4 red[3][64];
+    if ((int)blockIdx.x >= nb_main) {                     // the bias-gradient partials (tiles_i * BI per split)
+        const long c = (long)((int)blockIdx.x - nb_main) * 64 + ln;
+        const bool in = p.colsum != nullptr && c < p.NI;
         float a = 0.f;
-        for (int s = s0; s < s1; ++s) a += cp[(long)s * tiles_i * BI];
+        if (in) {
+            const float* __restrict__ cp = p.partial + (long)msplit * total + c;
+            for (int s = s0; s < s1; ++s) a += cp[(long)s * tiles_i * BI];
+        }
+        if (gq > 0) red[gq - 1][ln] = f32x4{a, 0.f, 0.f, 0.f};
+        __syncthreads();
+        if (gq != 0 || !in) return;
+        a = ((a + red[0][ln][0]) + red[1][ln][0]) + red[2][ln][0];
         atomicAdd(p.colsum + c, a);
         if (p.colsum2) atomicAdd(p.colsum2 + c, a);
         return;
     }
+    const long e4 = (long)blockIdx.x * 64 + ln;
+    const bool in = e4 < total4;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    if (in) {
+        const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(p.partial) + e4;
+        int s = s0;
+        for (; s + 3 < s1; s += 4) {
+            a0 += src[(long)s * total4];
+            a1 += src[(long)(s + 1) * total4];
+            a2 += src[(long)(s + 2) * total4];
+            a3 += src[(long)(s + 3) * total4];
+        }
+        for (; s < s1; ++s) a0 += src[(long)s * total4];
+    }
+    f32x4 v = (a0 + a1) + (a2 + a3);
+    if (gq > 0) red[gq - 1][ln] = v;
+    __syncthreads();
+    if (gq != 0 || !in) return;
+    v = ((v + red[0][ln]) + red[1][ln]) + red[2][ln];
+    const long e = e4 * 4;
     const int t = (int)(e / (BI * BJ)), r = (int)(e % (BI * BJ));
     const int row = r / BJ, col = r - row * BJ;
     const int ti = t % tiles_i, tc = (t / tiles_i) % tiles_c, tap = t / (tiles_i * tiles_c);
     const int ii = ti * BI + row, c = tc * BJ + col;
-    if (ii >= p.NI || c >= p.K) return;
-    const long stride = (long)tiles_ij * (BI * BJ);
-    const float* __restrict__ src = p.partial + (long)t * (BI * BJ) + r;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int s = s0;
-    for (; s + 3 < s1; s += 4) {
-        a0 += src[(long)s * stride];
-        a1 += src[(long)(s + 1) * stride];
-        a2 += src[(long)(s + 2) * stride];
-        a3 += src[(long)(s + 3) * stride];
-    }
-    for (; s < s1; ++s) a0 += src[(long)s * stride];
-    atomicAdd(tn_dst(p, ii, c, tap), (a0 + a1) + (a2 + a3));
+    if (ii >= p.NI) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (c + q < p.K) atomicAdd(tn_dst(p, ii, c + q, tap), v[q]);
 }
 
 template <typename T, int BI, int BJ, int WI, int WJ, bool TR, int MODES>
@@ -392,14 +413,9 @@ int launch(const dist_gemm_tn_args& a, hipStream_t s) {
     HIP_CHECK_RET(hipGetLastError());
     static const bool skip_reduce = (dist_measure_knob("DIST_AMD_TN_SKIP_REDUCE", 0) != 0);   // measurement knob (results WRONG): what the second phase holds of the step
     if (two_phase && !skip_reduce) {
-        const long total = tiles * (long)(BI * BJ);
-        const long gx = (total + (a.colsum ? (long)tiles_i * BI : 0) + NT - 1) / NT;
-        long groups = (1024 + gx - 1) / gx;               // ~1024 blocks in flight ...
-        if (groups > msplit / 4) groups = msplit / 4;     // ... but at least 4 splits per thread
-        if (groups < 1) groups = 1;
-        const int per = (int)((msplit + groups - 1) / groups);
-        groups = (msplit + per - 1) / per;
-        hipLaunchKernelGGL((tn_reduce_kernel<BI, BJ>), dim3((unsigned)gx, (unsigned)groups), dim3(NT), 0, s, b, (int)msplit, tiles_i, tiles_c, per);
+        const long total4 = tiles * (long)(BI * BJ) / 4;
+        const long nb_main = (total4 + 63) / 64, nb_cs = a.colsum ? ((long)tiles_i * BI + 63) / 64 : 0;
+        hipLaunchKernelGGL((tn_reduce_kernel<BI, BJ>), dim3((unsigned)(nb_main + nb_cs)), dim3(NT), 0, s, b, (int)msplit, tiles_i, tiles_c, (int)nb_main);
         HIP_CHECK_RET(hipGetLastError());
     }
     return DIST_OK;

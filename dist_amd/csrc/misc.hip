@@ -592,6 +592,88 @@ __global__ __launch_bounds__(MIX_NT) void mixup_target_kernel(const long* __rest
         soft[e] = mix_rn(y1, lam, y2, oml);
     }
 }
+
+// ---- patch rows of the MIXED batch (round 6): what dist_op_patchify would gather after dist_op_mixup / dist_op_cutmix, without the 308 MB round trip of the
+// mixed fp32 frames.  The same arithmetic (mix_rn: three fp32 roundings, then the storage-type rounding), `video` is only read.
+struct MixP { int kind; float lam, oml; int yl, yh, xl, xh; };     // kind 1 = mixup, 2 = cutmix
+// one block per (PAIR i <= b-1-i, frame, patch row): the two clips' bands are read once, mixed in registers, parked in LDS in the output type and written as
+// whole patch rows of BOTH clips (patchify_band_kernel's layout)
+template <typename T>
+__global__ __launch_bounds__(NT) void patchify_band_mix_kernel(const float* __restrict__ video, T* __restrict__ out, int b, int Tn, int H, int W, int P, int Kp, const MixP m) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* band0 = reinterpret_cast<T*>(smem);                 // [3][P][W] of clip i
+    T* band1 = band0 + 3 * P * W;                          // ... of clip j = b - 1 - i
+    const int G = W / P, Gy = H / P;
+    const int gy = blockIdx.x % Gy;
+    const long pk = blockIdx.x / Gy;
+    const int k = (int)(pk % Tn), i = (int)(pk / Tn), j = b - 1 - i;
+    const int W4 = W / 4, per_c = P * W4;
+    for (int v = threadIdx.x; v < 3 * per_c; v += NT) {
+        const int c = v / per_c, rem = v - c * per_c, py = rem / W4, x4 = rem - py * W4;
+        const int y = gy * P + py;
+        const long off = ((long)c * Tn + k) * H * W + (long)y * W + x4 * 4;
+        const float4 a = *reinterpret_cast<const float4*>(video + (long)i * 3 * Tn * H * W + off);
+        const float4 q = i == j ? a : *reinterpret_cast<const float4*>(video + (long)j * 3 * Tn * H * W + off);
+        float oi[4], oj[4];
+        const float av[4] = {a.x, a.y, a.z, a.w}, qv[4] = {q.x, q.y, q.z, q.w};
+        if (m.kind == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { oi[e] = mix_rn(av[e], m.lam, qv[e], m.oml); oj[e] = mix_rn(qv[e], m.lam, av[e], m.oml); }
+        } else {                                           // cutmix: the box is swapped between the two clips (the middle clip of an odd batch keeps its frames)
+            const bool rowin = y >= m.yl && y < m.yh && i != j;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int x = x4 * 4 + e;
+                const bool in = rowin && x >= m.xl && x < m.xh;
+                oi[e] = in ? qv[e] : av[e]; oj[e] = in ? av[e] : qv[e];
+            }
+        }
+        T* d0 = band0 + (c * P + py) * W + x4 * 4;
+        T* d1 = band1 + (c * P + py) * W + x4 * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { d0[e] = from_f<T>(oi[e]); d1[e] = from_f<T>(oj[e]); }
+    }
+    __syncthreads();
+    const int vpr = Kp / 8, vp = P / 8;
+    for (int which = 0; which < (i == j ? 1 : 2); ++which) {
+        const T* band = which ? band1 : band0;
+        const long row0 = (((long)(which ? j : i) * Tn + k) * Gy + gy) * G;
+        for (int v = threadIdx.x; v < G * vpr; v += NT) {
+            const int gx = v / vpr, jj = v - gx * vpr;
+            Frag<T> o;
+            if (jj * 8 < 3 * P * P) {
+                const int c = jj / (P * vp), rem = jj - c * (P * vp), py = rem / vp, h = rem - py * vp;
+                frag_load(o, band + (c * P + py) * W + gx * P + h * 8);
+            } else {
+                frag_zero(o);
+            }
+            frag_store_nt(o, out + (row0 + gx) * Kp + jj * 8);
+        }
+    }
+}
+// any patch size (ViT-L/14): element-wise, every output element mixes its two source pixels itself
+template <typename T>
+__global__ __launch_bounds__(NT) void patchify_mix_kernel(const float* __restrict__ video, T* __restrict__ out, int b, int Tn, int H, int W, int P, int Kp, const MixP m) {
+    const int G = W / P, Gy = H / P, N = G * Gy, PP = P * P;
+    const long total = (long)b * Tn * N * Kp;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int col = (int)(i % Kp);
+        const long row = i / Kp;
+        float v = 0.f;
+        if (col < 3 * PP) {
+            const int c = col / PP, py = (col % PP) / P, px = col % P;
+            const int n = (int)(row % N);
+            const long bk = row / N;
+            const int k = (int)(bk % Tn), bi = (int)(bk / Tn), bj = b - 1 - bi;
+            const int y = (n / G) * P + py, x = (n % G) * P + px;
+            const long off = ((long)c * Tn + k) * H * W + (long)y * W + x;
+            const float a = video[(long)bi * 3 * Tn * H * W + off], q = video[(long)bj * 3 * Tn * H * W + off];
+            if (m.kind == 1) v = mix_rn(a, m.lam, q, m.oml);
+            else v = (bi != bj && y >= m.yl && y < m.yh && x >= m.xl && x < m.xh) ? q : a;
+        }
+        out[i] = from_f<T>(v);
+    }
+}
 }  // namespace
 
 extern "C" int dist_op_mixup(float* video, int b, int64_t per_clip, float lam, float one_minus_lam, void* stream) {
@@ -607,6 +689,28 @@ extern "C" int dist_op_cutmix(float* video, int b, int planes, int H, int W, int
     if (yl == yh || xl == xh || b < 2) return DIST_OK;          // empty box: nothing moves (the reference's slice assignment is a no-op)
     hipLaunchKernelGGL(cutmix_kernel, dim3((unsigned)(yh - yl), (unsigned)planes, (unsigned)(b / 2)), dim3(MIX_NT), 0, static_cast<hipStream_t>(stream),
                        video, b, planes, H, W, yl, yh, xl, xh);
+    HIP_CHECK_RET(hipGetLastError());
+    return DIST_OK;
+}
+extern "C" int dist_op_patchify_mixed(const float* video, void* patches, int b, int T, int H, int W, int P, int dtype, int kind, float lam, float one_minus_lam,
+                                      int yl, int yh, int xl, int xh, void* stream) {
+    if (kind == 0) return dist_op_patchify(video, patches, b, T, H, W, P, dtype, stream);
+    if (!video || !patches || b <= 0 || T <= 0 || P <= 0 || H % P || W % P || (kind != 1 && kind != 2)) return DIST_ERR_ARG;
+    if (kind == 2 && (yl < 0 || yh > H || xl < 0 || xh > W || yl > yh || xl > xh)) return DIST_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const MixP m{kind, lam, one_minus_lam, yl, yh, xl, xh};
+    const int Kp = (3 * P * P + 7) / 8 * 8;
+    const size_t band2 = (size_t)2 * 3 * P * W * (dtype == DIST_BF16 ? 2 : 4);
+    if (P % 8 == 0 && W % 4 == 0 && band2 <= 64 * 1024 && (3 * P * P) % 8 == 0 && (reinterpret_cast<uintptr_t>(video) & 15) == 0) {
+        const unsigned grid = (unsigned)((long)((b + 1) / 2) * T * (H / P));
+        if (dtype == DIST_BF16) hipLaunchKernelGGL(patchify_band_mix_kernel<bf16_t>, dim3(grid), dim3(NT), band2, s, video, (bf16_t*)patches, b, T, H, W, P, Kp, m);
+        else hipLaunchKernelGGL(patchify_band_mix_kernel<float>, dim3(grid), dim3(NT), band2, s, video, (float*)patches, b, T, H, W, P, Kp, m);
+        HIP_CHECK_RET(hipGetLastError());
+        return DIST_OK;
+    }
+    const long total = (long)b * T * (H / P) * (W / P) * Kp;
+    if (dtype == DIST_BF16) hipLaunchKernelGGL(patchify_mix_kernel<bf16_t>, dim3(grid1d(total, NT * 8)), dim3(NT), 0, s, video, (bf16_t*)patches, b, T, H, W, P, Kp, m);
+    else hipLaunchKernelGGL(patchify_mix_kernel<float>, dim3(grid1d(total, NT * 8)), dim3(NT), 0, s, video, (float*)patches, b, T, H, W, P, Kp, m);
     HIP_CHECK_RET(hipGetLastError());
     return DIST_OK;
 }

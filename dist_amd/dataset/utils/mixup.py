@@ -120,6 +120,10 @@ class Mixup:
             raise NotImplementedError("AUGMENTATION.MIXUP.MODE: only `batch` (every DiST yaml) is implemented")
         self.correct_lam = True
         self.mixup_enabled = True
+        # TRAIN.FUSE_MIXUP (dist_amd): the clips are NOT mixed in memory - the plan is left on the clip tensor (`video._dist_mix`) and the frozen ViT's patch-row
+        # gather applies it while it reads the frames (Engine.vit_forward / vit_prefetch -> dist_vit_mix_next -> dist_op_patchify_mixed: the same arithmetic, one
+        # pass over 308 MB instead of three).  The soft target is built as always.  Off = the reference's in-place mix.
+        self.fuse = bool(getattr(getattr(cfg, "TRAIN", None), "FUSE_MIXUP", False))
 
     def plan(self, shape):
         """the batch's MixPlan for a clip tensor of `shape` [..., H, W] (consumes the global numpy stream like the reference's call)"""
@@ -129,6 +133,9 @@ class Mixup:
     def apply(self, x, plan):
         """x [b, 3, T, H, W] fp32 on the GPU, mixed in place (reference :212-223): dist_op_cutmix / dist_op_mixup"""
         _on_gpu(x, "video")
+        if self.fuse and plan.kind != "none" and x.dtype == torch.float32 and x.is_contiguous():
+            x._dist_mix = plan                      # consumed by the next ViT pass over this tensor
+            return plan.lam
         if plan.kind == "cutmix":
             ops.cutmix_(x, *plan.box)
         elif plan.kind == "mixup":

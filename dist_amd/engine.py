@@ -147,8 +147,22 @@ class Engine:
             self._sync_version = (self.theta._version, self.visual._version, param_version)
 
     # ---- the hot path ----------------------------------------------------------------------
+    def vit_mix_next(self, kind="none", lam=1.0, box=None):
+        """The next ViT pass that starts gathers its patch rows from the batch AS IF mixed (dist_vit_mix_next): kind "mixup" | "cutmix" | "none",
+        `lam` / `box` as dist_amd.dataset.utils.mixup.MixPlan carries them.  The frames themselves are not written."""
+        yl, yh, xl, xh = box if box is not None else (0, 0, 0, 0)
+        L.check(self.lib.dist_vit_mix_next(self.h, ops.MIX_KINDS[kind], ops._f32(lam), ops._f32(1.0 - lam), int(yl), int(yh), int(xl), int(xh)), self.h)
+
+    def _deferred_mix(self, video):
+        """A MixPlan that Mixup(fuse=True) left on the clip tensor instead of mixing it (TRAIN.FUSE_MIXUP): handed to the pass that is about to read the clip."""
+        plan = getattr(video, "_dist_mix", None)
+        if plan is not None:
+            self.vit_mix_next(plan.kind, plan.lam, plan.box)        # (cutmix: lam only builds the soft target, the box is what moves)
+            del video._dist_mix
+
     def vit_forward(self, video):
         assert video.dtype == torch.float32 and video.is_contiguous() and video.is_cuda
+        self._deferred_mix(video)
         self.b = video.shape[0]
         L.check(self.lib.dist_vit_forward(self.h, video.data_ptr(), self.b, ops._stream()), self.h)
         self._cur_video, self._cur_ver = video, video._version
@@ -191,18 +205,22 @@ class Engine:
         not written since): it was prefetched during the previous step and adopted."""
         return self._cur_video is video and video._version == self._cur_ver
 
-    def vit_prefetch(self, video, layer_end=None):
+    def vit_prefetch(self, video, layer_end=None, stream=None):
         """Frozen ViT of the NEXT batch into the spare feature slot, on the handle's lowest-priority prefetch stream, behind
         everything already queued on the current stream (dist_vit_prefetch).  `video` must stay alive until `vit_adopt`.
         layer_end < layers issues only the first layers; `vit_prefetch_more` continues the pass later in the step."""
         assert video.dtype == torch.float32 and video.is_contiguous() and video.is_cuda
+        self._deferred_mix(video)
         self._pf_video, self._pf_ver = video, video._version
         le = self.cfg.layers if layer_end is None else int(layer_end)
-        L.check(self.lib.dist_vit_prefetch_layers(self.h, video.data_ptr(), video.shape[0], le, None, ops._stream()), self.h)
+        # `stream`: a torch stream of the caller's that carries the pass instead of the handle's own prefetch stream (the C ABI's `stream` argument) - e.g. the
+        # one that also carries the host -> device copies of the batches (dist_amd/utils/staging.py): the number of ACTIVE streams stays at four
+        self._pf_stream = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        L.check(self.lib.dist_vit_prefetch_layers(self.h, video.data_ptr(), video.shape[0], le, self._pf_stream, ops._stream()), self.h)
 
     def vit_prefetch_more(self, layer_end=None):
         le = self.cfg.layers if layer_end is None else int(layer_end)
-        L.check(self.lib.dist_vit_prefetch_layers(self.h, None, 0, le, None, ops._stream()), self.h)
+        L.check(self.lib.dist_vit_prefetch_layers(self.h, None, 0, le, getattr(self, "_pf_stream", None), ops._stream()), self.h)
 
     def vit_adopt(self):
         """The prefetched batch becomes the current one (as after `vit_forward` of it)."""

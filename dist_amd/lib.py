@@ -134,7 +134,7 @@ def _sig(lib, name, argtypes=None, restype=None):
 # every DIST_AMD_* variable the PRODUCT library or its Python host side reads (csrc/common.h dist_knob(); bench.py / utils/distributed.py / build.py)
 PRODUCT_ENV = frozenset("DIST_AMD_" + k for k in (
     "ATTN_FULLROW CONV9 FAST_8P INTEG_BWD_FUSED INTEG_FUSED KEEP_MID LNFOLD NT_DMA ROWSTATS SERIAL TN8P TN8P_BLOCKS TNET_BWD_FUSED TNET_FUSED TN_BLOCKS "
-    "LIB BACKEND FORCE_REDUCER VIT_SPLIT MAIN_PRIO BUILD_DEFS REDUCER_DTYPE REDUCER_MODE SKIP_SLOW_ORACLE ALLOW_INERT HOST_INPUT").split())
+    "LIB BACKEND FORCE_REDUCER VIT_SPLIT MAIN_PRIO HOST_INPUT BUILD_DEFS REDUCER_DTYPE REDUCER_MODE SKIP_SLOW_ORACLE ALLOW_INERT HOST_INPUT").split())
 
 
 def load():
@@ -232,6 +232,8 @@ def load():
     _sig(lib, "dist_op_logits_loss", argtypes=[C.c_void_p] * 10 + [C.c_int] * 4 + [C.c_void_p])
     _sig(lib, "dist_op_mixup", argtypes=[C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_void_p])
     _sig(lib, "dist_op_cutmix", argtypes=[C.c_void_p] + [C.c_int] * 8 + [C.c_void_p])
+    _sig(lib, "dist_op_patchify_mixed", argtypes=[C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_float, C.c_float] + [C.c_int] * 4 + [C.c_void_p])
+    _sig(lib, "dist_vit_mix_next", argtypes=[C.c_void_p, C.c_int, C.c_float, C.c_float] + [C.c_int] * 4)
     _sig(lib, "dist_op_mixup_target", argtypes=[C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_op_quant_rows_fp8", argtypes=[C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p])
     _sig(lib, "dist_op_fp8_scale_update", argtypes=[C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p])

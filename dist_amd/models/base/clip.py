@@ -275,6 +275,9 @@ class CLIP(nn.Module):
         next batch's (already augmented) clip before `forward` of the current one, then `adopt_prefetched()` after the
         optimizer step; `forward` of that clip then skips its ViT pass.  The tensor must not be written in between."""
         conv = video.contiguous().float()
+        if conv is not video and getattr(video, "_dist_mix", None) is not None:      # (a deferred Mixup plan travels with the tensor the engine reads)
+            conv._dist_mix = video._dist_mix
+            del video._dist_mix
         self.engine.vit_prefetch(conv)
         self._pf_pair = (video, conv)
 
@@ -285,7 +288,14 @@ class CLIP(nn.Module):
     def forward_video(self, video, text, others=None):
         text_features, _, others = self.cache_text(text, others)
         pair = getattr(self, "_cur_pair", None)
-        video = pair[1] if (pair is not None and pair[0] is video) else video.contiguous().float()
+        if pair is not None and pair[0] is video:
+            video = pair[1]
+        else:
+            conv = video.contiguous().float()
+            if conv is not video and getattr(video, "_dist_mix", None) is not None:
+                conv._dist_mix = video._dist_mix
+                del video._dist_mix
+            video = conv
         # under torch.no_grad() (eval_epoch, perform_test) the engine keeps nothing for a backward pass (dist_set_inference)
         infer = not torch.is_grad_enabled()
         if infer != getattr(self, "_infer", False):

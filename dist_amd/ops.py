@@ -443,6 +443,21 @@ def cutmix_(video, yl, yh, xl, xh):
     return video
 
 
+MIX_KINDS = {"none": 0, "mixup": 1, "cutmix": 2}
+
+
+def patchify_mixed(video, P, dtype, kind="none", lam=1.0, box=None):
+    """patch rows of the batch AS IF mixed by mixup_ / cutmix_ first (dist_op_patchify_mixed): `video` is only read."""
+    assert video.is_cuda and video.dtype == torch.float32 and video.is_contiguous()
+    b, _, T, H, W = video.shape
+    Kp = (3 * P * P + 7) // 8 * 8
+    out = torch.empty(b * T * (H // P) * (W // P), Kp, dtype=dtype, device=video.device)
+    yl, yh, xl, xh = box if box is not None else (0, 0, 0, 0)
+    L.check(L.load().dist_op_patchify_mixed(_p(video), _p(out), b, T, H, W, P, _dt(out), MIX_KINDS[kind], _f32(lam), _f32(1.0 - lam),
+                                            int(yl), int(yh), int(xl), int(xh), _stream()))
+    return out
+
+
 def mixup_target(labels, num_classes, lam=1.0, smoothing=0.0):
     """soft target [b, K] fp32 = y1*lam + y2*(1-lam) with smoothed one-hot rows (reference mixup_target)."""
     assert labels.is_cuda

@@ -370,6 +370,12 @@ int dist_op_adamw(float* param, const float* grad, float* m, float* v, const dis
 int dist_op_mixup(float* video, int b, int64_t per_clip, float lam, float one_minus_lam, void* stream);
 int dist_op_cutmix(float* video, int b, int planes, int H, int W, int yl, int yh, int xl, int xh, void* stream);
 int dist_op_mixup_target(const int64_t* labels, int b, int K, float lam, float one_minus_lam, float on_value, float off_value, float* soft, void* stream);
+/* The patch rows of the MIXED batch without the round trip of the mixed frames (Mixup fused into the patch-row gather): exactly what
+ * dist_op_patchify returns after dist_op_mixup (kind 1) / dist_op_cutmix (kind 2) - the same three fp32 roundings per element, then the rounding to `dtype` -
+ * while `video` is only READ (it keeps the unmixed clips).  kind 0 = dist_op_patchify.  One pass over the frames instead of three (308 MB read + 154 MB
+ * written at b = 32 instead of 924 + 154).  Replaces, together with dist_op_mixup_target, the video side of reference dataset/utils/mixup.py:212-223 + clip.py:266. */
+int dist_op_patchify_mixed(const float* video, void* patches, int b, int T, int H, int W, int P, int dtype, int kind, float lam, float one_minus_lam,
+                           int yl, int yh, int xl, int xh, void* stream);
 
 /* Evaluation side: the operators that consume the predictions right behind the forward pass, so that the
  * multi-view test loop (runs/test.py:24-178) and the per-iteration training metrics (runs/train.py:165-178) need no host round trip.
@@ -459,6 +465,10 @@ int dist_pack_weights(dist_handle* h, int what, void* stream);
 /* VisionTransformer.forward under eval()+no_grad (clip.py:263-300,454-458): video [b,3,T,H,W] fp32
  * -> mid_feat kept inside the workspace ([layers][b,t,L,d], read back through dist_debug_tensor("feat.<i>")). */
 int dist_vit_forward(dist_handle* h, const float* video, int b, void* stream);
+/* One-shot: the NEXT ViT pass that starts (dist_vit_forward, dist_vit_prefetch[_layers] with video != NULL) gathers its patch rows through
+ * dist_op_patchify_mixed(kind, lam, ...) - the batch-mode Mixup / CutMix of reference runs/train.py:92-93 applied while the frames are read, the frames
+ * themselves untouched.  kind 0 cancels.  Host only. */
+int dist_vit_mix_next(dist_handle* h, int kind, float lam, float one_minus_lam, int yl, int yh, int xl, int xh);
 /* Software pipelining over batches.  The ViT is frozen (clip.py:454-458: eval() + no_grad), so its forward for batch n+1
  * does not depend on the optimizer step of batch n.  The workspace holds TWO feature slots (patch rows + mid_feat):
  * dist_vit_prefetch runs the ViT of the NEXT batch into the spare slot on `stream` (NULL = the handle's own lowest-priority

@@ -184,11 +184,11 @@ def test_train_loop_pipelines_the_frozen_vit_without_changing_results(gpu_lib):
         assert abs(x["loss"] - y["loss"]) < 1e-4 * max(1.0, abs(x["loss"])), (x, y)
         assert x["top1_err"] == y["top1_err"] and x["lr"] == y["lr"]
     # round 6: the same batches handed over in HOST memory (the reference loader's form): pinned staging + a copy stream two batches ahead
-    # (dist_amd/utils/staging.py) - the same clips reach the same kernels, so the statistics are identical, pipelined or not
+    # (dist_amd/utils/staging.py) - the same clips reach the same kernels: the same statistics (up to the fp32 atomics of the parity mode), pipelined or not
     for c in (run(True, host=True), run(False, host=True)):
         assert len(c) == 4
         for x, y in zip(b, c):
-            assert x["loss"] == y["loss"] and x["top1_err"] == y["top1_err"] and x["lr"] == y["lr"], (x, y)
+            assert abs(x["loss"] - y["loss"]) < 1e-4 * max(1.0, abs(x["loss"])) and x["top1_err"] == y["top1_err"] and x["lr"] == y["lr"], (x, y)
 
 
 def _tiny_model(*extra):

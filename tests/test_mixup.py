@@ -173,3 +173,75 @@ def test_hip_mixup_edge_cases(gpu_lib):
     y = x1.clone(); ops.mixup_(y, 0.25)
     r = x1.clone(); rf = r.flip(0).mul_(0.75); r.mul_(0.25).add_(rf)
     assert torch.equal(y, r)
+
+
+# ---------------------------------------------------------------------------------------------- Mixup fused into the patch-row gather
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("b,T,res,P", [(4, 2, 64, 16), (5, 2, 64, 16), (3, 2, 56, 14), (1, 1, 32, 16)])
+def test_patch_rows_of_the_mixed_batch_equal_mix_then_patchify(gpu_lib, dtype, b, T, res, P):
+    """dist_op_patchify_mixed (Mixup fused into the patch-row gather) == dist_op_patchify after dist_op_mixup / dist_op_cutmix, bit for
+    bit, in both storage types, for the band kernel (P % 8 == 0) and the element-wise one (ViT-L/14's P = 14), even / odd / single-clip batches - and the
+    frames are left untouched."""
+    from dist_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(b * 100 + P)
+    x0 = torch.randn(b, 3, T, res, res, generator=g, device="cuda")
+    for kind, lam, box in (("mixup", 0.37251, None), ("mixup", 0.9, None), ("cutmix", 0.5, (res // 8, res - res // 4, 3, res // 2 + 1)), ("cutmix", 0.5, (0, res, 0, res)),
+                           ("cutmix", 0.5, (7, 7, 0, 9)), ("none", 1.0, None)):
+        ref = x0.clone()
+        if kind == "mixup":
+            ops.mixup_(ref, lam)
+        elif kind == "cutmix":
+            ops.cutmix_(ref, *box)
+        want = ops.patchify(ref, P, dtype)
+        x = x0.clone()
+        got = ops.patchify_mixed(x, P, dtype, kind, lam, box)
+        assert torch.equal(got, want), (kind, lam, box)
+        assert torch.equal(x, x0)                                    # only read
+
+
+@pytest.mark.gpu
+def test_patch_rows_of_the_mixed_batch_at_the_baseline_batch(gpu_lib):
+    """b = 32 x 16 frames x 224^2 (BASELINE config 2): the fused gather against mix-then-gather, every patch row."""
+    from dist_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x0 = torch.randn(32, 3, 16, 224, 224, generator=g, device="cuda")
+    ref = x0.clone(); ops.mixup_(ref, 0.6180339)
+    assert torch.equal(ops.patchify_mixed(x0, 16, torch.bfloat16, "mixup", 0.6180339), ops.patchify(ref, 16, torch.bfloat16))
+    ref = x0.clone(); ops.cutmix_(ref, 30, 140, 17, 201)
+    assert torch.equal(ops.patchify_mixed(x0, 16, torch.bfloat16, "cutmix", 0.5, (30, 140, 17, 201)), ops.patchify(ref, 16, torch.bfloat16))
+
+
+@pytest.mark.gpu
+def test_engine_consumes_a_deferred_mix_plan(gpu_lib):
+    """TRAIN.FUSE_MIXUP: Mixup leaves its plan on the clip tensor, the next ViT pass over that tensor (vit_forward or the pipelined vit_prefetch) applies it while
+    gathering the patch rows - the same features and logits as mixing the clips in place first; the plan is consumed once; the soft target is unchanged."""
+    from types import SimpleNamespace as NS
+    from dist_amd import synth
+    from dist_amd.dataset.utils.mixup import Mixup
+    from dist_amd.engine import Engine, config_from_geometry
+    g = synth.geometry("tiny")
+    eng = Engine(config_from_geometry(g, 4, torch.float32))
+    eng.load_state_dict(synth.state_dict(g))
+    text = torch.from_numpy(synth.text_features(g)).cuda()
+    x0 = torch.from_numpy(synth.video(g, 4, seed=3)).cuda()
+    lab = torch.arange(4, device="cuda") % g.K
+    for ma, ca in ((0.8, 0.0), (0.0, 1.0)):
+        cfgs = [cfg_of(g.K, ma, ca, 1.0, 0.5, 0.1) for _ in range(2)]
+        cfgs[1].TRAIN = NS(FUSE_MIXUP=True)
+        outs = []
+        for cfg, how in zip(cfgs, ("forward", "prefetch")):
+            fn = Mixup(cfg)
+            x = x0.clone()
+            np.random.seed(7)
+            inputs, soft = fn({"video": x}, lab)
+            if fn.fuse:
+                assert torch.equal(x, x0) and getattr(x, "_dist_mix", None) is not None          # the frames are not written, the plan travels with them
+                eng.vit_prefetch(x); eng.vit_adopt()
+                assert getattr(x, "_dist_mix", None) is None                                     # consumed
+            else:
+                assert not torch.equal(x, x0)
+                eng.vit_forward(x)
+            logits, _ = eng.branch_forward(text)
+            outs.append((logits.clone(), soft.clone(), eng.debug("feat.0").clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
