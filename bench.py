@@ -156,6 +156,7 @@ def main():
     torch.cuda.set_device(local_rank % torch.cuda.device_count() if os.environ.get("DIST_AMD_BACKEND") == "gloo" else local_rank)
 
     from dist_amd import synth
+    from dist_amd import ops as ops_mod
     from dist_amd.utils import distributed as du
     from dist_amd.engine import Engine, config_from_geometry
 
@@ -182,7 +183,8 @@ def main():
     it = [0]
     split = int(os.environ.get("DIST_AMD_VIT_SPLIT", g.layers))   # ViT layers issued before the branch forward (the rest before the backward)
 
-    H, tickets = {"stager": None, "host": None}, {}
+    H, tickets = {"stager": None, "host": None, "mix": None}, {}
+    MIX_LAM = 0.6180339
 
     def host_input_on():
         from dist_amd.utils.staging import HostStager
@@ -206,6 +208,12 @@ def main():
         n = it[0]
         it[0] += 1
         stager = H["stager"]
+        if H["mix"] is not None:                       # the loop's Mixup of the batch whose ViT pass this step issues (reference runs/train.py:92-93)
+            nv = batch_video(n + 1 if pipelined else n)
+            if H["mix"] == "fused":
+                eng.vit_mix_next("mixup", MIX_LAM)     # applied while the patch rows are gathered (dist_op_patchify_mixed): the frames are only read
+            else:
+                ops_mod.mixup_(nv, MIX_LAM)            # the reference's order: mixed in place (308 MB read + written), then gathered
         if pipelined:
             eng.vit_prefetch(batch_video(n + 1), layer_end=split)   # frozen ViT of the NEXT batch, beside this batch's branch work
             if stager is not None and (n + 2) not in tickets:
@@ -375,6 +383,13 @@ def main():
             fwd_only["path_mfma_frac"] = round(b / dtf * gff / 1e3 / pk_f, 4)
             if pk_note:
                 fwd_only["path_peak"] = pk_note
+        fj = os.path.join(ROOT, "profiles", "r06_fwd_kernel_stats.json")
+        if args.config == "b16_8+16f" and b == 32 and not args.vit_fp8 and os.path.exists(fj):
+            with open(fj) as f:
+                fp = json.load(f)
+            # the packing bound of the forward launches alone, from the committed profile of tools/fwd_only.py (tools/r06_fwd_budget.sh): a number of THAT box
+            fwd_only["cu_time_floor_ms"] = {"value": fp.get("cu_time_floor_ms"), "from": "profiles/r06_fwd_kernel_stats.json (budget: profiles/r06_forward_budget.md)",
+                                            "from_box_ms_per_iteration": fp.get("wall_ms_per_step")}
 
     # the same step fed from HOST memory (the reference's loader hands over host batches, runs/train.py:81-101): pinned staging + a copy stream two steps
     # ahead of the frozen-ViT pass (dist_amd/utils/staging.py).  Reported beside `value`, never as it (the contract: inputs resident)
@@ -395,6 +410,27 @@ def main():
         host_leg = {"ms_per_step": round(dth * 1e3, 3), "value": round(b / dth, 1), "unit": "clips/s", "steps": nh,
                     "vs_resident": round((dt / args.steps) / dth, 4),
                     "note": "batches in pinned host memory; the 308 MB H2D copy of batch n+2 runs on a host-ordered copy stream beside step n (python bench.py --host-input)"}
+
+    # the same step with the loop's batch-mode Mixup in front of every ViT pass (reference runs/train.py:92-93; the timed `value` has none, as BASELINE's metric):
+    # mixed in place and then gathered (the reference's order), and fused into the patch-row gather (TRAIN.FUSE_MIXUP, dist_vit_mix_next)
+    mix_leg = None
+    if not args.no_roofline and world == 1 and pipelined and not args.host_input:
+        mix_leg = {}
+        for how in ("unfused", "fused"):
+            H["mix"] = how
+            eng.vit_forward(batch_video(it[0]))
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            tm0 = time.perf_counter()
+            nm = max(1, min(10, args.steps))
+            for _ in range(nm):
+                step()
+            torch.cuda.synchronize()
+            mix_leg[how + "_ms_per_step"] = round((time.perf_counter() - tm0) / nm * 1e3, 3)
+        H["mix"] = None
+        mix_leg["note"] = ("pipelined step with a batch-mode mixup of every batch in front of its frozen-ViT pass: `unfused` = dist_op_mixup in place + the patch gather, "
+                           "`fused` = dist_vit_mix_next (the mix applied while the patch rows are gathered; bit-identical patch rows, tests/test_mixup.py)")
 
     if rank == 0:
         clips = world * b * args.steps
@@ -458,6 +494,8 @@ def main():
             out["forward_only"] = fwd_only
         if host_leg:
             out["host_input"] = host_leg
+        if mix_leg:
+            out["with_mixup"] = mix_leg
         if cpu_leg is not None:
             out["cpu_baseline"] = cpu_leg
         # RCCL's version banner sits in the C stdio buffer until exit: flush it first so that the JSON line is the LAST line of stdout

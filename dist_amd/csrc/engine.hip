@@ -443,9 +443,7 @@ static int ensure_streams(dist_handle* h) {
     const int prio = DIST_AB_KNOB("DIST_AMD_SIDE_PRIO", 1) == 0 ? 0 : least;
     // the frozen ViT's stream (DIST_AMD_PF_PRIO in the timing-only library: 0 = default priority, 2 = the highest)
     const int pf_knob = DIST_AB_KNOB("DIST_AMD_PF_PRIO", 1);
-    h->pf_auto = pf_knob == 1;                            // (the shipped setting: dist_set_inference moves the stream between lowest and default priority)
-    h->pf_hi = h->pf_auto && h->inference;
-    const int pf_prio = (pf_knob == 0 || h->pf_hi) ? 0 : (pf_knob == 2 ? greatest : least);
+    const int pf_prio = pf_knob == 0 ? 0 : (pf_knob == 2 ? greatest : least);
     bool ok = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio) == hipSuccess &&
               hipStreamCreateWithPriority(&h->side2, hipStreamNonBlocking, prio) == hipSuccess &&
               hipStreamCreateWithPriority(&h->pf, hipStreamNonBlocking, pf_prio) == hipSuccess;
@@ -605,20 +603,9 @@ extern "C" int dist_pack_weights(dist_handle* h, int what, void* stream) {
 extern "C" int dist_set_inference(dist_handle* h, int on) {
     if (!h) return DIST_ERR_ARG;
     h->inference = on != 0;
-    // The prefetch stream's priority follows the mode.  Training: the ViT pass of batch n+1 is off the critical path (the backward of batch n is) - lowest
-    // priority.  Forward-only (evaluation loops): the ViT pass IS the critical path and the branch forward the filler - default priority, measured
-    // 12.26 / 12.30 -> 12.06 / 12.09 ms per 32-clip iteration (profiles/r06_forward_budget.md).  Passes already queued on the old stream finish there
-    // (hipStreamDestroy releases it behind them); consecutive ViT passes are ordered by ev_vit_done whatever their streams.
-    if (h->pf && h->pf_auto && h->pf_hi != h->inference) {
-        int least = 0, greatest = 0;
-        hipDeviceGetStreamPriorityRange(&least, &greatest);
-        hipStream_t ns = nullptr;
-        if (hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, h->inference ? 0 : least) == hipSuccess) {
-            hipStreamDestroy(h->pf);
-            h->pf = ns;
-            h->pf_hi = h->inference;
-        }
-    }
+    // (round 6: moving the prefetch stream to default priority for forward-only loops - where the ViT pass is the critical path - was worth 0.2 ms of 12.3 when the
+    //  stream is CREATED that way (timing-only library, DIST_AMD_PF_PRIO=0: 12.26 / 12.30 -> 12.06 / 12.09 ms), and cost 1.7 ms when dist_set_inference re-created it:
+    //  the new stream lands on a hardware queue another of the step's streams already uses (11.82 -> 13.58 ms).  The stream keeps the priority it was created with.)
     return DIST_OK;
 }
 

@@ -159,7 +159,6 @@ struct dist_handle {
     // weight-gradient side stream (created once per handle; host-side objects only)
     hipStream_t side = nullptr, side2 = nullptr, pf = nullptr;   // pf: the handle's own ViT prefetch stream
     struct { int kind = 0; float lam = 1.f, oml = 0.f; int yl = 0, yh = 0, xl = 0, xh = 0; } mix;   // dist_vit_mix_next: consumed by the next pass that gathers patch rows
-    bool pf_auto = false, pf_hi = false;                         // pf's priority follows dist_set_inference (lowest while training, default in forward-only loops)
     hipStream_t chain2 = nullptr;                                // backward: the temporal data-gradient chain (T2I data gradient + TemporalNet backward), beside the integration chain
     std::vector<hipEvent_t> ev_dmp, ev_dx;                       // chain -> chain2: dM'_i written; chain2 -> chain: dX_i written
     hipEvent_t ev_c2 = nullptr;

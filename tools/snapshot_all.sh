@@ -1,5 +1,5 @@
 # everything profiles/r0N_* is built from, in one call: bash tools/snapshot_all.sh <tag>
-tag=${1:-r05b}
+tag=${1:-r06}
 cd $GRAFT_REPO_ROOT
 bash tools/snapshot.sh $tag
 bash tools/pmc_step.sh > gpurun_out/pmc_step_traffic.md 2>&1
