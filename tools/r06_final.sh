@@ -7,3 +7,4 @@ python tools/fwd_only.py --serial | grep fwd_only >> gpurun_out/r06_fwd_only.txt
 python tools/fwd_only.py --vit-only | grep fwd_only >> gpurun_out/r06_fwd_only.txt
 python tools/fwd_only.py --branch-only | grep fwd_only >> gpurun_out/r06_fwd_only.txt
 tail -c 700 gpurun_out/bench_r06.json
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
