@@ -725,6 +725,14 @@ __global__ __launch_bounds__(512, 1) void gemm_fast8p_kernel(const dist_gemm_arg
     int tm, tn;
     if (DIST_AB && (ngroups & 0x200000)) fast_tile(p, ngroups, BN, tm, tn);      // (timing-only library: the divisions in the kernel)
     else fast_tile_mapped(tmap, tm, tn);
+    if (DIST_AB && ((ngroups >> 22) & 63) && blockIdx.x < 256) {
+        // timing-only library (DIST_AMD_FAST_SKEW, round 6): the column tiles of one row panel start together, so ALL of them see the fabric latency of the panel's
+        // A pieces (the L2 merges their requests, it does not shorten them).  Column tile c of its group starts c x skew x 64 cycles late in the first round -
+        // later rounds inherit the order - so that the followers find the leader's lines in L2.
+        const int sk = (ngroups >> 22) & 63;
+        const int col = tmap.ngroups <= 1 ? tn : (tn < tmap.gr * (tmap.gq + 1) ? tn % (tmap.gq + 1) : (tn - tmap.gr * (tmap.gq + 1)) % max(tmap.gq, 1));
+        for (int i = 0; i < col * sk; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int M = (int)p.M, N = p.N, K = p.K;
 
@@ -1099,7 +1107,8 @@ static int launch_fast(const dist_gemm_args* a, hipStream_t s) {
         constexpr int K_NONE = 0, K_BIAS = DIST_EPI_BIAS, K_BIASRES = DIST_EPI_BIAS | DIST_EPI_RES;   // the branch's plain Linears (input_linear, data gradients)
         static const int kdiv = DIST_AB_KNOB("DIST_AMD_FAST_TILEMAP", 1) == 0 ? 0x200000 : 0;       // A/B: the tile map's divisions in the kernel
         static const int plain_st = DIST_AB_KNOB("DIST_AMD_FAST_PLAIN_ST", 0);     // 1: every output without the streaming hint; 2 / 3 / 4: only in_proj's / c_fc's / the residual GEMMs'
-        const int na = ng | late | gaux | dbg8 | kdiv | (((plain_st == 2 && key == K_INPROJ) || (plain_st == 3 && key == K_FC) || (plain_st == 4 && key == K_PROJ)) ? 4 << 18 : 0);
+        static const int skew = (DIST_AB_KNOB("DIST_AMD_FAST_SKEW", 0) & 63) << 22;                 // A/B: column tiles of a row panel start skew x 64 cycles apart (first round)
+        const int na = ng | late | gaux | dbg8 | kdiv | skew | (((plain_st == 2 && key == K_INPROJ) || (plain_st == 3 && key == K_FC) || (plain_st == 4 && key == K_PROJ)) ? 4 << 18 : 0);
 #ifdef DIST_AMD_MEASURE
         if (DIST_AB_KNOB("DIST_AMD_FAST_DBG", 0) & 4) {          // timing-only library: which epilogue shapes a workload launches
             static int seen[64]; static int nseen = 0;
