@@ -188,8 +188,8 @@ def main():
 
     def host_input_on():
         from dist_amd.utils.staging import HostStager
-        # a copy stream of its own that never sees an event (host-ordered: dist_amd/utils/staging.py) - with events on it the copy stream becomes a fifth
-        # compute queue and the step pays 1-2.6 ms (DIST_AMD_HOST_INPUT=events selects that form for the A/B; profiles/r06_host_input.md)
+        # a copy stream of its own that never sees an event (host-ordered: dist_amd/utils/staging.py) - with events on it the copies are tied to
+        # compute-queue signals and the step pays 1-2.6 ms (DIST_AMD_HOST_INPUT=events selects that form for the A/B; profiles/r06_host_input.md)
         H["stager"] = HostStager(depth=3, host_ordered=os.environ.get("DIST_AMD_HOST_INPUT", "") != "events")
         H["host"] = [v.cpu().pin_memory() for v in videos]
         tickets.clear()

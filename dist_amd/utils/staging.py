@@ -7,8 +7,8 @@ ahead, beside step n: by the time step n+1 hands batch n+2 to the prefetch, its 
 the "asynchronous" copy synchronous), a ring of device buffers, one event per buffer in each direction.
 
 What sits on the copy stream matters on this system (profiles/r06_host_input.md, tools/host_input_probe.py).  Copies alone - SDMA work - cost the step 0.2-0.4 ms.
-An EVENT recorded on the copy stream, or waited for by it, turns it into a fifth compute queue (barrier packets) beside the engine's four, and a fifth active
-compute queue costs 1.0 ms (record only) to 2.6 ms (record + wait) of a 16.4 ms step; putting the copies on the stream that carries the frozen-ViT prefetch
+An EVENT recorded on the copy stream, or waited for by it, ties the SDMA copies to compute-queue signals (barrier packets, probably the copy itself as a blit kernel) on a
+queue beside the engine's four, and that costs 1.0 ms (record only) to 2.6 ms (record + wait) of a 16.4 ms step; putting the copies on the stream that carries the frozen-ViT prefetch
 serialises 11 ms of ViT with 5.4 ms of copy (21 ms).  So the default is HOST-ordered: the host waits for `freed` before it issues a copy and for the copy stream
 to drain before it hands a buffer out - both waits find their work finished a step ago - and the copy stream never sees an event: 16.9 against 16.5 ms resident.
 """
@@ -29,7 +29,7 @@ class HostStager:
         self.k = 0
         # host_ordered: the copy stream never sees an event (no record on it, no wait on it): the HOST waits for `freed` before it issues a copy and for the copy
         # stream to drain before it hands a buffer out.  Both waits find their work finished a step ago, so they cost nothing - while an event recorded on / waited
-        # for by the copy stream makes it a fifth COMPUTE queue (barrier packets), and a fifth active compute queue costs the step 1-2.6 ms on this system
+        # for by the copy stream ties the copies to compute-queue signals and costs the step 1-2.6 ms on this system
         # (profiles/r06_host_input.md: 17.4 / 18.9 ms with events against 16.3 resident).
         self.host_ordered = host_ordered
 
